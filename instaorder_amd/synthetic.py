@@ -1,0 +1,182 @@
+"""Deterministic synthetic inputs for the pairwise order-prediction path.
+
+Everything here is seeded through ``numpy.random.RandomState`` so the same
+arrays are regenerated bit-for-bit in this container (golden generation,
+CPU tests) and on the GPU box (parity tests, smoke, bench).  Nothing is read
+from disk and nothing depends on torch's RNG.
+
+Tensor contract follows the reference datasets
+(datasets/occ_order_dataset.py:202-279, datasets/depth_occ_order_dataset.py:197-240):
+``rgb[B,3,S,S]`` fp32 (already mean/std normalised), ``modal1/modal2[B,1,S,S]``
+fp32 in {0,1}, ``occ_order[B,2]`` fp32 in {0,1} laid out as
+``[b_over_a, a_over_b]``, ``depth_order[B]`` int64 in {0,1,2},
+``count[B]`` fp32, ``is_overlap[B]`` int64 in {0,1}.
+"""
+from collections import OrderedDict
+import math
+
+import numpy as np
+
+LAYERS = (3, 4, 6, 3)          # ResNet-50 bottleneck counts (resnet_cls.py:266-267)
+PLANES = (64, 128, 256, 512)
+EXPANSION = 4
+
+
+def state_specs(in_channels=5, num_classes=2):
+    """(name, shape, kind) for every state_dict entry of ``resnet50_cls`` in
+    registration order (resnet_cls.py:121-177).  kind is one of
+    conv / bn_weight / bn_bias / bn_mean / bn_var / bn_count / fc_weight / fc_bias."""
+    specs = []
+
+    def conv(name, cout, cin, k):
+        specs.append((name + ".weight", (cout, cin, k, k), "conv"))
+
+    def bn(name, c):
+        specs.append((name + ".weight", (c,), "bn_weight"))
+        specs.append((name + ".bias", (c,), "bn_bias"))
+        specs.append((name + ".running_mean", (c,), "bn_mean"))
+        specs.append((name + ".running_var", (c,), "bn_var"))
+        specs.append((name + ".num_batches_tracked", (), "bn_count"))
+
+    conv("conv1", 64, in_channels, 7)
+    bn("bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip(PLANES, LAYERS)):
+        for b in range(blocks):
+            p = "layer%d.%d" % (li + 1, b)
+            conv(p + ".conv1", planes, inplanes, 1)
+            bn(p + ".bn1", planes)
+            conv(p + ".conv2", planes, planes, 3)
+            bn(p + ".bn2", planes)
+            conv(p + ".conv3", planes * EXPANSION, planes, 1)
+            bn(p + ".bn3", planes * EXPANSION)
+            if b == 0:
+                conv(p + ".downsample.0", planes * EXPANSION, inplanes, 1)
+                bn(p + ".downsample.1", planes * EXPANSION)
+            inplanes = planes * EXPANSION
+    feat = 512 * EXPANSION
+    if isinstance(num_classes, (list, tuple)):
+        specs.append(("fc_occ.weight", (num_classes[0], feat), "fc_weight"))
+        specs.append(("fc_occ.bias", (num_classes[0],), "fc_bias"))
+        specs.append(("fc_depth.weight", (num_classes[1], feat), "fc_weight"))
+        specs.append(("fc_depth.bias", (num_classes[1],), "fc_bias"))
+    else:
+        specs.append(("fc.weight", (num_classes, feat), "fc_weight"))
+        specs.append(("fc.bias", (num_classes,), "fc_bias"))
+    return specs
+
+
+def make_state_dict(seed, in_channels=5, num_classes=2, gain=0.02, prefix="", style="xavier"):
+    """Seeded weights.  ``style='xavier'`` has the statistics of the reference
+    initialisation (utils/common_utils.py:35-65: xavier-normal gain 0.02 on
+    conv/linear, BN weight ~ N(1, 0.02), zero biases) -- the regime training starts
+    from, where conv outputs have variance ~5e-5 and eval-mode BN with fresh running
+    statistics wipes out the input.  ``style='kaiming'`` has the statistics of a
+    trained-like network (He fan-out convs as resnet_cls.py:162-164, BN weight
+    ~ N(1, 0.1), small BN biases, 1/sqrt(fan_in) heads): activations are O(1), so
+    eval-mode outputs depend on the input.  Returns OrderedDict name -> ndarray
+    (OIHW fp32; ``num_batches_tracked`` int64)."""
+    rng = np.random.RandomState(seed)
+    kaiming = style == "kaiming"
+    out = OrderedDict()
+    for name, shape, kind in state_specs(in_channels, num_classes):
+        if kind == "conv":
+            cout, cin, kh, kw = shape
+            std = math.sqrt(2.0 / (cout * kh * kw)) if kaiming else gain * math.sqrt(2.0 / ((cin + cout) * kh * kw))
+            v = (rng.standard_normal(shape) * std).astype(np.float32)
+        elif kind == "fc_weight":
+            std = math.sqrt(1.0 / shape[1]) if kaiming else gain * math.sqrt(2.0 / (shape[0] + shape[1]))
+            v = (rng.standard_normal(shape) * std).astype(np.float32)
+        elif kind == "bn_weight":
+            v = (1.0 + (0.1 if kaiming else gain) * rng.standard_normal(shape)).astype(np.float32)
+            if kaiming and (name.endswith("bn3.weight") or name.endswith("downsample.1.weight")):
+                v *= np.float32(0.5)      # keep the residual sum from growing with depth
+        elif kind == "bn_bias" and kaiming:
+            v = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif kind in ("bn_bias", "fc_bias", "bn_mean"):
+            v = np.zeros(shape, np.float32)
+        elif kind == "bn_var":
+            v = np.ones(shape, np.float32)
+        elif kind == "bn_count":
+            v = np.zeros(shape, np.int64)
+        else:
+            raise ValueError(kind)
+        out[prefix + name] = v
+    return out
+
+
+def _mask(rng, S):
+    """One filled rectangle or ellipse covering 5-40 % of an SxS image."""
+    area = rng.uniform(0.05, 0.40) * S * S
+    aspect = rng.uniform(0.5, 2.0)
+    h = min(S, max(2, int(round(math.sqrt(area * aspect)))))
+    w = min(S, max(2, int(round(area / h))))
+    top = rng.randint(0, S - h + 1)
+    left = rng.randint(0, S - w + 1)
+    m = np.zeros((S, S), np.float32)
+    if rng.rand() < 0.5:
+        m[top:top + h, left:left + w] = 1.0
+    else:
+        yy, xx = np.mgrid[0:S, 0:S]
+        cy, cx = top + (h - 1) / 2.0, left + (w - 1) / 2.0
+        m[((yy - cy) / (h / 2.0)) ** 2 + ((xx - cx) / (w / 2.0)) ** 2 <= 1.0] = 1.0
+    return m
+
+
+def make_pair_batch(seed, B, S=256):
+    """One training batch of B instance pairs (dict of ndarrays)."""
+    rng = np.random.RandomState(seed)
+    rgb = rng.standard_normal((B, 3, S, S)).astype(np.float32)
+    modal1 = np.stack([_mask(rng, S) for _ in range(B)])[:, None]
+    modal2 = np.stack([_mask(rng, S) for _ in range(B)])[:, None]
+    occ_order = (rng.rand(B, 2) < 0.3).astype(np.float32)
+    depth_order = rng.randint(0, 3, size=B).astype(np.int64)
+    is_overlap = (rng.rand(B) < 0.5).astype(np.int64)
+    count = np.full((B,), 2.0, np.float32)
+    return dict(rgb=rgb, modal1=modal1, modal2=modal2, occ_order=occ_order,
+                depth_order=depth_order, count=count, is_overlap=is_overlap)
+
+
+def make_images(seed, n_images, n_inst, S=256):
+    """Synthetic 'validation images': uint8 RGB image [S,S,3], modal masks
+    [n_inst,S,S] uint8, xywh boxes, and random ground-truth order matrices
+    (occlusion in {0,1} with -1 on nothing; depth in {0,1,2}; overlap; count)."""
+    rng = np.random.RandomState(seed)
+    items = []
+    for _ in range(n_images):
+        image = rng.randint(0, 256, size=(S, S, 3)).astype(np.uint8)
+        modal = np.stack([_mask(rng, S) for _ in range(n_inst)]).astype(np.uint8)
+        bboxes = []
+        for m in modal:
+            ys, xs = np.where(m > 0)
+            bboxes.append([xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1])
+        bboxes = np.asarray(bboxes, np.int64)
+        gt_occ = (rng.rand(n_inst, n_inst) < 0.3).astype(np.int64)
+        np.fill_diagonal(gt_occ, 0)
+        gt_depth = np.zeros((n_inst, n_inst), np.int64)
+        gt_overlap = np.zeros((n_inst, n_inst), np.int64)
+        gt_count = np.ones((n_inst, n_inst), np.int64) * 2
+        for i in range(n_inst):
+            for j in range(i + 1, n_inst):
+                d = rng.randint(0, 3)
+                gt_depth[i, j] = d
+                gt_depth[j, i] = d if d == 2 else 1 - d
+                gt_overlap[i, j] = gt_overlap[j, i] = int(rng.rand() < 0.5)
+                gt_count[i, j] = gt_count[j, i] = rng.randint(1, 4)
+        items.append(dict(image=image, modal=modal, bboxes=bboxes, gt_occ=gt_occ,
+                          gt_depth=gt_depth, gt_overlap=gt_overlap, gt_count=gt_count))
+    return items
+
+
+def image_mode_inputs(image, modal, input_size):
+    """The reference's ``patch_or_image == 'image'`` preprocessing
+    (inference.py:467-482) for an image that is already square and already
+    ``input_size`` wide, where every resize is the identity: returns
+    rgb[1,3,S,S] fp32 normalised with the ImageNet mean/std
+    (utils/data_utils.py:9-10,28-34) and the float masks [N,S,S]."""
+    assert image.shape[0] == image.shape[1] == input_size
+    mean = np.asarray([0.485, 0.456, 0.406], np.float32)[:, None, None]
+    std = np.asarray([0.229, 0.224, 0.225], np.float32)[:, None, None]
+    rgb = image.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0)
+    rgb = ((rgb - mean) / std)[None]
+    return rgb.astype(np.float32), modal.astype(np.float32)

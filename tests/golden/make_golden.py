@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).
+The reference is imported unmodified; the shims below exist because this
+container has no GPU and lacks a few third-party packages the reference imports
+at module top but never calls on the path exercised here.
+
+Inputs and weights are regenerated from seeds by ``instaorder_amd.synthetic``;
+only the reference's OUTPUTS are stored (losses, logits, gradient norms +
+sampled elements, post-step weights norms + samples, BN running statistics,
+order matrices, metrics, scheduler values).
+
+usage:  python tests/golden/make_golden.py [case ...]
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from instaorder_amd import synthetic  # noqa: E402
+
+NSAMP = 64
+
+
+def sample_idx(n):
+    return (np.arange(NSAMP, dtype=np.int64) * 2654435761) % max(n, 1)
+
+
+def install_shims():
+    np.int = int  # inference.py:352,441,518 use the removed alias
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m = torch.tensor(mean, dtype=torch.float32)[:, None, None]
+            self.s = torch.tensor(std, dtype=torch.float32)[:, None, None]
+
+        def __call__(self, x):
+            return (x - self.m) / self.s
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tvt.Normalize, tvt.Compose = Normalize, Compose
+    tv.transforms, tv.models, tv.utils = tvt, mock.MagicMock(), mock.MagicMock()
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.models": tv.models, "torchvision.utils": tv.utils})
+    for n in ["skimage", "skimage.morphology", "skimage.io", "skimage.draw", "pycocotools",
+              "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval", "cvbase"]:
+        sys.modules[n] = mock.MagicMock(name=n)
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST = cv2.INTER_LINEAR = cv2.INTER_CUBIC = cv2.INTER_AREA = 0
+
+    def resize(img, size, interpolation=None):
+        assert tuple(img.shape[:2]) == tuple(size[::-1]), "identity resize only"
+        return img
+
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    os.environ.setdefault("HOME", "/root")
+    sys.path.insert(0, REF)
+
+
+def init_dist(rank, world, port):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def load_cfg(algo):
+    import yaml
+    with open(os.path.join(REF, "experiments/InstaOrder", algo, "config.yaml")) as f:
+        return yaml.safe_load(f)
+
+
+def model_cfg(algo):
+    """the 'model' section of experiments/InstaOrder/<algo>/config.yaml"""
+    return load_cfg(algo)["model"]
+
+
+def build(algo, seed, dist_model=True, style="xavier"):
+    import models
+    cfg = model_cfg(algo)
+    m = getattr(models, algo)(cfg, dist_model=dist_model)
+    nc = cfg["backbone_param"]["num_classes"]
+    sd = synthetic.make_state_dict(seed, 5, nc, prefix="module.", style=style)
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return m, cfg
+
+
+def set_input(m, algo, batch):
+    t = {k: torch.from_numpy(v.copy()) for k, v in batch.items()}
+    if algo == "InstaOrderNet_od":
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"],
+                    t["is_overlap"], t["occ_order"])
+    elif algo == "InstaOrderNet_d":
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"])
+    elif algo == "OrderNet":
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"])  # class ids 0..2
+    else:
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["occ_order"])
+
+
+def snapshot(m, what):
+    """norms + sampled elements of params ('p') or grads ('g'); BN buffers for 'bn'."""
+    names, norms, samp = [], [], []
+    if what in ("p", "g"):
+        for k, p in m.model.named_parameters():
+            t = p.detach() if what == "p" else p.grad.detach()
+            a = t.contiguous().view(-1).double().numpy()
+            names.append(k)
+            norms.append(np.sqrt((a * a).sum()))
+            samp.append(a[sample_idx(a.size)].astype(np.float32))
+        return np.array(names), np.array(norms), np.stack(samp)
+    rm = [b.detach().view(-1).numpy() for k, b in m.model.named_buffers() if k.endswith("running_mean")]
+    rv = [b.detach().view(-1).numpy() for k, b in m.model.named_buffers() if k.endswith("running_var")]
+    nb = [int(b) for k, b in m.model.named_buffers() if k.endswith("num_batches_tracked")]
+    return np.concatenate(rm), np.concatenate(rv), np.array(nb)
+
+
+def unpack_step(ret):
+    if isinstance(ret, tuple):
+        logs, l = ret
+        out = {k: float(v) for k, v in logs.items()}
+        out["loss"] = float(l["loss"])
+        return out
+    return {"loss": float(ret["loss"])}
+
+
+def eval_logits(m, algo, batch):
+    t = {k: torch.from_numpy(v.copy()) for k, v in batch.items()}
+    with torch.no_grad():
+        o = m.model(torch.cat([t["modal1"], t["modal2"], t["rgb"]], 1))
+    if isinstance(o, tuple):
+        return np.concatenate([x.numpy() for x in o], 1)
+    return o.numpy()
+
+
+def case_train(algo, S, B, seed, steps, tag, style="xavier"):
+    """eval forward at init -> `steps` training steps -> eval forward."""
+    m, cfg = build(algo, seed, style=style)
+    out = {}
+    b0 = synthetic.make_pair_batch(seed + 100, B, S)
+    m.switch_to("eval")
+    out["eval0_logits"] = eval_logits(m, algo, b0)
+    set_input(m, algo, b0)
+    out["eval0_loss"] = np.float64(float(m.forward_only()[1]["loss"]))
+    m.switch_to("train")
+    for it in range(steps):
+        batch = synthetic.make_pair_batch(seed + 100 + it, B, S)
+        set_input(m, algo, batch)
+        logs = unpack_step(m.step())
+        for k, v in logs.items():
+            out["step%d_%s" % (it, k)] = np.float64(v)
+        if it == 0:
+            n, gn, gs = snapshot(m, "g")
+            out["names"], out["grad_norms"], out["grad_samples"] = n, gn, gs
+        if it in (0, steps - 1):
+            _, pn, ps = snapshot(m, "p")
+            out["step%d_param_norms" % it], out["step%d_param_samples" % it] = pn, ps
+            rm, rv, nb = snapshot(m, "bn")
+            out["step%d_running_mean" % it], out["step%d_running_var" % it] = rm, rv
+            out["step%d_num_batches" % it] = nb
+    m.switch_to("eval")
+    out["eval1_logits"] = eval_logits(m, algo, b0)
+    set_input(m, algo, b0)
+    out["eval1_loss"] = np.float64(float(m.forward_only()[1]["loss"]))
+    out["meta"] = np.array([S, B, seed, steps])
+    out["lr"] = np.float64(cfg["lr"])
+    out["weight_decay"] = np.float64(cfg["weight_decay"])
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, {k: float(v) for k, v in out.items() if k.endswith("loss")})
+
+
+def _ws2_worker(rank, world, port, S, B, seed, q):
+    install_shims()
+    init_dist(rank, world, port)
+    algo = "InstaOrderNet_o"
+    # every rank starts from DIFFERENT weights; DistModule must broadcast rank 0's
+    m, cfg = build(algo, seed + rank * 7)
+    batch = synthetic.make_pair_batch(seed + 200 + rank, B, S)
+    m.switch_to("train")
+    set_input(m, algo, batch)
+    logs = unpack_step(m.step())
+    _, pn, ps = snapshot(m, "p")
+    _, gn, gs = snapshot(m, "g")
+    rm, rv, nb = snapshot(m, "bn")
+    q.put((rank, logs["loss"], pn, ps, gn, gs, rm, rv))
+
+
+def case_ws2(S, B, seed, tag):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ws2_worker, args=(r, 2, 29533, S, B, seed, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get() for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join()
+    out = {"meta": np.array([S, B, seed, 2])}
+    for r in res:
+        rank = r[0]
+        out["rank%d_loss" % rank] = np.float64(r[1])
+        out["rank%d_param_norms" % rank], out["rank%d_param_samples" % rank] = r[2], r[3]
+        out["rank%d_grad_norms" % rank], out["rank%d_grad_samples" % rank] = r[4], r[5]
+        out["rank%d_running_mean" % rank], out["rank%d_running_var" % rank] = r[6], r[7]
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, out["rank0_loss"], out["rank1_loss"])
+
+
+def case_plumbing(algo, seed, n_images, n_inst, S, warm_steps, tag):
+    """config 1: images x instances -> O(n^2) pair loop of the reference's
+    inference.py ('image' mode) -> order matrices -> metrics."""
+    import inference as infer
+    m, cfg = build(algo, seed, dist_model=False, style="kaiming")
+    # train-mode forward passes (no optimiser step) so that the BN running statistics
+    # are meaningful while the head stays undecided (decisions on both sides of 0.5)
+    m.switch_to("train")
+    for it in range(warm_steps):
+        b = synthetic.make_pair_batch(seed + 300 + it, 8, S)
+        with torch.no_grad():
+            m.model(torch.cat([torch.from_numpy(b["modal1"]), torch.from_numpy(b["modal2"]),
+                               torch.from_numpy(b["rgb"])], 1))
+    m.switch_to("eval")
+    items = synthetic.make_images(seed + 400, n_images, n_inst, S)
+    out = {"meta": np.array([S, n_images, n_inst, seed, warm_steps])}
+    # centre the head: bias := -median(logit) per output over all pairs/directions, so the
+    # decisions are not all on one side of 0.5.  The biases are INPUT data, stored below.
+    zs = []
+    with torch.no_grad():
+        for item in items:
+            rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
+            for i in range(n_inst):
+                for j in range(n_inst):
+                    if i != j:
+                        o = m.model(torch.cat([torch.from_numpy(masks[i])[None, None],
+                                               torch.from_numpy(masks[j])[None, None], torch.from_numpy(rgb)], 1))
+                        zs.append(torch.cat(o, 1)[0].numpy() if isinstance(o, tuple) else o[0].numpy())
+    med = -np.median(np.stack(zs), 0).astype(np.float32)
+    net = m.model.module
+    with torch.no_grad():
+        if algo == "InstaOrderNet_o":
+            net.fc.bias.copy_(torch.from_numpy(med))
+        else:
+            net.fc_occ.bias.copy_(torch.from_numpy(med[:2]))
+            net.fc_depth.bias.copy_(torch.from_numpy(med[2:]))
+    out["head_bias"] = med
+    for ii, item in enumerate(items):
+        if algo == "InstaOrderNet_o":
+            om = infer.infer_order_sup_occ(m, item["image"], item["modal"], item["bboxes"], "all",
+                                           algo, "image", S, True)
+            out["occ_%d" % ii] = om
+        else:
+            om, dm = infer.infer_order_sup_occ_depth(m, item["image"], item["modal"], item["bboxes"],
+                                                     "all", algo, "image", S, "")
+            out["occ_%d" % ii], out["depth_%d" % ii] = om, dm
+            w = infer.eval_depth_order_whdr(dm, (item["gt_depth"], item["gt_overlap"], item["gt_count"]))
+            keys = sorted(w.keys())
+            out["whdr_keys"] = np.array(keys)
+            out["whdr_%d" % ii] = np.array([float(w[k][0]) for k in keys])
+        out["prf_%d" % ii] = np.array(infer.eval_order_recall_precision_f1(om, item["gt_occ"], 0))
+        # the direction-averaged probabilities behind the decisions (for near-threshold slack)
+        rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
+        probs = []
+        with torch.no_grad():
+            for i in range(n_inst):
+                for j in range(i + 1, n_inst):
+                    mi = torch.from_numpy(masks[i])[None, None]
+                    mj = torch.from_numpy(masks[j])[None, None]
+                    r = torch.from_numpy(rgb)
+                    o1 = m.model(torch.cat([mi, mj, r], 1))
+                    o2 = m.model(torch.cat([mj, mi, r], 1))
+                    if isinstance(o1, tuple):
+                        o1 = torch.cat(o1, 1)
+                        o2 = torch.cat(o2, 1)
+                    probs.append(np.concatenate([o1.numpy()[0], o2.numpy()[0]]))
+        out["pair_logits_%d" % ii] = np.stack(probs)
+    _, pn, ps = snapshot(m, "p")
+    out["param_norms"] = pn
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, [out["occ_%d" % i].tolist() for i in range(n_images)])
+
+
+def case_scheduler(tag):
+    import utils
+    out = {}
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    its = [0, 1, 100, 31999, 32000, 32001, 47999, 48000, 85999]
+    opt = torch.optim.SGD(p, lr=0.001, momentum=0.9, weight_decay=1e-4)
+    s = utils.StepLRScheduler(opt, [32000, 48000], [0.1, 0.1], 0.001, [], [], -1)
+    lrs = []
+    for it in its:
+        s.step(it)
+        lrs.append(opt.param_groups[0]["lr"])
+    out["its"], out["lrs_plain"] = np.array(its), np.array(lrs, np.float64)
+    opt = torch.optim.SGD(p, lr=0.001, momentum=0.9, weight_decay=1e-4)
+    s = utils.StepLRScheduler(opt, [300, 600], [0.1, 0.5], 0.001, [0.004, 0.01], [50, 200], -1)
+    its2 = [0, 10, 49, 50, 51, 125, 199, 200, 299, 300, 599, 600, 1000]
+    lrs = []
+    for it in its2:
+        s.step(it)
+        lrs.append(opt.param_groups[0]["lr"])
+    out["its_warm"], out["lrs_warm"] = np.array(its2), np.array(lrs, np.float64)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, out["lrs_plain"], out["lrs_warm"])
+
+
+def case_decisions(tag):
+    """Direction-averaged decision rules on crafted logits, incl. near-threshold
+    values and argmax ties, through the reference's own net_forward_* functions."""
+    import inference as infer
+    rng = np.random.RandomState(7)
+    n = 64
+    occ1 = rng.uniform(-0.2, 0.2, (n, 2)).astype(np.float32)
+    occ2 = rng.uniform(-0.2, 0.2, (n, 2)).astype(np.float32)
+    dep1 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    dep2 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    # exact symmetric cases: averaged probability exactly 0.5 -> not ">" 0.5
+    occ1[0], occ2[0] = [0.3, -0.7], [0.7, -0.3]
+    occ1[1], occ2[1] = [0.0, 0.0], [0.0, 0.0]
+    dep1[0], dep2[0] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]        # three-way tie -> class 0
+    dep1[1], dep2[1] = [1.0, 0.0, 1.0], [0.0, 1.0, 1.0]        # tie closer/equal
+
+    class Fake:
+        def __init__(self):
+            self.k = 0
+            self.calls = 0
+
+        def model(self, x):
+            first = (self.calls % 2 == 0)
+            self.calls += 1
+            o = torch.from_numpy((occ1 if first else occ2)[self.k:self.k + 1])
+            d = torch.from_numpy((dep1 if first else dep2)[self.k:self.k + 1])
+            return (o, d) if self.mode == "od" else (o if self.mode == "o" else d)
+
+    img = torch.zeros(1, 3, 8, 8)
+    mk = np.zeros((8, 8), np.float32)
+    fk = Fake()
+    res_o, res_od, res_d = [], [], []
+    for k in range(n):
+        fk.k = k
+        fk.mode, fk.calls = "o", 0
+        res_o.append(infer.net_forward_occ(fk, img, mk, mk, True))
+        fk.mode, fk.calls = "od", 0
+        res_od.append(infer.net_forward_occ_depth(fk, img, mk, mk))
+        fk.mode, fk.calls = "d", 0
+        res_d.append(infer.net_forward_depth(fk, img, mk, mk, True))
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), occ1=occ1, occ2=occ2, dep1=dep1, dep2=dep2,
+                        res_o=np.array(res_o).astype(np.int64), res_od=np.array(res_od).astype(np.int64),
+                        res_d=np.array(res_d).astype(np.int64))
+    print(tag, np.array(res_o)[:4].tolist(), np.array(res_od)[:4].tolist())
+
+
+CASES = {
+    "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),
+    "od_S64_B6": lambda: case_train("InstaOrderNet_od", 64, 6, 12, 3, "od_S64_B6"),
+    "d_S64_B6": lambda: case_train("InstaOrderNet_d", 64, 6, 13, 1, "d_S64_B6"),
+    "ordernet_S64_B4": lambda: case_train("OrderNet", 64, 4, 14, 1, "ordernet_S64_B4"),
+    "o_S64_B4_k": lambda: case_train("InstaOrderNet_o", 64, 4, 21, 2, "o_S64_B4_k", "kaiming"),
+    "od_S64_B6_k": lambda: case_train("InstaOrderNet_od", 64, 6, 22, 2, "od_S64_B6_k", "kaiming"),
+    "o_S256_B4": lambda: case_train("InstaOrderNet_o", 256, 4, 15, 1, "o_S256_B4"),
+    "od_S256_B4": lambda: case_train("InstaOrderNet_od", 256, 4, 16, 1, "od_S256_B4"),
+    "ws2_o_S64_B4": lambda: case_ws2(64, 4, 17, "ws2_o_S64_B4"),
+    "plumbing_o": lambda: case_plumbing("InstaOrderNet_o", 18, 4, 3, 256, 6, "plumbing_o"),
+    "plumbing_od": lambda: case_plumbing("InstaOrderNet_od", 19, 2, 4, 256, 6, "plumbing_od"),
+    "scheduler": lambda: case_scheduler("scheduler"),
+    "decisions": lambda: case_decisions("decisions"),
+}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    install_shims()
+    if any(c != "ws2_o_S64_B4" for c in which):
+        init_dist(0, 1, 29531)
+    torch.manual_seed(0)
+    for c in which:
+        if c == "ws2_o_S64_B4":
+            continue
+        CASES[c]()
+    if "ws2_o_S64_B4" in which:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        CASES["ws2_o_S64_B4"]()

@@ -1,0 +1,152 @@
+"""Pins the CPU oracle (oracle/resnet_oracle.py) to golden vectors produced by the
+REAL reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (ALGO_LR, bn_vectors, eval_logits_oracle, load_golden, norms_and_samples,
+                     oracle_state, orc, rel_err, synthetic)
+
+TOL = 2e-5   # same torch build on both sides: expected bitwise, allow thread-order noise
+
+
+def run_train_case(tag, algo, style="xavier"):
+    g = load_golden(tag)
+    S, B, seed, steps = [int(v) for v in g["meta"]]
+    state = oracle_state(seed, algo, style)
+    b0 = synthetic.make_pair_batch(seed + 100, B, S)
+    assert rel_err(eval_logits_oracle(state, b0), g["eval0_logits"]) < TOL
+    lr, wd = float(g["lr"]), float(g["weight_decay"])
+    assert lr == ALGO_LR[algo]
+    mom = {}
+    for it in range(steps):
+        batch = synthetic.make_pair_batch(seed + 100 + it, B, S)
+        logs, grads = orc.train_step(state, mom, batch, algo, lr, wd)
+        for k, v in logs.items():
+            assert abs(float(v) - float(g["step%d_%s" % (it, k)])) < 1e-5, (it, k)
+        names = orc.param_names(state)
+        if it == 0:
+            assert list(g["names"]) == ["module." + n for n in names]
+            gn, gs = norms_and_samples(grads.values())
+            assert rel_err(gn, g["grad_norms"]) < 1e-4
+            assert np.abs(gs - g["grad_samples"]).max() <= 1e-4 * np.abs(g["grad_samples"]).max()
+        if it in (0, steps - 1):
+            pn, ps = norms_and_samples([state[n] for n in names])
+            assert rel_err(pn, g["step%d_param_norms" % it]) < 1e-6
+            assert rel_err(ps, g["step%d_param_samples" % it]) < 1e-5
+            rm, rv, nb = bn_vectors(state)
+            assert rel_err(rm, g["step%d_running_mean" % it]) < 1e-5
+            assert rel_err(rv, g["step%d_running_var" % it]) < 1e-5
+            assert (nb == g["step%d_num_batches" % it]).all()
+            assert (nb == 2 * (it + 1)).all()       # two directional passes per step
+    assert rel_err(eval_logits_oracle(state, b0), g["eval1_logits"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,algo", [("o_S64_B4", "InstaOrderNet_o"), ("od_S64_B6", "InstaOrderNet_od"),
+                                      ("d_S64_B6", "InstaOrderNet_d"), ("ordernet_S64_B4", "OrderNet")])
+def test_train_small(tag, algo):
+    run_train_case(tag, algo)
+
+
+@pytest.mark.parametrize("tag,algo", [("o_S64_B4_k", "InstaOrderNet_o"), ("od_S64_B6_k", "InstaOrderNet_od")])
+def test_train_small_kaiming(tag, algo):
+    run_train_case(tag, algo, "kaiming")
+
+
+@pytest.mark.parametrize("tag,algo", [("o_S256_B4", "InstaOrderNet_o"), ("od_S256_B4", "InstaOrderNet_od")])
+def test_train_256(tag, algo):
+    run_train_case(tag, algo)
+
+
+def test_eval_losses():
+    g = load_golden("o_S64_B4")
+    S, B, seed, steps = [int(v) for v in g["meta"]]
+    state = oracle_state(seed, "InstaOrderNet_o")
+    b0 = {k: torch.as_tensor(v) for k, v in synthetic.make_pair_batch(seed + 100, B, S).items()}
+    with torch.no_grad():
+        l = orc.loss_o(state, b0, 1, False)[0]
+    assert abs(float(l) - float(g["eval0_loss"])) < 1e-6
+    g = load_golden("od_S64_B6")
+    S, B, seed, steps = [int(v) for v in g["meta"]]
+    state = oracle_state(seed, "InstaOrderNet_od")
+    b0 = {k: torch.as_tensor(v) for k, v in synthetic.make_pair_batch(seed + 100, B, S).items()}
+    with torch.no_grad():
+        l = orc.loss_od(state, b0, 1, False, 0.1, 0.9)[0]
+    assert abs(float(l) - float(g["eval0_loss"])) < 1e-6
+    # InstaOrderNet_d.forward_only is NOT subset-weighted (quirk)
+    g = load_golden("d_S64_B6")
+    S, B, seed, steps = [int(v) for v in g["meta"]]
+    state = oracle_state(seed, "InstaOrderNet_d")
+    b0 = {k: torch.as_tensor(v) for k, v in synthetic.make_pair_batch(seed + 100, B, S).items()}
+    with torch.no_grad():
+        l = orc.loss_softmax_ce(state, b0, 1, False)[0]
+    assert abs(float(l) - float(g["eval0_loss"])) < 1e-6
+
+
+def test_scheduler():
+    g = load_golden("scheduler")
+    for it, lr in zip(g["its"], g["lrs_plain"]):
+        assert abs(orc.step_lr(int(it), 0.001, [32000, 48000], [0.1, 0.1]) - lr) <= 1e-12 * max(lr, 1)
+    for it, lr in zip(g["its_warm"], g["lrs_warm"]):
+        got = orc.step_lr(int(it), 0.001, [300, 600], [0.1, 0.5], [0.004, 0.01], [50, 200])
+        assert abs(got - lr) <= 1e-9 * lr, (it, got, lr)
+
+
+def test_decisions():
+    g = load_golden("decisions")
+    o1, o2 = torch.sigmoid(torch.from_numpy(g["occ1"])), torch.sigmoid(torch.from_numpy(g["occ2"]))
+    q1, q2 = torch.softmax(torch.from_numpy(g["dep1"]), 1), torch.softmax(torch.from_numpy(g["dep2"]), 1)
+    a, b = orc.decide_occ(o1, o2)
+    d = orc.decide_depth(q1, q2)
+    assert (a.numpy().astype(np.int64) == g["res_o"][:, 0]).all()
+    assert (b.numpy().astype(np.int64) == g["res_o"][:, 1]).all()
+    assert (d.numpy() == g["res_od"][:, 0]).all()
+    assert (a.numpy().astype(np.int64) == g["res_od"][:, 1]).all()
+    assert (b.numpy().astype(np.int64) == g["res_od"][:, 2]).all()
+    assert (d.numpy() == g["res_d"]).all()
+
+
+@pytest.mark.parametrize("tag,algo", [("plumbing_o", "InstaOrderNet_o"), ("plumbing_od", "InstaOrderNet_od")])
+def test_plumbing(tag, algo):
+    """config 1: 4 synthetic 256x256 images x 3 instances through the O(n^2) pair loop."""
+    g = load_golden(tag)
+    S, n_images, n_inst, seed, warm = [int(v) for v in g["meta"]]
+    state = oracle_state(seed, algo, "kaiming")
+    for it in range(warm):
+        b = synthetic.make_pair_batch(seed + 300 + it, 8, S)
+        with torch.no_grad():
+            orc.resnet_forward(state, torch.cat([torch.from_numpy(b["modal1"]), torch.from_numpy(b["modal2"]),
+                                                 torch.from_numpy(b["rgb"])], 1), True)
+    items = synthetic.make_images(seed + 400, n_images, n_inst, S)
+    pairs = [(i, j) for i in range(n_inst) for j in range(i + 1, n_inst)]
+    hb = torch.from_numpy(g["head_bias"])
+    if algo == "InstaOrderNet_o":
+        state["fc.bias"] = hb.clone()
+    else:
+        state["fc_occ.bias"], state["fc_depth.bias"] = hb[:2].clone(), hb[2:].clone()
+    for ii, item in enumerate(items):
+        rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
+        r = torch.from_numpy(rgb).expand(len(pairs), -1, -1, -1)
+        mi = torch.from_numpy(np.stack([masks[i] for i, j in pairs]))[:, None]
+        mj = torch.from_numpy(np.stack([masks[j] for i, j in pairs]))[:, None]
+        with torch.no_grad():
+            z1 = orc.resnet_forward(state, torch.cat([mi, mj, r], 1), False)
+            z2 = orc.resnet_forward(state, torch.cat([mj, mi, r], 1), False)
+        if isinstance(z1, tuple):
+            zz = torch.cat([z1[0], z1[1], z2[0], z2[1]], 1).numpy()
+            a, b = orc.decide_occ(torch.sigmoid(z1[0]), torch.sigmoid(z2[0]))
+            d = orc.decide_depth(torch.softmax(z1[1], 1), torch.softmax(z2[1], 1))
+        else:
+            zz = torch.cat([z1, z2], 1).numpy()
+            a, b = orc.decide_occ(torch.sigmoid(z1), torch.sigmoid(z2))
+            d = None
+        assert rel_err(zz, g["pair_logits_%d" % ii]) < 1e-4
+        occ, dep = orc.order_matrices(n_inst, pairs, a, b, d)
+        assert (occ == g["occ_%d" % ii]).all()
+        prf = orc.recall_precision_f1(occ, item["gt_occ"], 0)
+        assert np.allclose(prf, g["prf_%d" % ii], atol=1e-9)
+        if d is not None:
+            assert (dep == g["depth_%d" % ii]).all()
+            w = orc.whdr(dep, item["gt_depth"], item["gt_overlap"], item["gt_count"])
+            keys = [str(k) for k in g["whdr_keys"]]
+            assert np.allclose([w[k] for k in keys], g["whdr_%d" % ii], atol=1e-9)
