@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: instance-pairs/sec, forward + backward + SGD, InstaOrderNet_o (ResNet-50 + order
+head) on synthetic 256x256x5 pair batches, fp32 -- BASELINE.json configs[1]: pair-batch 256 per GPU.
+
+One "step" = what the reference's ``InstaOrderNet_o.step()`` does for one batch of B pairs
+(supervised_order.py:535-548): both mask orders through the network, BCE loss, backward, gradient
+all-reduce (N>1), SGD.  Inputs are resident in HBM before the timed region.  N>1: one process per GPU
+(torch.distributed.run), pairs sharded by rank = B pairs per GPU (weak scaling), one flat RCCL
+all-reduce of the 94 MB gradient per step.
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel class (by GPU time), timed with
+HIP events on the launch stream inside the timed region; ``cpu_baseline`` times the CPU oracle
+(plain-PyTorch restatement of the reference, pinned by tests/golden) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR_TRAIN = 64.27e9      # 2 x (3 x 10.882 - 0.514) GFLOP, conv+FC MACs x 2
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--algo", default="InstaOrderNet_o")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import instaorder_amd as ia
+    from instaorder_amd import _lib, engine, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    B, S = args.batch, args.size
+    nc = {"InstaOrderNet_o": 2, "InstaOrderNet_od": [2, 3]}[args.algo]
+    cfg = dict(algo=args.algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=nc), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
+    sd = synthetic.make_state_dict(1, 5, nc, prefix="module.")          # reference-init statistics
+    model.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.switch_to("train")
+
+    # synthetic pair batch; a small seeded block tiled to B to keep host set-up short
+    base = synthetic.make_pair_batch(1000 + rank, min(B, 32), S)
+    reps = (B + min(B, 32) - 1) // min(B, 32)
+    dev = {k: torch.from_numpy(np.concatenate([v] * reps, 0)[:B]).cuda() for k, v in base.items()}
+
+    def one_step():
+        if args.algo == "InstaOrderNet_o":
+            model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["occ_order"])
+        else:
+            model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["depth_order"], dev["count"],
+                            dev["is_overlap"], dev["occ_order"])
+        return model.step()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_prof:
+        engine.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = engine.prof_end() if not args.no_prof else {}
+    loss = float(out[1]["loss"] if isinstance(out, tuple) else out["loss"])
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    pairs_per_s = world * B * args.steps / dt
+
+    result = {
+        "metric": "instance-pairs/sec (fwd+bwd)", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, fp32, fwd+bwd+SGD "
+                               "(BASELINE.json configs[1])" % (args.algo, B, S, S),
+                   "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss},
+        "achieved_tflops_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12,
+        "mfma_frac_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12
+        / (world * PEAK_FP32_MFMA_TFLOPS),
+    }
+    if prof:
+        tot_ms = sum(v["total_ms"] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        name, d = dom
+        avg_ms = d["total_ms"] / d["launches"]
+        tfl = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                              "launches": d["launches"], "avg_launch_ms": avg_ms,
+                              "flops_per_launch": d["flops"] / d["launches"],
+                              "share_of_gpu_time": d["total_ms"] / tot_ms}
+        result["kernel_classes"] = {
+            k: {"launches": v["launches"], "ms_per_step": v["total_ms"] / args.steps,
+                "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                "gbs": v["bytes"] / (v["total_ms"] * 1e-3) / 1e9}
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import resnet_oracle as orc                       # CPU baseline leg only
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cb = 12                                                        # config-1 size: 4 images x 3 pairs
+        state = orc.state_from_numpy(sd, prefix="module.")
+        cbatch = synthetic.make_pair_batch(2000, cb, S)
+        mom = {}
+        orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)     # warm-up
+        c0 = time.perf_counter()
+        nrep = 2
+        for _ in range(nrep):
+            orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)
+        cdt = (time.perf_counter() - c0) / nrep
+        result["cpu_baseline"] = {"value": cb / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                  "sample": "%d pairs (4 images x 3 instance pairs) at %dx%d, InstaOrderNet_o "
+                                            "fwd+bwd+SGD, PyTorch-CPU fp32 oracle, mean of %d steps after 1 warm-up"
+                                            % (cb, S, S, nrep)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/* instaorder_hip.h -- C ABI of libinstaorder_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the pairwise order-prediction hot path of POSTECH-CVLab/InstaOrder.
+ * The reference has no FFI of its own (100 % Python on torch.nn); what it binds for this path
+ * are torch.nn modules and functions, so each entry point below names the reference call site
+ * it replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers unless stated otherwise; fp32, NHWC activations,
+ *     filters as [Cout][R*S][Cin] ("KRSC"); the 5-channel network input is padded to 8 channels;
+ *   - return 0 on success, a negative IO_ERR_* code on failure; never throw; the message of the
+ *     last failure on the calling thread is returned by io_last_error_string();
+ *   - never allocate device memory, never synchronise: work is enqueued on `stream`
+ *     (hipStream_t passed as void*; NULL = the default stream); scratch comes from the caller;
+ *   - no global mutable state: safe to call from several host threads on different streams.
+ */
+#ifndef INSTAORDER_HIP_H
+#define INSTAORDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IO_OK 0
+#define IO_ERR_SHAPE (-1)      /* unsupported / inconsistent shape argument            */
+#define IO_ERR_WORKSPACE (-2)  /* caller-provided scratch too small                    */
+#define IO_ERR_LAUNCH (-3)     /* HIP reported an error for a launch                   */
+#define IO_ERR_STATE (-4)      /* call sequence violated (e.g. backward before forward) */
+#define IO_ERR_NODEVICE (-5)   /* no gfx950 device visible                             */
+
+#ifndef __HIP__
+typedef void* hipStream_t;
+#endif
+
+int io_abi_version(void);
+const char* io_last_error_string(void);
+/* number of visible HIP devices whose arch is gfx950; <= 0 means the library cannot run */
+int io_device_count(void);
+
+/* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
+ * nn.Conv2d(bias=False) forward as used by conv1x1 / conv3x3 / the 7x7 stem
+ * (models/backbone/resnet_cls.py:23-31, :140).  x[N,H,W,Cin], w[Cout][R*S][Cin],
+ * y[N,Ho,Wo,Cout], Ho = (H + 2*pad - R)/stride + 1.  Cin % 32 == 0 (or Cin == 8 for the stem,
+ * R = S = 7), Cout % 64 == 0. */
+int io_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R,
+                  int S, int stride, int pad, hipStream_t stream);
+/* gradient w.r.t. the input (autograd of the above, models/supervised_order.py:545 loss.backward()).
+ * wt is the transposed filter [Cin][R*S][Cout] produced by io_filter_transpose; when `add` is not
+ * NULL it is summed into the result (residual / accumulation; may alias dx). */
+int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
+                    int Cout, int R, int S, int stride, int pad, hipStream_t stream);
+/* gradient w.r.t. the filter; workspace from io_conv2d_wgrad_workspace_bytes (split-K partials). */
+size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+int io_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int R,
+                    int S, int stride, int pad, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int io_filter_transpose(const float* w, int Cout, int taps, int Cin, float* wt, hipStream_t stream);
+
+/* ---- BatchNorm2d (resnet_cls.py:142, :87-92, :189), G independent statistic groups ----------- */
+size_t io_bn_partial_floats(int M, int C, int G);
+/* training statistics of y[M][C] (M = N*H*W rows, G consecutive equal groups): writes per-group
+ * mean, rstd, scale = gamma*rstd, shift = beta - mean*scale ([G][C] each) and advances the running
+ * estimates once per group, in group order (momentum 0.1 / unbiased variance in the reference). */
+int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                         float* rstd, float* scale, float* shift, float* partial, size_t partial_floats,
+                         hipStream_t stream);
+/* eval mode: scale/shift [C] from the running estimates */
+int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
+/* out = [relu]( y*scale + shift  [+ identity | + identity*scale2 + shift2] ): BN (+ residual add of
+ * Bottleneck.forward, resnet_cls.py:96-116, with or without the downsample BN) (+ nn.ReLU). */
+int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* scale, const float* shift,
+                const float* identity, const float* scale2, const float* shift2, int relu, float* out,
+                hipStream_t stream);
+/* backward of [ReLU o] BN: dz = dout*[act>0] (act NULL: no ReLU), dgamma/dbeta [C] summed over groups,
+ * dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional, may alias dout) gets dz.
+ * coef: 2*G*C floats of scratch. */
+int io_bn_bwd(const float* dout, const float* act, const float* y, int M, int C, int G, const float* gamma,
+              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dy, float* dz_out,
+              float* partial, size_t partial_floats, float* coef, hipStream_t stream);
+
+/* ---- pooling / heads ------------------------------------------------------------------------
+ * nn.MaxPool2d(3, 2, 1) (resnet_cls.py:144); idx: one byte per output element (packed x4). */
+int io_maxpool_fwd(const float* x, int N, int H, int W, int C, float* out, uint32_t* idx, hipStream_t stream);
+int io_maxpool_bwd(const float* dy, const uint32_t* idx, int N, int H, int W, int C, float* dx,
+                   hipStream_t stream);
+/* AdaptiveAvgPool2d(1) + flatten + fc | (fc_occ, fc_depth) (resnet_cls.py:152-160, 214-222);
+ * logits[N][K0+K1] (head 0 first). */
+int io_avgpool_fc_fwd(const float* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
+                      const float* w1, const float* b1, int K1, float* pooled, float* logits, hipStream_t stream);
+int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
+                      const float* w1, int K1, float* dx, float* dw0, float* db0, float* dw1, float* db1,
+                      hipStream_t stream);
+
+/* ---- input packing: torch.cat([modal_a, modal_b, rgb], 1) (supervised_order.py:537-538) fused with
+ * NCHW -> NHWC and channel padding 5 -> 8.  planes/sample_strides are HOST arrays of nplanes entries. */
+int io_pack_planes_nhwc8(const float* const* planes, const long* sample_strides, int nplanes, int N, int H, int W,
+                         float* out, hipStream_t stream);
+
+/* ---- losses: sigmoid+BCELoss and softmax+CrossEntropyLoss over both mask orders, /world_size
+ * (supervised_order.py:59-95, 413-438, 481-493, 535-548).  N = G*B rows (direction-major),
+ * logits[N][Kocc+Kdep]; occ_target[N][2] fp32; depth_target[N] int64; is_overlap[B] int64 or NULL
+ * (NULL: plain mean).  losses[3] = {total/world, occlusion, depth}; dlogits may be NULL. */
+int io_order_loss(const float* logits, int N, int B, int Kocc, int Kdep, const float* occ_target,
+                  const long* depth_target, const long* is_overlap, float overlap_weight, float distinct_weight,
+                  float inv_world, float* losses, float* dlogits, hipStream_t stream);
+
+/* ---- torch.optim.SGD(momentum=0.9, weight_decay) step over a flat buffer (single_stage_model.py:35-38) */
+int io_sgd_momentum(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum,
+                    float weight_decay, hipStream_t stream);
+
+/* ---- whole-network executor: resnet50_cls(in_channels=5, num_classes=K | [K0,K1])
+ * (resnet_cls.py:259-268) forward / backward over caller-owned flat buffers. ----------------- */
+typedef struct io_net io_net;
+
+typedef struct io_tensor_info {
+    char name[64];      /* state_dict key without the "module." prefix              */
+    int kind;           /* 0 conv filter, 1 bn weight, 2 bn bias, 3 fc weight, 4 fc bias */
+    int ndim;
+    long shape[4];      /* logical (torch) shape: OIHW for filters                   */
+    long offset;        /* float offset into the flat parameter / gradient buffer    */
+    long numel_storage; /* floats occupied (stem filter is stored with 8 channels)   */
+    int cin_storage;    /* innermost storage channels (8 for the stem, else Cin)     */
+    int bn_index;       /* for bn tensors: which BN (running stats offset = index)   */
+    long running_offset; /* float offset of this BN's running_mean in the running buffer; var follows at +C */
+} io_tensor_info;
+
+io_net* io_net_create(int in_channels, int n_heads, const int* head_dims);
+void io_net_destroy(io_net* net);
+long io_net_param_floats(const io_net* net);    /* size of the flat parameter buffer        */
+long io_net_running_floats(const io_net* net);  /* size of the flat running-statistics buffer */
+int io_net_num_tensors(const io_net* net);
+int io_net_tensor_info(const io_net* net, int i, io_tensor_info* out);
+int io_net_num_logits(const io_net* net);
+/* bytes of workspace needed for a forward(/backward) of N samples of size S x S */
+size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training);
+/* x8[N,S,S,8] -> logits[N][K].  training != 0: batch statistics in G groups, running stats updated,
+ * activations kept in `workspace` for io_net_backward. */
+int io_net_forward(io_net* net, const float* params, float* running, const float* x8, int N, int S, int G,
+                   int training, void* workspace, size_t workspace_bytes, float* logits, hipStream_t stream);
+/* gradient of every parameter into grads (same layout as params; fully overwritten).  Must follow a
+ * training io_net_forward with the same x8 / N / S / G / workspace. */
+int io_net_backward(io_net* net, const float* params, float* grads, const float* x8, const float* dlogits, int N,
+                    int S, int G, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
+ * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of
+ * classes written.  flops / bytes are the ALGORITHMIC figures of the timed launches. */
+typedef struct io_prof_entry {
+    char name[48];
+    long launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} io_prof_entry;
+int io_prof_begin(void);
+int io_prof_end(io_prof_entry* out, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSTAORDER_HIP_H */

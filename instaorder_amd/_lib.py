@@ -1,0 +1,102 @@
+"""ctypes binding of libinstaorder_hip.so (the C ABI declared in include/instaorder_hip.h).
+
+There is NO fallback: if the shared library is missing, or an op is invoked without a
+gfx950 device, a RuntimeError is raised.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C instaorder_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinstaorder_hip.so")
+_lib = None
+
+c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("kind", C.c_int), ("ndim", C.c_int), ("shape", C.c_long * 4),
+                ("offset", C.c_long), ("numel_storage", C.c_long), ("cin_storage", C.c_int),
+                ("bn_index", C.c_int), ("running_offset", C.c_long)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/instaorder_hip.h declares
+SIGNATURES = {
+    "io_abi_version": (_I, []),
+    "io_last_error_string": (C.c_char_p, []),
+    "io_device_count": (_I, []),
+    "io_conv2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "io_conv2d_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "io_filter_transpose": (_I, [_P, _I, _I, _I, _P, _P]),
+    "io_bn_partial_floats": (_Z, [_I, _I, _I]),
+    "io_bn_stats_finalize": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "io_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "io_bn_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "io_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "io_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "io_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "io_avgpool_fc_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "io_avgpool_fc_bwd": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "io_pack_planes_nhwc8": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), _I, _I, _I, _I, _P, _P]),
+    "io_order_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P]),
+    "io_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),
+    "io_net_create": (_P, [_I, _I, C.POINTER(C.c_int)]),
+    "io_net_destroy": (None, [_P]),
+    "io_net_param_floats": (_L, [_P]),
+    "io_net_running_floats": (_L, [_P]),
+    "io_net_num_tensors": (_I, [_P]),
+    "io_net_tensor_info": (_I, [_P, _I, C.POINTER(TensorInfo)]),
+    "io_net_num_logits": (_I, [_P]),
+    "io_net_workspace_bytes": (_Z, [_P, _I, _I, _I]),
+    "io_net_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    "io_net_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "io_prof_begin": (_I, []),
+    "io_prof_end": (_I, [C.POINTER(ProfEntry), _I]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "instaorder_amd: %s is missing -- the HIP extension has not been built "
+                "(run `make -C instaorder_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def last_error():
+    return lib().io_last_error_string().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("instaorder_hip %s failed (%d): %s" % (what, rc, last_error()))
+
+
+_gpu_ok = None
+
+
+def require_gpu():
+    """Fail loudly unless a gfx950 device is visible to HIP."""
+    global _gpu_ok
+    if _gpu_ok is None:
+        _gpu_ok = lib().io_device_count() > 0
+    if not _gpu_ok:
+        raise RuntimeError("instaorder_amd: no gfx950 (MI355X) device visible; the HIP path cannot run "
+                           "and there is no CPU fallback")

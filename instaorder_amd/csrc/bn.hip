@@ -1,0 +1,359 @@
+// BatchNorm2d (train + eval) over NHWC fp32 activations, with "groups": the N samples are split
+// into G equal consecutive groups that are normalised with SEPARATE batch statistics.  G = 2 is how
+// one launch serves the reference's two directional passes (supervised_order.py:537-538), which are
+// separate module calls and therefore separate BN batches; running statistics are advanced group by
+// group so they end up exactly as after two sequential calls.
+//
+// All kernels are HBM-bound streaming passes: each thread owns one float4 of channels and strides
+// over rows, so a wave reads whole contiguous NHWC rows (1 KiB per wave-instruction for C >= 256).
+// Reductions are two-level (per-block fp32 partials, fp64 finalize) and deterministic.
+// Reference semantics: nn.BatchNorm2d, resnet_cls.py:142, 87-92, 189 (eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased for the running estimate).
+#include "io_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+struct ColMap {
+    int TX, TY, tx, ty, nq;   // column threads, row lanes, my coords, quads per thread
+};
+__device__ __forceinline__ ColMap col_map(int C4) {
+    ColMap m;
+    m.TX = C4 < kThreads ? C4 : kThreads;
+    m.TY = kThreads / m.TX;
+    m.tx = threadIdx.x % m.TX;
+    m.ty = threadIdx.x / m.TX;
+    m.nq = (C4 + m.TX - 1) / m.TX;
+    return m;
+}
+
+// block-level reduction over the TY row lanes of two float4 accumulators per owned quad; result is
+// written by ty == 0 to dst0/dst1[(quad)*4 ..]
+template <int MAXQ>
+__device__ __forceinline__ void reduce_rows_store(const ColMap& cm, f32x4 (&s0)[MAXQ], f32x4 (&s1)[MAXQ],
+                                                  float* dst0, float* dst1, int C4) {
+    __shared__ f32x4 red[2][kThreads];
+    for (int i = 0; i < MAXQ; ++i) {
+        if (i >= cm.nq) break;
+        red[0][threadIdx.x] = s0[i];
+        red[1][threadIdx.x] = s1[i];
+        __syncthreads();
+        for (int off = cm.TY >> 1; off > 0; off >>= 1) {
+            if (cm.ty < off) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + off * cm.TX];
+                red[1][threadIdx.x] += red[1][threadIdx.x + off * cm.TX];
+            }
+            __syncthreads();
+        }
+        const int q = cm.tx + cm.TX * i;
+        if (cm.ty == 0 && q < C4) {
+            st4(dst0 + q * 4, red[0][threadIdx.x]);
+            st4(dst1 + q * 4, red[1][threadIdx.x]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- forward statistics --------------------------------------------------------------------
+// grid (nb, G): block b of group g reduces rows [g*Mg + b*rpb, ...) -> partial[(g*nb+b)*C + c]
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, int Mg, int C, int rpb,
+                                                           float* __restrict__ psum, float* __restrict__ psq) {
+    const int C4 = C >> 2;
+    const ColMap cm = col_map(C4);
+    const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+    const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
+    const float* xg = x + (size_t)g * Mg * C;
+    f32x4 s[2], ss[2];
+    for (int i = 0; i < 2; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    for (int r = r0 + cm.ty; r < r1; r += cm.TY) {
+        const float* row = xg + (size_t)r * C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = cm.tx + cm.TX * i;
+            if (i < cm.nq && q < C4) {
+                const f32x4 v = ld4(row + q * 4);
+                s[i] += v;
+                ss[i] += v * v;
+            }
+        }
+    }
+    const size_t o = ((size_t)g * nb + b) * C;
+    reduce_rows_store<2>(cm, s, ss, psum + o, psq + o, C4);
+}
+
+// one thread per channel; loops groups in order so running stats see group 0 then group 1 ...
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nb, int G,
+                                   int Mg, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, float momentum, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            s += (double)psum[((size_t)g * nb + b) * C + c];
+            q += (double)psq[((size_t)g * nb + b) * C + c];
+        }
+        const double mu = s / Mg;
+        double var = q / Mg - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * r;
+        mean[g * C + c] = (float)mu;
+        rstd[g * C + c] = r;
+        scale[g * C + c] = sc;
+        shift[g * C + c] = beta[c] - (float)mu * sc;
+        const float unb = (float)(Mg > 1 ? var * ((double)Mg / (double)(Mg - 1)) : var);
+        rm = (1.f - momentum) * rm + momentum * (float)mu;
+        rv = (1.f - momentum) * rv + momentum * unb;
+    }
+    if (run_mean) run_mean[c] = rm;
+    if (run_var) run_var[c] = rv;
+}
+
+// eval mode: scale/shift from the running statistics (one "group")
+__global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                       float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(run_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - run_mean[c] * sc;
+}
+
+// ---- apply: out = [relu]( y*scale+shift  (+ id | + yd*scale2+shift2) ) ------------------------
+// sg = stride (in channels) between groups of the scale/shift tables: C in training, 0 in eval.
+template <int MODE>   // 0 none, 1 identity tensor, 2 second BN (downsample branch)
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, size_t total4, int c4shift,
+                                                           int Mg, int sg, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ idt,
+                                                           const float* __restrict__ scale2,
+                                                           const float* __restrict__ shift2, int relu,
+                                                           float* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int c4mask = (1 << c4shift) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const int q = (int)(i & c4mask);
+        const size_t row = i >> c4shift;
+        const int g = (int)(row / Mg);
+        const int co = g * sg + q * 4;
+        f32x4 v = ld4(y + i * 4) * ld4(scale + co) + ld4(shift + co);
+        if (MODE == 1) v += ld4(idt + i * 4);
+        if (MODE == 2) v += ld4(idt + i * 4) * ld4(scale2 + co) + ld4(shift2 + co);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        st4(out + i * 4, v);
+    }
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+// dz = dout * [act > 0] (act may be null: no ReLU behind this BN), xhat = (y - mean) * rstd
+// partial sums of dz and dz*xhat per (group, block, channel)
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ act,
+                                                                const float* __restrict__ y, int Mg, int C, int rpb,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                float* __restrict__ p1, float* __restrict__ p2) {
+    const int C4 = C >> 2;
+    const ColMap cm = col_map(C4);
+    const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+    const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
+    const size_t goff = (size_t)g * Mg * C;
+    f32x4 s1[2], s2[2], mu[2], rs[2];
+    for (int i = 0; i < 2; ++i) {
+        s1[i] = 0.f; s2[i] = 0.f; mu[i] = 0.f; rs[i] = 0.f;
+        const int q = cm.tx + cm.TX * i;
+        if (i < cm.nq && q < C4) {
+            mu[i] = ld4(mean + g * C + q * 4);
+            rs[i] = ld4(rstd + g * C + q * 4);
+        }
+    }
+    for (int r = r0 + cm.ty; r < r1; r += cm.TY) {
+        const size_t ro = goff + (size_t)r * C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = cm.tx + cm.TX * i;
+            if (i < cm.nq && q < C4) {
+                f32x4 d = ld4(dout + ro + q * 4);
+                if (act) {
+                    const f32x4 a = ld4(act + ro + q * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = a[k] > 0.f ? d[k] : 0.f;
+                }
+                const f32x4 xh = (ld4(y + ro + q * 4) - mu[i]) * rs[i];
+                s1[i] += d;
+                s2[i] += d * xh;
+            }
+        }
+    }
+    const size_t o = ((size_t)g * nb + b) * C;
+    reduce_rows_store<2>(cm, s1, s2, p1 + o, p2 + o, C4);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int nb, int G,
+                                       int Mg, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double a = 0.0, b2 = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            a += (double)p1[((size_t)g * nb + b) * C + c];
+            b2 += (double)p2[((size_t)g * nb + b) * C + c];
+        }
+        db += a;
+        dg += b2;
+        c1[g * C + c] = (float)(a / Mg);
+        c2[g * C + c] = (float)(b2 / Mg);
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+// dy = gamma*rstd*(dz - c1 - xhat*c2); optionally also stores dz (may alias dout)
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act,
+                                                               const float* __restrict__ y, size_t total4,
+                                                               int c4shift, int Mg, int C,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ c1,
+                                                               const float* __restrict__ c2,
+                                                               float* __restrict__ dy, float* dz_out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int c4mask = (1 << c4shift) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const int q = (int)(i & c4mask);
+        const size_t row = i >> c4shift;
+        const int g = (int)(row / Mg);
+        const int co = g * C + q * 4;
+        f32x4 d = ld4(dout + i * 4);
+        if (act) {
+            const f32x4 a = ld4(act + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = a[k] > 0.f ? d[k] : 0.f;
+        }
+        const f32x4 rs = ld4(rstd + co);
+        const f32x4 xh = (ld4(y + i * 4) - ld4(mean + co)) * rs;
+        const f32x4 r = (d - ld4(c1 + co) - xh * ld4(c2 + co)) * (ld4(gamma + q * 4) * rs);
+        if (dz_out) st4(dz_out + i * 4, d);
+        st4(dy + i * 4, r);
+    }
+}
+
+int ilog2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+}
+
+int ew_blocks(size_t total4) {
+    size_t b = (total4 + kThreads - 1) / kThreads;
+    return (int)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+}  // namespace
+
+static int bn_rows_per_block(int Mg, int G, int* nb) {
+    int want = 1024 / (G > 0 ? G : 1);
+    if (want < 1) want = 1;
+    int rpb = io_cdiv(Mg, want);
+    if (rpb < 64) rpb = Mg < 64 ? Mg : 64;
+    *nb = io_cdiv(Mg, rpb);
+    return rpb;
+}
+
+extern "C" size_t io_bn_partial_floats(int M, int C, int G) {
+    if (M <= 0 || G <= 0) return 0;
+    int nb;
+    bn_rows_per_block(M / G, G, &nb);
+    return (size_t)2 * G * nb * C;
+}
+
+extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps,
+                                    float* mean, float* rstd, float* scale, float* shift, float* partial,
+                                    size_t partial_floats, hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && C <= 2048, IO_ERR_SHAPE, "bn_stats: C=%d unsupported", C);
+    IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_stats: M=%d not divisible by G=%d", M, G);
+    IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_stats: partial too small");
+    const int Mg = M / G;
+    int nb;
+    const int rpb = bn_rows_per_block(Mg, G, &nb);
+    float* psum = partial;
+    float* psq = partial + (size_t)G * nb * C;
+    IoProfScope prof(IO_PROF_BN_STATS, 0.0, 4.0 * M * C, st);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, G), dim3(kThreads), 0, st, y, Mg, C, rpb, psum, psq);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, psum, psq, nb, G, Mg, C, gamma,
+                       beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+    return io_check_launch("bn_stats_finalize");
+}
+
+extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    return io_check_launch("bn_eval_prepare");
+}
+
+extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* scale,
+                           const float* shift, const float* identity, const float* scale2, const float* shift2,
+                           int relu, float* out, hipStream_t st) {
+    const int sh = ilog2_exact(C / 4);
+    IO_REQUIRE(C % 4 == 0 && sh >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be 4*2^k", C);
+    IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_apply: M=%d not divisible by G=%d", M, G);
+    const size_t total4 = (size_t)M * (C / 4);
+    const int Mg = M / G, sg = per_group_tables ? C : 0;
+    dim3 grid(ew_blocks(total4)), block(kThreads);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 4.0 * M * C * (identity ? 3.0 : 2.0), st);
+    if (identity && scale2)
+        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
+                           scale2, shift2, relu, out);
+    else if (identity)
+        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
+                           scale2, shift2, relu, out);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
+                           scale2, shift2, relu, out);
+    return io_check_launch("bn_apply");
+}
+
+extern "C" int io_bn_bwd(const float* dout, const float* act, const float* y, int M, int C, int G,
+                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                         float* dy, float* dz_out, float* partial, size_t partial_floats, float* coef,
+                         hipStream_t st) {
+    const int sh = ilog2_exact(C / 4);
+    IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
+    IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_bwd: M=%d not divisible by G=%d", M, G);
+    IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_bwd: partial too small");
+    const int Mg = M / G;
+    int nb;
+    const int rpb = bn_rows_per_block(Mg, G, &nb);
+    float* p1 = partial;
+    float* p2 = partial + (size_t)G * nb * C;
+    float* c1 = coef;
+    float* c2 = coef + (size_t)G * C;
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, G), dim3(kThreads), 0, st, dout, act, y, Mg, C, rpb, mean,
+                       rstd, p1, p2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
+                       dgamma, dbeta, c1, c2);
+    const size_t total4 = (size_t)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dout, act, y, total4,
+                       sh, Mg, C, gamma, mean, rstd, c1, c2, dy, dz_out);
+    return io_check_launch("bn_bwd");
+}

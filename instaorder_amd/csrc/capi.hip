@@ -1,0 +1,189 @@
+// C ABI glue: error plumbing, device probe, convolution entry points (geometry builders).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "io_common.h"
+
+static thread_local char g_err[512] = "";
+
+void io_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int io_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        io_set_error("%s: %s", what, hipGetErrorString(e));
+        return IO_ERR_LAUNCH;
+    }
+    return IO_OK;
+}
+
+extern "C" int io_abi_version(void) { return 1; }
+extern "C" const char* io_last_error_string(void) { return g_err; }
+
+extern "C" int io_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+// ---- geometry builders ---------------------------------------------------------------------
+IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+    IoConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Hi = H; g.Wi = W; g.Ci = Cin;
+    g.Ho = (H + 2 * pad - R) / stride + 1;
+    g.Wo = (W + 2 * pad - S) / stride + 1;
+    g.Co = Cout;
+    g.outH = g.Ho; g.outW = g.Wo;
+    g.os = 1; g.ooh = 0; g.oow = 0;
+    g.is = stride;
+    g.Th = R; g.Tw = S;
+    g.dh0 = -pad; g.dhs = 1; g.dw0 = -pad; g.dws = 1;
+    g.r0 = 0; g.rs = 1; g.s0 = 0; g.ss = 1;
+    g.S = S; g.wT = R * S;
+    return g;
+}
+
+// data gradient of the conv above for the output-pixel parity class (ph, pw) of dx[N,H,W,Cin]:
+// dx[h] = sum_r dy[(h + pad - r)/stride] W[r] over r == (h + pad) mod stride.
+IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph,
+                         int pw) {
+    IoConvGeom g;
+    memset(&g, 0, sizeof(g));
+    const int Hy = (H + 2 * pad - R) / stride + 1, Wy = (W + 2 * pad - S) / stride + 1;
+    g.N = N; g.Hi = Hy; g.Wi = Wy; g.Ci = Cout;
+    g.Ho = (H - ph + stride - 1) / stride;
+    g.Wo = (W - pw + stride - 1) / stride;
+    g.Co = Cin;
+    g.outH = H; g.outW = W;
+    g.os = stride; g.ooh = ph; g.oow = pw;
+    g.is = 1;
+    const int rf = (ph + pad) % stride, sf = (pw + pad) % stride;
+    g.Th = rf < R ? (R - rf + stride - 1) / stride : 0;
+    g.Tw = sf < S ? (S - sf + stride - 1) / stride : 0;
+    g.dh0 = (ph + pad - rf) / stride; g.dhs = -1;
+    g.dw0 = (pw + pad - sf) / stride; g.dws = -1;
+    g.r0 = rf; g.rs = stride; g.s0 = sf; g.ss = stride;
+    g.S = S; g.wT = R * S;
+    return g;
+}
+
+int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
+                 int Cout, int R, int S, int stride, int pad, hipStream_t st) {
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            IoConvGeom g = io_geom_dgrad(N, H, W, Cin, Cout, R, S, stride, pad, ph, pw);
+            if (g.Ho <= 0 || g.Wo <= 0) continue;
+            if ((g.Th == 0 || g.Tw == 0) && add == dx) continue;   // nothing to add, values stay
+            int rc = io_launch_conv_nt(g, dy, wt, dx, add, 0, st);
+            if (rc) return rc;
+        }
+    return IO_OK;
+}
+
+extern "C" int io_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout,
+                             int R, int S, int stride, int pad, hipStream_t st) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    return io_launch_conv_nt(g, x, w, y, nullptr, Cin == 8, st);
+}
+
+extern "C" int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W,
+                               int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st) {
+    IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad: Cin=%d must be a multiple of 64", Cin);
+    return io_run_dgrad(dy, wt, dx, add, N, H, W, Cin, Cout, R, S, stride, pad, st);
+}
+
+extern "C" size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                                                  int pad) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    return io_conv_wgrad_partial_bytes(g, Cin == 8);
+}
+
+extern "C" int io_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                               int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    return io_launch_conv_wgrad(g, x, dy, dw, (float*)ws, ws_bytes, Cin == 8, st);
+}
+
+// ---- profiling: start/stop events around every launch group of a class, summed at io_prof_end ------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+const char* kProfNames[IO_PROF_NCLASS] = {"conv_nt_kernel<128,false>", "conv_nt_kernel<64,false>",
+    "conv_nt_kernel<64,true>", "conv_wgrad_kernel", "conv_wgrad_kernel<64,64,true>", "bn_stats_finalize",
+    "bn_apply", "bn_bwd", "pool_head", "filter_transpose", "pack_planes", "order_loss", "sgd_momentum"};
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+IoProfScope::IoProfScope(int cls, double flops, double bytes, hipStream_t stream) : idx(-1), st(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.e0 = prof_event(); r.e1 = prof_event();
+    (void)hipEventRecord(r.e0, st);
+    idx = (int)g_prof_recs.size();
+    g_prof_recs.push_back(r);
+}
+IoProfScope::~IoProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].e1, st);
+}
+
+extern "C" int io_prof_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRec& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+    g_prof_recs.clear();
+    g_prof_on = true;
+    return IO_OK;
+}
+
+extern "C" int io_prof_end(io_prof_entry* out, int max_entries) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    io_prof_entry acc[IO_PROF_NCLASS];
+    memset(acc, 0, sizeof(acc));
+    for (int c = 0; c < IO_PROF_NCLASS; ++c) snprintf(acc[c].name, sizeof(acc[c].name), "%s", kProfNames[c]);
+    for (ProfRec& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            acc[r.cls].launches += 1;
+            acc[r.cls].total_ms += ms;
+            acc[r.cls].flops += r.flops;
+            acc[r.cls].bytes += r.bytes;
+        }
+        g_prof_pool.push_back(r.e0);
+        g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
+    int n = 0;
+    for (int c = 0; c < IO_PROF_NCLASS && n < max_entries; ++c)
+        if (acc[c].launches > 0) out[n++] = acc[c];
+    return n;
+}

@@ -1,0 +1,63 @@
+// Shared declarations for the instaorder_hip library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/instaorder_hip.h"
+
+// ---- error plumbing (thread-local last-error string, never throws) ----------
+void io_set_error(const char* fmt, ...);
+int io_check_launch(const char* what);
+
+#define IO_REQUIRE(cond, code, ...)        \
+    do {                                   \
+        if (!(cond)) {                     \
+            io_set_error(__VA_ARGS__);     \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+static inline int io_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Geometry of one implicit-GEMM launch ("gather conv"): forward convolution and
+// both data-gradient forms are instances of it (see conv_igemm.hip).
+struct IoConvGeom {
+    int N, Hi, Wi, Ci;   // gathered tensor  [N,Hi,Wi,Ci]   (NHWC)
+    int Ho, Wo, Co;      // logical output grid of THIS launch, Co channels
+    int outH, outW;      // spatial dims of the output tensor in memory
+    int os, ooh, oow;    // output lattice: mem (h,w) = (ho*os+ooh, wo*os+oow)
+    int is;              // hi = ho*is + dh,  wi = wo*is + dw
+    int Th, Tw;          // tap grid of this launch
+    int dh0, dhs, dw0, dws;   // dh = dh0 + dhs*th ; dw = dw0 + dws*tw
+    int r0, rs, s0, ss;       // filter tap (r,s) = (r0+rs*th, s0+ss*tw)
+    int S, wT;           // filter width S and total taps wT=R*S: weights [Co][wT][Ci]
+};
+
+// internal launchers shared between the C ABI and the network executor
+int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,
+                      const float* add, int stem, hipStream_t st);
+int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, float* dw,
+                         float* partial, size_t partial_bytes, int stem, hipStream_t st);
+size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
+
+IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
+int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
+                 int Cout, int R, int S, int stride, int pad, hipStream_t st);
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench / profiling) ----
+enum IoProfClass {
+    IO_PROF_CONV_NT128 = 0, IO_PROF_CONV_NT64, IO_PROF_CONV_STEM, IO_PROF_WGRAD, IO_PROF_WGRAD_STEM,
+    IO_PROF_BN_STATS, IO_PROF_BN_APPLY, IO_PROF_BN_BWD, IO_PROF_POOL_HEAD, IO_PROF_TRANSPOSE, IO_PROF_PACK,
+    IO_PROF_LOSS, IO_PROF_SGD, IO_PROF_NCLASS
+};
+struct IoProfScope {
+    int idx;
+    hipStream_t st;
+    IoProfScope(int cls, double flops, double bytes, hipStream_t stream);
+    ~IoProfScope();
+};

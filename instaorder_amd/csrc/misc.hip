@@ -1,0 +1,400 @@
+// Small HBM-bound / latency-bound kernels of the order-prediction path: input packing, max-pool,
+// global-average-pool + FC heads, order losses, momentum SGD, filter transposition.
+#include "io_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+int ew_blocks(size_t n) {
+    size_t b = (n + kThreads - 1) / kThreads;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+// ---- pack: up to 5 NCHW planes -> NHWC with 8 channels (5 real + 3 zero) --------------------
+// The reference feeds torch.cat([modal_a, modal_b, rgb], 1) (supervised_order.py:537-538): channel
+// order (mask_a, mask_b, R, G, B).  Planes are given per channel with a per-sample stride so the
+// same kernel serves the concatenated [N,5,S,S] tensor and the separate rgb / mask tensors.
+struct PackArgs {
+    const float* plane[5];
+    long stride[5];   // floats between consecutive samples of that plane
+};
+__global__ __launch_bounds__(kThreads) void pack_planes_kernel(PackArgs a, int nplanes, int N, int HW,
+                                                              float* __restrict__ out) {
+    const size_t total = (size_t)N * HW;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t n = i / HW, p = i - n * HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) v[c] = c < nplanes ? a.plane[c][n * a.stride[c] + p] : 0.f;
+        v[5] = v[6] = v[7] = 0.f;
+        const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        st4(out + i * 8, lo);
+        st4(out + i * 8 + 4, hi);
+    }
+}
+
+// ---- max-pool 3x3 stride 2 pad 1 (resnet_cls.py:144), NHWC -----------------------------------
+// idx keeps, per output element, which of the 9 window taps won (first maximum in (kh,kw) scan
+// order, as the PyTorch CPU kernel); one byte per element, 4 channels packed per uint32.
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                              int C, float* __restrict__ out,
+                                                              uint32_t* __restrict__ idx) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int q = (int)(i % C4);
+        size_t t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        uint32_t bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * 2 - 1 + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const f32x4 v = ld4(x + (((size_t)n * H + h) * W + w) * C + q * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
+            }
+        }
+        st4(out + i * 4, best);
+        if (idx) idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                              const uint32_t* __restrict__ idx, int N, int H, int W,
+                                                              int C, float* __restrict__ dx) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
+    const size_t total = (size_t)N * H * W * C4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int q = (int)(i % C4);
+        size_t t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows (ho,wo) with 2*ho-1 <= h <= 2*ho+1
+        for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+            if (ho >= Ho) continue;
+            const int kh = h - (2 * ho - 1);
+            for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+                if (wo >= Wo) continue;
+                const int kw = w - (2 * wo - 1);
+                const uint32_t k = kh * 3 + kw;
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C4 + q;
+                const uint32_t id = idx[o];
+                const f32x4 g = ld4(dy + o * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((id >> (8 * e)) & 0xffu) == k) acc[e] += g[e];
+            }
+        }
+        st4(dx + i * 4, acc);
+    }
+}
+
+// ---- global average pool + FC heads (resnet_cls.py:152-160, 214-222) ----------------------------
+// one block per sample: pooled[n][c] = mean_p x[n][p][c]; logits[n][k] = pooled . W[k] + b[k]
+__global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const float* __restrict__ x, int HW, int C,
+                                                             const float* __restrict__ w0,
+                                                             const float* __restrict__ b0, int K0,
+                                                             const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, int K1,
+                                                             float* __restrict__ pooled,
+                                                             float* __restrict__ logits) {
+    extern __shared__ float sp[];   // C floats + 8*4 reduction slots
+    const int n = blockIdx.x, C4 = C >> 2;
+    const float inv = 1.f / (float)HW;
+    const float* xn = x + (size_t)n * HW * C;
+    for (int q = threadIdx.x; q < C4; q += blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < HW; ++p) s += ld4(xn + (size_t)p * C + q * 4);
+        s *= inv;
+        st4(sp + q * 4, s);
+        st4(pooled + (size_t)n * C + q * 4, s);
+    }
+    __syncthreads();
+    const int K = K0 + K1;
+    float* red = sp + C;
+    for (int k = 0; k < K; ++k) {
+        const float* wk = k < K0 ? w0 + (size_t)k * C : w1 + (size_t)(k - K0) * C;
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) s += sp[c] * wk[c];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+            logits[(size_t)n * K + k] = t + (k < K0 ? b0[k] : b1[k - K0]);
+        }
+        __syncthreads();
+    }
+}
+
+// d_x[n][p][c] = (sum_k dlogits[n][k] W[k][c]) / HW
+__global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const float* __restrict__ dlogits,
+                                                                      const float* __restrict__ w0, int K0,
+                                                                      const float* __restrict__ w1, int K1, int HW,
+                                                                      int C, float* __restrict__ dx) {
+    const int n = blockIdx.x, K = K0 + K1;
+    const float inv = 1.f / (float)HW;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float wv = k < K0 ? w0[(size_t)k * C + c] : w1[(size_t)(k - K0) * C + c];
+            s += dlogits[(size_t)n * K + k] * wv;
+        }
+        s *= inv;
+        for (int p = 0; p < HW; ++p) dx[((size_t)n * HW + p) * C + c] = s;
+    }
+}
+
+// dW[k][c] = sum_n dlogits[n][k] pooled[n][c];  db[k] = sum_n dlogits[n][k]
+__global__ __launch_bounds__(kThreads) void fc_bwd_weight_kernel(const float* __restrict__ dlogits,
+                                                                const float* __restrict__ pooled, int N, int C,
+                                                                int K, int kofs, int Kh, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+    const int k = blockIdx.y;   // row of this head
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dlogits[(size_t)n * K + kofs + k] * pooled[(size_t)n * C + c];
+        dw[(size_t)k * C + c] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dlogits[(size_t)n * K + kofs + k];
+        db[k] = s;
+    }
+    (void)Kh;
+}
+
+// ---- order losses (supervised_order.py:59-95, 413-438, 481-493, 535-548) ---------------------------
+// Rows are G direction-groups of B samples.  Occlusion head: sigmoid -> BCELoss (mean over B*2 per
+// direction, log clamped at -100).  Depth head: softmax -> CrossEntropyLoss *on the probabilities*
+// (log-softmax of a softmax), optionally split into overlap / distinct subsets, each a mean over its
+// own size, weighted.  losses[0] = total * inv_world, losses[1] = occlusion, losses[2] = depth.
+// dlogits = d(total * inv_world)/dlogits.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(kThreads) void order_loss_kernel(const float* __restrict__ logits, int N, int B, int K,
+                                                             int Kocc, int Kdep,
+                                                             const float* __restrict__ occ_t,
+                                                             const long* __restrict__ dep_t,
+                                                             const long* __restrict__ is_overlap, float w_ov,
+                                                             float w_di, float inv_world,
+                                                             float* __restrict__ losses,
+                                                             float* __restrict__ dlogits) {
+    __shared__ float red[8];
+    float n_ov = 0.f;
+    if (Kdep && is_overlap) {
+        float c = 0.f;
+        for (int n = threadIdx.x; n < B; n += blockDim.x) c += is_overlap[n] == 1 ? 1.f : 0.f;
+        n_ov = block_sum(c, red);
+    }
+    const float n_di = (float)B - n_ov;
+    float l_occ = 0.f, l_dep = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* z = logits + (size_t)n * K;
+        float* dz = dlogits ? dlogits + (size_t)n * K : nullptr;
+        if (Kocc) {
+            const float wrow = 1.f / (float)(B * Kocc);
+            for (int k = 0; k < Kocc; ++k) {
+                const float p = 1.f / (1.f + expf(-z[k]));
+                const float y = occ_t[(size_t)n * Kocc + k];
+                const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+                l_occ += -(y * lp + (1.f - y) * lq) * wrow;
+                if (dz) {
+                    // BCELoss backward then sigmoid backward, as autograd composes them
+                    const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * wrow * inv_world;
+                    dz[k] = gp * p * (1.f - p);
+                }
+            }
+        }
+        if (Kdep) {
+            const float* zd = z + Kocc;
+            float wrow;
+            if (is_overlap) {
+                const bool ov = is_overlap[n % B] == 1;
+                const float cnt = ov ? n_ov : n_di;
+                wrow = cnt > 0.f ? (ov ? w_ov : w_di) / cnt : 0.f;
+            } else {
+                wrow = 1.f / (float)B;
+            }
+            float q[4], s[4];
+            float mx = zd[0];
+            for (int k = 1; k < Kdep; ++k) mx = fmaxf(mx, zd[k]);
+            float sum = 0.f;
+            for (int k = 0; k < Kdep; ++k) { q[k] = expf(zd[k] - mx); sum += q[k]; }
+            for (int k = 0; k < Kdep; ++k) q[k] /= sum;
+            float mq = q[0];
+            for (int k = 1; k < Kdep; ++k) mq = fmaxf(mq, q[k]);
+            float s2 = 0.f;
+            for (int k = 0; k < Kdep; ++k) { s[k] = expf(q[k] - mq); s2 += s[k]; }
+            const int t = (int)dep_t[n];
+            l_dep += -(q[t] - mq - logf(s2)) * wrow;
+            if (dz) {
+                float dq[4], dot = 0.f;
+                for (int k = 0; k < Kdep; ++k) {
+                    dq[k] = (s[k] / s2 - (k == t ? 1.f : 0.f)) * wrow * inv_world;
+                    dot += q[k] * dq[k];
+                }
+                for (int k = 0; k < Kdep; ++k) dz[Kocc + k] = q[k] * (dq[k] - dot);
+            }
+        }
+    }
+    const float so = block_sum(l_occ, red);
+    const float sd = block_sum(l_dep, red);
+    if (threadIdx.x == 0) {
+        losses[0] = (so + sd) * inv_world;
+        losses[1] = so;
+        losses[2] = sd;
+    }
+}
+
+// ---- momentum SGD over the flat parameter buffer (single_stage_model.py:35-38) -------------------
+// d = g + wd*p ; buf = momentum*buf + d ; p -= lr*buf      (buf starts at 0 == "first step buf=d")
+__global__ __launch_bounds__(kThreads) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                               float* __restrict__ buf, size_t n4, float lr,
+                                                               float momentum, float wd) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 pv = ld4(p + i * 4);
+        const f32x4 d = ld4(g + i * 4) + wd * pv;
+        const f32x4 b = momentum * ld4(buf + i * 4) + d;
+        st4(buf + i * 4, b);
+        st4(p + i * 4, pv - lr * b);
+    }
+}
+
+// ---- filter transpose  W[O][T][C] -> Wt[C][T][O]  (operand of the data-gradient GEMM) ------------
+__global__ void filter_transpose_kernel(const float* __restrict__ w, int O, int T, int C, float* __restrict__ wt) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int o = o0 + r, c = c0 + tx;
+        tile[r][tx] = (o < O && c < C) ? w[((size_t)o * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, o = o0 + tx;
+        if (c < C && o < O) wt[((size_t)c * T + t) * O + o] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* sample_strides, int nplanes, int N,
+                                    int H, int W, float* out, hipStream_t st) {
+    IO_REQUIRE(nplanes >= 1 && nplanes <= 5, IO_ERR_SHAPE, "pack: nplanes=%d (1..5)", nplanes);
+    PackArgs a;
+    for (int c = 0; c < 5; ++c) {
+        a.plane[c] = c < nplanes ? planes[c] : nullptr;
+        a.stride[c] = c < nplanes ? sample_strides[c] : 0;
+    }
+    const size_t total = (size_t)N * H * W;
+    IoProfScope prof(IO_PROF_PACK, 0.0, 4.0 * total * (nplanes + 8.0), st);
+    hipLaunchKernelGGL(pack_planes_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, a, nplanes, N, H * W, out);
+    return io_check_launch("pack_planes");
+}
+
+extern "C" int io_maxpool_fwd(const float* x, int N, int H, int W, int C, float* out, uint32_t* idx,
+                              hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
+    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 4.0 * N * H * W * C * 1.3125, st);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, x, N, H, W, C, out, idx);
+    return io_check_launch("maxpool_fwd");
+}
+
+extern "C" int io_maxpool_bwd(const float* dy, const uint32_t* idx, int N, int H, int W, int C, float* dx,
+                              hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
+    const size_t total = (size_t)N * H * W * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 4.0 * N * H * W * C * 1.3125, st);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, dy, idx, N, H, W, C, dx);
+    return io_check_launch("maxpool_bwd");
+}
+
+extern "C" int io_avgpool_fc_fwd(const float* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
+                                 const float* w1, const float* b1, int K1, float* pooled, float* logits,
+                                 hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && K0 >= 1 && K1 >= 0, IO_ERR_SHAPE, "avgpool_fc: C=%d K0=%d K1=%d", C, K0, K1);
+    const size_t lds = (size_t)(C + 32) * sizeof(float);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * N * C * (K0 + K1), 4.0 * N * HW * C, st);
+    hipLaunchKernelGGL(avgpool_fc_kernel, dim3(N), dim3(kThreads), lds, st, x, HW, C, w0, b0, K0, w1, b1, K1, pooled,
+                       logits);
+    return io_check_launch("avgpool_fc_fwd");
+}
+
+extern "C" int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0,
+                                 int K0, const float* w1, int K1, float* dx, float* dw0, float* db0, float* dw1,
+                                 float* db1, hipStream_t st) {
+    const int K = K0 + K1;
+    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, 4.0 * N * HW * C, st);
+    hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1, HW, C, dx);
+    hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K0), dim3(kThreads), 0, st, dlogits, pooled,
+                       N, C, K, 0, K0, dw0, db0);
+    if (K1 > 0)
+        hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K1), dim3(kThreads), 0, st, dlogits,
+                           pooled, N, C, K, K0, K1, dw1, db1);
+    return io_check_launch("avgpool_fc_bwd");
+}
+
+extern "C" int io_order_loss(const float* logits, int N, int B, int Kocc, int Kdep, const float* occ_target,
+                             const long* depth_target, const long* is_overlap, float overlap_weight,
+                             float distinct_weight, float inv_world, float* losses, float* dlogits,
+                             hipStream_t st) {
+    IO_REQUIRE(B > 0 && N % B == 0, IO_ERR_SHAPE, "order_loss: N=%d B=%d", N, B);
+    IO_REQUIRE((Kocc == 0 || Kocc == 2) && Kdep >= 0 && Kdep <= 4 && Kocc + Kdep > 0, IO_ERR_SHAPE,
+               "order_loss: Kocc=%d Kdep=%d", Kocc, Kdep);
+    IoProfScope prof(IO_PROF_LOSS, 0.0, 8.0 * N * (Kocc + Kdep), st);
+    hipLaunchKernelGGL(order_loss_kernel, dim3(1), dim3(kThreads), 0, st, logits, N, B, Kocc + Kdep, Kocc, Kdep,
+                       occ_target, depth_target, is_overlap, overlap_weight, distinct_weight, inv_world, losses,
+                       dlogits);
+    return io_check_launch("order_loss");
+}
+
+extern "C" int io_sgd_momentum(float* params, const float* grads, float* momentum_buf, size_t n, float lr,
+                               float momentum, float weight_decay, hipStream_t st) {
+    IO_REQUIRE(n % 4 == 0, IO_ERR_SHAPE, "sgd: n=%zu must be a multiple of 4", n);
+    const size_t n4 = n / 4;
+    IoProfScope prof(IO_PROF_SGD, 0.0, 20.0 * n, st);
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(ew_blocks(n4)), dim3(kThreads), 0, st, params, grads, momentum_buf,
+                       n4, lr, momentum, weight_decay);
+    return io_check_launch("sgd_momentum");
+}
+
+extern "C" int io_filter_transpose(const float* w, int O, int T, int C, float* wt, hipStream_t st) {
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 8.0 * O * T * C, st);
+    hipLaunchKernelGGL(filter_transpose_kernel, dim3(io_cdiv(C, 32), io_cdiv(O, 32), T), dim3(256), 0, st, w, O, T,
+                       C, wt);
+    return io_check_launch("filter_transpose");
+}

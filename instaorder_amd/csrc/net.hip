@@ -1,0 +1,517 @@
+// Whole-network executor for resnet50_cls (models/backbone/resnet_cls.py:121-222, 259-268):
+// stem 7x7/2 -> BN -> ReLU -> maxpool -> Bottleneck x [3,4,6,3] (stride on the 3x3, downsample =
+// strided 1x1 + BN on the first block of each stage) -> avgpool -> fc | (fc_occ, fc_depth).
+//
+// The executor owns no device memory: parameters, gradients, running statistics and the workspace
+// arena are caller buffers; the plan (offsets into the arena) is a pure function of (N, S, mode),
+// so forward and backward agree on it without shared state.  One forward = ~220 launches on one
+// stream, no host synchronisation.
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "io_common.h"
+
+namespace {
+
+constexpr int kMaxGroups = 8;
+constexpr float kBnEps = 1e-5f, kBnMomentum = 0.1f;   // nn.BatchNorm2d defaults (resnet_cls.py:142)
+
+struct ConvL {
+    int cin, cout, k, stride, pad, cin_store;
+    long w_off;   // float offset in params / grads
+};
+struct BnL {
+    int C;
+    long g_off, b_off, run_off;   // gamma, beta offsets in params; running_mean offset (var at +C)
+    int index;
+};
+struct Block {
+    ConvL c1, c2, c3, cd;
+    BnL b1, b2, b3, bd;
+    bool down;
+    int stride, inC, planes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct io_net {
+    int in_ch, n_heads, head_dims[2];
+    ConvL stem;
+    BnL bn1;
+    std::vector<Block> blocks;
+    long fcw_off[2], fcb_off[2];
+    long param_floats, running_floats;
+    int n_bn;
+    long bn_channels;
+    std::vector<io_tensor_info> tensors;
+};
+
+namespace {
+
+void add_tensor(io_net* net, const char* name, int kind, int ndim, const long* shape, long numel_storage,
+                int cin_storage, long* off_out, int bn_index = -1, long run_off = -1) {
+    io_tensor_info t;
+    memset(&t, 0, sizeof(t));
+    snprintf(t.name, sizeof(t.name), "%s", name);
+    t.kind = kind;
+    t.ndim = ndim;
+    for (int i = 0; i < ndim; ++i) t.shape[i] = shape[i];
+    t.offset = net->param_floats;
+    t.numel_storage = numel_storage;
+    t.cin_storage = cin_storage;
+    t.bn_index = bn_index;
+    t.running_offset = run_off;
+    *off_out = net->param_floats;
+    net->param_floats = (long)align_up((size_t)(net->param_floats + numel_storage), 64);
+    net->tensors.push_back(t);
+}
+
+ConvL add_conv(io_net* net, const char* name, int cout, int cin, int k, int stride, int pad) {
+    ConvL c;
+    c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad;
+    c.cin_store = (cin % 32 == 0) ? cin : 8;
+    char nm[64];
+    snprintf(nm, sizeof(nm), "%s.weight", name);
+    const long shape[4] = {cout, cin, k, k};
+    add_tensor(net, nm, 0, 4, shape, (long)cout * k * k * c.cin_store, c.cin_store, &c.w_off);
+    return c;
+}
+
+BnL add_bn(io_net* net, const char* name, int C) {
+    BnL b;
+    b.C = C;
+    b.index = net->n_bn++;
+    b.run_off = net->running_floats;
+    net->running_floats += 2L * C;
+    net->bn_channels += C;
+    char nm[64];
+    const long shape[1] = {C};
+    snprintf(nm, sizeof(nm), "%s.weight", name);
+    add_tensor(net, nm, 1, 1, shape, C, C, &b.g_off, b.index, b.run_off);
+    snprintf(nm, sizeof(nm), "%s.bias", name);
+    add_tensor(net, nm, 2, 1, shape, C, C, &b.b_off, b.index, b.run_off);
+    return b;
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------
+struct BlockBufs {
+    size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets
+};
+struct Plan {
+    size_t y0, a0, p0, idx0, pooled;
+    std::vector<BlockBufs> blk;
+    size_t tables;       // per-BN [4][kMaxGroups][C] floats, BN i at tables + 4*kMaxGroups*chan_prefix[i]
+    size_t bn_partial, bn_partial_floats, coef;
+    size_t gbuf[5];      // gradient scratch (training only)
+    size_t wt, wg_partial, wg_partial_bytes;
+    size_t total;
+};
+
+struct Arena {
+    size_t top = 0;
+    size_t take(size_t bytes) {
+        const size_t o = top;
+        top = align_up(top + bytes, 256);
+        return o;
+    }
+};
+
+Plan make_plan(const io_net* net, int N, int S, bool training) {
+    Plan p;
+    Arena a;
+    const int H0 = S / 2, H1 = S / 4;
+    const size_t f = sizeof(float);
+    const size_t maxact = (size_t)N * H0 * H0 * 64 * f;   // == N*H1*H1*256*f, the largest activations
+    p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
+    p.bn_partial_floats = (size_t)2 * 1100 * 2048;
+    p.bn_partial = a.take(p.bn_partial_floats * f);
+    p.coef = a.take((size_t)2 * kMaxGroups * 2048 * f);
+    p.pooled = a.take((size_t)N * 2048 * f);
+    p.blk.resize(net->blocks.size());
+    if (training) {
+        p.y0 = a.take(maxact);
+        p.a0 = a.take(maxact);
+        p.p0 = a.take((size_t)N * H1 * H1 * 64 * f);
+        p.idx0 = a.take((size_t)N * H1 * H1 * 16 * sizeof(uint32_t));
+        int H = H1;
+        for (size_t i = 0; i < net->blocks.size(); ++i) {
+            const Block& b = net->blocks[i];
+            const int Ho = H / b.stride;
+            BlockBufs& bb = p.blk[i];
+            bb.y1 = a.take((size_t)N * H * H * b.planes * f);
+            bb.a1 = a.take((size_t)N * H * H * b.planes * f);
+            bb.y2 = a.take((size_t)N * Ho * Ho * b.planes * f);
+            bb.a2 = a.take((size_t)N * Ho * Ho * b.planes * f);
+            bb.y3 = a.take((size_t)N * Ho * Ho * b.planes * 4 * f);
+            bb.yd = b.down ? a.take((size_t)N * Ho * Ho * b.planes * 4 * f) : 0;
+            bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * f);
+            H = Ho;
+        }
+        for (int i = 0; i < 5; ++i) p.gbuf[i] = a.take(maxact);
+        // filter-gradient split-K partials: largest over all convs
+        size_t wg = 0, wtmax = 0;
+        {
+            IoConvGeom g = io_geom_fwd(N, S, S, 8, 64, 7, 7, 2, 3);
+            wg = io_conv_wgrad_partial_bytes(g, 1);
+        }
+        H = H1;
+        for (const Block& b : net->blocks) {
+            const ConvL* cs[4] = {&b.c1, &b.c2, &b.c3, b.down ? &b.cd : nullptr};
+            for (int j = 0; j < 4; ++j) {
+                if (!cs[j]) continue;
+                const ConvL& c = *cs[j];
+                const int Hin = (j == 2) ? H / b.stride : H;
+                IoConvGeom g = io_geom_fwd(N, Hin, Hin, c.cin, c.cout, c.k, c.k, c.stride, c.pad);
+                const size_t need = io_conv_wgrad_partial_bytes(g, 0);
+                if (need > wg) wg = need;
+                const size_t wsz = (size_t)c.cout * c.k * c.k * c.cin * f;
+                if (wsz > wtmax) wtmax = wsz;
+            }
+            H /= b.stride;
+        }
+        p.wg_partial_bytes = wg;
+        p.wg_partial = a.take(wg);
+        p.wt = a.take(wtmax);
+    } else {
+        // eval: rotating buffers (block input / a1 / a2 / y / yd / output)
+        const size_t r0 = a.take(maxact), r1 = a.take(maxact), r2 = a.take(maxact), r3 = a.take(maxact),
+                     r4 = a.take(maxact), r5 = a.take(maxact);
+        p.y0 = r3; p.a0 = r1; p.p0 = r0; p.idx0 = 0;
+        size_t xin = r0, xout = r5;
+        for (size_t i = 0; i < net->blocks.size(); ++i) {
+            BlockBufs& bb = p.blk[i];
+            bb.y1 = r3; bb.a1 = r1; bb.y2 = r3; bb.a2 = r2; bb.y3 = r3; bb.yd = r4; bb.out = xout;
+            const size_t t = xin; xin = xout; xout = t;
+        }
+        for (int i = 0; i < 5; ++i) p.gbuf[i] = 0;
+        p.wg_partial = p.wt = 0;
+        p.wg_partial_bytes = 0;
+    }
+    p.total = a.top;
+    return p;
+}
+
+struct Tables {
+    float *mean, *rstd, *scale, *shift;
+};
+
+struct Ctx {
+    const io_net* net;
+    const float* params;
+    float* running;
+    float* grads;
+    char* ws;
+    Plan plan;
+    int N, S, G;
+    bool training;
+    hipStream_t st;
+    std::vector<long> chan_prefix;
+
+    float* buf(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    Tables tables(const BnL& b) const {
+        float* base = buf(plan.tables) + (size_t)4 * kMaxGroups * chan_prefix[b.index];
+        const size_t gs = (size_t)kMaxGroups * b.C;
+        return Tables{base, base + gs, base + 2 * gs, base + 3 * gs};
+    }
+};
+
+int conv_fwd(const Ctx& c, const ConvL& L, const float* x, float* y, int H) {
+    IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
+    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, L.cin_store == 8, c.st);
+}
+
+// BN statistics (training) or table preparation (eval) for y[M][C]
+int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M) {
+    Tables t = c.tables(b);
+    if (c.training)
+        return io_bn_stats_finalize(y, M, b.C, c.G, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
+                                    c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
+                                    t.shift, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.st);
+    return io_bn_eval_prepare(b.C, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
+                              c.running + b.run_off + b.C, kBnEps, t.scale, t.shift, c.st);
+}
+
+int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, const BnL* b2, int relu,
+           float* out) {
+    Tables t = c.tables(b);
+    const float *s2 = nullptr, *h2 = nullptr;
+    if (b2) {
+        Tables t2 = c.tables(*b2);
+        s2 = t2.scale;
+        h2 = t2.shift;
+    }
+    // tables are laid out with a group stride of C (training) -- eval uses one shared row
+    return io_bn_apply(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.scale, t.shift, idt, s2, h2, relu,
+                       out, c.st);
+}
+
+#define IO_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_) return rc_;    \
+    } while (0)
+
+int run_forward(Ctx& c, const float* x8, float* logits) {
+    const io_net* net = c.net;
+    const Plan& p = c.plan;
+    const int H0 = c.S / 2, H1 = c.S / 4;
+    // stem
+    IO_TRY(conv_fwd(c, net->stem, x8, c.buf(p.y0), c.S));
+    IO_TRY(bn_prepare(c, net->bn1, c.buf(p.y0), c.N * H0 * H0));
+    IO_TRY(bn_act(c, net->bn1, c.buf(p.y0), c.N * H0 * H0, nullptr, nullptr, 1, c.buf(p.a0)));
+    IO_TRY(io_maxpool_fwd(c.buf(p.a0), c.N, H0, H0, 64, c.buf(p.p0),
+                          c.training ? reinterpret_cast<uint32_t*>(c.ws + p.idx0) : nullptr, c.st));
+    const float* x = c.buf(p.p0);
+    int H = H1;
+    for (size_t i = 0; i < net->blocks.size(); ++i) {
+        const Block& b = net->blocks[i];
+        const BlockBufs& bb = p.blk[i];
+        const int Ho = H / b.stride;
+        const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
+        IO_TRY(conv_fwd(c, b.c1, x, c.buf(bb.y1), H));
+        IO_TRY(bn_prepare(c, b.b1, c.buf(bb.y1), Min));
+        IO_TRY(bn_act(c, b.b1, c.buf(bb.y1), Min, nullptr, nullptr, 1, c.buf(bb.a1)));
+        IO_TRY(conv_fwd(c, b.c2, c.buf(bb.a1), c.buf(bb.y2), H));
+        IO_TRY(bn_prepare(c, b.b2, c.buf(bb.y2), Mout));
+        IO_TRY(bn_act(c, b.b2, c.buf(bb.y2), Mout, nullptr, nullptr, 1, c.buf(bb.a2)));
+        IO_TRY(conv_fwd(c, b.c3, c.buf(bb.a2), c.buf(bb.y3), Ho));
+        IO_TRY(bn_prepare(c, b.b3, c.buf(bb.y3), Mout));
+        if (b.down) {
+            IO_TRY(conv_fwd(c, b.cd, x, c.buf(bb.yd), H));
+            IO_TRY(bn_prepare(c, b.bd, c.buf(bb.yd), Mout));
+            IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, c.buf(bb.yd), &b.bd, 1, c.buf(bb.out)));
+        } else {
+            IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, x, nullptr, 1, c.buf(bb.out)));
+        }
+        x = c.buf(bb.out);
+        H = Ho;
+    }
+    const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
+    const float* b1 = net->n_heads > 1 ? c.params + net->fcb_off[1] : nullptr;
+    IO_TRY(io_avgpool_fc_fwd(x, c.N, H * H, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
+                             net->head_dims[0], w1, b1, net->n_heads > 1 ? net->head_dims[1] : 0, c.buf(p.pooled),
+                             logits, c.st));
+    return IO_OK;
+}
+
+int bn_back(const Ctx& c, const BnL& b, const float* dout, const float* act, const float* y, int M, float* dy,
+            float* dz_out) {
+    Tables t = c.tables(b);
+    return io_bn_bwd(dout, act, y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off,
+                     c.grads + b.b_off, dy, dz_out, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats,
+                     c.buf(c.plan.coef), c.st);
+}
+
+int conv_wgrad(const Ctx& c, const ConvL& L, const float* x, const float* dy, int H) {
+    IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
+    return io_launch_conv_wgrad(g, x, dy, c.grads + L.w_off, c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes,
+                                L.cin_store == 8, c.st);
+}
+
+int conv_dgrad(const Ctx& c, const ConvL& L, const float* dy, float* dx, const float* add, int H) {
+    float* wt = c.buf(c.plan.wt);
+    IO_TRY(io_filter_transpose(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, c.st));
+    return io_run_dgrad(dy, wt, dx, add, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st);
+}
+
+int run_backward(Ctx& c, const float* dlogits, const float* x8) {
+    const io_net* net = c.net;
+    const Plan& p = c.plan;
+    float* Gd = c.buf(p.gbuf[0]);
+    float* Ge = c.buf(p.gbuf[1]);
+    float* Ga = c.buf(p.gbuf[2]);
+    float* Gb = c.buf(p.gbuf[3]);
+    float* Gc = c.buf(p.gbuf[4]);
+    const int H0 = c.S / 2, H1 = c.S / 4;
+    // spatial size of the last stage
+    int Hlast = H1;
+    for (const Block& b : net->blocks) Hlast /= b.stride;
+    const size_t nb = net->blocks.size();
+    const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
+    IO_TRY(io_avgpool_fc_bwd(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
+                             net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0, Gd,
+                             c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
+                             net->n_heads > 1 ? c.grads + net->fcw_off[1] : nullptr,
+                             net->n_heads > 1 ? c.grads + net->fcb_off[1] : nullptr, c.st));
+    // per-block input resolution
+    std::vector<int> Hin(nb);
+    {
+        int H = H1;
+        for (size_t i = 0; i < nb; ++i) { Hin[i] = H; H /= net->blocks[i].stride; }
+    }
+    for (size_t ii = nb; ii-- > 0;) {
+        const Block& b = net->blocks[ii];
+        const BlockBufs& bb = p.blk[ii];
+        const int H = Hin[ii], Ho = H / b.stride;
+        const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
+        const float* xin = ii == 0 ? c.buf(p.p0) : c.buf(p.blk[ii - 1].out);
+        // bn3 (+ReLU of the block output): dy3 -> Ga, masked dout kept in Gd for the identity branch
+        IO_TRY(bn_back(c, b.b3, Gd, c.buf(bb.out), c.buf(bb.y3), Mout, Ga, Gd));
+        IO_TRY(conv_wgrad(c, b.c3, c.buf(bb.a2), Ga, Ho));
+        IO_TRY(conv_dgrad(c, b.c3, Ga, Gb, nullptr, Ho));
+        IO_TRY(bn_back(c, b.b2, Gb, c.buf(bb.a2), c.buf(bb.y2), Mout, Gc, nullptr));
+        IO_TRY(conv_wgrad(c, b.c2, c.buf(bb.a1), Gc, H));
+        IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, H));
+        IO_TRY(bn_back(c, b.b1, Ga, c.buf(bb.a1), c.buf(bb.y1), Min, Gb, nullptr));
+        IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
+        IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, H));
+        if (b.down) {
+            IO_TRY(bn_back(c, b.bd, Gd, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
+            IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
+            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, H));
+        }
+        float* t = Gd; Gd = Ge; Ge = t;
+    }
+    // Gd = d(maxpool output)
+    IO_TRY(io_maxpool_bwd(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st));
+    IO_TRY(bn_back(c, net->bn1, Ge, c.buf(p.a0), c.buf(p.y0), c.N * H0 * H0, Ga, nullptr));
+    // stem filter gradient only: the network input needs no data gradient
+    IO_TRY(conv_wgrad(c, net->stem, x8, Ga, c.S));
+    return IO_OK;
+}
+
+}  // namespace
+
+extern "C" io_net* io_net_create(int in_channels, int n_heads, const int* head_dims) {
+    if (in_channels < 1 || in_channels > 5 || n_heads < 1 || n_heads > 2) {
+        io_set_error("io_net_create: in_channels=%d (1..5), n_heads=%d (1..2)", in_channels, n_heads);
+        return nullptr;
+    }
+    for (int i = 0; i < n_heads; ++i)
+        if (head_dims[i] < 1 || head_dims[i] > 4 || (n_heads == 2 && i == 0 && head_dims[i] != 2)) {
+            io_set_error("io_net_create: unsupported head dims");
+            return nullptr;
+        }
+    io_net* net = new io_net();
+    net->in_ch = in_channels;
+    net->n_heads = n_heads;
+    net->head_dims[0] = head_dims[0];
+    net->head_dims[1] = n_heads > 1 ? head_dims[1] : 0;
+    net->param_floats = 0;
+    net->running_floats = 0;
+    net->n_bn = 0;
+    net->bn_channels = 0;
+    net->stem = add_conv(net, "conv1", 64, in_channels, 7, 2, 3);
+    net->stem.cin_store = 8;
+    net->bn1 = add_bn(net, "bn1", 64);
+    const int layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    int inC = 64;
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < layers[li]; ++bi) {
+            Block b;
+            char nm[64];
+            b.planes = planes[li];
+            b.inC = inC;
+            b.stride = (bi == 0 && li > 0) ? 2 : 1;
+            b.down = bi == 0;
+            snprintf(nm, sizeof(nm), "layer%d.%d.conv1", li + 1, bi);
+            b.c1 = add_conv(net, nm, b.planes, inC, 1, 1, 0);
+            snprintf(nm, sizeof(nm), "layer%d.%d.bn1", li + 1, bi);
+            b.b1 = add_bn(net, nm, b.planes);
+            snprintf(nm, sizeof(nm), "layer%d.%d.conv2", li + 1, bi);
+            b.c2 = add_conv(net, nm, b.planes, b.planes, 3, b.stride, 1);
+            snprintf(nm, sizeof(nm), "layer%d.%d.bn2", li + 1, bi);
+            b.b2 = add_bn(net, nm, b.planes);
+            snprintf(nm, sizeof(nm), "layer%d.%d.conv3", li + 1, bi);
+            b.c3 = add_conv(net, nm, b.planes * 4, b.planes, 1, 1, 0);
+            snprintf(nm, sizeof(nm), "layer%d.%d.bn3", li + 1, bi);
+            b.b3 = add_bn(net, nm, b.planes * 4);
+            if (b.down) {
+                snprintf(nm, sizeof(nm), "layer%d.%d.downsample.0", li + 1, bi);
+                b.cd = add_conv(net, nm, b.planes * 4, inC, 1, b.stride, 0);
+                snprintf(nm, sizeof(nm), "layer%d.%d.downsample.1", li + 1, bi);
+                b.bd = add_bn(net, nm, b.planes * 4);
+            }
+            inC = b.planes * 4;
+            net->blocks.push_back(b);
+        }
+    const char* hn1[1] = {"fc"};
+    const char* hn2[2] = {"fc_occ", "fc_depth"};
+    for (int i = 0; i < n_heads; ++i) {
+        char nm[64];
+        const char* base = n_heads == 1 ? hn1[0] : hn2[i];
+        const long ws[2] = {head_dims[i], 2048};
+        snprintf(nm, sizeof(nm), "%s.weight", base);
+        add_tensor(net, nm, 3, 2, ws, (long)head_dims[i] * 2048, 2048, &net->fcw_off[i]);
+        const long bs[1] = {head_dims[i]};
+        snprintf(nm, sizeof(nm), "%s.bias", base);
+        add_tensor(net, nm, 4, 1, bs, head_dims[i], head_dims[i], &net->fcb_off[i]);
+    }
+    return net;
+}
+
+extern "C" void io_net_destroy(io_net* net) { delete net; }
+extern "C" long io_net_param_floats(const io_net* net) { return net->param_floats; }
+extern "C" long io_net_running_floats(const io_net* net) { return net->running_floats; }
+extern "C" int io_net_num_tensors(const io_net* net) { return (int)net->tensors.size(); }
+extern "C" int io_net_num_logits(const io_net* net) { return net->head_dims[0] + net->head_dims[1]; }
+
+extern "C" int io_net_tensor_info(const io_net* net, int i, io_tensor_info* out) {
+    IO_REQUIRE(i >= 0 && i < (int)net->tensors.size(), IO_ERR_SHAPE, "tensor index %d out of range", i);
+    *out = net->tensors[i];
+    return IO_OK;
+}
+
+static int check_shape(int N, int S, int G) {
+    IO_REQUIRE(S >= 32 && S % 32 == 0, IO_ERR_SHAPE, "input size S=%d must be a multiple of 32", S);
+    IO_REQUIRE(N >= 1 && G >= 1 && G <= kMaxGroups && N % G == 0, IO_ERR_SHAPE, "N=%d G=%d (G<=%d, G | N)", N, G,
+               kMaxGroups);
+    IO_REQUIRE((double)N * S * S * 16.0 < 2.0e9, IO_ERR_SHAPE, "N=%d x S=%d overflows 32-bit indexing", N, S);
+    return IO_OK;
+}
+
+extern "C" size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training) {
+    if (check_shape(N, S, 1)) return 0;
+    return make_plan(net, N, S, training != 0).total;
+}
+
+static void fill_ctx(Ctx& c, io_net* net, const float* params, float* running, float* grads, int N, int S, int G,
+                     bool training, void* ws, hipStream_t st) {
+    c.net = net;
+    c.params = params;
+    c.running = running;
+    c.grads = grads;
+    c.ws = (char*)ws;
+    c.N = N; c.S = S; c.G = G;
+    c.training = training;
+    c.st = st;
+    c.plan = make_plan(net, N, S, training);
+    c.chan_prefix.assign(net->n_bn, 0);
+    // BN index -> channel prefix (tables are packed in BN creation order)
+    std::vector<int> Cs(net->n_bn, 0);
+    Cs[net->bn1.index] = net->bn1.C;
+    for (const Block& b : net->blocks) {
+        Cs[b.b1.index] = b.b1.C;
+        Cs[b.b2.index] = b.b2.C;
+        Cs[b.b3.index] = b.b3.C;
+        if (b.down) Cs[b.bd.index] = b.bd.C;
+    }
+    long acc = 0;
+    for (int i = 0; i < net->n_bn; ++i) { c.chan_prefix[i] = acc; acc += Cs[i]; }
+}
+
+extern "C" int io_net_forward(io_net* net, const float* params, float* running, const float* x8, int N, int S,
+                              int G, int training, void* ws, size_t ws_bytes, float* logits, hipStream_t st) {
+    IO_TRY(check_shape(N, S, G));
+    IO_REQUIRE(training || G == 1, IO_ERR_SHAPE, "eval forward uses running statistics: G must be 1");
+    Ctx c;
+    fill_ctx(c, net, params, running, nullptr, N, S, G, training != 0, ws, st);
+    IO_REQUIRE(ws_bytes >= c.plan.total, IO_ERR_WORKSPACE, "io_net_forward: workspace %zu < %zu bytes", ws_bytes,
+               c.plan.total);
+    return run_forward(c, x8, logits);
+}
+
+extern "C" int io_net_backward(io_net* net, const float* params, float* grads, const float* x8,
+                               const float* dlogits, int N, int S, int G, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
+    IO_TRY(check_shape(N, S, G));
+    Ctx c;
+    fill_ctx(c, net, params, nullptr, grads, N, S, G, true, ws, st);
+    IO_REQUIRE(ws_bytes >= c.plan.total, IO_ERR_WORKSPACE, "io_net_backward: workspace %zu < %zu bytes", ws_bytes,
+               c.plan.total);
+    return run_backward(c, dlogits, x8);
+}

@@ -1,0 +1,147 @@
+"""Thin object layer over the C ABI: the ResNet-50 plan (`Net`) and the stand-alone ops.
+
+Tensors are torch tensors used purely as device memory; every call is enqueued on torch's
+current HIP stream and returns without synchronising.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float32 tensor on the GPU" % name)
+    return t
+
+
+class Net(object):
+    """Plan of resnet50_cls(in_channels, num_classes) -- mirrors models/backbone/resnet_cls.py:259-268.
+    Creating it needs no GPU (it only lays out the flat parameter buffer)."""
+
+    def __init__(self, in_channels=5, num_classes=2):
+        self.lib = _lib.lib()
+        heads = list(num_classes) if isinstance(num_classes, (list, tuple)) else [int(num_classes)]
+        self.head_dims = heads
+        arr = (C.c_int * len(heads))(*heads)
+        self.handle = self.lib.io_net_create(int(in_channels), len(heads), arr)
+        if not self.handle:
+            raise RuntimeError("io_net_create failed: " + _lib.last_error())
+        self.in_channels = int(in_channels)
+        self.param_floats = int(self.lib.io_net_param_floats(self.handle))
+        self.running_floats = int(self.lib.io_net_running_floats(self.handle))
+        self.num_logits = int(self.lib.io_net_num_logits(self.handle))
+        self.tensors = []
+        info = _lib.TensorInfo()
+        for i in range(self.lib.io_net_num_tensors(self.handle)):
+            _lib.check(self.lib.io_net_tensor_info(self.handle, i, C.byref(info)), "io_net_tensor_info")
+            self.tensors.append(dict(name=info.name.decode(), kind=info.kind,
+                                     shape=tuple(info.shape[k] for k in range(info.ndim)),
+                                     offset=int(info.offset), numel_storage=int(info.numel_storage),
+                                     cin_storage=int(info.cin_storage), bn_index=int(info.bn_index),
+                                     running_offset=int(info.running_offset)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.io_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace_bytes(self, N, S, training):
+        n = int(self.lib.io_net_workspace_bytes(self.handle, int(N), int(S), int(bool(training))))
+        if n == 0:
+            raise RuntimeError("io_net_workspace_bytes: " + _lib.last_error())
+        return n
+
+    def forward(self, params, running, x8, N, S, G, training, ws, logits):
+        _lib.require_gpu()
+        _lib.check(self.lib.io_net_forward(self.handle, _ptr(params), _ptr(running), _ptr(x8), int(N), int(S),
+                                           int(G), int(bool(training)), _ptr(ws), ws.numel() * ws.element_size(),
+                                           _ptr(logits), _stream()), "io_net_forward")
+
+    def backward(self, params, grads, x8, dlogits, N, S, G, ws):
+        _lib.require_gpu()
+        _lib.check(self.lib.io_net_backward(self.handle, _ptr(params), _ptr(grads), _ptr(x8), _ptr(dlogits),
+                                            int(N), int(S), int(G), _ptr(ws), ws.numel() * ws.element_size(),
+                                            _stream()), "io_net_backward")
+
+
+def pack_planes(planes, strides, N, H, W, out):
+    """planes: list of (tensor, element offset) giving channel 0.. of sample 0; strides: floats between
+    samples.  Writes out[N,H,W,8] (torch.cat + NCHW->NHWC + pad, supervised_order.py:537)."""
+    _lib.require_gpu()
+    n = len(planes)
+    pa = (C.c_void_p * n)(*[t.data_ptr() + 4 * off for t, off in planes])
+    sa = (C.c_long * n)(*[int(s) for s in strides])
+    _lib.check(_lib.lib().io_pack_planes_nhwc8(pa, sa, n, int(N), int(H), int(W), _ptr(out), _stream()),
+               "io_pack_planes_nhwc8")
+
+
+def pack_nchw(x, out=None):
+    """x[N,C<=5,H,W] (NCHW fp32) -> [N,H,W,8]."""
+    _dev_f32(x, "x")
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
+    pack_planes([(x, c * H * W) for c in range(Cc)], [Cc * H * W] * Cc, N, H, W, out)
+    return out
+
+
+def pack_pair_directions(rgb, modal1, modal2, out=None):
+    """Both mask orders of a pair batch in one buffer: rows [0,B) = (modal1, modal2, rgb), rows
+    [B,2B) = (modal2, modal1, rgb) -- the two model calls of supervised_order.py:537-538."""
+    for t, nme in ((rgb, "rgb"), (modal1, "modal1"), (modal2, "modal2")):
+        _dev_f32(t, nme)
+    B, _, H, W = rgb.shape
+    if out is None:
+        out = torch.empty((2 * B, H, W, 8), device=rgb.device, dtype=torch.float32)
+    HW = H * W
+    rgbp = [(rgb, c * HW) for c in range(3)]
+    st = [HW, HW, 3 * HW, 3 * HW, 3 * HW]
+    pack_planes([(modal1, 0), (modal2, 0)] + rgbp, st, B, H, W, out[:B])
+    pack_planes([(modal2, 0), (modal1, 0)] + rgbp, st, B, H, W, out[B:])
+    return out
+
+
+def order_loss(logits, B, Kocc, Kdep, occ_target=None, depth_target=None, is_overlap=None,
+               overlap_weight=0.0, distinct_weight=0.0, inv_world=1.0, want_grad=True):
+    """losses[3] = (total/world, occlusion, depth) and d(total/world)/dlogits."""
+    _lib.require_gpu()
+    N = logits.shape[0]
+    losses = torch.empty(3, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.check(_lib.lib().io_order_loss(_ptr(logits), int(N), int(B), int(Kocc), int(Kdep), _ptr(occ_target),
+                                        _ptr(depth_target), _ptr(is_overlap), float(overlap_weight),
+                                        float(distinct_weight), float(inv_world), _ptr(losses), _ptr(dlogits),
+                                        _stream()), "io_order_loss")
+    return losses, dlogits
+
+
+def sgd_momentum(params, grads, buf, lr, momentum, weight_decay):
+    _lib.require_gpu()
+    _lib.check(_lib.lib().io_sgd_momentum(_ptr(params), _ptr(grads), _ptr(buf), params.numel(), float(lr),
+                                          float(momentum), float(weight_decay), _stream()), "io_sgd_momentum")
+
+
+def prof_begin():
+    """Start HIP-event timing of every library launch (per kernel class, on the launch stream)."""
+    _lib.check(_lib.lib().io_prof_begin(), "io_prof_begin")
+
+
+def prof_end():
+    """Stop and return {class name: dict(launches, total_ms, flops, bytes)} (synchronises)."""
+    arr = (_lib.ProfEntry * 32)()
+    n = _lib.lib().io_prof_end(arr, 32)
+    return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                                       flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)}

@@ -1,0 +1,210 @@
+"""Pairwise order inference -- host-side mirror of the hot-path part of the reference's inference.py.
+
+The reference evaluates the O(n^2) instance pairs of an image one at a time (batch 1, two model
+calls and two ``.cpu().item()`` syncs per pair: inference.py:439-512, 196-214).  Here all pairs of an
+image (both mask orders) form ONE batch for the HIP network, the direction-averaged decision rule
+runs on the device, and a single copy brings the decisions back.  The rule itself is unchanged:
+
+  occlusion (inference.py:210-213):  P(i over j) = (out1[:,1] + out2[:,0]) / 2 > 0.5
+                                     P(j over i) = (out1[:,0] + out2[:,1]) / 2 > 0.5
+  depth     (inference.py:152-167):  argmax( (d1[:,0]+d2[:,1])/2, (d1[:,1]+d2[:,0])/2, (d1[:,2]+d2[:,2])/2 )
+                                     0: i closer, 1: i farther, 2: equal
+
+with out* = sigmoid(logits), d* = softmax(logits).  Metrics (recall/precision/F1, WHDR) follow
+inference.py:757-802.  Image pre-processing (crop / resize / normalise, cv2) is out of scope: callers
+pass the already normalised ``rgb[1,3,S,S]`` and the float masks ``[N,S,S]`` (what the reference's
+``patch_or_image == 'image'`` branch produces for a square image of the network size).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import distributed_utils, engine
+
+
+def upper_pairs(n):
+    return [(i, j) for i in range(n) for j in range(i + 1, n)]
+
+
+def _heads(method):
+    if method in ("InstaOrderNet_od",):
+        return 2, 3
+    if method in ("InstaOrderNet_o",):
+        return 2, 0
+    if method in ("InstaOrderNet_d",):
+        return 0, 3
+    raise ValueError("method name should be one of InstaOrderNet_o / InstaOrderNet_od / InstaOrderNet_d")
+
+
+def decide(logits1, logits2, kocc, kdep):
+    """Direction-averaged decisions for P pairs from raw logits of the two mask orders."""
+    res = {}
+    if kocc:
+        o1, o2 = torch.sigmoid(logits1[:, :kocc]), torch.sigmoid(logits2[:, :kocc])
+        res["i_over_j"] = (o1[:, 1] + o2[:, 0]) / 2 > 0.5
+        res["j_over_i"] = (o1[:, 0] + o2[:, 1]) / 2 > 0.5
+    if kdep:
+        d1 = torch.softmax(logits1[:, kocc:], 1)
+        d2 = torch.softmax(logits2[:, kocc:], 1)
+        avg = torch.stack([(d1[:, 0] + d2[:, 1]) / 2, (d1[:, 1] + d2[:, 0]) / 2, (d1[:, 2] + d2[:, 2]) / 2], 1)
+        res["depth"] = avg.argmax(1)
+    return res
+
+
+def decision_margins(pair_logits, method):
+    """Distance of each decision from its threshold (|p - 0.5| for the two occlusion directions, gap
+    between the two largest averaged depth probabilities) -- used by parity tests to leave aside
+    decisions the reference itself takes inside fp32 noise.  pair_logits: [P, 2K] = (order a,b | order b,a)."""
+    kocc, kdep = _heads(method)
+    K = kocc + kdep
+    l1, l2 = pair_logits[:, :K].double(), pair_logits[:, K:].double()
+    out = {}
+    if kocc:
+        o1, o2 = torch.sigmoid(l1[:, :kocc]), torch.sigmoid(l2[:, :kocc])
+        out["occ"] = torch.stack([((o1[:, 1] + o2[:, 0]) / 2 - 0.5).abs(), ((o1[:, 0] + o2[:, 1]) / 2 - 0.5).abs()],
+                                 1).numpy()
+    if kdep:
+        d1, d2 = torch.softmax(l1[:, kocc:], 1), torch.softmax(l2[:, kocc:], 1)
+        avg = torch.stack([(d1[:, 0] + d2[:, 1]) / 2, (d1[:, 1] + d2[:, 0]) / 2, (d1[:, 2] + d2[:, 2]) / 2], 1)
+        top = avg.topk(2, 1).values
+        out["depth"] = (top[:, 0] - top[:, 1]).numpy()
+    return out
+
+
+def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, return_logits=False,
+                        world_size=1, rank=0):
+    """Order matrices of one image.  rgb[1,3,S,S] normalised fp32, masks[N,S,S] in {0,1}.
+
+    With ``world_size > 1`` the pair list is sharded contiguously across ranks
+    (``distributed_utils.shard_range``) and the tiny per-pair decisions are all-gathered."""
+    net = model.net
+    kocc, kdep = _heads(method)
+    n = masks.shape[0]
+    pairs = upper_pairs(n) if pairs is None else list(pairs)
+    P = len(pairs)
+    S = masks.shape[-1]
+    dev = net.flat_params.device
+    rgb = rgb.to(dev, torch.float32).contiguous()
+    masks = masks.to(dev, torch.float32).contiguous()
+    beg, end = 0, P
+    if world_size > 1:
+        beg, end, _ = distributed_utils.shard_range(P, world_size, rank)
+    my = [pairs[k % P] for k in range(beg, end)] if P else []
+    K = kocc + kdep
+    l1 = torch.empty((len(my), K), device=dev)
+    l2 = torch.empty((len(my), K), device=dev)
+    HW = S * S
+    was_training = net.training
+    net.eval()
+    with torch.no_grad():
+        for c0 in range(0, len(my), max_pairs):
+            chunk = my[c0:c0 + max_pairs]
+            p = len(chunk)
+            ii = torch.tensor([a for a, _ in chunk], device=dev)
+            jj = torch.tensor([b for _, b in chunk], device=dev)
+            mi, mj = masks[ii].contiguous(), masks[jj].contiguous()
+            x8 = torch.empty((2 * p, S, S, 8), device=dev)
+            rgbp = [(rgb, c * HW) for c in range(3)]
+            engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[:p])
+            engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[p:])
+            z = net.forward_packed(x8, 1)
+            l1[c0:c0 + p], l2[c0:c0 + p] = z[:p], z[p:]
+    net.train(was_training)
+    if world_size > 1:
+        import torch.distributed as dist
+        both = torch.cat([l1, l2], 1)
+        gathered = [torch.empty_like(both) for _ in range(world_size)]
+        dist.all_gather(gathered, both)
+        both = torch.cat(gathered, 0)[:P]
+        l1, l2 = both[:, :K], both[:, K:]
+    dec = decide(l1, l2, kocc, kdep)
+    occ = np.zeros((n, n), dtype=np.int64)
+    dep = np.zeros((n, n), dtype=np.int64)
+    host = {k: v.cpu().numpy() for k, v in dec.items()}      # one D2H for the whole image
+    for k, (i, j) in enumerate(pairs):
+        if kocc:
+            if host["i_over_j"][k]:
+                occ[i, j] = 1
+            if host["j_over_i"][k]:
+                occ[j, i] = 1
+        if kdep:
+            d = int(host["depth"][k])
+            if d == 0:
+                dep[i, j], dep[j, i] = 1, 0
+            elif d == 1:
+                dep[i, j], dep[j, i] = 0, 1
+            else:
+                dep[i, j] = dep[j, i] = 2
+    res = {"pairs": pairs, "occ_order": occ, "depth_order": dep}
+    if return_logits:
+        res["pair_logits"] = torch.cat([l1, l2], 1).cpu().numpy()
+    return res
+
+
+def _image_mode_only(patch_or_image, image, inmodal, input_size):
+    if patch_or_image != "image" or image.shape[0] != image.shape[1] or image.shape[0] != input_size:
+        raise NotImplementedError(
+            "only patch_or_image='image' on square images of the network size is built here; crop/resize "
+            "pre-processing (cv2) is outside the hot path (SURVEY.md section 8)")
+    from .synthetic import image_mode_inputs
+    return image_mode_inputs(image, inmodal, input_size)
+
+
+def infer_order_sup_occ(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size=256, use_rgb=True):
+    """Reference signature (inference.py:439-512); returns the occlusion order matrix
+    (1 at [i, j] = i occludes j)."""
+    if pairs != "all":
+        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
+    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
+    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+    return res["occ_order"]
+
+
+def infer_order_sup_occ_depth(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size,
+                              disp_select_method=""):
+    """Reference signature (inference.py:349-436); returns (occ_order, depth_order)."""
+    if pairs != "all":
+        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
+    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
+    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+    return res["occ_order"], res["depth_order"]
+
+
+# ---- metrics (host) -------------------------------------------------------------------------------
+def eval_order_recall_precision_f1(order_matrix, gt_order_matrix, zd=0):
+    """Binary recall / precision / F1 (x100) over entries whose ground truth is not -1
+    (inference.py:794-802, sklearn semantics with zero_division=zd)."""
+    sel = gt_order_matrix != -1
+    y, p = gt_order_matrix[sel].reshape(-1), order_matrix[sel].reshape(-1)
+    tp = float(np.sum((y == 1) & (p == 1)))
+    fp = float(np.sum((y != 1) & (p == 1)))
+    fn = float(np.sum((y == 1) & (p != 1)))
+    recall = tp / (tp + fn) if tp + fn > 0 else float(zd)
+    precision = tp / (tp + fp) if tp + fp > 0 else float(zd)
+    f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else float(zd)
+    return recall * 100, precision * 100, f1 * 100
+
+
+def calculate_whdr(order_matrix, gt_order_matrix, score_matrix, mask):
+    if mask.sum() == 0:
+        return -1
+    return ((gt_order_matrix[mask] != order_matrix[mask]) * score_matrix[mask]).sum() / score_matrix[mask].sum() * 100
+
+
+def eval_depth_order_whdr(order_matrix, gt_order_ovl_count):
+    """Weighted human disagreement rate per overlap x equality subset (inference.py:764-791):
+    upper triangle, weights 2/count."""
+    gt_order, gt_overlap, gt_count = gt_order_ovl_count
+    iu = np.triu_indices_from(gt_order, k=1)
+    g, ov, cnt, o = gt_order[iu], gt_overlap[iu], gt_count[iu], order_matrix[iu]
+    score = 2 / cnt
+    m_ovl = collections.OrderedDict([("ovlX", ov == 0), ("ovlO", ov == 1)])
+    m_ovl["ovlOX"] = m_ovl["ovlX"] | m_ovl["ovlO"]
+    m_eq = collections.OrderedDict([("eq", g == 2), ("neq", (g == 0) | (g == 1))])
+    m_eq["all"] = m_eq["eq"] | m_eq["neq"]
+    out = collections.defaultdict(list)
+    for ko, mo in m_ovl.items():
+        for ke, me in m_eq.items():
+            out["%s_%s" % (ko, ke)].append(calculate_whdr(o, g, score, mo & me))
+    return out

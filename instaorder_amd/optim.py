@@ -1,0 +1,78 @@
+"""Fused momentum-SGD over the network's flat parameter buffer.
+
+Behaves as ``torch.optim.SGD(model.parameters(), lr, momentum=0.9, weight_decay=wd)`` does in the
+reference (models/single_stage_model.py:35-38): ONE parameter group (BN affine terms and biases are
+decayed too), coupled L2, dampening 0, no Nesterov, momentum buffer = first decayed gradient.  It IS
+a ``torch.optim.Optimizer`` (utils/scheduler.py:7-9 type-checks it and rewrites
+``param_groups[i]['lr']``), and its ``state_dict`` has torch.optim.SGD's layout (one
+``momentum_buffer`` per parameter) so checkpoints interchange with the reference
+(single_stage_model.py:66-72).  The update itself is one HIP launch over 23.5 M floats.
+"""
+import torch
+
+from . import engine
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, module, lr, momentum=0.9, weight_decay=0.0):
+        net = getattr(module, "module", module)     # DistModule / FixModule wrap the ResNet
+        if not hasattr(net, "flat_params"):
+            raise TypeError("FusedSGD needs an instaorder_amd ResNet (flat parameter buffer)")
+        self._net = net
+        defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False)
+        super(FusedSGD, self).__init__(list(net.parameters()), defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedSGD supports exactly one parameter group")
+        self._buf = None
+        self._views = None
+
+    def _ensure_buf(self):
+        flat = self._net.flat_params
+        if self._buf is None or self._buf.device != flat.device:
+            old = self._buf
+            self._buf = torch.zeros_like(flat)
+            if old is not None:
+                self._buf.copy_(old)
+            self._views = [self._net._view(self._buf, t) for t, _ in self._net._param_list]
+        return self._buf
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are rewritten in full by every backward of the engine; nothing to clear
+        for p in self.param_groups[0]["params"]:
+            if set_to_none:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        if g.get("nesterov") or g.get("dampening", 0) != 0:
+            raise ValueError("FusedSGD: nesterov / dampening are not supported")
+        buf = self._ensure_buf()
+        engine.sgd_momentum(self._net.flat_params, self._net.flat_grads, buf, g["lr"], g["momentum"],
+                            g["weight_decay"])
+        return None
+
+    # ---- checkpoint interchange with torch.optim.SGD ------------------------------------------------
+    def state_dict(self):
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        n = len(self.param_groups[0]["params"])
+        group["params"] = list(range(n))
+        state = {}
+        if self._buf is not None:
+            for i, v in enumerate(self._views):
+                state[i] = {"momentum_buffer": v.detach().clone().contiguous()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        grp = sd["param_groups"][0]
+        for k, v in grp.items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        if sd["state"]:
+            self._ensure_buf()
+            with torch.no_grad():
+                self._buf.zero_()
+                for i, st in sd["state"].items():
+                    mb = st.get("momentum_buffer")
+                    if mb is not None:
+                        self._views[int(i)].copy_(mb)

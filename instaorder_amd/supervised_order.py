@@ -1,0 +1,193 @@
+"""Order-prediction model wrappers -- host-side mirror of models/supervised_order.py.
+
+``InstaOrderNet_o`` (:496-548), ``InstaOrderNet_od`` (:18-95), ``InstaOrderNet_d`` (:370-438) and
+``OrderNet`` (:442-493) keep the reference API consumed by trainer.py / tools/test.py / inference.py:
+``set_input(*batch)``, ``step()``, ``forward_only()``, ``switch_to()``, ``load_state()``,
+``save_state()``, attributes ``.model .optim .world_size``.
+
+What differs is how a step executes.  The reference runs the backbone twice (mask order a,b then
+b,a), builds the loss with torch ops and lets autograd walk back.  Here both mask orders are packed
+into ONE batch of 2B samples that the engine normalises as two independent BatchNorm groups
+(identical statistics and running-stat updates to two sequential calls), the loss + its logit
+gradient come from one HIP kernel, the backward is ``io_net_backward``, the gradient exchange is one
+flat all-reduce and the update one fused SGD launch -- with no host synchronisation in between.
+"""
+import torch
+import torch.distributed as dist
+
+from . import distributed_utils, engine
+from .single_stage_model import SingleStageModel
+
+
+def _dev(t, dtype=None):
+    t = t.cuda(non_blocking=True)
+    return t.to(dtype) if dtype is not None and t.dtype != dtype else t
+
+
+class _OrderBase(SingleStageModel):
+    """Shared mechanics of the four wrappers; subclasses define labels and loss configuration."""
+
+    KOCC = 0          # occlusion logits (sigmoid + BCE)
+    KDEP = 0          # depth / order-class logits (softmax + CE on the probabilities)
+
+    def __init__(self, params, load_pretrain=None, dist_model=False):
+        super(_OrderBase, self).__init__(params, dist_model)
+        self.params = params
+        self.use_rgb = params.get("use_rgb", False)
+        if not self.use_rgb:
+            raise NotImplementedError("use_rgb=False (2-channel input) is not part of the hot path")
+        self._x8 = None
+        if load_pretrain is not None:
+            self.load_pretrain(load_pretrain)
+
+    # -- inputs ------------------------------------------------------------------------------------
+    def _set_images(self, rgb, modal1, modal2):
+        self.rgb = _dev(rgb, torch.float32).contiguous()
+        self.modal1 = _dev(modal1, torch.float32).contiguous()
+        self.modal2 = _dev(modal2, torch.float32).contiguous()
+        B = self.rgb.shape[0]
+        if self._x8 is None or self._x8.shape[0] != 2 * B or self._x8.shape[1:3] != self.rgb.shape[2:]:
+            self._x8 = None
+        self._x8 = engine.pack_pair_directions(self.rgb, self.modal1, self.modal2, self._x8)
+        self.B = B
+
+    # -- loss plumbing -------------------------------------------------------------------------------
+    def _loss_args(self, training):
+        raise NotImplementedError
+
+    def _loss(self, logits, training, want_grad):
+        kw = self._loss_args(training)
+        return engine.order_loss(logits, self.B, self.KOCC, self.KDEP, inv_world=1.0 / self.world_size,
+                                 want_grad=want_grad, **kw)
+
+    def _logs(self, losses):
+        return None
+
+    def _pack_return(self, losses):
+        logs = self._logs(losses)
+        out = {"loss": losses[0]}
+        return (logs, out) if logs is not None else out
+
+    # -- API -------------------------------------------------------------------------------------------
+    def forward_only(self, ret_loss=True):
+        with torch.no_grad():
+            if self.net.training:
+                logits = self.net.forward_packed(self._x8, groups=2)
+            else:
+                logits = self.net.forward_packed(self._x8, groups=1)
+            self.last_logits = logits
+            if not ret_loss:
+                return {}
+            losses, _ = self._loss(logits, False, False)
+        logs = self._logs(losses)
+        return (logs if logs is not None else {}), {"loss": losses[0]}
+
+    def step(self):
+        net = self.net
+        if not net.training:
+            raise RuntimeError("step() needs switch_to('train')")
+        N = 2 * self.B
+        S = self._x8.shape[1]
+        logits, ws = net._run_forward(self._x8, N, S, 2, True)
+        self.last_logits = logits
+        losses, dlogits = self._loss(logits, True, True)
+        net._run_backward(self._x8, dlogits, N, S, 2, ws)
+        net._pool.give(ws)
+        if self.world_size > 1:
+            distributed_utils.average_gradients(self.model)
+        net.attach_grads()
+        self.optim.step()
+        return self._pack_return(losses)
+
+
+def _mirror_occ(occ_order):
+    return occ_order[:, [1, 0]]
+
+
+def _mirror_classes(order):
+    # 0 <-> 1, anything >= 2 unchanged  (supervised_order.py:39-42, 456-460)
+    return torch.where(order >= 2, order, 1 - order)
+
+
+class InstaOrderNet_o(_OrderBase):
+    """Occlusion order: 2 logits, sigmoid + BCELoss (supervised_order.py:496-548)."""
+    KOCC = 2
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, occ_order=None):
+        self._set_images(rgb, modal1, modal2)
+        self.occ_order1 = _dev(occ_order, torch.float32)
+        self.occ_order2 = _mirror_occ(self.occ_order1)
+        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+
+    def _loss_args(self, training):
+        return dict(occ_target=self._occ_t)
+
+
+class InstaOrderNet_od(_OrderBase):
+    """Joint occlusion (2, BCE) + depth (3, CE on softmax, overlap/distinct weighted) heads
+    (supervised_order.py:18-95); ``step`` returns ``(losses_to_log, {'loss'})``."""
+    KOCC = 2
+    KDEP = 3
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None,
+                  occ_order=None):
+        self._set_images(rgb, modal1, modal2)
+        self.depth_order1 = _dev(depth_order, torch.long)
+        self.depth_order2 = _mirror_classes(self.depth_order1)
+        self.count = _dev(count)
+        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
+        self.occ_order1 = _dev(occ_order, torch.float32)
+        self.occ_order2 = _mirror_occ(self.occ_order1)
+        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0).contiguous()
+
+    def _loss_args(self, training):
+        return dict(occ_target=self._occ_t, depth_target=self._dep_t, is_overlap=self.is_overlap,
+                    overlap_weight=self.params["overlap_weight"], distinct_weight=self.params["distinct_weight"])
+
+    def _logs(self, losses):
+        return {"loss_occ": losses[1], "loss_depth": losses[2]}
+
+
+class InstaOrderNet_d(_OrderBase):
+    """Depth order only: 3 logits, CE on softmax; the TRAINING loss is overlap/distinct weighted but
+    forward_only's is the plain mean (supervised_order.py:370-438 -- reference quirk, kept)."""
+    KDEP = 3
+
+    def __init__(self, params, load_pretrain=None, dist_model=False):
+        super(InstaOrderNet_d, self).__init__(params, load_pretrain, dist_model)
+        self.KDEP = int(params["backbone_param"]["num_classes"])
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None):
+        self._set_images(rgb, modal1, modal2)
+        self.depth_order1 = _dev(depth_order, torch.long)
+        self.depth_order2 = _mirror_classes(self.depth_order1)
+        self.count = _dev(count)
+        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
+        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0).contiguous()
+
+    def _loss_args(self, training):
+        if training:
+            return dict(depth_target=self._dep_t, is_overlap=self.is_overlap,
+                        overlap_weight=self.params["overlap_weight"],
+                        distinct_weight=self.params["distinct_weight"])
+        return dict(depth_target=self._dep_t)
+
+
+class OrderNet(_OrderBase):
+    """PCNet-style order classifier: 3 (or 4, OrderNet_ext) classes, CE on softmax
+    (supervised_order.py:442-493); labels arrive as class ids in ``occ_order``."""
+    KDEP = 3
+
+    def __init__(self, params, load_pretrain=None, dist_model=False):
+        super(OrderNet, self).__init__(params, load_pretrain, dist_model)
+        self.KDEP = int(params["backbone_param"]["num_classes"])
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, occ_order=None):
+        self._set_images(rgb, modal1, modal2)
+        self.occ_order1 = _dev(occ_order, torch.long)
+        self.occ_order2 = _mirror_classes(self.occ_order1)
+        self._dep_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+
+    def _loss_args(self, training):
+        return dict(depth_target=self._dep_t)

@@ -38,7 +38,7 @@ def state_from_numpy(sd, prefix=""):
     for k, v in sd.items():
         if prefix and k.startswith(prefix):
             k = k[len(prefix):]
-        out[k] = torch.from_numpy(np.array(v, copy=True))
+        out[k] = torch.from_numpy(np.array(v, copy=True, order="C"))
     return out
 
 

@@ -194,8 +194,18 @@ def _ws2_worker(rank, world, port, S, B, seed, q):
     install_shims()
     init_dist(rank, world, port)
     algo = "InstaOrderNet_o"
-    # every rank starts from DIFFERENT weights; DistModule must broadcast rank 0's
-    m, cfg = build(algo, seed + rank * 7)
+    # every rank is CONSTRUCTED with different weights (the reference initialises randomly inside
+    # SingleStageModel.__init__, before DistModule wraps the net); DistModule must broadcast rank 0's.
+    import models
+    import utils as ref_utils
+    sd = synthetic.make_state_dict(seed + rank * 7, 5, 2)
+
+    def seeded_init(net, init_type="xavier", init_gain=0.02):
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+
+    ref_utils.init_weights = seeded_init
+    cfg = model_cfg(algo)
+    m = getattr(models, algo)(cfg, dist_model=True)
     batch = synthetic.make_pair_batch(seed + 200 + rank, B, S)
     m.switch_to("train")
     set_input(m, algo, batch)

@@ -1,0 +1,328 @@
+"""Per-kernel parity: every HIP entry point of include/instaorder_hip.h, called through the C ABI
+(ctypes), against the plain torch op the reference uses at that site, evaluated in fp64 on the CPU
+on the same seeded inputs.  Tolerance for fp32 GEMM-like kernels: 2e-5 of the output scale (the
+north-star bar is 1e-3; single kernels are far inside it)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from instaorder_amd import _lib, engine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def ST():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def L():
+    return _lib.lib()
+
+
+def nhwc(x):     # NCHW cpu -> NHWC cuda fp32
+    return x.permute(0, 2, 3, 1).contiguous().float().to(DEV)
+
+
+def krsc(w, cin_store=None):   # OIHW -> [O][R*S][C] cuda
+    O, I, R, S = w.shape
+    k = w.permute(0, 2, 3, 1).contiguous().float()
+    if cin_store and cin_store != I:
+        pad = torch.zeros(O, R, S, cin_store - I)
+        k = torch.cat([k, pad], 3).contiguous()
+    return k.to(DEV)
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (3, 10, 14, 64, 256, 1, 1, 0),      # M not a multiple of the 128-row tile
+    (2, 16, 16, 256, 64, 1, 1, 0),
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 12, 20, 128, 128, 3, 2, 1),
+    (1, 9, 9, 128, 128, 3, 1, 1),       # odd spatial size, M < tile
+    (2, 16, 16, 256, 512, 1, 2, 0),     # strided 1x1 downsample
+    (2, 8, 8, 512, 2048, 1, 1, 0),
+    (1, 8, 8, 512, 512, 3, 1, 1),
+]
+
+
+def _conv_inputs(case, seed=0):
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)
+    return x, w
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case):
+    N, H, W, Cin, Cout, k, s, p = case
+    x, w = _conv_inputs(case)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    y = torch.full((N, ref.shape[2], ref.shape[3], Cout), float("nan"), device=DEV)
+    _lib.check(L().io_conv2d_fwd(P(nhwc(x)), P(krsc(w)), P(y), N, H, W, Cin, Cout, k, k, s, p, ST()), "conv")
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(case):
+    N, H, W, Cin, Cout, k, s, p = case
+    x, w = _conv_inputs(case, 1)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    ref = torch.autograd.grad(y, x, dy)[0]
+    wk = krsc(w)
+    wt = torch.empty(Cin, k * k, Cout, device=DEV)
+    _lib.check(L().io_filter_transpose(P(wk), Cout, k * k, Cin, P(wt), ST()), "transpose")
+    assert torch.equal(wt.cpu(), wk.cpu().view(Cout, k * k, Cin).permute(2, 1, 0).contiguous())
+    dx = torch.full((N, H, W, Cin), float("nan"), device=DEV)
+    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(dx), None, N, H, W, Cin, Cout, k, k, s, p, ST()), "dgrad")
+    assert relerr(dx.permute(0, 3, 1, 2), ref) < 2e-5
+    # with accumulation into an existing tensor (residual / downsample sum), in place
+    base = torch.randn(N, H, W, Cin, generator=torch.Generator().manual_seed(9)).to(DEV)
+    acc = base.clone()
+    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(acc), P(acc), N, H, W, Cin, Cout, k, k, s, p, ST()),
+               "dgrad+add")
+    assert relerr(acc.permute(0, 3, 1, 2), ref + base.cpu().double().permute(0, 3, 1, 2)) < 2e-5
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case):
+    N, H, W, Cin, Cout, k, s, p = case
+    x, w = _conv_inputs(case, 2)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    ref = torch.autograd.grad(y, w, dy)[0]
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, k, k, s, p)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((Cout, k * k, Cin), float("nan"), device=DEV)
+    _lib.check(L().io_conv2d_wgrad(P(nhwc(x)), P(nhwc(dy)), P(dw), N, H, W, Cin, Cout, k, k, s, p, P(ws), nb, ST()),
+               "wgrad")
+    got = dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert relerr(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("N,S", [(2, 64), (1, 40)])
+def test_stem(N, S):
+    """7x7/2 conv on the 5-channel (mask_a, mask_b, R, G, B) input stored with 8 channels."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 5, S, S, generator=g, dtype=torch.float64)
+    w = (torch.randn(64, 5, 7, 7, generator=g, dtype=torch.float64) / 15.0).requires_grad_(True)
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    x8 = engine.pack_nchw(x.float().to(DEV))
+    assert torch.equal(x8[..., :5].cpu(), x.float().permute(0, 2, 3, 1)) and float(x8[..., 5:].abs().max()) == 0
+    Ho = ref.shape[2]
+    y = torch.full((N, Ho, Ho, 64), float("nan"), device=DEV)
+    _lib.check(L().io_conv2d_fwd(P(x8), P(krsc(w.detach(), 8)), P(y), N, S, S, 8, 64, 7, 7, 2, 3, ST()), "stem")
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gref = torch.autograd.grad(ref, w, dy)[0]
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, S, S, 8, 64, 7, 7, 2, 3)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 49, 8), float("nan"), device=DEV)
+    _lib.check(L().io_conv2d_wgrad(P(x8), P(nhwc(dy)), P(dw), N, S, S, 8, 64, 7, 7, 2, 3, P(ws), nb, ST()), "stem wg")
+    got = dw.view(64, 7, 7, 8).permute(0, 3, 1, 2)
+    assert relerr(got[:, :5], gref) < 2e-5
+    assert float(got[:, 5:].abs().max()) == 0.0      # padded channels never receive gradient
+
+
+@pytest.mark.parametrize("N,H,C,G", [(4, 8, 64, 1), (4, 8, 256, 2), (6, 4, 2048, 2), (2, 16, 128, 1), (8, 1, 512, 2)])
+def test_batchnorm(N, H, C, G):
+    """train-mode BN (+ReLU, + residual) forward, running statistics, backward; G groups == G
+    independent nn.BatchNorm2d calls on consecutive sample groups."""
+    g = torch.Generator().manual_seed(C + G)
+    x = (torch.randn(N, C, H, H, generator=g, dtype=torch.float64) * 0.3 + 0.2)
+    idt = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm0 = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rv0 = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    xr = x.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    outs = []
+    for gi in range(G):
+        sl = slice(gi * N // G, (gi + 1) * N // G)
+        outs.append(F.batch_norm(xr[sl], rm, rv, gamma, beta, True, 0.1, 1e-5))
+    pre = torch.cat(outs, 0)
+    ref = F.relu(pre + idt)
+    dout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gx, gg, gb = torch.autograd.grad(ref, [xr, gamma, beta], dout)
+
+    M = N * H * H
+    y = nhwc(x)
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    d_rm, d_rv = f(rm0), f(rv0)
+    mean, rstd, scale, shift = (torch.empty(G * C, device=DEV) for _ in range(4))
+    npart = L().io_bn_partial_floats(M, C, G)
+    part = torch.empty(npart, device=DEV)
+    _lib.check(L().io_bn_stats_finalize(P(y), M, C, G, P(f(gamma)), P(f(beta)), P(d_rm), P(d_rv), 0.1, 1e-5, P(mean),
+                                        P(rstd), P(scale), P(shift), P(part), npart, ST()), "bn_stats")
+    assert relerr(d_rm, rm) < 1e-5 and relerr(d_rv, rv) < 1e-5
+    out = torch.empty_like(y)
+    _lib.check(L().io_bn_apply(P(y), M, C, G, 1, P(scale), P(shift), P(nhwc(idt)), None, None, 1, P(out), ST()),
+               "bn_apply")
+    assert relerr(out.permute(0, 3, 1, 2), ref) < 1e-5
+    # backward (ReLU mask taken from the stored output)
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy, dz = torch.empty_like(y), torch.empty_like(y)
+    coef = torch.empty(2 * G * C, device=DEV)
+    _lib.check(L().io_bn_bwd(P(nhwc(dout)), P(out), P(y), M, C, G, P(f(gamma)), P(mean), P(rstd), P(dgam), P(dbet),
+                             P(dy), P(dz), P(part), npart, P(coef), ST()), "bn_bwd")
+    assert relerr(dy.permute(0, 3, 1, 2), gx) < 2e-5
+    assert relerr(dgam, gg) < 2e-5 and relerr(dbet, gb) < 2e-5
+    assert relerr(dz.permute(0, 3, 1, 2), dout * (ref > 0)) < 1e-6
+
+
+def test_batchnorm_eval_and_downsample_mode():
+    g = torch.Generator().manual_seed(1)
+    N, C, H = 3, 256, 4
+    x = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    xd = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    par = [torch.rand(C, generator=g, dtype=torch.float64) + 0.5 for _ in range(8)]
+    ga, be, rm, rv, ga2, be2, rm2, rv2 = par
+    ref = F.relu(F.batch_norm(x, rm, rv, ga, be, False, 0.1, 1e-5) + F.batch_norm(xd, rm2, rv2, ga2, be2, False, 0.1, 1e-5))
+    f = lambda t: t.float().to(DEV).contiguous()
+    sc, sh, sc2, sh2 = (torch.empty(C, device=DEV) for _ in range(4))
+    _lib.check(L().io_bn_eval_prepare(C, P(f(ga)), P(f(be)), P(f(rm)), P(f(rv)), 1e-5, P(sc), P(sh), ST()), "prep")
+    _lib.check(L().io_bn_eval_prepare(C, P(f(ga2)), P(f(be2)), P(f(rm2)), P(f(rv2)), 1e-5, P(sc2), P(sh2), ST()), "prep")
+    out = torch.empty(N, H, H, C, device=DEV)
+    _lib.check(L().io_bn_apply(P(nhwc(x)), N * H * H, C, 1, 0, P(sc), P(sh), P(nhwc(xd)), P(sc2), P(sh2), 1, P(out),
+                               ST()), "apply2")
+    assert relerr(out.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 16), (1, 10, 14)])
+def test_maxpool(N, H, W):
+    g = torch.Generator().manual_seed(2)
+    x = F.relu(torch.randn(N, 64, H, W, generator=g, dtype=torch.float64)).requires_grad_(True)   # many exact ties at 0
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    gref = torch.autograd.grad(ref, x, dy)[0]
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty(N, Ho, Wo, 64, device=DEV)
+    idx = torch.empty(N * Ho * Wo * 16, dtype=torch.int32, device=DEV)
+    _lib.check(L().io_maxpool_fwd(P(nhwc(x.detach())), N, H, W, 64, P(out), P(idx), ST()), "maxpool")
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref.detach().float())
+    dx = torch.empty(N, H, W, 64, device=DEV)
+    _lib.check(L().io_maxpool_bwd(P(nhwc(dy)), P(idx), N, H, W, 64, P(dx), ST()), "maxpool_bwd")
+    # where the window maximum is an exact tie, only positions with x > 0 matter downstream (ReLU)
+    m = (x.detach() > 0)
+    assert relerr(dx.permute(0, 3, 1, 2).cpu() * m, gref * m) < 1e-6
+    assert abs(float(dx.sum()) - float(dy.sum())) < 1e-3 * float(dy.abs().sum())
+
+
+@pytest.mark.parametrize("heads", [[2], [2, 3], [4]])
+def test_avgpool_fc(heads):
+    g = torch.Generator().manual_seed(4)
+    N, HW, Cc = 5, 4, 2048
+    x = torch.randn(N, Cc, 2, 2, generator=g, dtype=torch.float64).requires_grad_(True)
+    ws = [torch.randn(k, Cc, generator=g, dtype=torch.float64).requires_grad_(True) for k in heads]
+    bs = [torch.randn(k, generator=g, dtype=torch.float64).requires_grad_(True) for k in heads]
+    pooled = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+    ref = torch.cat([F.linear(pooled, w, b) for w, b in zip(ws, bs)], 1)
+    dl = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    grads = torch.autograd.grad(ref, [x] + ws + bs, dl)
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    K0, K1 = heads[0], (heads[1] if len(heads) > 1 else 0)
+    dw = [f(w) for w in ws]
+    db = [f(b) for b in bs]
+    pl = torch.empty(N, Cc, device=DEV)
+    lg = torch.empty(N, K0 + K1, device=DEV)
+    _lib.check(L().io_avgpool_fc_fwd(P(nhwc(x.detach())), N, HW, Cc, P(dw[0]), P(db[0]), K0, P(dw[1]) if K1 else None,
+                                     P(db[1]) if K1 else None, K1, P(pl), P(lg), ST()), "head")
+    assert relerr(lg, ref) < 1e-5 and relerr(pl, pooled) < 1e-6
+    dx = torch.empty(N, 2, 2, Cc, device=DEV)
+    gw = [torch.empty_like(w) for w in dw]
+    gb = [torch.empty_like(b) for b in db]
+    _lib.check(L().io_avgpool_fc_bwd(P(f(dl)), P(pl), N, HW, Cc, P(dw[0]), K0, P(dw[1]) if K1 else None, K1, P(dx),
+                                     P(gw[0]), P(gb[0]), P(gw[1]) if K1 else None, P(gb[1]) if K1 else None, ST()),
+               "head bwd")
+    assert relerr(dx.permute(0, 3, 1, 2), grads[0]) < 1e-5
+    for i in range(len(heads)):
+        assert relerr(gw[i], grads[1 + i]) < 1e-5
+        assert relerr(gb[i], grads[1 + len(heads) + i]) < 1e-5
+
+
+def _ref_losses(z, B, Kocc, Kdep, occ_t, dep_t, ov, w_ov, w_di, inv_world):
+    z = z.clone().requires_grad_(True)
+    l_occ = torch.zeros((), dtype=torch.float64)
+    l_dep = torch.zeros((), dtype=torch.float64)
+    for d in range(z.shape[0] // B):
+        sl = slice(d * B, (d + 1) * B)
+        if Kocc:
+            l_occ = l_occ + F.binary_cross_entropy(torch.sigmoid(z[sl, :Kocc]), occ_t[sl])
+        if Kdep:
+            q = F.softmax(z[sl, Kocc:], 1)
+            if ov is None:
+                l_dep = l_dep + F.cross_entropy(q, dep_t[sl])
+            else:
+                for msk, wgt in ((ov == 1, w_ov), (ov == 0, w_di)):
+                    if int(msk.sum()) > 0:
+                        l_dep = l_dep + wgt * F.cross_entropy(q[msk], dep_t[sl][msk])
+    tot = (l_occ + l_dep) * inv_world
+    return tot, l_occ, l_dep, torch.autograd.grad(tot, z)[0]
+
+
+@pytest.mark.parametrize("Kocc,Kdep,weighted,B", [(2, 0, False, 7), (2, 3, True, 9), (0, 3, True, 6), (0, 3, False, 6),
+                                                  (0, 4, False, 5), (2, 3, True, 300)])
+def test_order_loss(Kocc, Kdep, weighted, B):
+    g = torch.Generator().manual_seed(B)
+    N = 2 * B
+    z = torch.randn(N, Kocc + Kdep, generator=g, dtype=torch.float64) * 2
+    occ_t = (torch.rand(N, 2, generator=g) < 0.4).double()
+    dep_t = torch.randint(0, max(Kdep, 1), (N,), generator=g)
+    ov = (torch.rand(B, generator=g) < 0.5).long() if weighted else None
+    tot, lo, ld, dz = _ref_losses(z, B, Kocc, Kdep, occ_t, dep_t, ov, 0.1, 0.9, 0.5)
+    losses, dl = engine.order_loss(z.float().to(DEV), B, Kocc, Kdep, occ_t.float().to(DEV), dep_t.to(DEV),
+                                   ov.to(DEV) if weighted else None, 0.1, 0.9, 0.5, True)
+    got = losses.cpu().double()
+    assert abs(got[0] - tot) < 2e-6 * max(1, abs(float(tot)))
+    assert abs(got[1] - lo) < 2e-6 * max(1, abs(float(lo))) and abs(got[2] - ld) < 2e-6 * max(1, abs(float(ld)))
+    assert relerr(dl, dz) < 1e-5
+
+
+def test_order_loss_subset_empty_and_saturated():
+    """all pairs 'distinct' (overlap subset empty -> skipped), and saturated logits (BCE log clamp)."""
+    B = 4
+    z = torch.tensor([[60.0, -60.0, 1.0, 0.0, -1.0]] * (2 * B), dtype=torch.float64)
+    occ_t = torch.tensor([[0.0, 1.0]] * (2 * B), dtype=torch.float64)
+    dep_t = torch.zeros(2 * B, dtype=torch.long)
+    ov = torch.zeros(B, dtype=torch.long)
+    tot, lo, ld, dz = _ref_losses(z.float().double(), B, 2, 3, occ_t, dep_t, ov, 0.1, 0.9, 1.0)
+    losses, dl = engine.order_loss(z.float().to(DEV), B, 2, 3, occ_t.float().to(DEV), dep_t.to(DEV), ov.to(DEV), 0.1,
+                                   0.9, 1.0, True)
+    # fp32 sigmoid saturates to exactly 0/1 at +-60 -> the reference's fp32 path clamps log at -100
+    ref32 = F.binary_cross_entropy(torch.sigmoid(z[:B, :2].float()), occ_t[:B].float()) * 2
+    assert abs(float(losses[1]) - float(ref32)) < 1e-3
+    assert abs(float(losses[2]) - float(ld)) < 1e-5
+    assert torch.isfinite(dl).all()
+
+
+def test_sgd_momentum():
+    g = torch.Generator().manual_seed(8)
+    n = 4096 + 64
+    p0 = torch.randn(n, generator=g)
+    par = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([par], lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    dp, buf = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    for it in range(3):
+        gr = torch.randn(n, generator=g)
+        par.grad = gr.clone()
+        opt.step()
+        engine.sgd_momentum(dp, gr.to(DEV), buf, 1e-2, 0.9, 1e-3)
+    assert relerr(dp, par.detach()) < 1e-6

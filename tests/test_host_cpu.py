@@ -1,0 +1,218 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/instaorder_hip.h declares, and the
+host-side logic of the package (parameter layout, state_dict contract, optimiser/scheduler contract,
+samplers, decision rules, metrics, label mirroring).  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, load_golden, orc, synthetic
+from instaorder_amd import _lib, distributed_utils, inference, optim, resnet_cls, scheduler, supervised_order
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "instaorder_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(io_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), "missing symbol " + name
+        assert name in _lib.SIGNATURES, "no ctypes signature for " + name
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.io_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert _lib.lib().io_device_count() == 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.require_gpu()
+    net = resnet_cls.resnet50_cls(in_channels=5, num_classes=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 5, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.forward_packed(torch.zeros(1, 64, 64, 8))
+
+
+@pytest.mark.parametrize("nc", [2, 3, 4, [2, 3]])
+def test_state_dict_contract(nc):
+    """Keys, order, logical shapes = the reference module's (pinned through synthetic.state_specs, whose
+    names the reference-generated goldens carry) and the flat storage is KRSC with the stem padded to 8."""
+    net = resnet_cls.resnet50_cls(in_channels=5, num_classes=nc)
+    specs = synthetic.state_specs(5, nc)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [n for n, _, _ in specs]
+    for (n, shape, kind), v in zip(specs, sd.values()):
+        assert tuple(v.shape) == tuple(shape), n
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [n for n, _, k in specs if not k.startswith("bn_m") and k not in ("bn_var", "bn_count")]
+    n_par = sum(p.numel() for p in net.parameters())
+    assert n_par == {2: 23518402, 3: 23520451, 4: 23522500}.get(nc if not isinstance(nc, list) else -1, 23524549)
+    src = synthetic.make_state_dict(3, 5, nc)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in src.items()}, strict=True)
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), src[k]), k
+    flat = net.flat_params
+    for t in net.plan.tensors:
+        if t["kind"] == 0:
+            O, I, R, S = t["shape"]
+            cs = t["cin_storage"]
+            st = flat[t["offset"]:t["offset"] + O * R * S * cs].view(O, R, S, cs).numpy()
+            w = src[t["name"]]
+            assert np.array_equal(st[..., :I], w.transpose(0, 2, 3, 1)), t["name"]
+            assert (st[..., I:] == 0).all()
+        assert t["offset"] % 64 == 0
+    g = load_golden("o_S64_B4" if nc == 2 else "od_S64_B6") if nc in (2, [2, 3]) else None
+    if g is not None:
+        assert list(g["names"]) == ["module." + n for n in names]
+
+
+def test_module_moves_keep_flat_sharing():
+    net = resnet_cls.resnet50_cls(in_channels=5, num_classes=2)
+    net.float()
+    p = net.conv1.weight
+    assert p.data_ptr() >= net.flat_params.data_ptr()
+    with torch.no_grad():
+        net.flat_params.zero_()
+    assert float(p.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        net.half()
+    wrapped = distributed_utils.DistModule.__new__(distributed_utils.DistModule)
+    torch.nn.Module.__init__(wrapped)
+    wrapped.module = net
+    assert list(wrapped.state_dict().keys())[0] == "module.conv1.weight"
+    wrapped.train(False)
+    assert not net.training
+
+
+def test_fused_sgd_is_a_torch_optimizer_with_sgd_checkpoint_layout():
+    net = resnet_cls.resnet50_cls(in_channels=5, num_classes=[2, 3])
+    opt = optim.FusedSGD(net, lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+    assert len(opt.param_groups[0]["params"]) == 163
+    sch = scheduler.StepLRScheduler(opt, [2, 4], [0.1, 0.1], 1e-4, [], [], -1)
+    sch.step(3)
+    assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-18
+    # a torch.optim.SGD checkpoint (the reference's format) loads into the flat momentum buffer
+    ref_params = [torch.nn.Parameter(p.detach().clone().contiguous()) for p in net.parameters()]
+    ref = torch.optim.SGD(ref_params, lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    for p in ref_params:
+        p.grad = torch.full_like(p, 0.5)
+    ref.step()
+    opt.load_state_dict(ref.state_dict())
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == 163
+    assert sd["param_groups"][0]["params"] == list(range(163))
+    for i, p in enumerate(ref_params):
+        assert torch.equal(sd["state"][i]["momentum_buffer"], ref.state[p]["momentum_buffer"])
+    assert sd["param_groups"][0]["momentum"] == 0.9 and sd["param_groups"][0]["weight_decay"] == 1e-4
+
+
+def test_scheduler_matches_reference_golden():
+    g = load_golden("scheduler")
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(p, lr=0.001, momentum=0.9)
+    s = scheduler.StepLRScheduler(opt, [32000, 48000], [0.1, 0.1], 0.001, [], [], -1)
+    for it, lr in zip(g["its"], g["lrs_plain"]):
+        s.step(int(it))
+        assert opt.param_groups[0]["lr"] == lr
+    opt = torch.optim.SGD(p, lr=0.001, momentum=0.9)
+    s = scheduler.StepLRScheduler(opt, [300, 600], [0.1, 0.5], 0.001, [0.004, 0.01], [50, 200], -1)
+    for it, lr in zip(g["its_warm"], g["lrs_warm"]):
+        s.step(int(it))
+        assert opt.param_groups[0]["lr"] == lr
+    with pytest.raises(TypeError):
+        scheduler.StepLRScheduler(object(), [1], [0.1], 0.1, [], [])
+    with pytest.raises(KeyError):
+        scheduler.StepLRScheduler(torch.optim.SGD(p, lr=0.1), [1], [0.1], 0.1, [], [], last_iter=5)
+
+
+def test_samplers():
+    data = list(range(103))
+    parts = [distributed_utils.DistributedGivenIterationSampler(data, 5, 4, world_size=3, rank=r) for r in range(3)]
+    idx = [np.asarray(list(iter(p))) for p in parts]
+    assert all(len(i) == 20 for i in idx)
+    np.random.seed(0)
+    full = np.arange(103)[:60]
+    np.random.shuffle(full)
+    assert np.array_equal(np.concatenate(idx), full)           # same global shuffle, contiguous slices
+    with pytest.raises(RuntimeError):
+        iter(parts[0])
+    resumed = distributed_utils.DistributedGivenIterationSampler(data, 5, 4, world_size=3, rank=1, last_iter=1)
+    assert np.array_equal(np.asarray(list(iter(resumed))), idx[1][8:])
+    # more samples requested than the dataset holds: tiled
+    big = distributed_utils.DistributedGivenIterationSampler(list(range(7)), 3, 4, world_size=2, rank=1)
+    assert len(list(iter(big))) == 12 and max(big.indices) < 7
+    seq = [distributed_utils.DistributedSequentialSampler(list(range(10)), world_size=4, rank=r) for r in range(4)]
+    got = [list(iter(s)) for s in seq]
+    assert got == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 0, 1]]
+    for total, world in [(190, 8), (3, 2), (12, 8), (1, 4)]:
+        cover = []
+        for r in range(world):
+            b, e, sub = distributed_utils.shard_range(total, world, r)
+            cover += [k % total for k in range(b, e)]
+        assert set(cover) == set(range(total)) and len(cover) == sub * world
+
+
+def test_decision_rules_match_reference_golden():
+    g = load_golden("decisions")
+    l1 = torch.from_numpy(np.concatenate([g["occ1"], g["dep1"]], 1))
+    l2 = torch.from_numpy(np.concatenate([g["occ2"], g["dep2"]], 1))
+    d = inference.decide(l1, l2, 2, 3)
+    assert (d["i_over_j"].numpy().astype(np.int64) == g["res_od"][:, 1]).all()
+    assert (d["j_over_i"].numpy().astype(np.int64) == g["res_od"][:, 2]).all()
+    assert (d["depth"].numpy() == g["res_od"][:, 0]).all()
+    d = inference.decide(l1[:, :2], l2[:, :2], 2, 0)
+    assert (d["i_over_j"].numpy().astype(np.int64) == g["res_o"][:, 0]).all()
+    d = inference.decide(l1[:, 2:], l2[:, 2:], 0, 3)
+    assert (d["depth"].numpy() == g["res_d"]).all()
+    m = inference.decision_margins(torch.cat([l1, l2], 1), "InstaOrderNet_od")
+    assert m["occ"].shape == (64, 2) and m["depth"].shape == (64,) and m["occ"][1].max() == 0.0
+
+
+def test_metrics_match_oracle_and_reference_golden():
+    rng = np.random.RandomState(0)
+    for n in (3, 5, 20):
+        gt = rng.randint(-1, 2, (n, n))
+        pr = rng.randint(0, 2, (n, n))
+        assert np.allclose(inference.eval_order_recall_precision_f1(pr, gt, 0), orc.recall_precision_f1(pr, gt, 0))
+        gd, ov, cnt, od = rng.randint(0, 3, (n, n)), rng.randint(0, 2, (n, n)), rng.randint(1, 4, (n, n)), rng.randint(0, 3, (n, n))
+        a, b = inference.eval_depth_order_whdr(od, (gd, ov, cnt)), orc.whdr(od, gd, ov, cnt)
+        assert all(abs(a[k][0] - b[k]) < 1e-9 for k in b)
+    assert inference.eval_order_recall_precision_f1(np.zeros((2, 2), int), np.zeros((2, 2), int), 0) == (0, 0, 0)
+    g = load_golden("plumbing_od")
+    items = synthetic.make_images(int(g["meta"][3]) + 400, int(g["meta"][1]), int(g["meta"][2]), int(g["meta"][0]))
+    for ii, item in enumerate(items):
+        assert np.allclose(inference.eval_order_recall_precision_f1(g["occ_%d" % ii], item["gt_occ"], 0), g["prf_%d" % ii])
+        w = inference.eval_depth_order_whdr(g["depth_%d" % ii], (item["gt_depth"], item["gt_overlap"], item["gt_count"]))
+        assert np.allclose([w[str(k)][0] for k in g["whdr_keys"]], g["whdr_%d" % ii])
+
+
+def test_label_mirroring():
+    occ = torch.tensor([[0., 1.], [1., 0.], [1., 1.]])
+    assert torch.equal(supervised_order._mirror_occ(occ), torch.tensor([[1., 0.], [0., 1.], [1., 1.]]))
+    cls = torch.tensor([0, 1, 2, 3, 1])
+    assert torch.equal(supervised_order._mirror_classes(cls), torch.tensor([1, 0, 2, 3, 0]))
+    assert torch.equal(supervised_order._mirror_classes(cls), orc.mirror_depth(cls))
+
+
+def test_package_surface():
+    import instaorder_amd as ia
+    for name in ("InstaOrderNet_o", "InstaOrderNet_od", "InstaOrderNet_d", "OrderNet", "SingleStageModel"):
+        assert callable(getattr(ia, name))
+    assert callable(ia.backbone.resnet50_cls) and callable(ia.utils.average_gradients)
+    assert callable(ia.utils.StepLRScheduler) and callable(ia.utils.DistModule) and callable(ia.utils.init_weights)
+    with pytest.raises(NotImplementedError):
+        ia.SingleStageModel({"algo": "InstaDepthNet_od"})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "instaorder_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
