@@ -61,20 +61,22 @@ int io_filter_transpose(const float* w, int Cout, int taps, int Cin, float* wt, 
 /* ---- BatchNorm2d (resnet_cls.py:142, :87-92, :189), G independent statistic groups ----------- */
 size_t io_bn_partial_floats(int M, int C, int G);
 /* training statistics of y[M][C] (M = N*H*W rows, G consecutive equal groups): writes per-group
- * mean, rstd, scale = gamma*rstd, shift = beta - mean*scale ([G][C] each) and advances the running
+ * mean, rstd, scale = gamma*rstd, shift = beta ([G][C] each) and advances the running
  * estimates once per group, in group order (momentum 0.1 / unbiased variance in the reference). */
 int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, float eps, float* mean,
                          float* rstd, float* scale, float* shift, float* partial, size_t partial_floats,
                          hipStream_t stream);
-/* eval mode: scale/shift [C] from the running estimates */
+/* eval mode: mean/scale/shift [C] from the running estimates */
 int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
-/* out = [relu]( y*scale + shift  [+ identity | + identity*scale2 + shift2] ): BN (+ residual add of
- * Bottleneck.forward, resnet_cls.py:96-116, with or without the downsample BN) (+ nn.ReLU). */
-int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* scale, const float* shift,
-                const float* identity, const float* scale2, const float* shift2, int relu, float* out,
-                hipStream_t stream);
+                       const float* running_var, float eps, float* mean, float* scale, float* shift,
+                       hipStream_t stream);
+/* out = [relu]( (y-mean)*scale + shift  [+ identity | + (identity-mean2)*scale2 + shift2] ): BN
+ * (+ residual add of Bottleneck.forward, resnet_cls.py:96-116, with or without the downsample BN)
+ * (+ nn.ReLU). */
+int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
+                const float* shift, const float* identity, const float* mean2, const float* scale2,
+                const float* shift2, int relu, float* out, hipStream_t stream);
 /* backward of [ReLU o] BN: dz = dout*[act>0] (act NULL: no ReLU), dgamma/dbeta [C] summed over groups,
  * dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional, may alias dout) gets dz.
  * coef: 2*G*C floats of scratch. */

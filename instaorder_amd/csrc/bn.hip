@@ -59,57 +59,75 @@ __device__ __forceinline__ void reduce_rows_store(const ColMap& cm, f32x4 (&s0)[
 }
 
 // ---- forward statistics --------------------------------------------------------------------
-// grid (nb, G): block b of group g reduces rows [g*Mg + b*rpb, ...) -> partial[(g*nb+b)*C + c]
+// grid (nb, G): block b of group g reduces rows [g*Mg + b*rpb, ...).  Sums are taken of d = x - pivot
+// with pivot = the block's first row (per channel): conv outputs whose |mean| >> std would otherwise
+// lose the variance in E[x^2] - E[x]^2.  Partials: sum d, sum d^2, pivot, per (g, b, c); merged in
+// fp64 with the pairwise (Chan) update -- the same robustness as the reference's two-pass CPU kernel.
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, int Mg, int C, int rpb,
-                                                           float* __restrict__ psum, float* __restrict__ psq) {
+                                                           float* __restrict__ psum, float* __restrict__ psq,
+                                                           float* __restrict__ ppiv) {
     const int C4 = C >> 2;
     const ColMap cm = col_map(C4);
     const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
     const float* xg = x + (size_t)g * Mg * C;
-    f32x4 s[2], ss[2];
-    for (int i = 0; i < 2; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    f32x4 s[2], ss[2], pv[2];
+    for (int i = 0; i < 2; ++i) {
+        s[i] = 0.f; ss[i] = 0.f; pv[i] = 0.f;
+        const int q = cm.tx + cm.TX * i;
+        if (i < cm.nq && q < C4) pv[i] = ld4(xg + (size_t)r0 * C + q * 4);
+    }
     for (int r = r0 + cm.ty; r < r1; r += cm.TY) {
         const float* row = xg + (size_t)r * C;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = cm.tx + cm.TX * i;
             if (i < cm.nq && q < C4) {
-                const f32x4 v = ld4(row + q * 4);
+                const f32x4 v = ld4(row + q * 4) - pv[i];
                 s[i] += v;
                 ss[i] += v * v;
             }
         }
     }
     const size_t o = ((size_t)g * nb + b) * C;
+    if (cm.ty == 0)
+        for (int i = 0; i < 2; ++i) {
+            const int q = cm.tx + cm.TX * i;
+            if (i < cm.nq && q < C4) st4(ppiv + o + q * 4, pv[i]);
+        }
     reduce_rows_store<2>(cm, s, ss, psum + o, psq + o, C4);
 }
 
 // one thread per channel; loops groups in order so running stats see group 0 then group 1 ...
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nb, int G,
-                                   int Mg, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, float momentum, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd,
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                   const float* __restrict__ ppiv, int nb, int rpb, int G, int Mg, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                   float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
+        double n = 0.0, mu = 0.0, m2 = 0.0;
         for (int b = 0; b < nb; ++b) {
-            s += (double)psum[((size_t)g * nb + b) * C + c];
-            q += (double)psq[((size_t)g * nb + b) * C + c];
+            const size_t o = ((size_t)g * nb + b) * C + c;
+            const double nbk = (double)(min((b + 1) * rpb, Mg) - b * rpb);
+            const double sd = (double)psum[o], sq = (double)psq[o];
+            const double mb = (double)ppiv[o] + sd / nbk;
+            const double m2b = sq - sd * sd / nbk;
+            const double tot = n + nbk, delta = mb - mu;
+            mu += delta * (nbk / tot);
+            m2 += m2b + delta * delta * (n * nbk / tot);
+            n = tot;
         }
-        const double mu = s / Mg;
-        double var = q / Mg - mu * mu;
+        double var = m2 / Mg;
         if (var < 0.0) var = 0.0;
         const float r = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * r;
         mean[g * C + c] = (float)mu;
         rstd[g * C + c] = r;
-        scale[g * C + c] = sc;
-        shift[g * C + c] = beta[c] - (float)mu * sc;
+        scale[g * C + c] = gamma[c] * r;
+        shift[g * C + c] = beta[c];
         const float unb = (float)(Mg > 1 ? var * ((double)Mg / (double)(Mg - 1)) : var);
         rm = (1.f - momentum) * rm + momentum * (float)mu;
         rv = (1.f - momentum) * rv + momentum * unb;
@@ -118,27 +136,27 @@ __global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* 
     if (run_var) run_var[c] = rv;
 }
 
-// eval mode: scale/shift from the running statistics (one "group")
+// eval mode: tables from the running statistics (one "group")
 __global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ run_mean, const float* __restrict__ run_var,
-                                       float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                       float eps, float* __restrict__ mean, float* __restrict__ scale,
+                                       float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float sc = gamma[c] / sqrtf(run_var[c] + eps);
-    scale[c] = sc;
-    shift[c] = beta[c] - run_mean[c] * sc;
+    mean[c] = run_mean[c];
+    scale[c] = gamma[c] / sqrtf(run_var[c] + eps);
+    shift[c] = beta[c];
 }
 
-// ---- apply: out = [relu]( y*scale+shift  (+ id | + yd*scale2+shift2) ) ------------------------
-// sg = stride (in channels) between groups of the scale/shift tables: C in training, 0 in eval.
+// ---- apply: out = [relu]( (y-mean)*scale+shift  (+ id | + (yd-mean2)*scale2+shift2) ) -----------
+// sg = stride (in channels) between groups of the tables: C in training, 0 in eval.
+struct BnTab {
+    const float *mean, *scale, *shift;
+};
 template <int MODE>   // 0 none, 1 identity tensor, 2 second BN (downsample branch)
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, size_t total4, int c4shift,
-                                                           int Mg, int sg, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift,
-                                                           const float* __restrict__ idt,
-                                                           const float* __restrict__ scale2,
-                                                           const float* __restrict__ shift2, int relu,
-                                                           float* __restrict__ out) {
+                                                           int Mg, int sg, BnTab t, const float* __restrict__ idt,
+                                                           BnTab t2, int relu, float* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int c4mask = (1 << c4shift) - 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -146,9 +164,9 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
         const size_t row = i >> c4shift;
         const int g = (int)(row / Mg);
         const int co = g * sg + q * 4;
-        f32x4 v = ld4(y + i * 4) * ld4(scale + co) + ld4(shift + co);
+        f32x4 v = (ld4(y + i * 4) - ld4(t.mean + co)) * ld4(t.scale + co) + ld4(t.shift + co);
         if (MODE == 1) v += ld4(idt + i * 4);
-        if (MODE == 2) v += ld4(idt + i * 4) * ld4(scale2 + co) + ld4(shift2 + co);
+        if (MODE == 2) v += (ld4(idt + i * 4) - ld4(t2.mean + co)) * ld4(t2.scale + co) + ld4(t2.shift + co);
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -280,14 +298,14 @@ extern "C" size_t io_bn_partial_floats(int M, int C, int G) {
     if (M <= 0 || G <= 0) return 0;
     int nb;
     bn_rows_per_block(M / G, G, &nb);
-    return (size_t)2 * G * nb * C;
+    return (size_t)3 * G * nb * C;
 }
 
 extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float eps,
                                     float* mean, float* rstd, float* scale, float* shift, float* partial,
                                     size_t partial_floats, hipStream_t st) {
-    IO_REQUIRE(C % 4 == 0 && C <= 2048, IO_ERR_SHAPE, "bn_stats: C=%d unsupported", C);
+    IO_REQUIRE(C % 4 == 0 && C <= 2048 && ilog2_exact(C / 4) >= 0, IO_ERR_SHAPE, "bn_stats: C=%d unsupported", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_stats: M=%d not divisible by G=%d", M, G);
     IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_stats: partial too small");
     const int Mg = M / G;
@@ -295,24 +313,25 @@ extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const f
     const int rpb = bn_rows_per_block(Mg, G, &nb);
     float* psum = partial;
     float* psq = partial + (size_t)G * nb * C;
+    float* ppiv = partial + (size_t)2 * G * nb * C;
     IoProfScope prof(IO_PROF_BN_STATS, 0.0, 4.0 * M * C, st);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, G), dim3(kThreads), 0, st, y, Mg, C, rpb, psum, psq);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, psum, psq, nb, G, Mg, C, gamma,
-                       beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, G), dim3(kThreads), 0, st, y, Mg, C, rpb, psum, psq, ppiv);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, psum, psq, ppiv, nb, rpb, G, Mg,
+                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
     return io_check_launch("bn_stats_finalize");
 }
 
 extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
-                                  const float* running_var, float eps, float* scale, float* shift,
+                                  const float* running_var, float eps, float* mean, float* scale, float* shift,
                                   hipStream_t st) {
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, C, gamma, beta,
-                       running_mean, running_var, eps, scale, shift);
+                       running_mean, running_var, eps, mean, scale, shift);
     return io_check_launch("bn_eval_prepare");
 }
 
-extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* scale,
-                           const float* shift, const float* identity, const float* scale2, const float* shift2,
-                           int relu, float* out, hipStream_t st) {
+extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* mean,
+                           const float* scale, const float* shift, const float* identity, const float* mean2,
+                           const float* scale2, const float* shift2, int relu, float* out, hipStream_t st) {
     const int sh = ilog2_exact(C / 4);
     IO_REQUIRE(C % 4 == 0 && sh >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be 4*2^k", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_apply: M=%d not divisible by G=%d", M, G);
@@ -320,15 +339,13 @@ extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_ta
     const int Mg = M / G, sg = per_group_tables ? C : 0;
     dim3 grid(ew_blocks(total4)), block(kThreads);
     IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 4.0 * M * C * (identity ? 3.0 : 2.0), st);
+    const BnTab t{mean, scale, shift}, t2{mean2, scale2, shift2};
     if (identity && scale2)
-        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
-                           scale2, shift2, relu, out);
+        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
     else if (identity)
-        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
-                           scale2, shift2, relu, out);
+        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, y, total4, sh, Mg, sg, scale, shift, identity,
-                           scale2, shift2, relu, out);
+        hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
     return io_check_launch("bn_apply");
 }
 

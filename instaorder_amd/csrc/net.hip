@@ -127,7 +127,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     const size_t f = sizeof(float);
     const size_t maxact = (size_t)N * H0 * H0 * 64 * f;   // == N*H1*H1*256*f, the largest activations
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
-    p.bn_partial_floats = (size_t)2 * 1100 * 2048;
+    p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
     p.coef = a.take((size_t)2 * kMaxGroups * 2048 * f);
     p.pooled = a.take((size_t)N * 2048 * f);
@@ -232,21 +232,22 @@ int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M) {
                                     c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
                                     t.shift, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.st);
     return io_bn_eval_prepare(b.C, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
-                              c.running + b.run_off + b.C, kBnEps, t.scale, t.shift, c.st);
+                              c.running + b.run_off + b.C, kBnEps, t.mean, t.scale, t.shift, c.st);
 }
 
 int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, const BnL* b2, int relu,
            float* out) {
     Tables t = c.tables(b);
-    const float *s2 = nullptr, *h2 = nullptr;
+    const float *m2 = nullptr, *s2 = nullptr, *h2 = nullptr;
     if (b2) {
         Tables t2 = c.tables(*b2);
+        m2 = t2.mean;
         s2 = t2.scale;
         h2 = t2.shift;
     }
     // tables are laid out with a group stride of C (training) -- eval uses one shared row
-    return io_bn_apply(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.scale, t.shift, idt, s2, h2, relu,
-                       out, c.st);
+    return io_bn_apply(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.mean, t.scale, t.shift, idt, m2, s2,
+                       h2, relu, out, c.st);
 }
 
 #define IO_TRY(expr)            \

@@ -125,20 +125,28 @@ def test_backward_tight_on_relu_free_network(algo, S, B):
     batch = synthetic.make_pair_batch(600, B, S)
     b64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in batch.items()}
     logs, grads = orc.train_step(state, {}, b64, algo, 0.0, 0.0)
+    _, g32 = orc.train_step(orc.state_from_numpy(sd), {}, batch, algo, 0.0, 0.0)   # PyTorch-CPU fp32, same graph
     m.switch_to("train")
     m.optim.param_groups[0]["lr"] = 0.0
     set_input(m, algo, batch)
     out = unpack(m.step())
     assert abs(out["loss"] - float(logs["loss"])) < 1e-4 * abs(float(logs["loss"]))
     names = orc.param_names(state)
-    worst = 0.0
+    worst = worst_cpu = 0.0
+    # BN biases that feed (through a linear conv) straight into another BN have an exactly-zero true
+    # gradient here; measure those against the typical tensor scale instead of their own ~1e-17 norm
+    floor = 1e-4 * float(np.median([float(grads[n].norm()) for n in names]))
     for n, p in zip(names, m.net.parameters()):
         g = p.grad.detach().cpu().double()
         ref = grads[n]
-        e = float((g - ref).norm() / ref.norm().clamp_min(1e-30))
-        worst = max(worst, e)
-        assert e < 1e-3, (n, e)
-    print("relu-free backward: worst per-tensor rel L2 err %.2e" % worst)
+        den = max(float(ref.norm()), floor)
+        e = float((g - ref).norm()) / den
+        ec = float((g32[n].double() - ref).norm()) / den
+        worst, worst_cpu = max(worst, e), max(worst_cpu, ec)
+        # 1e-3 is the bar; the deepest tensors accumulate rounding through ~50 layers of large-mean
+        # activations, where PyTorch-CPU fp32 itself sits near 1e-3, hence the relative clause
+        assert e < max(1e-3, 3 * ec), (n, e, ec)
+    print("relu-free backward: worst per-tensor rel L2 err vs fp64: HIP %.2e, torch-CPU-fp32 %.2e" % (worst, worst_cpu))
 
 
 @pytest.mark.parametrize("algo,style,S,B", [("InstaOrderNet_o", "kaiming", 64, 8), ("InstaOrderNet_od", "xavier", 128, 4)])
@@ -208,9 +216,16 @@ def test_golden_first_step(tag, algo, style):
     gerr = np.abs(gn - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-30)
     print(tag, "grad-norm rel diff: median %.2e max %.2e" % (np.median(gerr), gerr.max()))
     assert np.median(gerr) < 0.02 and gerr.max() < 0.15
+    # post-step weights: p - lr*(g + wd*p).  The weights themselves agree to ~1e-6; what can differ is
+    # lr x (gradient difference), and gradients carry the ReLU-flip conditioning discussed above, so the
+    # sampled elements are held to lr x 15 % of the tensor's typical gradient element (+ fp32 rounding).
     pn, ps = norms_and_samples(params)
     assert rel_err(pn, g["step0_param_norms"]) < 1e-4
-    assert np.abs(ps - g["step0_param_samples"]).max() < 1e-4 * np.abs(g["step0_param_samples"]).max()
+    lr = float(g["lr"])
+    numel = np.array([p.numel() for p in params], np.float64)
+    dps = np.sqrt(((ps.astype(np.float64) - g["step0_param_samples"]) ** 2).sum(1))
+    bound = lr * 0.15 * g["grad_norms"] * np.sqrt(64.0 / numel) + 1e-6 * np.abs(g["step0_param_samples"]).max(1) * 8
+    assert (dps <= bound).all(), (np.argmax(dps / bound), (dps / bound).max())
     rm, rv, nb = bn_vectors(hip_state(m))
     assert rel_err(rm, g["step0_running_mean"]) < FWD_TOL and rel_err(rv, g["step0_running_var"]) < FWD_TOL
     assert (nb == g["step0_num_batches"]).all()

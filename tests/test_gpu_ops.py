@@ -15,8 +15,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+_KEEP = []
+
+
 def P(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Device pointer of t.  The tensor is kept alive (launches are asynchronous: a temporary freed
+    right after taking its pointer would be recycled by the caching allocator under the kernel)."""
+    if t is None:
+        return C.c_void_p(0)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:-64]
+    return C.c_void_p(t.data_ptr())
 
 
 def ST():
@@ -147,6 +158,8 @@ def test_batchnorm(N, H, C, G):
     independent nn.BatchNorm2d calls on consecutive sample groups."""
     g = torch.Generator().manual_seed(C + G)
     x = (torch.randn(N, C, H, H, generator=g, dtype=torch.float64) * 0.3 + 0.2)
+    if C == 128:
+        x = x + 300.0       # |mean| = 1000 sigma: E[x^2]-E[x]^2 in fp32 would lose the variance entirely
     idt = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
     gamma = (1 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
     beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
@@ -174,17 +187,18 @@ def test_batchnorm(N, H, C, G):
                                         P(rstd), P(scale), P(shift), P(part), npart, ST()), "bn_stats")
     assert relerr(d_rm, rm) < 1e-5 and relerr(d_rv, rv) < 1e-5
     out = torch.empty_like(y)
-    _lib.check(L().io_bn_apply(P(y), M, C, G, 1, P(scale), P(shift), P(nhwc(idt)), None, None, 1, P(out), ST()),
-               "bn_apply")
-    assert relerr(out.permute(0, 3, 1, 2), ref) < 1e-5
+    _lib.check(L().io_bn_apply(P(y), M, C, G, 1, P(mean), P(scale), P(shift), P(nhwc(idt)), None, None, None, 1,
+                               P(out), ST()), "bn_apply")
+    assert relerr(out.permute(0, 3, 1, 2), ref) < (1e-5 if C != 128 else 2e-3)   # x itself is only 24-bit at 300
     # backward (ReLU mask taken from the stored output)
     dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dy, dz = torch.empty_like(y), torch.empty_like(y)
     coef = torch.empty(2 * G * C, device=DEV)
     _lib.check(L().io_bn_bwd(P(nhwc(dout)), P(out), P(y), M, C, G, P(f(gamma)), P(mean), P(rstd), P(dgam), P(dbet),
                              P(dy), P(dz), P(part), npart, P(coef), ST()), "bn_bwd")
-    assert relerr(dy.permute(0, 3, 1, 2), gx) < 2e-5
-    assert relerr(dgam, gg) < 2e-5 and relerr(dbet, gb) < 2e-5
+    tol = 2e-5 if C != 128 else 1e-3
+    assert relerr(dy.permute(0, 3, 1, 2), gx) < tol
+    assert relerr(dgam, gg) < tol and relerr(dbet, gb) < 2e-5
     assert relerr(dz.permute(0, 3, 1, 2), dout * (ref > 0)) < 1e-6
 
 
@@ -197,12 +211,13 @@ def test_batchnorm_eval_and_downsample_mode():
     ga, be, rm, rv, ga2, be2, rm2, rv2 = par
     ref = F.relu(F.batch_norm(x, rm, rv, ga, be, False, 0.1, 1e-5) + F.batch_norm(xd, rm2, rv2, ga2, be2, False, 0.1, 1e-5))
     f = lambda t: t.float().to(DEV).contiguous()
-    sc, sh, sc2, sh2 = (torch.empty(C, device=DEV) for _ in range(4))
-    _lib.check(L().io_bn_eval_prepare(C, P(f(ga)), P(f(be)), P(f(rm)), P(f(rv)), 1e-5, P(sc), P(sh), ST()), "prep")
-    _lib.check(L().io_bn_eval_prepare(C, P(f(ga2)), P(f(be2)), P(f(rm2)), P(f(rv2)), 1e-5, P(sc2), P(sh2), ST()), "prep")
+    mu, sc, sh, mu2, sc2, sh2 = (torch.empty(C, device=DEV) for _ in range(6))
+    _lib.check(L().io_bn_eval_prepare(C, P(f(ga)), P(f(be)), P(f(rm)), P(f(rv)), 1e-5, P(mu), P(sc), P(sh), ST()), "prep")
+    _lib.check(L().io_bn_eval_prepare(C, P(f(ga2)), P(f(be2)), P(f(rm2)), P(f(rv2)), 1e-5, P(mu2), P(sc2), P(sh2), ST()),
+               "prep")
     out = torch.empty(N, H, H, C, device=DEV)
-    _lib.check(L().io_bn_apply(P(nhwc(x)), N * H * H, C, 1, 0, P(sc), P(sh), P(nhwc(xd)), P(sc2), P(sh2), 1, P(out),
-                               ST()), "apply2")
+    _lib.check(L().io_bn_apply(P(nhwc(x)), N * H * H, C, 1, 0, P(mu), P(sc), P(sh), P(nhwc(xd)), P(mu2), P(sc2), P(sh2),
+                               1, P(out), ST()), "apply2")
     assert relerr(out.permute(0, 3, 1, 2), ref) < 1e-5
 
 
