@@ -77,15 +77,24 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
         const int q = cm.tx + cm.TX * i;
         if (i < cm.nq && q < C4) pv[i] = ld4(xg + (size_t)r0 * C + q * 4);
     }
-    for (int r = r0 + cm.ty; r < r1; r += cm.TY) {
-        const float* row = xg + (size_t)r * C;
+    constexpr int U = 4;   // rows in flight per thread (memory-level parallelism)
+    for (int r = r0 + cm.ty; r < r1; r += U * cm.TY) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = cm.tx + cm.TX * i;
             if (i < cm.nq && q < C4) {
-                const f32x4 v = ld4(row + q * 4) - pv[i];
-                s[i] += v;
-                ss[i] += v * v;
+                f32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int rr = r + u * cm.TY;
+                    v[u] = rr < r1 ? ld4(xg + (size_t)rr * C + q * 4) : pv[i];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const f32x4 d = v[u] - pv[i];
+                    s[i] += d;
+                    ss[i] += d * d;
+                }
             }
         }
     }
@@ -98,42 +107,71 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
     reduce_rows_store<2>(cm, s, ss, psum + o, psq + o, C4);
 }
 
-// one thread per channel; loops groups in order so running stats see group 0 then group 1 ...
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
-                                   const float* __restrict__ ppiv, int nb, int rpb, int G, int Mg, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
-                                   float eps, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+// block = 32 channels x 8 lanes over the per-block partials (coalesced 128-B reads, short serial chains);
+// groups are processed in order so the running statistics see group 0, then group 1, ...
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum,
+                                                         const float* __restrict__ psq,
+                                                         const float* __restrict__ ppiv, int nb, int rpb, int G,
+                                                         int Mg, int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                         float momentum, float eps, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, float* __restrict__ scale,
+                                                         float* __restrict__ shift) {
+    __shared__ double sh[3][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const bool ok = c < C;
+    float rm = 0.f, rv = 0.f;
+    if (ok && ty == 0) {
+        rm = run_mean ? run_mean[c] : 0.f;
+        rv = run_var ? run_var[c] : 0.f;
+    }
     for (int g = 0; g < G; ++g) {
         double n = 0.0, mu = 0.0, m2 = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            const size_t o = ((size_t)g * nb + b) * C + c;
-            const double nbk = (double)(min((b + 1) * rpb, Mg) - b * rpb);
-            const double sd = (double)psum[o], sq = (double)psq[o];
-            const double mb = (double)ppiv[o] + sd / nbk;
-            const double m2b = sq - sd * sd / nbk;
-            const double tot = n + nbk, delta = mb - mu;
-            mu += delta * (nbk / tot);
-            m2 += m2b + delta * delta * (n * nbk / tot);
-            n = tot;
+        if (ok)
+            for (int b = ty; b < nb; b += 8) {
+                const size_t o = ((size_t)g * nb + b) * C + c;
+                const double nbk = (double)(min((b + 1) * rpb, Mg) - b * rpb);
+                const double sd = (double)psum[o], sq = (double)psq[o];
+                const double mb = (double)ppiv[o] + sd / nbk;
+                const double m2b = sq - sd * sd / nbk;
+                const double tot = n + nbk, delta = mb - mu;
+                mu += delta * (nbk / tot);
+                m2 += m2b + delta * delta * (n * nbk / tot);
+                n = tot;
+            }
+        sh[0][ty][tx] = n;
+        sh[1][ty][tx] = mu;
+        sh[2][ty][tx] = m2;
+        __syncthreads();
+        if (ok && ty == 0) {
+            for (int k = 1; k < 8; ++k) {
+                const double nk = sh[0][k][tx];
+                if (nk > 0.0) {
+                    const double tot = n + nk, delta = sh[1][k][tx] - mu;
+                    mu += delta * (nk / tot);
+                    m2 += sh[2][k][tx] + delta * delta * (n * nk / tot);
+                    n = tot;
+                }
+            }
+            double var = m2 / Mg;
+            if (var < 0.0) var = 0.0;
+            const float r = (float)(1.0 / sqrt(var + (double)eps));
+            mean[g * C + c] = (float)mu;
+            rstd[g * C + c] = r;
+            scale[g * C + c] = gamma[c] * r;
+            shift[g * C + c] = beta[c];
+            const float unb = (float)(Mg > 1 ? var * ((double)Mg / (double)(Mg - 1)) : var);
+            rm = (1.f - momentum) * rm + momentum * (float)mu;
+            rv = (1.f - momentum) * rv + momentum * unb;
         }
-        double var = m2 / Mg;
-        if (var < 0.0) var = 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)eps));
-        mean[g * C + c] = (float)mu;
-        rstd[g * C + c] = r;
-        scale[g * C + c] = gamma[c] * r;
-        shift[g * C + c] = beta[c];
-        const float unb = (float)(Mg > 1 ? var * ((double)Mg / (double)(Mg - 1)) : var);
-        rm = (1.f - momentum) * rm + momentum * (float)mu;
-        rv = (1.f - momentum) * rv + momentum * unb;
+        __syncthreads();
     }
-    if (run_mean) run_mean[c] = rm;
-    if (run_var) run_var[c] = rv;
+    if (ok && ty == 0) {
+        if (run_mean) run_mean[c] = rm;
+        if (run_var) run_var[c] = rv;
+    }
 }
 
 // eval mode: tables from the running statistics (one "group")
@@ -198,21 +236,33 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
             rs[i] = ld4(rstd + g * C + q * 4);
         }
     }
-    for (int r = r0 + cm.ty; r < r1; r += cm.TY) {
-        const size_t ro = goff + (size_t)r * C;
+    constexpr int U = 2;   // rows in flight per thread (x3 tensors)
+    for (int r = r0 + cm.ty; r < r1; r += U * cm.TY) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = cm.tx + cm.TX * i;
             if (i < cm.nq && q < C4) {
-                f32x4 d = ld4(dout + ro + q * 4);
-                if (act) {
-                    const f32x4 a = ld4(act + ro + q * 4);
+                f32x4 d[U], a[U], yv[U];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] = a[k] > 0.f ? d[k] : 0.f;
+                for (int u = 0; u < U; ++u) {
+                    const int rr = r + u * cm.TY;
+                    const size_t ro = goff + (size_t)rr * C + q * 4;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const bool in = rr < r1;
+                    d[u] = in ? ld4(dout + ro) : z;
+                    yv[u] = in ? ld4(y + ro) : mu[i];
+                    a[u] = (in && act) ? ld4(act + ro) : d[u];
                 }
-                const f32x4 xh = (ld4(y + ro + q * 4) - mu[i]) * rs[i];
-                s1[i] += d;
-                s2[i] += d * xh;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (act) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[u][k] = a[u][k] > 0.f ? d[u][k] : 0.f;
+                    }
+                    const f32x4 xh = (yv[u] - mu[i]) * rs[i];
+                    s1[i] += d[u];
+                    s2[i] += d[u] * xh;
+                }
             }
         }
     }
@@ -220,25 +270,39 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
     reduce_rows_store<2>(cm, s1, s2, p1 + o, p2 + o, C4);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int nb, int G,
-                                       int Mg, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1,
+                                                             const float* __restrict__ p2, int nb, int G, int Mg,
+                                                             int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ c1,
+                                                             float* __restrict__ c2) {
+    __shared__ double sh[2][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const bool ok = c < C;
     double dg = 0.0, db = 0.0;
     for (int g = 0; g < G; ++g) {
         double a = 0.0, b2 = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            a += (double)p1[((size_t)g * nb + b) * C + c];
-            b2 += (double)p2[((size_t)g * nb + b) * C + c];
+        if (ok)
+            for (int b = ty; b < nb; b += 8) {
+                a += (double)p1[((size_t)g * nb + b) * C + c];
+                b2 += (double)p2[((size_t)g * nb + b) * C + c];
+            }
+        sh[0][ty][tx] = a;
+        sh[1][ty][tx] = b2;
+        __syncthreads();
+        if (ok && ty == 0) {
+            for (int k = 1; k < 8; ++k) { a += sh[0][k][tx]; b2 += sh[1][k][tx]; }
+            db += a;
+            dg += b2;
+            c1[g * C + c] = (float)(a / Mg);
+            c2[g * C + c] = (float)(b2 / Mg);
         }
-        db += a;
-        dg += b2;
-        c1[g * C + c] = (float)(a / Mg);
-        c2[g * C + c] = (float)(b2 / Mg);
+        __syncthreads();
     }
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
+    if (ok && ty == 0) {
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+    }
 }
 
 // dy = gamma*rstd*(dz - c1 - xhat*c2); optionally also stores dz (may alias dout)
@@ -316,7 +380,7 @@ extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const f
     float* ppiv = partial + (size_t)2 * G * nb * C;
     IoProfScope prof(IO_PROF_BN_STATS, 0.0, 4.0 * M * C, st);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, G), dim3(kThreads), 0, st, y, Mg, C, rpb, psum, psq, ppiv);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, psum, psq, ppiv, nb, rpb, G, Mg,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, psum, psq, ppiv, nb, rpb, G, Mg,
                        C, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
     return io_check_launch("bn_stats_finalize");
 }
@@ -367,7 +431,7 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* y, in
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, G), dim3(kThreads), 0, st, dout, act, y, Mg, C, rpb, mean,
                        rstd, p1, p2);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 256)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
                        dgamma, dbeta, c1, c2);
     const size_t total4 = (size_t)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dout, act, y, total4,

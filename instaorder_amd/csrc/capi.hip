@@ -55,6 +55,7 @@ IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int
     g.dh0 = -pad; g.dhs = 1; g.dw0 = -pad; g.dws = 1;
     g.r0 = 0; g.rs = 1; g.s0 = 0; g.ss = 1;
     g.S = S; g.wT = R * S;
+    io_geom_finish(g);
     return g;
 }
 
@@ -79,6 +80,7 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
     g.dw0 = (pw + pad - sf) / stride; g.dws = -1;
     g.r0 = rf; g.rs = stride; g.s0 = sf; g.ss = stride;
     g.S = S; g.wT = R * S;
+    io_geom_finish(g);
     return g;
 }
 

@@ -16,6 +16,8 @@
 // per SIMD busy: 128x128x32 block tile, 4 waves in 2x2, 2x2 MFMA tiles per wave (4 independent
 // accumulators), register-staged double buffering (global loads of tile k+1 fly under the 64
 // MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.
+#include <stdlib.h>
+
 #include "io_common.h"
 
 namespace {
@@ -33,53 +35,71 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+__device__ __forceinline__ int fdiv(int n, IoFastDiv f) {
+    return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift);
+}
+
+// predicated 16-byte load without a branch: invalid lanes read the (always mapped) tensor base and
+// are zeroed afterwards, so the loads stay straight-line code the scheduler can hoist and overlap
+__device__ __forceinline__ f32x4 ld4_if(const float* base, size_t off, bool ok) {
+    const f32x4 v = ld4(base + (ok ? off : 0));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
+}
+
 // ------------------------------------------------------------------------------------------
-// NT kernel
+// NT kernel.  NW waves per block share one 128 x BN tile: NW = 4 -> 2x2 waves of 64 x BN/2,
+// NW = 8 -> 2x4 waves of 64 x BN/4 (more waves per SIMD to cover HBM latency, smaller fragments).
 // ------------------------------------------------------------------------------------------
-template <int BN, bool STEM>
-__global__ __launch_bounds__(kThreads) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
-                                                          const float* __restrict__ wgt,
-                                                          float* __restrict__ out,
-                                                          const float* __restrict__ add, int ntn) {
-    constexpr int BM = 128, BK = 32, LDT = BK + 4;
-    constexpr int TI = 2, TJ = BN / 64;     // MFMA tiles per wave (wave tile 64 x BN/2)
-    constexpr int BR = BN / 32;             // weight rows loaded per thread
+template <int BN, bool STEM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
+                                                         const float* __restrict__ wgt, float* __restrict__ out,
+                                                         const float* __restrict__ add, int ntn) {
+    constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
+    constexpr int WN = NW / 2;              // waves along N (2 along M)
+    constexpr int TI = 2, TJ = BN / (32 * WN);
+    constexpr int AR = (BM * 8) / NT;       // A rows loaded per thread (8 float4 per row)
+    constexpr int BR = (BN * 8) / NT;       // weight rows loaded per thread
+    constexpr int RS = NT / 8;              // row step between a thread's rows
+    static_assert(TJ >= 1 && BR >= 1, "tile too small for this wave count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                       // [2][BM][LDT]
     float* sB = smem + 2 * BM * LDT;        // [2][BN][LDT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int mt = tile / ntn;
+    const int m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
     const int HoWo = g.Ho * g.Wo;
     const int M = g.N * HoWo;
     const int lr = tid >> 3, kq = tid & 7;
-
-    const float* rowbase[4];
-    int hi0[4], wi0[4];
-    bool rvalid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + lr + 32 * j;
-        rvalid[j] = m < M;
-        const int mm = rvalid[j] ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-        hi0[j] = ho * g.is;
-        wi0[j] = wo * g.is;
-        rowbase[j] = in + (size_t)n * g.Hi * g.Wi * g.Ci;
-    }
-    const float* wrow[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) wrow[j] = wgt + (size_t)(n0 + lr + 32 * j) * g.wT * g.Ci;
-
     const int nkc = STEM ? 1 : g.Ci / BK;
     const int nk = STEM ? (g.wT + 3) / 4 : g.Th * g.Tw * nkc;
 
-    f32x4 ra[4], rb[BR];
-    int th = 0, tw = 0, cc = 0;   // running tap / channel-chunk counters of the tile being LOADED
+    size_t rowoff[AR];
+    int hi0[AR], wi0[AR];
+    bool rvalid[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int m = m0 + lr + RS * j;
+        rvalid[j] = m < M;
+        const int mm = rvalid[j] ? m : 0;
+        const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+        const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+        hi0[j] = ho * g.is;
+        wi0[j] = wo * g.is;
+        rowoff[j] = (size_t)n * g.Hi * g.Wi * g.Ci;
+    }
+    size_t wrow[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) wrow[j] = (size_t)(n0 + lr + RS * j) * g.wT * g.Ci;
 
+    f32x4 ra[AR], rb[BR];
+    int th = 0, tw = 0, cc = 0;   // tap / channel-chunk counters of the k-tile being LOADED (non-stem)
+    // Loads are branch-free and the loop body below is ONE basic block (the last iteration simply
+    // re-fetches the final k-tile and discards it), so the scheduler is free to sink the address
+    // arithmetic and the global loads of tile k+1 into the shadow of the 64 MFMAs of tile k.
     auto load_tile = [&](int kt) {
         int dh, dw, widx, coff;
         bool tapok = true;
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void conv_nt_kernel(IoConvGeom g, const f
             const int r = tap / g.S, s = tap - r * g.S;
             dh = g.dh0 + g.dhs * r;
             dw = g.dw0 + g.dws * s;
-            widx = tap;
+            widx = tapok ? tap : 0;
             coff = (kq & 1) * 4;
         } else {
             dh = g.dh0 + g.dhs * th;
@@ -98,31 +118,32 @@ __global__ __launch_bounds__(kThreads) void conv_nt_kernel(IoConvGeom g, const f
             coff = cc * BK + kq * 4;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AR; ++j) {
             const int hi = hi0[j] + dh, wi = wi0[j] + dw;
             const bool ok = tapok && rvalid[j] && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[j] = ok ? ld4(rowbase[j] + ((size_t)(hi * g.Wi + wi)) * g.Ci + coff) : z;
+            ra[j] = ld4_if(in, rowoff[j] + ((size_t)(hi * g.Wi + wi)) * g.Ci + coff, ok);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rb[j] = tapok ? ld4(wrow[j] + (size_t)widx * g.Ci + coff) : z;
-        }
+        for (int j = 0; j < BR; ++j) rb[j] = ld4_if(wgt, wrow[j] + (size_t)widx * g.Ci + coff, tapok);
+    };
+    auto advance = [&](bool really) {    // step the (th, tw, cc) counters unless we are re-fetching
         if (!STEM) {
-            if (++cc == nkc) {
-                cc = 0;
-                if (++tw == g.Tw) { tw = 0; ++th; }
-            }
+            const int c1 = cc + 1;
+            const bool wrapc = c1 == nkc;
+            const int t1 = tw + (wrapc ? 1 : 0);
+            const bool wrapt = t1 == g.Tw;
+            cc = really ? (wrapc ? 0 : c1) : cc;
+            tw = really ? (wrapt ? 0 : t1) : tw;
+            th = really ? th + (wrapt ? 1 : 0) : th;
         }
     };
     auto store_tile = [&](int buf) {
         float* a = sA + buf * BM * LDT + lr * LDT + kq * 4;
         float* b = sB + buf * BN * LDT + lr * LDT + kq * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st4(a + 32 * j * LDT, ra[j]);
+        for (int j = 0; j < AR; ++j) st4(a + RS * j * LDT, ra[j]);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) st4(b + 32 * j * LDT, rb[j]);
+        for (int j = 0; j < BR; ++j) st4(b + RS * j * LDT, rb[j]);
     };
 
     f32x16 acc[TI][TJ];
@@ -133,58 +154,104 @@ __global__ __launch_bounds__(kThreads) void conv_nt_kernel(IoConvGeom g, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Software pipeline.  Two waves share each SIMD's matrix pipe; if a wave had a long MFMA-free phase
+    // per k-tile (address math, global loads, LDS refill, barrier) the two waves fall into lock-step
+    // and the pipe idles during that phase (measured: 78 % MfmaUtil).  So the MFMA stream of a wave is
+    // kept continuous: fragments are prefetched one 16-MFMA group ahead, the loads of tile k+1 are
+    // issued under the first 48 MFMAs of tile k, and the LDS refill + barrier sit between MFMA groups
+    // 3 and 4 of tile k -- whose operands are already in registers -- with the first fragments of
+    // tile k+1 fetched right behind the barrier, under that last group.
+    const int a_off = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int b_off = (wn * (BN / WN) + (lane & 31)) * LDT + (lane >> 5) * 4;
+    auto read_frags = [&](int buf, int kk, f32x4 (&a)[TI], f32x4 (&b)[TJ]) {
+        const float* al = sA + buf * BM * LDT + a_off + kk * 8;
+        const float* bl = sB + buf * BN * LDT + b_off + kk * 8;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) a[i] = ld4(al + i * 32 * LDT);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[j] = ld4(bl + j * 32 * LDT);
+    };
+    auto mma16 = [&](const f32x4 (&a)[TI], const f32x4 (&b)[TJ]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][tt], b[j][tt], acc[i][j], 0, 0, 0);
+    };
+
+    f32x4 fa[TI], fb[TJ];
     if (nk > 0) {
         load_tile(0);
         store_tile(0);
     }
     __syncthreads();
-
+    if (nk > 0) read_frags(0, 0, fa, fb);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const float* a_lds = sA + buf * BM * LDT + (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-        const float* b_lds = sB + buf * BN * LDT + (wn * (BN / 2) + (lane & 31)) * LDT + (lane >> 5) * 4;
+        const bool more = kt + 1 < nk;
+        advance(more);
+        load_tile(more ? kt + 1 : kt);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 a[TI], b[TJ];
+        for (int kk = 0; kk < 3; ++kk) {
+            f32x4 na[TI], nb[TJ];
+            read_frags(buf, kk + 1, na, nb);
+            mma16(fa, fb);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = ld4(a_lds + i * 32 * LDT + kk * 8);
+            for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = ld4(b_lds + j * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf ^ 1);
         __syncthreads();
+        f32x4 na[TI], nb[TJ];
+        read_frags(buf ^ 1, 0, na, nb);       // first fragments of tile kt+1 (unused after the last tile)
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(fa, fb);                         // group 4 of tile kt, operands already in registers
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[i] = na[i];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
     }
 
-    // epilogue: D layout col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: D layout col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // One row pointer per (i, r); the `add` variant issues all its loads before the stores.
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
+    const int ncol = n0 + wn * (BN / WN) + (lane & 31);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+        size_t rowidx[16];
+        bool rowok[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m >= M) continue;
-            size_t pix;
-            if (dense) {
-                pix = (size_t)m;
-            } else {
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+            rowok[r] = m < M;
+            size_t pix = (size_t)(rowok[r] ? m : 0);
+            if (!dense) {
+                const int mm = rowok[r] ? m : 0;
+                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 pix = ((size_t)n * g.outH + (ho * g.os + g.ooh)) * g.outW + (wo * g.os + g.oow);
             }
+            rowidx[r] = pix * g.Co + ncol;
+        }
+        if (add) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const size_t idx = pix * g.Co + n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-                float v = acc[i][j][r];
-                if (add) v += add[idx];
-                out[idx] = v;
+                float av[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = add[rowidx[r] + j * 32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (rowok[r]) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) out[rowidx[r] + j * 32] = acc[i][j][r];
             }
         }
     }
@@ -257,20 +324,18 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int m = mb + ra0 + SA * j;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[j] = (m < M) ? ld4(dy + (size_t)m * g.Co + o0 + qa * 4) : z;
+            ra[j] = ld4_if(dy, (size_t)m * g.Co + o0 + qa * 4, m < M);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int m = mb + rb0 + SB * j;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             bool ok = tapok && m < M;
             const int mm = ok ? m : 0;
-            const int n = mm / HoWo, rem = mm - n * HoWo;
-            const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
             const int hi = ho * g.is + dh, wi = wo * g.is + dw;
             ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-            rb[j] = ok ? ld4(in + (((size_t)n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) : z;
+            rb[j] = ld4_if(in, (((size_t)n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff, ok);
         }
     };
     auto store_tile = [&](int buf) {
@@ -290,31 +355,67 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // same software pipeline as the NT kernel: fragments one 16-MFMA group (4 k-steps) ahead, LDS refill
+    // and barrier between groups 3 and 4 of a k-tile.
+    const int a_off = (lane >> 5) * BMO + wm * (BMO / 2) + (lane & 31);
+    const int b_off = (lane >> 5) * BNC + wn * (BNC / 2) + (lane & 31);
+    auto read_frags = [&](int buf, int grp, float (&a)[4][TI], float (&b)[4][TJ]) {
+        const float* al = sA + buf * BKM * BMO + a_off + grp * 8 * BMO;
+        const float* bl = sB + buf * BKM * BNC + b_off + grp * 8 * BNC;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[s4][i] = al[s4 * 2 * BMO + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[s4][j] = bl[s4 * 2 * BNC + j * 32];
+        }
+    };
+    auto mma16 = [&](const float (&a)[4][TI], const float (&b)[4][TJ]) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4][i], b[s4][j], acc[i][j], 0, 0, 0);
+    };
+    float fa[4][TI], fb[4][TJ];
     if (kt0 < kt1) {
         load_tile(kt0);
         store_tile(0);
     }
     __syncthreads();
+    if (kt0 < kt1) read_frags(0, 0, fa, fb);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1);
-        const float* a_lds = sA + buf * BKM * BMO + (lane >> 5) * BMO + wm * (BMO / 2) + (lane & 31);
-        const float* b_lds = sB + buf * BKM * BNC + (lane >> 5) * BNC + wn * (BNC / 2) + (lane & 31);
+        load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
 #pragma unroll
-        for (int kk = 0; kk < BKM / 2; ++kk) {
-            float a[TI], b[TJ];
+        for (int grp = 0; grp < 3; ++grp) {
+            float na[4][TI], nb[4][TJ];
+            read_frags(buf, grp + 1, na, nb);
+            mma16(fa, fb);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = a_lds[kk * 2 * BMO + i * 32];
+            for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = b_lds[kk * 2 * BNC + j * 32];
+                for (int i = 0; i < TI; ++i) fa[s4][i] = na[s4][i];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) fb[s4][j] = nb[s4][j];
+            }
         }
-        if (kt + 1 < kt1) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf ^ 1);
         __syncthreads();
+        float na[4][TI], nb[4][TJ];
+        read_frags(buf ^ 1, 0, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(fa, fb);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[s4][i] = na[s4][i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[s4][j] = nb[s4][j];
+        }
     }
 
     // epilogue: rows = output channel o, cols = input channel (or flattened stem column)
@@ -397,29 +498,34 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
     const size_t lds = (size_t)2 * (128 + bn) * 36 * sizeof(float);
-    dim3 grid((unsigned)tiles), block(kThreads);
+    static const int nw_env = getenv("IO_NT_WAVES") ? atoi(getenv("IO_NT_WAVES")) : 0;
+    const int nw = (nw_env == 8 && bn == 128 && !stem) ? 8 : 4;
+    dim3 grid((unsigned)tiles), block(nw * 64);
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
                      4.0 * ((double)M * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred), st);
-#define IO_LAUNCH_NT(BN_, STEM_)                                                                             \
+#define IO_LAUNCH_NT(BN_, STEM_, NW_)                                                                        \
     do {                                                                                                     \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<BN_, STEM_>,                                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + BN_) * 36 * 4);       \
+            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<BN_, STEM_, NW_>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + BN_) * 36 * 4); \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_>), grid, block, lds, st, g, in, wgt, out, add, ntn);   \
+        hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
+                           ntn);                                                                             \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
-        IO_LAUNCH_NT(64, true);
+        IO_LAUNCH_NT(64, true, 4);
+    } else if (bn == 128 && nw == 8) {
+        IO_LAUNCH_NT(128, false, 8);
     } else if (bn == 128) {
-        IO_LAUNCH_NT(128, false);
+        IO_LAUNCH_NT(128, false, 4);
     } else {
-        IO_LAUNCH_NT(64, false);
+        IO_LAUNCH_NT(64, false, 4);
     }
 #undef IO_LAUNCH_NT
     return io_check_launch("conv_nt");

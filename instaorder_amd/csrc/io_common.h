@@ -23,6 +23,22 @@ static inline int io_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// exact n / d for 0 <= n < 2^31 by multiply-high: q = umulhi(n, magic) >> shift (shift < 0: d == 1)
+struct IoFastDiv {
+    unsigned magic;
+    int shift;
+};
+static inline IoFastDiv io_fastdiv(int d) {
+    IoFastDiv f;
+    if (d <= 1) { f.magic = 0; f.shift = -1; return f; }
+    int s = 0;
+    while ((1LL << s) < d) ++s;                       // 2^(s-1) < d <= 2^s
+    const unsigned long long num = 1ULL << (31 + s);
+    f.magic = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);   // ceil, < 2^32
+    f.shift = s - 1;
+    return f;
+}
+
 // Geometry of one implicit-GEMM launch ("gather conv"): forward convolution and
 // both data-gradient forms are instances of it (see conv_igemm.hip).
 struct IoConvGeom {
@@ -35,7 +51,12 @@ struct IoConvGeom {
     int dh0, dhs, dw0, dws;   // dh = dh0 + dhs*th ; dw = dw0 + dws*tw
     int r0, rs, s0, ss;       // filter tap (r,s) = (r0+rs*th, s0+ss*tw)
     int S, wT;           // filter width S and total taps wT=R*S: weights [Co][wT][Ci]
+    IoFastDiv fd_howo, fd_wo;   // division by Ho*Wo and by Wo (filled by io_geom_finish)
 };
+static inline void io_geom_finish(IoConvGeom& g) {
+    g.fd_howo = io_fastdiv(g.Ho * g.Wo);
+    g.fd_wo = io_fastdiv(g.Wo);
+}
 
 // internal launchers shared between the C ABI and the network executor
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,

@@ -382,3 +382,31 @@ def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
         set_input(mm, algo, synthetic.make_pair_batch(961, 4, 64))
         mm.step()
     assert torch.equal(m.net.flat_params, m2.net.flat_params)
+
+
+def test_nccl_single_rank_dp_path():
+    """The data-parallel wrapper path (DistModule broadcast, flat RCCL all-reduce, loss/world) on one
+    rank: same numbers as the non-distributed path."""
+    import os
+    import torch.distributed as dist
+    from instaorder_amd import distributed_utils as du
+    import instaorder_amd as ia
+    algo = "InstaOrderNet_o"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    du.dist_init_("pytorch", backend="nccl")
+    try:
+        batch = synthetic.make_pair_batch(970, 4, 64)
+        res = []
+        for dist_model in (True, False):
+            m = getattr(ia, algo)(cfg_for(algo), dist_model=dist_model)
+            sd = synthetic.make_state_dict(71, 5, 2, prefix="module.", style="kaiming")
+            m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+            assert m.world_size == 1
+            m.switch_to("train")
+            set_input(m, algo, batch)
+            out = m.step()
+            tot = du.reduce_tensors(out["loss"])
+            res.append((float(tot), m.net.flat_params.clone()))
+        assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
