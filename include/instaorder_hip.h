@@ -77,12 +77,15 @@ int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float
 int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
                 const float* shift, const float* identity, const float* mean2, const float* scale2,
                 const float* shift2, int relu, float* out, hipStream_t stream);
-/* backward of [ReLU o] BN: dz = dout*[act>0] (act NULL: no ReLU), dgamma/dbeta [C] summed over groups,
- * dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional, may alias dout) gets dz.
- * coef: 2*G*C floats of scratch. */
-int io_bn_bwd(const float* dout, const float* act, const float* y, int M, int C, int G, const float* gamma,
-              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dy, float* dz_out,
-              float* partial, size_t partial_floats, float* coef, hipStream_t stream);
+/* backward of [ReLU o] BN: dz = dout*[a>0] where the post-ReLU value a is either read from `act`, or
+ * recomputed from y with the forward's own scale/shift tables (mask_scale/mask_shift: saves re-reading the
+ * activation when no residual is added before the ReLU), or absent (all three NULL: no ReLU behind this BN).
+ * dgamma/dbeta [C] summed over groups, dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out
+ * (optional, may alias dout) gets dz.  coef: 2*G*C floats of scratch. */
+int io_bn_bwd(const float* dout, const float* act, const float* mask_scale, const float* mask_shift, const float* y,
+              int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+              float* dbeta, float* dy, float* dz_out, float* partial, size_t partial_floats, float* coef,
+              hipStream_t stream);
 
 /* ---- pooling / heads ------------------------------------------------------------------------
  * nn.MaxPool2d(3, 2, 1) (resnet_cls.py:144); idx: one byte per output element (packed x4). */

@@ -41,7 +41,7 @@ SIGNATURES = {
     "io_bn_stats_finalize": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "io_bn_eval_prepare": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
     "io_bn_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "io_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "io_bn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "io_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "io_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "io_avgpool_fc_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),

@@ -18,6 +18,15 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// BN affine output; the SAME expression is used by the forward apply and by the backward kernels that
+// recompute the ReLU mask from y, so the mask bit is reproduced exactly
+__device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 mean, f32x4 scale, f32x4 shift) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __builtin_fmaf(y[k] - mean[k], scale[k], shift[k]);
+    return r;
+}
+
 struct ColMap {
     int TX, TY, tx, ty, nq;   // column threads, row lanes, my coords, quads per thread
 };
@@ -130,16 +139,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     for (int g = 0; g < G; ++g) {
         double n = 0.0, mu = 0.0, m2 = 0.0;
         if (ok)
-            for (int b = ty; b < nb; b += 8) {
-                const size_t o = ((size_t)g * nb + b) * C + c;
-                const double nbk = (double)(min((b + 1) * rpb, Mg) - b * rpb);
-                const double sd = (double)psum[o], sq = (double)psq[o];
-                const double mb = (double)ppiv[o] + sd / nbk;
-                const double m2b = sq - sd * sd / nbk;
-                const double tot = n + nbk, delta = mb - mu;
-                mu += delta * (nbk / tot);
-                m2 += m2b + delta * delta * (n * nbk / tot);
-                n = tot;
+            for (int b0 = ty; b0 < nb; b0 += 64) {
+                float vs[8], vq[8], vp[8];     // 24 independent loads in flight, then the serial merges
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + 8 * u;
+                    const size_t o = ((size_t)g * nb + (b < nb ? b : 0)) * C + c;
+                    vs[u] = psum[o]; vq[u] = psq[o]; vp[u] = ppiv[o];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + 8 * u;
+                    if (b < nb) {
+                        const double nbk = (double)(min((b + 1) * rpb, Mg) - b * rpb);
+                        const double sd = (double)vs[u], sq = (double)vq[u];
+                        const double mb = (double)vp[u] + sd / nbk;
+                        const double m2b = sq - sd * sd / nbk;
+                        const double tot = n + nbk, delta = mb - mu;
+                        mu += delta * (nbk / tot);
+                        m2 += m2b + delta * delta * (n * nbk / tot);
+                        n = tot;
+                    }
+                }
             }
         sh[0][ty][tx] = n;
         sh[1][ty][tx] = mu;
@@ -202,9 +223,9 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
         const size_t row = i >> c4shift;
         const int g = (int)(row / Mg);
         const int co = g * sg + q * 4;
-        f32x4 v = (ld4(y + i * 4) - ld4(t.mean + co)) * ld4(t.scale + co) + ld4(t.shift + co);
+        f32x4 v = bn_affine(ld4(y + i * 4), ld4(t.mean + co), ld4(t.scale + co), ld4(t.shift + co));
         if (MODE == 1) v += ld4(idt + i * 4);
-        if (MODE == 2) v += (ld4(idt + i * 4) - ld4(t2.mean + co)) * ld4(t2.scale + co) + ld4(t2.shift + co);
+        if (MODE == 2) v += bn_affine(ld4(idt + i * 4), ld4(t2.mean + co), ld4(t2.scale + co), ld4(t2.shift + co));
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -221,19 +242,25 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
                                                                 const float* __restrict__ y, int Mg, int C, int rpb,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd,
+                                                                const float* __restrict__ mscale,
+                                                                const float* __restrict__ mshift,
                                                                 float* __restrict__ p1, float* __restrict__ p2) {
     const int C4 = C >> 2;
     const ColMap cm = col_map(C4);
     const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
     const size_t goff = (size_t)g * Mg * C;
-    f32x4 s1[2], s2[2], mu[2], rs[2];
+    f32x4 s1[2], s2[2], mu[2], rs[2], msc[2], msh[2];
     for (int i = 0; i < 2; ++i) {
-        s1[i] = 0.f; s2[i] = 0.f; mu[i] = 0.f; rs[i] = 0.f;
+        s1[i] = 0.f; s2[i] = 0.f; mu[i] = 0.f; rs[i] = 0.f; msc[i] = 0.f; msh[i] = 0.f;
         const int q = cm.tx + cm.TX * i;
         if (i < cm.nq && q < C4) {
             mu[i] = ld4(mean + g * C + q * 4);
             rs[i] = ld4(rstd + g * C + q * 4);
+            if (mscale) {
+                msc[i] = ld4(mscale + g * C + q * 4);
+                msh[i] = ld4(mshift + g * C + q * 4);
+            }
         }
     }
     constexpr int U = 2;   // rows in flight per thread (x3 tensors)
@@ -255,7 +282,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (act) {
+                    if (mscale) a[u] = bn_affine(yv[u], mu[i], msc[i], msh[i]);   // ReLU mask recomputed from y
+                    if (act || mscale) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) d[u][k] = a[u][k] > 0.f ? d[u][k] : 0.f;
                     }
@@ -283,9 +311,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     for (int g = 0; g < G; ++g) {
         double a = 0.0, b2 = 0.0;
         if (ok)
-            for (int b = ty; b < nb; b += 8) {
-                a += (double)p1[((size_t)g * nb + b) * C + c];
-                b2 += (double)p2[((size_t)g * nb + b) * C + c];
+            for (int b0 = ty; b0 < nb; b0 += 64) {
+                float v1[8], v2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + 8 * u;
+                    const size_t o = ((size_t)g * nb + (b < nb ? b : 0)) * C + c;
+                    v1[u] = b < nb ? p1[o] : 0.f;
+                    v2[u] = b < nb ? p2[o] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a += (double)v1[u]; b2 += (double)v2[u]; }
             }
         sh[0][ty][tx] = a;
         sh[1][ty][tx] = b2;
@@ -314,6 +350,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* dou
                                                                const float* __restrict__ rstd,
                                                                const float* __restrict__ c1,
                                                                const float* __restrict__ c2,
+                                                               const float* __restrict__ mscale,
+                                                               const float* __restrict__ mshift,
                                                                float* __restrict__ dy, float* dz_out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int c4mask = (1 << c4shift) - 1;
@@ -323,13 +361,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* dou
         const int g = (int)(row / Mg);
         const int co = g * C + q * 4;
         f32x4 d = ld4(dout + i * 4);
-        if (act) {
-            const f32x4 a = ld4(act + i * 4);
+        const f32x4 yv = ld4(y + i * 4), muv = ld4(mean + co);
+        if (act || mscale) {
+            const f32x4 a = act ? ld4(act + i * 4) : bn_affine(yv, muv, ld4(mscale + co), ld4(mshift + co));
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = a[k] > 0.f ? d[k] : 0.f;
         }
         const f32x4 rs = ld4(rstd + co);
-        const f32x4 xh = (ld4(y + i * 4) - ld4(mean + co)) * rs;
+        const f32x4 xh = (yv - muv) * rs;
         const f32x4 r = (d - ld4(c1 + co) - xh * ld4(c2 + co)) * (ld4(gamma + q * 4) * rs);
         if (dz_out) st4(dz_out + i * 4, d);
         st4(dy + i * 4, r);
@@ -413,10 +452,12 @@ extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_ta
     return io_check_launch("bn_apply");
 }
 
-extern "C" int io_bn_bwd(const float* dout, const float* act, const float* y, int M, int C, int G,
-                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                         float* dy, float* dz_out, float* partial, size_t partial_floats, float* coef,
-                         hipStream_t st) {
+extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_scale, const float* mask_shift,
+                         const float* y, int M, int C, int G, const float* gamma, const float* mean,
+                         const float* rstd, float* dgamma, float* dbeta, float* dy, float* dz_out, float* partial,
+                         size_t partial_floats, float* coef, hipStream_t st) {
+    IO_REQUIRE(!(act && mask_scale), IO_ERR_SHAPE, "bn_bwd: give the activation OR the mask tables, not both");
+    IO_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), IO_ERR_SHAPE, "bn_bwd: mask tables come in pairs");
     const int sh = ilog2_exact(C / 4);
     IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_bwd: M=%d not divisible by G=%d", M, G);
@@ -430,11 +471,11 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* y, in
     float* c2 = coef + (size_t)G * C;
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, G), dim3(kThreads), 0, st, dout, act, y, Mg, C, rpb, mean,
-                       rstd, p1, p2);
+                       rstd, mask_scale, mask_shift, p1, p2);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
                        dgamma, dbeta, c1, c2);
     const size_t total4 = (size_t)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dout, act, y, total4,
-                       sh, Mg, C, gamma, mean, rstd, c1, c2, dy, dz_out);
+                       sh, Mg, C, gamma, mean, rstd, c1, c2, mask_scale, mask_shift, dy, dz_out);
     return io_check_launch("bn_bwd");
 }

@@ -439,12 +439,33 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
         }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dst, size_t n4,
-                                     int splits) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 s = reinterpret_cast<const f32x4*>(partial)[i];
-        for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(partial)[(size_t)z * n4 + i];
+// dst[i] = sum_z partial[z][i]: block = 32 float4 columns x 8 split lanes (8 loads in flight per lane),
+// fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ dst, size_t n4, int splits) {
+    __shared__ f32x4 red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + tx;
+    const bool ok = i < n4;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        for (int z0 = ty; z0 < splits; z0 += 64) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + 8 * u;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                v[u] = z < splits ? p4[(size_t)z * n4 + i] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && ok) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += red[k][tx];
         reinterpret_cast<f32x4*>(dst)[i] = s;
     }
 }
@@ -570,9 +591,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, 
     if (rc) return rc;
     if (p.splits > 1) {
         const size_t n4 = (size_t)g.Co * g.wT * g.Ci / 4;
-        int blocks = io_cdiv((long)n4, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, dw, n4, p.splits);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
+                           p.splits);
         rc = io_check_launch("splitk_reduce");
     }
     return rc;

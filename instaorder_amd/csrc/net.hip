@@ -299,12 +299,13 @@ int run_forward(Ctx& c, const float* x8, float* logits) {
     return IO_OK;
 }
 
-int bn_back(const Ctx& c, const BnL& b, const float* dout, const float* act, const float* y, int M, float* dy,
-            float* dz_out) {
+// mask: 0 = no ReLU behind this BN, 1 = recompute relu(bn(y)) > 0 from y, 2 = read the stored activation
+int bn_back(const Ctx& c, const BnL& b, const float* dout, int mask, const float* act, const float* y, int M,
+            float* dy, float* dz_out) {
     Tables t = c.tables(b);
-    return io_bn_bwd(dout, act, y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off,
-                     c.grads + b.b_off, dy, dz_out, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats,
-                     c.buf(c.plan.coef), c.st);
+    return io_bn_bwd(dout, mask == 2 ? act : nullptr, mask == 1 ? t.scale : nullptr, mask == 1 ? t.shift : nullptr,
+                     y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off, dy,
+                     dz_out, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.buf(c.plan.coef), c.st);
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& L, const float* x, const float* dy, int H) {
@@ -351,17 +352,17 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
         const float* xin = ii == 0 ? c.buf(p.p0) : c.buf(p.blk[ii - 1].out);
         // bn3 (+ReLU of the block output): dy3 -> Ga, masked dout kept in Gd for the identity branch
-        IO_TRY(bn_back(c, b.b3, Gd, c.buf(bb.out), c.buf(bb.y3), Mout, Ga, Gd));
+        IO_TRY(bn_back(c, b.b3, Gd, 2, c.buf(bb.out), c.buf(bb.y3), Mout, Ga, Gd));
         IO_TRY(conv_wgrad(c, b.c3, c.buf(bb.a2), Ga, Ho));
         IO_TRY(conv_dgrad(c, b.c3, Ga, Gb, nullptr, Ho));
-        IO_TRY(bn_back(c, b.b2, Gb, c.buf(bb.a2), c.buf(bb.y2), Mout, Gc, nullptr));
+        IO_TRY(bn_back(c, b.b2, Gb, 1, nullptr, c.buf(bb.y2), Mout, Gc, nullptr));
         IO_TRY(conv_wgrad(c, b.c2, c.buf(bb.a1), Gc, H));
         IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, H));
-        IO_TRY(bn_back(c, b.b1, Ga, c.buf(bb.a1), c.buf(bb.y1), Min, Gb, nullptr));
+        IO_TRY(bn_back(c, b.b1, Ga, 1, nullptr, c.buf(bb.y1), Min, Gb, nullptr));
         IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, H));
         if (b.down) {
-            IO_TRY(bn_back(c, b.bd, Gd, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
+            IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
             IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, H));
         }
@@ -369,7 +370,7 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
     }
     // Gd = d(maxpool output)
     IO_TRY(io_maxpool_bwd(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st));
-    IO_TRY(bn_back(c, net->bn1, Ge, c.buf(p.a0), c.buf(p.y0), c.N * H0 * H0, Ga, nullptr));
+    IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.buf(p.y0), c.N * H0 * H0, Ga, nullptr));
     // stem filter gradient only: the network input needs no data gradient
     IO_TRY(conv_wgrad(c, net->stem, x8, Ga, c.S));
     return IO_OK;

@@ -174,7 +174,7 @@ def test_batchnorm(N, H, C, G):
     pre = torch.cat(outs, 0)
     ref = F.relu(pre + idt)
     dout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
-    gx, gg, gb = torch.autograd.grad(ref, [xr, gamma, beta], dout)
+    gx, gg, gb = torch.autograd.grad(ref, [xr, gamma, beta], dout, retain_graph=True)
 
     M = N * H * H
     y = nhwc(x)
@@ -194,12 +194,27 @@ def test_batchnorm(N, H, C, G):
     dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dy, dz = torch.empty_like(y), torch.empty_like(y)
     coef = torch.empty(2 * G * C, device=DEV)
-    _lib.check(L().io_bn_bwd(P(nhwc(dout)), P(out), P(y), M, C, G, P(f(gamma)), P(mean), P(rstd), P(dgam), P(dbet),
-                             P(dy), P(dz), P(part), npart, P(coef), ST()), "bn_bwd")
+    _lib.check(L().io_bn_bwd(P(nhwc(dout)), P(out), None, None, P(y), M, C, G, P(f(gamma)), P(mean), P(rstd), P(dgam),
+                             P(dbet), P(dy), P(dz), P(part), npart, P(coef), ST()), "bn_bwd")
     tol = 2e-5 if C != 128 else 1e-3
     assert relerr(dy.permute(0, 3, 1, 2), gx) < tol
     assert relerr(dgam, gg) < tol and relerr(dbet, gb) < 2e-5
     assert relerr(dz.permute(0, 3, 1, 2), dout * (ref > 0)) < 1e-6
+    # no residual: the ReLU mask is recomputed from y with the forward's tables -- must reproduce the stored
+    # activation's mask bit for bit
+    out2 = torch.empty_like(y)
+    _lib.check(L().io_bn_apply(P(y), M, C, G, 1, P(mean), P(scale), P(shift), None, None, None, None, 1, P(out2), ST()),
+               "bn_apply")
+    ref2 = F.relu(pre)
+    gx2, gg2, gb2 = torch.autograd.grad(ref2, [xr, gamma, beta], dout)
+    dy_a, dy_b = torch.empty_like(y), torch.empty_like(y)
+    dg_a, db_a, dg_b, db_b = (torch.empty(C, device=DEV) for _ in range(4))
+    _lib.check(L().io_bn_bwd(P(nhwc(dout)), P(out2), None, None, P(y), M, C, G, P(f(gamma)), P(mean), P(rstd), P(dg_a),
+                             P(db_a), P(dy_a), None, P(part), npart, P(coef), ST()), "bn_bwd act")
+    _lib.check(L().io_bn_bwd(P(nhwc(dout)), None, P(scale), P(shift), P(y), M, C, G, P(f(gamma)), P(mean), P(rstd),
+                             P(dg_b), P(db_b), P(dy_b), None, P(part), npart, P(coef), ST()), "bn_bwd mask-from-y")
+    assert torch.equal(dy_a, dy_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    assert relerr(dy_b.permute(0, 3, 1, 2), gx2) < tol and relerr(dg_b, gg2) < tol
 
 
 def test_batchnorm_eval_and_downsample_mode():
