@@ -39,6 +39,17 @@ __device__ __forceinline__ int fdiv(int n, IoFastDiv f) {
     return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift);
 }
 
+// 16-byte load through a buffer descriptor: 32-bit byte offset, and an offset past the end of the tensor
+// (kInvalidOff, or rows beyond M) returns zeros in hardware -- no 64-bit address arithmetic, no selects.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
 // predicated 16-byte load without a branch: invalid lanes read the (always mapped) tensor base and
 // are zeroed afterwards, so the loads stay straight-line code the scheduler can hoist and overlap
 __device__ __forceinline__ f32x4 ld4_if(const float* base, size_t off, bool ok) {
@@ -54,7 +65,8 @@ __device__ __forceinline__ f32x4 ld4_if(const float* base, size_t off, bool ok) 
 template <int BN, bool STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
                                                          const float* __restrict__ wgt, float* __restrict__ out,
-                                                         const float* __restrict__ add, int ntn) {
+                                                         const float* __restrict__ add, int ntn, unsigned in_bytes,
+                                                         unsigned w_bytes) {
     constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
@@ -77,7 +89,11 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     const int nkc = STEM ? 1 : g.Ci / BK;
     const int nk = STEM ? (g.wT + 3) / 4 : g.Th * g.Tw * nkc;
 
-    size_t rowoff[AR];
+    // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
+    // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
+    // unit returns zeros.
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_w = make_rsrc(wgt, w_bytes);
+    unsigned rowv[AR];
     int hi0[AR], wi0[AR];
     bool rvalid[AR];
 #pragma unroll
@@ -89,11 +105,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
         const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
         hi0[j] = ho * g.is;
         wi0[j] = wo * g.is;
-        rowoff[j] = (size_t)n * g.Hi * g.Wi * g.Ci;
+        rowv[j] = (unsigned)(((n * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * 4)) * 4u;
     }
-    size_t wrow[BR];
+    unsigned wv[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) wrow[j] = (size_t)(n0 + lr + RS * j) * g.wT * g.Ci;
+    for (int j = 0; j < BR; ++j) wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * g.Ci + (STEM ? 0 : kq * 4)) * 4u;
+    const bool nopad = g.Th == 1 && g.Tw == 1 && g.dh0 == 0 && g.dw0 == 0 && g.is == 1 && g.Hi >= g.Ho &&
+                       g.Wi >= g.Wo;   // 1x1 stride-1: a row is valid for every k-tile or for none
 
     f32x4 ra[AR], rb[BR];
     int th = 0, tw = 0, cc = 0;   // tap / channel-chunk counters of the k-tile being LOADED (non-stem)
@@ -101,7 +119,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     // re-fetches the final k-tile and discards it), so the scheduler is free to sink the address
     // arithmetic and the global loads of tile k+1 into the shadow of the 64 MFMAs of tile k.
     auto load_tile = [&](int kt) {
-        int dh, dw, widx, coff;
+        int dh, dw;
+        unsigned aoff, woff;     // wave-uniform for the regular path
         bool tapok = true;
         if (STEM) {
             const int tap = kt * 4 + (kq >> 1);
@@ -109,22 +128,26 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
             const int r = tap / g.S, s = tap - r * g.S;
             dh = g.dh0 + g.dhs * r;
             dw = g.dw0 + g.dws * s;
-            widx = tapok ? tap : 0;
-            coff = (kq & 1) * 4;
+            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + (kq & 1) * 4) * 4u;
+            woff = (unsigned)((tapok ? tap : 0) * g.Ci + (kq & 1) * 4) * 4u;
         } else {
             dh = g.dh0 + g.dhs * th;
             dw = g.dw0 + g.dws * tw;
-            widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
-            coff = cc * BK + kq * 4;
+            const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
+            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cc * BK) * 4u;
+            woff = (unsigned)(widx * g.Ci + cc * BK) * 4u;
         }
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            const int hi = hi0[j] + dh, wi = wi0[j] + dw;
-            const bool ok = tapok && rvalid[j] && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-            ra[j] = ld4_if(in, rowoff[j] + ((size_t)(hi * g.Wi + wi)) * g.Ci + coff, ok);
+            bool ok = tapok && rvalid[j];
+            if (!nopad) {
+                const int hi = hi0[j] + dh, wi = wi0[j] + dw;
+                ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+            }
+            ra[j] = bld4(rs_in, ok ? rowv[j] + aoff : kInvalidOff);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = ld4_if(wgt, wrow[j] + (size_t)widx * g.Ci + coff, tapok);
+        for (int j = 0; j < BR; ++j) rb[j] = bld4(rs_w, tapok ? wv[j] + woff : kInvalidOff);
     };
     auto advance = [&](bool really) {    // step the (th, tw, cc) counters unless we are re-fetching
         if (!STEM) {
@@ -263,7 +286,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
 template <int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const float* __restrict__ in,
                                                              const float* __restrict__ dy,
-                                                             float* __restrict__ dst, int ntile_c, int kps) {
+                                                             float* __restrict__ dst, int ntile_c, int kps,
+                                                             unsigned in_bytes, unsigned dy_bytes) {
     constexpr int BKM = 32;
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     constexpr int QA = BMO / 4, QB = BNC / 4;          // float4 per tile row
@@ -318,24 +342,34 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const int kt0 = blockIdx.y * kps;
     const int kt1 = min(kt0 + kps, nkt);
 
+    // 32-bit byte offsets through buffer descriptors; rows past M fall off the end of dY / In and read 0.
+    // `lin`: 1x1 stride-1 (the gathered pixel of row m is pixel m): no per-k-tile decoding at all.
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
+    const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     f32x4 ra[RA], rb[RB];
     auto load_tile = [&](int kt) {
         const int mb = kt * BKM;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int m = mb + ra0 + SA * j;
-            ra[j] = ld4_if(dy, (size_t)m * g.Co + o0 + qa * 4, m < M);
+            ra[j] = bld4(rs_dy, (unsigned)(m * g.Co + o0 + qa * 4) * 4u);   // m >= M: past the end -> 0
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int m = mb + rb0 + SB * j;
-            bool ok = tapok && m < M;
-            const int mm = ok ? m : 0;
-            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
-            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
-            const int hi = ho * g.is + dh, wi = wo * g.is + dw;
-            ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-            rb[j] = ld4_if(in, (((size_t)n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff, ok);
+            unsigned off;
+            if (lin) {
+                off = (unsigned)(m * g.Ci + coff) * 4u;
+            } else {
+                bool ok = tapok && m < M;
+                const int mm = ok ? m : 0;
+                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+                const int hi = ho * g.is + dh, wi = wo * g.is + dw;
+                ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * 4u : kInvalidOff;
+            }
+            rb[j] = bld4(rs_in, off);
         }
     };
     auto store_tile = [&](int buf) {
@@ -514,6 +548,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
         IO_REQUIRE(g.Ci % 32 == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of 32", g.Ci);
     const long M = (long)g.N * g.Ho * g.Wo;
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
+    const double in_b = 4.0 * g.N * g.Hi * g.Wi * g.Ci, w_b = 4.0 * g.Co * g.wT * g.Ci;
+    IO_REQUIRE(in_b < 4.0e9 && w_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: operand larger than 4 GB (32-bit offsets)");
+    const unsigned in_bytes = (unsigned)in_b, w_bytes = (unsigned)w_b;
     const int bn = (g.Co % 128 == 0) ? 128 : 64;
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
@@ -536,7 +573,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           ntn);                                                                             \
+                           ntn, in_bytes, w_bytes);                                                          \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
@@ -566,6 +603,9 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, 
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     float* dst = p.splits == 1 ? dw : partial;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(kThreads);
+    const double in_b = 4.0 * g.N * g.Hi * g.Wi * g.Ci, dy_b = 4.0 * g.N * g.Ho * g.Wo * g.Co;
+    IO_REQUIRE(in_b < 4.0e9 && dy_b < 4.0e9, IO_ERR_SHAPE, "conv_wgrad: operand larger than 4 GB (32-bit offsets)");
+    const unsigned in_bytes = (unsigned)in_b, dy_bytes = (unsigned)dy_b;
     const double Md = (double)g.N * g.Ho * g.Wo;
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_WGRAD_STEM : IO_PROF_WGRAD, 2.0 * Md * g.Co * kred,
@@ -574,7 +614,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, 
     do {                                                                                                  \
         const size_t lds = (size_t)2 * 32 * (BMO_ + BNC_) * sizeof(float);                                \
         hipLaunchKernelGGL((conv_wgrad_kernel<BMO_, BNC_, STEM_>), grid, block, lds, st, g, in, dy, dst,  \
-                           p.ntile_c, p.kps);                                                             \
+                           p.ntile_c, p.kps, in_bytes, dy_bytes);                                         \
     } while (0)
     if (stem)
         IO_LAUNCH_WG(64, 64, true);
