@@ -66,7 +66,7 @@ template <int BN, bool STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
                                                          const float* __restrict__ wgt, float* __restrict__ out,
                                                          const float* __restrict__ add, int ntn, unsigned in_bytes,
-                                                         unsigned w_bytes) {
+                                                         unsigned w_bytes, unsigned out_bytes) {
     constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
@@ -240,41 +240,47 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     }
 
     // epilogue: D layout col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // One row pointer per (i, r); the `add` variant issues all its loads before the stores.
+    // One 32-bit byte offset per (i, r) row through a buffer descriptor (rows past M get kInvalidOff:
+    // their stores are dropped and their `add` loads return 0); the `add` variant issues all its loads
+    // before the stores.
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
-    const int ncol = n0 + wn * (BN / WN) + (lane & 31);
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? add : out, out_bytes);
+    const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * 4u;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        size_t rowidx[16];
-        bool rowok[16];
+        unsigned rowb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            rowok[r] = m < M;
-            size_t pix = (size_t)(rowok[r] ? m : 0);
+            const bool ok = m < M;
+            int pix = ok ? m : 0;
             if (!dense) {
-                const int mm = rowok[r] ? m : 0;
-                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                const int n = fdiv(pix, g.fd_howo), rem = pix - n * HoWo;
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
-                pix = ((size_t)n * g.outH + (ho * g.os + g.ooh)) * g.outW + (wo * g.os + g.oow);
+                pix = (n * g.outH + (ho * g.os + g.ooh)) * g.outW + (wo * g.os + g.oow);
             }
-            rowidx[r] = pix * g.Co + ncol;
+            rowb[r] = ok ? (unsigned)(pix * g.Co) * 4u + colb : kInvalidOff;
         }
         if (add) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 float av[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) av[r] = add[rowidx[r] + j * 32];
+                for (int r = 0; r < 16; ++r)
+                    av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rs_add, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (rowok[r]) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) out[rowidx[r] + j * 32] = acc[i][j][r];
+            for (int j = 0; j < TJ; ++j) {
+                const float v = acc[i][j][r];      // (bit_cast straight from the vector element miscompiles)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out,
+                                                      rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0);
             }
         }
     }
@@ -550,7 +556,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
     const double in_b = 4.0 * g.N * g.Hi * g.Wi * g.Ci, w_b = 4.0 * g.Co * g.wT * g.Ci;
     IO_REQUIRE(in_b < 4.0e9 && w_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: operand larger than 4 GB (32-bit offsets)");
-    const unsigned in_bytes = (unsigned)in_b, w_bytes = (unsigned)w_b;
+    const double out_b = 4.0 * g.N * g.outH * g.outW * g.Co;
+    IO_REQUIRE(out_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: output larger than 4 GB (32-bit offsets)");
+    const unsigned in_bytes = (unsigned)in_b, w_bytes = (unsigned)w_b, out_bytes = (unsigned)out_b;
     const int bn = (g.Co % 128 == 0) ? 128 : 64;
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
@@ -573,7 +581,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           ntn, in_bytes, w_bytes);                                                          \
+                           ntn, in_bytes, w_bytes, out_bytes);                                               \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
