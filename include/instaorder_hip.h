@@ -49,9 +49,12 @@ int io_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W,
                   int S, int stride, int pad, hipStream_t stream);
 /* gradient w.r.t. the input (autograd of the above, models/supervised_order.py:545 loss.backward()).
  * wt is the transposed filter [Cin][R*S][Cout] produced by io_filter_transpose; when `add` is not
- * NULL it is summed into the result (residual / accumulation; may alias dx). */
-int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
-                    int Cout, int R, int S, int stride, int pad, hipStream_t stream);
+ * NULL it is summed into the result (residual / accumulation; may alias dx); when `relu_mask` is not
+ * NULL (a tensor shaped like dx: the post-ReLU activation this gradient belongs to) the result is zeroed
+ * where relu_mask <= 0, i.e. the ReLU backward of Bottleneck.forward's final nn.ReLU (resnet_cls.py:114)
+ * is applied in the epilogue. */
+int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* relu_mask, int N,
+                    int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t stream);
 /* gradient w.r.t. the filter; workspace from io_conv2d_wgrad_workspace_bytes (split-K partials). */
 size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 int io_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int R,
@@ -96,9 +99,10 @@ int io_maxpool_bwd(const float* dy, const uint32_t* idx, int N, int H, int W, in
  * logits[N][K0+K1] (head 0 first). */
 int io_avgpool_fc_fwd(const float* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
                       const float* w1, const float* b1, int K1, float* pooled, float* logits, hipStream_t stream);
+/* relu_mask (optional, shaped like x): dx is zeroed where relu_mask <= 0 (ReLU backward of the pooled tensor) */
 int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
-                      const float* w1, int K1, float* dx, float* dw0, float* db0, float* dw1, float* db1,
-                      hipStream_t stream);
+                      const float* w1, int K1, const float* relu_mask, float* dx, float* dw0, float* db0, float* dw1,
+                      float* db1, hipStream_t stream);
 
 /* ---- input packing: torch.cat([modal_a, modal_b, rgb], 1) (supervised_order.py:537-538) fused with
  * NCHW -> NHWC and channel padding 5 -> 8.  planes/sample_strides are HOST arrays of nplanes entries. */

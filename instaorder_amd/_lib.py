@@ -33,7 +33,7 @@ SIGNATURES = {
     "io_last_error_string": (C.c_char_p, []),
     "io_device_count": (_I, []),
     "io_conv2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "io_conv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "io_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "io_conv2d_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "io_filter_transpose": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -45,7 +45,7 @@ SIGNATURES = {
     "io_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "io_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "io_avgpool_fc_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
-    "io_avgpool_fc_bwd": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "io_avgpool_fc_bwd": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "io_pack_planes_nhwc8": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), _I, _I, _I, _I, _P, _P]),
     "io_order_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P]),
     "io_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),

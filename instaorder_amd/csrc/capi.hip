@@ -84,14 +84,16 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
     return g;
 }
 
-int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
-                 int Cout, int R, int S, int stride, int pad, hipStream_t st) {
+int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
+                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st) {
     for (int ph = 0; ph < stride; ++ph)
         for (int pw = 0; pw < stride; ++pw) {
             IoConvGeom g = io_geom_dgrad(N, H, W, Cin, Cout, R, S, stride, pad, ph, pw);
             if (g.Ho <= 0 || g.Wo <= 0) continue;
-            if ((g.Th == 0 || g.Tw == 0) && add == dx) continue;   // nothing to add, values stay
-            int rc = io_launch_conv_nt(g, dy, wt, dx, add, 0, st);
+            // a lattice class no tap reaches keeps its values when accumulating in place -- unless a ReLU
+            // mask has to be applied to them
+            if ((g.Th == 0 || g.Tw == 0) && add == dx && !mask) continue;
+            int rc = io_launch_conv_nt(g, dy, wt, dx, add, mask, 0, st);
             if (rc) return rc;
         }
     return IO_OK;
@@ -100,13 +102,14 @@ int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, 
 extern "C" int io_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout,
                              int R, int S, int stride, int pad, hipStream_t st) {
     IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
-    return io_launch_conv_nt(g, x, w, y, nullptr, Cin == 8, st);
+    return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, Cin == 8, st);
 }
 
-extern "C" int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W,
-                               int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st) {
+extern "C" int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* relu_mask,
+                               int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                               hipStream_t st) {
     IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad: Cin=%d must be a multiple of 64", Cin);
-    return io_run_dgrad(dy, wt, dx, add, N, H, W, Cin, Cout, R, S, stride, pad, st);
+    return io_run_dgrad(dy, wt, dx, add, relu_mask, N, H, W, Cin, Cout, R, S, stride, pad, st);
 }
 
 extern "C" size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride,

@@ -65,7 +65,8 @@ __device__ __forceinline__ f32x4 ld4_if(const float* base, size_t off, bool ok) 
 template <int BN, bool STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
                                                          const float* __restrict__ wgt, float* __restrict__ out,
-                                                         const float* __restrict__ add, int ntn, unsigned in_bytes,
+                                                         const float* __restrict__ add,
+                                                         const float* __restrict__ mask, int ntn, unsigned in_bytes,
                                                          unsigned w_bytes, unsigned out_bytes) {
     constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
     constexpr int WN = NW / 2;              // waves along N (2 along M)
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out, out_bytes);
     const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? add : out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mask ? mask : out, out_bytes);
     const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * 4u;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -272,6 +274,18 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                                                           rs_add, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
+            }
+        }
+        if (mask) {      // ReLU backward of the tensor this gradient belongs to: zero where it was clipped
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rs_mask, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
             }
         }
 #pragma unroll
@@ -546,7 +560,7 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out, const float* add,
-                      int stem, hipStream_t st) {
+                      const float* mask, int stem, hipStream_t st) {
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_nt: Co=%d must be a multiple of 64", g.Co);
     if (stem)
         IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): Ci=%d must be 8 (5 channels padded)", g.Ci);
@@ -581,7 +595,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           ntn, in_bytes, w_bytes, out_bytes);                                               \
+                           mask, ntn, in_bytes, w_bytes, out_bytes);                                         \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");

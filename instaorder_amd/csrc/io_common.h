@@ -60,15 +60,15 @@ static inline void io_geom_finish(IoConvGeom& g) {
 
 // internal launchers shared between the C ABI and the network executor
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,
-                      const float* add, int stem, hipStream_t st);
+                      const float* add, const float* mask, int stem, hipStream_t st);
 int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, float* dw,
                          float* partial, size_t partial_bytes, int stem, hipStream_t st);
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
 
 IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
-int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, int N, int H, int W, int Cin,
-                 int Cout, int R, int S, int stride, int pad, hipStream_t st);
+int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
+                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench / profiling) ----
 enum IoProfClass {

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const float* __res
 __global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const float* __restrict__ dlogits,
                                                                       const float* __restrict__ w0, int K0,
                                                                       const float* __restrict__ w1, int K1, int HW,
-                                                                      int C, float* __restrict__ dx) {
+                                                                      int C, const float* __restrict__ mask,
+                                                                      float* __restrict__ dx) {
     const int n = blockIdx.x, K = K0 + K1;
     const float inv = 1.f / (float)HW;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -162,7 +163,10 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const flo
             s += dlogits[(size_t)n * K + k] * wv;
         }
         s *= inv;
-        for (int p = 0; p < HW; ++p) dx[((size_t)n * HW + p) * C + c] = s;
+        for (int p = 0; p < HW; ++p) {
+            const size_t o = ((size_t)n * HW + p) * C + c;
+            dx[o] = (!mask || mask[o] > 0.f) ? s : 0.f;
+        }
     }
 }
 
@@ -355,11 +359,12 @@ extern "C" int io_avgpool_fc_fwd(const float* x, int N, int HW, int C, const flo
 }
 
 extern "C" int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0,
-                                 int K0, const float* w1, int K1, float* dx, float* dw0, float* db0, float* dw1,
-                                 float* db1, hipStream_t st) {
+                                 int K0, const float* w1, int K1, const float* relu_mask, float* dx, float* dw0,
+                                 float* db0, float* dw1, float* db1, hipStream_t st) {
     const int K = K0 + K1;
     IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, 4.0 * N * HW * C, st);
-    hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1, HW, C, dx);
+    hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1, HW, C,
+                       relu_mask, dx);
     hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K0), dim3(kThreads), 0, st, dlogits, pooled,
                        N, C, K, 0, K0, dw0, db0);
     if (K1 > 0)

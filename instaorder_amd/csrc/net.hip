@@ -221,7 +221,7 @@ struct Ctx {
 
 int conv_fwd(const Ctx& c, const ConvL& L, const float* x, float* y, int H) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
-    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, L.cin_store == 8, c.st);
+    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, nullptr, L.cin_store == 8, c.st);
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
@@ -314,10 +314,11 @@ int conv_wgrad(const Ctx& c, const ConvL& L, const float* x, const float* dy, in
                                 L.cin_store == 8, c.st);
 }
 
-int conv_dgrad(const Ctx& c, const ConvL& L, const float* dy, float* dx, const float* add, int H) {
+int conv_dgrad(const Ctx& c, const ConvL& L, const float* dy, float* dx, const float* add, const float* mask,
+               int H) {
     float* wt = c.buf(c.plan.wt);
     IO_TRY(io_filter_transpose(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, c.st));
-    return io_run_dgrad(dy, wt, dx, add, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st);
+    return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st);
 }
 
 int run_backward(Ctx& c, const float* dlogits, const float* x8) {
@@ -334,9 +335,12 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
     for (const Block& b : net->blocks) Hlast /= b.stride;
     const size_t nb = net->blocks.size();
     const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
+    // Gradients of block outputs are kept ALREADY MASKED by that output's ReLU: whoever writes the last
+    // contribution to d(out) applies [out > 0] in its epilogue (here: the pooling backward; below: the
+    // data-gradient kernels), so the BN backward of the block needs neither the activation nor a mask pass.
     IO_TRY(io_avgpool_fc_bwd(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
-                             net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0, Gd,
-                             c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
+                             net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0,
+                             c.buf(p.blk[nb - 1].out), Gd, c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
                              net->n_heads > 1 ? c.grads + net->fcw_off[1] : nullptr,
                              net->n_heads > 1 ? c.grads + net->fcb_off[1] : nullptr, c.st));
     // per-block input resolution
@@ -351,20 +355,25 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         const int H = Hin[ii], Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
         const float* xin = ii == 0 ? c.buf(p.p0) : c.buf(p.blk[ii - 1].out);
-        // bn3 (+ReLU of the block output): dy3 -> Ga, masked dout kept in Gd for the identity branch
-        IO_TRY(bn_back(c, b.b3, Gd, 2, c.buf(bb.out), c.buf(bb.y3), Mout, Ga, Gd));
+        // the block input is the previous block's post-ReLU output (for block 0 it is the max-pool output,
+        // whose gradient is not masked here)
+        const float* xmask = ii == 0 ? nullptr : xin;
+        // bn3: Gd holds dz = d(out) * [out > 0]; dy3 -> Ga
+        IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.buf(bb.y3), Mout, Ga, nullptr));
         IO_TRY(conv_wgrad(c, b.c3, c.buf(bb.a2), Ga, Ho));
-        IO_TRY(conv_dgrad(c, b.c3, Ga, Gb, nullptr, Ho));
+        IO_TRY(conv_dgrad(c, b.c3, Ga, Gb, nullptr, nullptr, Ho));
         IO_TRY(bn_back(c, b.b2, Gb, 1, nullptr, c.buf(bb.y2), Mout, Gc, nullptr));
         IO_TRY(conv_wgrad(c, b.c2, c.buf(bb.a1), Gc, H));
-        IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, H));
+        IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, nullptr, H));
         IO_TRY(bn_back(c, b.b1, Ga, 1, nullptr, c.buf(bb.y1), Min, Gb, nullptr));
         IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
-        IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, H));
+        // d(x_in) = dgrad(conv1) + identity path; the mask is idempotent, so with a downsample branch it is
+        // applied by both kernels (the strided one only touches its own output lattice)
+        IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, xmask, H));
         if (b.down) {
             IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
-            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, H));
+            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, xmask, H));
         }
         float* t = Gd; Gd = Ge; Ge = t;
     }

@@ -101,14 +101,21 @@ def test_conv_dgrad(case):
     _lib.check(L().io_filter_transpose(P(wk), Cout, k * k, Cin, P(wt), ST()), "transpose")
     assert torch.equal(wt.cpu(), wk.cpu().view(Cout, k * k, Cin).permute(2, 1, 0).contiguous())
     dx = torch.full((N, H, W, Cin), float("nan"), device=DEV)
-    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(dx), None, N, H, W, Cin, Cout, k, k, s, p, ST()), "dgrad")
+    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(dx), None, None, N, H, W, Cin, Cout, k, k, s, p, ST()), "dgrad")
     assert relerr(dx.permute(0, 3, 1, 2), ref) < 2e-5
     # with accumulation into an existing tensor (residual / downsample sum), in place
     base = torch.randn(N, H, W, Cin, generator=torch.Generator().manual_seed(9)).to(DEV)
     acc = base.clone()
-    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(acc), P(acc), N, H, W, Cin, Cout, k, k, s, p, ST()),
+    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(acc), P(acc), None, N, H, W, Cin, Cout, k, k, s, p, ST()),
                "dgrad+add")
     assert relerr(acc.permute(0, 3, 1, 2), ref + base.cpu().double().permute(0, 3, 1, 2)) < 2e-5
+    # ... and with the ReLU mask of the tensor the gradient belongs to applied in the epilogue
+    msk = torch.randn(N, H, W, Cin, generator=torch.Generator().manual_seed(10)).to(DEV)
+    acc2 = base.clone()
+    _lib.check(L().io_conv2d_dgrad(P(nhwc(dy)), P(wt), P(acc2), P(acc2), P(msk), N, H, W, Cin, Cout, k, k, s, p, ST()),
+               "dgrad+add+mask")
+    want = (ref + base.cpu().double().permute(0, 3, 1, 2)) * (msk.cpu().permute(0, 3, 1, 2) > 0)
+    assert relerr(acc2.permute(0, 3, 1, 2), want) < 2e-5
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -279,10 +286,16 @@ def test_avgpool_fc(heads):
     dx = torch.empty(N, 2, 2, Cc, device=DEV)
     gw = [torch.empty_like(w) for w in dw]
     gb = [torch.empty_like(b) for b in db]
-    _lib.check(L().io_avgpool_fc_bwd(P(f(dl)), P(pl), N, HW, Cc, P(dw[0]), K0, P(dw[1]) if K1 else None, K1, P(dx),
-                                     P(gw[0]), P(gb[0]), P(gw[1]) if K1 else None, P(gb[1]) if K1 else None, ST()),
-               "head bwd")
+    _lib.check(L().io_avgpool_fc_bwd(P(f(dl)), P(pl), N, HW, Cc, P(dw[0]), K0, P(dw[1]) if K1 else None, K1, None,
+                                     P(dx), P(gw[0]), P(gb[0]), P(gw[1]) if K1 else None, P(gb[1]) if K1 else None,
+                                     ST()), "head bwd")
     assert relerr(dx.permute(0, 3, 1, 2), grads[0]) < 1e-5
+    msk = torch.randn(N, 2, 2, Cc, generator=g).to(DEV)
+    dxm = torch.empty_like(dx)
+    _lib.check(L().io_avgpool_fc_bwd(P(f(dl)), P(pl), N, HW, Cc, P(dw[0]), K0, P(dw[1]) if K1 else None, K1, P(msk),
+                                     P(dxm), P(gw[0]), P(gb[0]), P(gw[1]) if K1 else None, P(gb[1]) if K1 else None,
+                                     ST()), "head bwd mask")
+    assert torch.equal(dxm, dx * (msk > 0))
     for i in range(len(heads)):
         assert relerr(gw[i], grads[1 + i]) < 1e-5
         assert relerr(gb[i], grads[1 + len(heads) + i]) < 1e-5
