@@ -47,6 +47,16 @@ int io_device_count(void);
  * R = S = 7), Cout % 64 == 0. */
 int io_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R,
                   int S, int stride, int pad, hipStream_t stream);
+/* the same convolution with the training-mode BatchNorm statistics of its output (see
+ * io_bn_stats_finalize) accumulated in the GEMM epilogue instead of a second pass over y: what
+ * `out = self.bnK(self.convK(x))` needs before the normalisation (resnet_cls.py:100-110).  N*Ho*Wo/G must be
+ * a multiple of 128 (a row tile never straddles two BN groups). */
+size_t io_conv2d_bnstats_workspace_floats(int N, int H, int W, int Cout, int R, int S, int stride, int pad, int G);
+int io_conv2d_fwd_bnstats(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R,
+                          int S, int stride, int pad, int G, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                          float* rstd, float* scale, float* shift, float* workspace, size_t workspace_floats,
+                          hipStream_t stream);
 /* gradient w.r.t. the input (autograd of the above, models/supervised_order.py:545 loss.backward()).
  * wt is the transposed filter [Cin][R*S][Cout] produced by io_filter_transpose; when `add` is not
  * NULL it is summed into the result (residual / accumulation; may alias dx); when `relu_mask` is not

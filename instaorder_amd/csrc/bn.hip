@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                 for (int u = 0; u < 8; ++u) {
                     const int b = b0 + 8 * u;
                     const size_t o = ((size_t)g * nb + (b < nb ? b : 0)) * C + c;
-                    vs[u] = psum[o]; vq[u] = psq[o]; vp[u] = ppiv[o];
+                    vs[u] = psum ? psum[o] : 0.f; vq[u] = psq[o]; vp[u] = ppiv[o];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -387,6 +387,86 @@ int ew_blocks(size_t total4) {
 }
 
 }  // namespace
+
+namespace {
+// level-1 merge of per-tile (mean, M2) partials: block = 32 channels x 8 lanes, each block folds `chunk`
+// consecutive tiles of one group into one partial (same representation, count implied by position)
+__global__ __launch_bounds__(256) void bn_merge_tiles_kernel(const float* __restrict__ tmean,
+                                                            const float* __restrict__ tm2, int nt, int rows,
+                                                            int Mg, int C, int chunk, float* __restrict__ omean,
+                                                            float* __restrict__ om2) {
+    __shared__ double sh[3][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y, ch = blockIdx.z;
+    const bool ok = c < C;
+    const int t0 = ch * chunk, t1 = min(t0 + chunk, nt);
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    if (ok)
+        for (int b0 = t0 + ty; b0 < t1; b0 += 64) {
+            float vm[8], vq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u;
+                const size_t o = ((size_t)g * nt + (b < t1 ? b : t0)) * C + c;
+                vm[u] = tmean[o]; vq[u] = tm2[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u;
+                if (b < t1) {
+                    const double nbk = (double)(min((b + 1) * rows, Mg) - b * rows);
+                    const double tot = n + nbk, delta = (double)vm[u] - mu;
+                    mu += delta * (nbk / tot);
+                    m2 += (double)vq[u] + delta * delta * (n * nbk / tot);
+                    n = tot;
+                }
+            }
+        }
+    sh[0][ty][tx] = n; sh[1][ty][tx] = mu; sh[2][ty][tx] = m2;
+    __syncthreads();
+    if (ok && ty == 0) {
+        for (int k = 1; k < 8; ++k) {
+            const double nk = sh[0][k][tx];
+            if (nk > 0.0) {
+                const double tot = n + nk, delta = sh[1][k][tx] - mu;
+                mu += delta * (nk / tot);
+                m2 += sh[2][k][tx] + delta * delta * (n * nk / tot);
+                n = tot;
+            }
+        }
+        const size_t o = ((size_t)g * gridDim.z + ch) * C + c;
+        omean[o] = (float)mu;
+        om2[o] = (float)m2;
+    }
+}
+}  // namespace
+
+// Statistics from the per-tile partials the conv epilogue wrote (tile_mean/tile_m2: [M/128][C], tiles of
+// kIoStatTileRows rows, M/G a multiple of it).  The partial arrays are scratch: the level-1 merge output is
+// written behind the tile partials (caller provides room for (nt + nt/64 + G) * C floats in each array).
+int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* mean, float* rstd, float* scale, float* shift, hipStream_t st) {
+    const int rows = kIoStatTileRows;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % rows == 0, IO_ERR_SHAPE,
+               "bn_finalize_tiles: rows per group %d must be a multiple of %d", G ? M / G : 0, rows);
+    const int Mg = M / G, nt = Mg / rows;
+    IoProfScope prof(IO_PROF_BN_STATS, 0.0, 8.0 * (double)(M / rows) * C, st);
+    const float* pm = tile_mean;
+    const float* pq = tile_m2;
+    int nb = nt, rpb = rows;
+    if (nt > 128) {
+        const int chunk = 64, nch = io_cdiv(nt, chunk);
+        float* om = tile_mean + (size_t)G * nt * C;
+        float* oq = tile_m2 + (size_t)G * nt * C;
+        hipLaunchKernelGGL(bn_merge_tiles_kernel, dim3(io_cdiv(C, 32), G, nch), dim3(256), 0, st, tile_mean, tile_m2,
+                           nt, rows, Mg, C, chunk, om, oq);
+        pm = om; pq = oq; nb = nch; rpb = rows * chunk;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, (const float*)nullptr, pq, pm, nb,
+                       rpb, G, Mg, C, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+    return io_check_launch("bn_finalize_tiles");
+}
 
 static int bn_rows_per_block(int Mg, int G, int* nb) {
     int want = 1024 / (G > 0 ? G : 1);

@@ -105,6 +105,33 @@ extern "C" int io_conv2d_fwd(const float* x, const float* w, float* y, int N, in
     return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, Cin == 8, st);
 }
 
+extern "C" size_t io_conv2d_bnstats_workspace_floats(int N, int H, int W, int Cout, int R, int S, int stride, int pad,
+                                                     int G) {
+    const long Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const long tiles = (N * Ho * Wo + kIoStatTileRows - 1) / kIoStatTileRows;
+    return (size_t)2 * (size_t)((tiles + tiles / 64 + G + 2) * Cout);
+}
+
+extern "C" int io_conv2d_fwd_bnstats(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout,
+                                     int R, int S, int stride, int pad, int G, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                                     size_t workspace_floats, hipStream_t st) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    const int M = N * g.Ho * g.Wo;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_fwd_bnstats: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, Cout, R, S, stride, pad, G);
+    IO_REQUIRE(workspace_floats >= need, IO_ERR_WORKSPACE, "conv2d_fwd_bnstats: workspace %zu < %zu floats",
+               workspace_floats, need);
+    float* tmean = workspace;
+    float* tm2 = workspace + need / 2;
+    int rc = io_launch_conv_nt(g, x, w, y, nullptr, nullptr, Cin == 8, st, tmean, tm2);
+    if (rc) return rc;
+    return io_bn_finalize_tiles(tmean, tm2, M, Cout, G, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                rstd, scale, shift, st);
+}
+
 extern "C" int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* relu_mask,
                                int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                hipStream_t st) {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                                                          const float* __restrict__ wgt, float* __restrict__ out,
                                                          const float* __restrict__ add,
                                                          const float* __restrict__ mask, int ntn, unsigned in_bytes,
-                                                         unsigned w_bytes, unsigned out_bytes) {
+                                                         unsigned w_bytes, unsigned out_bytes,
+                                                         float* __restrict__ st_mean, float* __restrict__ st_m2) {
     constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
@@ -238,6 +239,48 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
         for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+    }
+
+    // Fused BatchNorm statistics (forward convs in training mode): per (row tile, channel) the mean of the
+    // tile's valid rows and the sum of squared deviations from it -- two in-register passes over the
+    // accumulators, combined across the two row-waves through LDS.  Merged later with Chan's update.
+    if (st_mean) {
+        __syncthreads();                     // every wave is done with the operand tiles: LDS is free
+        float* red = smem;                   // [2][BN]
+        const int nvalid = min(BM, M - m0);
+        float cmean[TJ];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float v = acc[i][j][r];
+                        const float d = pass == 0 ? v : (v - cmean[j]) * (v - cmean[j]);
+                        sacc += m < M ? d : 0.f;
+                    }
+                sacc += __shfl_xor(sacc, 32, 64);
+                if (lane < 32) red[wm * BN + wn * (BN / WN) + j * 32 + lane] = sacc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int cl = wn * (BN / WN) + j * 32 + (lane & 31);
+                const float tot = red[cl] + red[BN + cl];
+                if (pass == 0) {
+                    cmean[j] = tot / (float)nvalid;
+                } else if (wm == 0 && lane < 32) {
+                    const size_t o = (size_t)mt * g.Co + n0 + cl;
+                    st_mean[o] = cmean[j];
+                    st_m2[o] = tot;
+                }
+            }
+            __syncthreads();
+        }
     }
 
     // epilogue: D layout col = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -560,7 +603,10 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out, const float* add,
-                      const float* mask, int stem, hipStream_t st) {
+                      const float* mask, int stem, hipStream_t st, float* st_mean, float* st_m2) {
+    IO_REQUIRE((st_mean == nullptr) == (st_m2 == nullptr), IO_ERR_SHAPE, "conv_nt: statistics outputs come in pairs");
+    IO_REQUIRE(!st_mean || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && !add && !mask), IO_ERR_SHAPE,
+               "conv_nt: fused statistics need a plain dense forward convolution");
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_nt: Co=%d must be a multiple of 64", g.Co);
     if (stem)
         IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): Ci=%d must be 8 (5 channels padded)", g.Ci);
@@ -595,7 +641,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           mask, ntn, in_bytes, w_bytes, out_bytes);                                         \
+                           mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2);                         \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");

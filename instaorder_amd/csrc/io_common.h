@@ -60,7 +60,12 @@ static inline void io_geom_finish(IoConvGeom& g) {
 
 // internal launchers shared between the C ABI and the network executor
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,
-                      const float* add, const float* mask, int stem, hipStream_t st);
+                      const float* add, const float* mask, int stem, hipStream_t st, float* st_mean = nullptr,
+                      float* st_m2 = nullptr);
+constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics
+int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* mean, float* rstd, float* scale, float* shift, hipStream_t st);
 int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, float* dw,
                          float* partial, size_t partial_bytes, int stem, hipStream_t st);
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);

@@ -106,6 +106,7 @@ struct Plan {
     std::vector<BlockBufs> blk;
     size_t tables;       // per-BN [4][kMaxGroups][C] floats, BN i at tables + 4*kMaxGroups*chan_prefix[i]
     size_t bn_partial, bn_partial_floats, coef;
+    size_t tile_mean, tile_m2;   // fused-statistics partials written by the conv epilogue (training)
     size_t gbuf[5];      // gradient scratch (training only)
     size_t wt, wg_partial, wg_partial_bytes;
     size_t total;
@@ -131,6 +132,13 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     p.bn_partial = a.take(p.bn_partial_floats * f);
     p.coef = a.take((size_t)2 * kMaxGroups * 2048 * f);
     p.pooled = a.take((size_t)N * 2048 * f);
+    {
+        // per (128-row tile, channel) partials of the widest conv output + room for the level-1 merge
+        const size_t tiles_x_c = (size_t)N * H0 * H0 * 64 / kIoStatTileRows + (size_t)kMaxGroups * 2048;
+        const size_t fl = training ? tiles_x_c + tiles_x_c / 32 + (size_t)kMaxGroups * 2048 : 0;
+        p.tile_mean = a.take(fl * f);
+        p.tile_m2 = a.take(fl * f);
+    }
     p.blk.resize(net->blocks.size());
     if (training) {
         p.y0 = a.take(maxact);
@@ -195,6 +203,12 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     return p;
 }
 
+#define IO_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_) return rc_;    \
+    } while (0)
+
 struct Tables {
     float *mean, *rstd, *scale, *shift;
 };
@@ -219,20 +233,34 @@ struct Ctx {
     }
 };
 
-int conv_fwd(const Ctx& c, const ConvL& L, const float* x, float* y, int H) {
+int conv_fwd(const Ctx& c, const ConvL& L, const float* x, float* y, int H, bool stats = false) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
-    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, nullptr, L.cin_store == 8, c.st);
+    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, nullptr, L.cin_store == 8, c.st,
+                             stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr);
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
-int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M) {
+int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M, bool from_tiles = false) {
     Tables t = c.tables(b);
+    if (c.training && from_tiles)
+        return io_bn_finalize_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), M, b.C, c.G,
+                                    c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
+                                    c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
+                                    t.shift, c.st);
     if (c.training)
         return io_bn_stats_finalize(y, M, b.C, c.G, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
                                     c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
                                     t.shift, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.st);
     return io_bn_eval_prepare(b.C, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
                               c.running + b.run_off + b.C, kBnEps, t.mean, t.scale, t.shift, c.st);
+}
+
+// conv followed by the statistics of its output; the statistics ride in the conv epilogue whenever a
+// 128-row tile never straddles two BN groups
+int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const float* x, float* y, int Hin, int Mout) {
+    const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
+    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse));
+    return bn_prepare(c, b, y, Mout, fuse);
 }
 
 int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, const BnL* b2, int relu,
@@ -250,19 +278,12 @@ int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, 
                        h2, relu, out, c.st);
 }
 
-#define IO_TRY(expr)            \
-    do {                        \
-        int rc_ = (expr);       \
-        if (rc_) return rc_;    \
-    } while (0)
-
 int run_forward(Ctx& c, const float* x8, float* logits) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
     const int H0 = c.S / 2, H1 = c.S / 4;
     // stem
-    IO_TRY(conv_fwd(c, net->stem, x8, c.buf(p.y0), c.S));
-    IO_TRY(bn_prepare(c, net->bn1, c.buf(p.y0), c.N * H0 * H0));
+    IO_TRY(conv_bn(c, net->stem, net->bn1, x8, c.buf(p.y0), c.S, c.N * H0 * H0));
     IO_TRY(bn_act(c, net->bn1, c.buf(p.y0), c.N * H0 * H0, nullptr, nullptr, 1, c.buf(p.a0)));
     IO_TRY(io_maxpool_fwd(c.buf(p.a0), c.N, H0, H0, 64, c.buf(p.p0),
                           c.training ? reinterpret_cast<uint32_t*>(c.ws + p.idx0) : nullptr, c.st));
@@ -273,17 +294,13 @@ int run_forward(Ctx& c, const float* x8, float* logits) {
         const BlockBufs& bb = p.blk[i];
         const int Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
-        IO_TRY(conv_fwd(c, b.c1, x, c.buf(bb.y1), H));
-        IO_TRY(bn_prepare(c, b.b1, c.buf(bb.y1), Min));
+        IO_TRY(conv_bn(c, b.c1, b.b1, x, c.buf(bb.y1), H, Min));
         IO_TRY(bn_act(c, b.b1, c.buf(bb.y1), Min, nullptr, nullptr, 1, c.buf(bb.a1)));
-        IO_TRY(conv_fwd(c, b.c2, c.buf(bb.a1), c.buf(bb.y2), H));
-        IO_TRY(bn_prepare(c, b.b2, c.buf(bb.y2), Mout));
+        IO_TRY(conv_bn(c, b.c2, b.b2, c.buf(bb.a1), c.buf(bb.y2), H, Mout));
         IO_TRY(bn_act(c, b.b2, c.buf(bb.y2), Mout, nullptr, nullptr, 1, c.buf(bb.a2)));
-        IO_TRY(conv_fwd(c, b.c3, c.buf(bb.a2), c.buf(bb.y3), Ho));
-        IO_TRY(bn_prepare(c, b.b3, c.buf(bb.y3), Mout));
+        IO_TRY(conv_bn(c, b.c3, b.b3, c.buf(bb.a2), c.buf(bb.y3), Ho, Mout));
         if (b.down) {
-            IO_TRY(conv_fwd(c, b.cd, x, c.buf(bb.yd), H));
-            IO_TRY(bn_prepare(c, b.bd, c.buf(bb.yd), Mout));
+            IO_TRY(conv_bn(c, b.cd, b.bd, x, c.buf(bb.yd), H, Mout));
             IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, c.buf(bb.yd), &b.bd, 1, c.buf(bb.out)));
         } else {
             IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, x, nullptr, 1, c.buf(bb.out)));

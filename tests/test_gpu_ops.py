@@ -88,6 +88,46 @@ def test_conv_fwd(case):
     assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("case,G", [((4, 16, 16, 64, 64, 1, 1, 0), 2), ((2, 16, 16, 64, 256, 3, 1, 1), 1),
+                                    ((8, 16, 16, 256, 128, 3, 2, 1), 2), ((64, 8, 8, 512, 2048, 1, 1, 0), 2)])
+def test_conv_fwd_with_fused_bn_statistics(case, G):
+    """conv + BN statistics in the GEMM epilogue == conv, then nn.BatchNorm2d's batch statistics per group
+    (incl. |mean| >> sigma outputs: the per-tile mean / M2 merge must not cancel)."""
+    N, H, W, Cin, Cout, k, s, p = case
+    x, w = _conv_inputs(case, 4)
+    w = w + 0.5 / np.sqrt(Cin * k * k)              # biased filters -> conv outputs with a large mean
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+    g = torch.Generator().manual_seed(11)
+    gamma = torch.rand(Cout, generator=g) + 0.5
+    beta = torch.randn(Cout, generator=g)
+    rm, rv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
+    means, rstds = [], []
+    for gi in range(G):
+        yg = ref[gi * N // G:(gi + 1) * N // G]
+        mu, var = yg.mean((0, 2, 3)), yg.var((0, 2, 3), unbiased=False)
+        means.append(mu)
+        rstds.append(1.0 / torch.sqrt(var + 1e-5))
+        n = yg.numel() / Cout
+        rm = 0.9 * rm + 0.1 * mu
+        rv = 0.9 * rv + 0.1 * var * n / (n - 1)
+    f = lambda t: t.float().to(DEV).contiguous()
+    y = torch.empty(N, Ho, Wo, Cout, device=DEV)
+    d_rm, d_rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, rstd, scale, shift = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+    nws = L().io_conv2d_bnstats_workspace_floats(N, H, W, Cout, k, k, s, p, G)
+    ws = torch.empty(nws, device=DEV)
+    _lib.check(L().io_conv2d_fwd_bnstats(P(nhwc(x)), P(krsc(w)), P(y), N, H, W, Cin, Cout, k, k, s, p, G, P(f(gamma)),
+                                         P(f(beta)), P(d_rm), P(d_rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift),
+                                         P(ws), nws, ST()), "conv+stats")
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+    assert relerr(mean.view(G, Cout), torch.stack(means)) < 2e-5
+    assert relerr(rstd.view(G, Cout), torch.stack(rstds)) < 1e-4
+    assert relerr(d_rm, rm) < 2e-5 and relerr(d_rv, rv) < 1e-4
+    assert relerr(scale.view(G, Cout), torch.stack(rstds) * gamma.double()) < 1e-4
+    assert torch.equal(shift.view(G, Cout).cpu(), beta.expand(G, Cout))
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(case):
     N, H, W, Cin, Cout, k, s, p = case
