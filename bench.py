@@ -157,8 +157,15 @@ def main():
         name, d = dom
         avg_ms = d["total_ms"] / d["launches"]
         tfl = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+        traffic = None        # HBM bytes per launch from the committed PMC run of this command (not live)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj.get("kernel") == name:
+                traffic = tj["bytes_per_launch_corrected"]
+        except Exception:
+            pass
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                               "launches": d["launches"], "avg_launch_ms": avg_ms,
                               "flops_per_launch": d["flops"] / d["launches"],
                               "share_of_gpu_time": d["total_ms"] / tot_ms}

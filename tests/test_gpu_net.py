@@ -410,3 +410,55 @@ def test_nccl_single_rank_dp_path():
         assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] size (256 pairs at 256x256, 512 samples per step): the oracle cannot run this in
+    seconds, so parity rests on size-independent properties -- (1) the two-group step equals two independent
+    module calls, (2) bit-exact determinism and linearity of the backward, (3) the first 4 pairs embedded in
+    the 256-pair EVAL batch give the oracle's logits for those 4 pairs (eval has no cross-sample coupling)."""
+    import instaorder_amd as ia
+    from instaorder_amd import engine
+    algo, B, S = "InstaOrderNet_o", 256, 256
+    m = build(algo, 81, "kaiming")
+    base = synthetic.make_pair_batch(990, 8, S)
+    reps = B // 8
+    dev = {k: torch.from_numpy(np.concatenate([v] * reps, 0)).cuda() for k, v in base.items()}
+    dev["rgb"] = dev["rgb"] + 0.01 * torch.arange(B, device="cuda", dtype=torch.float32).view(B, 1, 1, 1)
+    net = m.net
+    m.switch_to("train")
+    st0 = {k: v.clone() for k, v in m.model.state_dict().items()}
+    x8 = engine.pack_pair_directions(dev["rgb"], dev["modal1"], dev["modal2"])
+    assert x8.shape == (2 * B, S, S, 8)
+    logits, ws = net._run_forward(x8, 2 * B, S, 2, True)
+    two = {k: v.clone() for k, v in m.model.state_dict().items()}
+    dl = torch.randn_like(logits) * 1e-3
+    net._run_backward(x8, dl, 2 * B, S, 2, ws)
+    g1 = net.flat_grads.clone()
+    assert torch.isfinite(g1).all() and float(g1.abs().sum()) > 0
+    net._run_backward(x8, dl, 2 * B, S, 2, ws)
+    assert torch.equal(net.flat_grads, g1)                       # deterministic
+    net._run_backward(x8, 4 * dl, 2 * B, S, 2, ws)
+    assert torch.equal(net.flat_grads, 4 * g1)                   # linear (power-of-two scaling is exact)
+    net._pool.give(ws)
+    del ws
+    # (1) two sequential single-group calls from the same starting state
+    m.model.load_state_dict(st0)
+    with torch.no_grad():
+        za = net.forward_packed(x8[:B], 1)
+        zb = net.forward_packed(x8[B:], 1)
+    assert rel_err(logits[:B].cpu().numpy(), za.cpu().numpy()) < 1e-4
+    assert rel_err(logits[B:].cpu().numpy(), zb.cpu().numpy()) < 1e-4
+    for k, v in m.model.state_dict().items():
+        if v.dtype == torch.float32:
+            assert rel_err(v.cpu().numpy(), two[k].cpu().numpy()) < 1e-5, k
+        else:
+            assert torch.equal(v, two[k]), k
+    # (3) eval: 4 of the 256 pairs against the CPU oracle
+    m.switch_to("eval")
+    state = orc.state_from_numpy({k[len("module."):]: v.cpu().numpy() for k, v in m.model.state_dict().items()})
+    with torch.no_grad():
+        ze = net.forward_packed(x8[:B], 1)[:4].cpu().numpy()
+        xo = torch.cat([dev["modal1"][:4], dev["modal2"][:4], dev["rgb"][:4]], 1).cpu()
+        zo = orc.resnet_forward(state, xo, False).numpy()
+    assert rel_err(ze, zo) < FWD_TOL

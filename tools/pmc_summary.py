@@ -16,7 +16,9 @@ for f in files:
         name = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
         if only and only not in name:
             continue
-        acc[name + " grid=" + r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = name if only else name + " grid=" + r["Grid_Size"]
+        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in acc.items():
     print(name[:100])
-    print("    " + "  ".join("%s=%.4g" % (c.replace("SQ_", ""), sum(v) / len(v)) for c, v in sorted(cs.items())))
+    print("    " + "  ".join("%s: n=%d mean=%.6g sum=%.6g" % (c.replace("SQ_", ""), len(v), sum(v) / len(v), sum(v))
+                             for c, v in sorted(cs.items())))
