@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--algo", default="InstaOrderNet_o")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank path when several ranks must share one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,10 +89,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     _lib.require_gpu()
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     B, S = args.batch, args.size
@@ -146,7 +148,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, fp32, fwd+bwd+SGD "
                                "(BASELINE.json configs[1])" % (args.algo, B, S, S),
-                   "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss},
+                   "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
+                   "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
+                       args.backend, model.net.flat_grads.numel())},
         "achieved_tflops_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12,
         "mfma_frac_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12
         / (world * PEAK_FP32_MFMA_TFLOPS),

@@ -100,15 +100,17 @@ def pack_nchw(x, out=None):
 
 def pack_pair_directions(rgb, modal1, modal2, out=None):
     """Both mask orders of a pair batch in one buffer: rows [0,B) = (modal1, modal2, rgb), rows
-    [B,2B) = (modal2, modal1, rgb) -- the two model calls of supervised_order.py:537-538."""
+    [B,2B) = (modal2, modal1, rgb) -- the two model calls of supervised_order.py:537-538.  ``rgb=None``
+    is the reference's ``use_rgb=False`` form (masks only)."""
     for t, nme in ((rgb, "rgb"), (modal1, "modal1"), (modal2, "modal2")):
-        _dev_f32(t, nme)
-    B, _, H, W = rgb.shape
+        if t is not None:
+            _dev_f32(t, nme)
+    B, _, H, W = modal1.shape
     if out is None:
-        out = torch.empty((2 * B, H, W, 8), device=rgb.device, dtype=torch.float32)
+        out = torch.empty((2 * B, H, W, 8), device=modal1.device, dtype=torch.float32)
     HW = H * W
-    rgbp = [(rgb, c * HW) for c in range(3)]
-    st = [HW, HW, 3 * HW, 3 * HW, 3 * HW]
+    rgbp = [(rgb, c * HW) for c in range(3)] if rgb is not None else []
+    st = [HW, HW] + [3 * HW] * len(rgbp)
     pack_planes([(modal1, 0), (modal2, 0)] + rgbp, st, B, H, W, out[:B])
     pack_planes([(modal2, 0), (modal1, 0)] + rgbp, st, B, H, W, out[B:])
     return out

@@ -34,8 +34,10 @@ class _OrderBase(SingleStageModel):
         super(_OrderBase, self).__init__(params, dist_model)
         self.params = params
         self.use_rgb = params.get("use_rgb", False)
-        if not self.use_rgb:
-            raise NotImplementedError("use_rgb=False (2-channel input) is not part of the hot path")
+        want = 5 if self.use_rgb else 2         # (mask_a, mask_b[, R, G, B])  supervised_order.py:521-526
+        if self.net.in_channels != want:
+            raise ValueError("use_rgb=%s needs backbone_param.in_channels=%d, got %d"
+                             % (self.use_rgb, want, self.net.in_channels))
         self._x8 = None
         if load_pretrain is not None:
             self.load_pretrain(load_pretrain)
@@ -48,7 +50,8 @@ class _OrderBase(SingleStageModel):
         B = self.rgb.shape[0]
         if self._x8 is None or self._x8.shape[0] != 2 * B or self._x8.shape[1:3] != self.rgb.shape[2:]:
             self._x8 = None
-        self._x8 = engine.pack_pair_directions(self.rgb, self.modal1, self.modal2, self._x8)
+        self._x8 = engine.pack_pair_directions(self.rgb if self.use_rgb else None, self.modal1, self.modal2,
+                                               self._x8)
         self.B = B
 
     # -- loss plumbing -------------------------------------------------------------------------------

@@ -462,3 +462,44 @@ def test_full_size_properties_config2():
         xo = torch.cat([dev["modal1"][:4], dev["modal2"][:4], dev["rgb"][:4]], 1).cpu()
         zo = orc.resnet_forward(state, xo, False).numpy()
     assert rel_err(ze, zo) < FWD_TOL
+
+
+def test_use_rgb_false_and_ordernet_ext():
+    """The reference's mask-only form (use_rgb False, in_channels 2) and the 4-class OrderNet_ext head."""
+    import instaorder_amd as ia
+    B, S = 4, 64
+    batch = synthetic.make_pair_batch(975, B, S)
+    cfg = cfg_for("InstaOrderNet_o")
+    cfg["use_rgb"] = False
+    cfg["backbone_param"] = dict(in_channels=2, num_classes=2)
+    m = ia.InstaOrderNet_o(cfg, dist_model=False)
+    sd = synthetic.make_state_dict(73, 2, 2, prefix="module.", style="kaiming")
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    state = orc.state_from_numpy(sd, prefix="module.")
+    m.switch_to("train")
+    m.optim.param_groups[0]["lr"] = 0.0
+    set_input(m, "InstaOrderNet_o", batch)
+    out = m.step()
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    x1, x2 = torch.cat([tb["modal1"], tb["modal2"]], 1), torch.cat([tb["modal2"], tb["modal1"]], 1)
+    with torch.no_grad():
+        o1 = torch.sigmoid(orc.resnet_forward(state, x1, True))
+        o2 = torch.sigmoid(orc.resnet_forward(state, x2, True))
+        ref = (torch.nn.functional.binary_cross_entropy(o1, tb["occ_order"])
+               + torch.nn.functional.binary_cross_entropy(o2, tb["occ_order"][:, [1, 0]]))
+    assert abs(float(out["loss"]) - float(ref)) < FWD_TOL * float(ref)
+    cfg = cfg_for("OrderNet")
+    cfg["backbone_param"] = dict(in_channels=5, num_classes=4)
+    m = ia.OrderNet(cfg, dist_model=False)
+    sd = synthetic.make_state_dict(74, 5, 4, prefix="module.", style="kaiming")
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    state = orc.state_from_numpy(sd, prefix="module.")
+    lab = torch.tensor([0, 3, 1, 2])
+    m.switch_to("train")
+    m.optim.param_groups[0]["lr"] = 0.0
+    m.set_input(tb["rgb"], tb["modal1"], tb["modal2"], lab)
+    out = m.step()
+    b2 = dict(batch)
+    b2["depth_order"] = lab.numpy()
+    logs, _ = orc.train_step(state, {}, b2, "OrderNet", 0.0, 0.0)
+    assert abs(float(out["loss"]) - float(logs["loss"])) < FWD_TOL * float(logs["loss"])
