@@ -468,6 +468,75 @@ int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, 
     return io_check_launch("bn_finalize_tiles");
 }
 
+namespace {
+// plain sums of per-tile partials: block = 32 channels x 8 lanes, `chunk` consecutive tiles of one group
+__global__ __launch_bounds__(256) void bn_sum_tiles_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                                          int nt, int C, int chunk, float* __restrict__ o1,
+                                                          float* __restrict__ o2) {
+    __shared__ double sh[2][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y, ch = blockIdx.z;
+    const bool ok = c < C;
+    const int t0 = ch * chunk, t1e = min(t0 + chunk, nt);
+    double a = 0.0, b2 = 0.0;
+    if (ok)
+        for (int b0 = t0 + ty; b0 < t1e; b0 += 64) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u;
+                const size_t o = ((size_t)g * nt + (b < t1e ? b : t0)) * C + c;
+                v1[u] = b < t1e ? t1[o] : 0.f;
+                v2[u] = b < t1e ? t2[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += (double)v1[u]; b2 += (double)v2[u]; }
+        }
+    sh[0][ty][tx] = a; sh[1][ty][tx] = b2;
+    __syncthreads();
+    if (ok && ty == 0) {
+        for (int k = 1; k < 8; ++k) { a += sh[0][k][tx]; b2 += sh[1][k][tx]; }
+        const size_t o = ((size_t)g * gridDim.z + ch) * C + c;
+        o1[o] = (float)a;
+        o2[o] = (float)b2;
+    }
+}
+}  // namespace
+
+// BN backward when sum(dz), sum(dz*xhat) per (128-row tile, channel) were already produced by the epilogue of
+// the kernel that wrote dz (IoBwStats): merge the tile partials, finalize, apply.  dz is already masked.
+// p1/p2 need room for (tiles + tiles/64 + G) * C floats each.
+int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, int M, int C, int G,
+                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                         float* dy, float* coef, hipStream_t st) {
+    const int sh = ilog2_exact(C / 4);
+    IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd_from_tiles: C=%d unsupported", C);
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "bn_bwd_from_tiles: rows per group must be a multiple of %d", kIoStatTileRows);
+    const int Mg = M / G, nt = Mg / kIoStatTileRows;
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * 3.0, st);
+    const float* q1 = p1;
+    const float* q2 = p2;
+    int nb = nt;
+    if (nt > 64) {
+        const int chunk = 64, nch = io_cdiv(nt, chunk);
+        float* o1 = p1 + (size_t)G * nt * C;
+        float* o2 = p2 + (size_t)G * nt * C;
+        hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3(io_cdiv(C, 32), G, nch), dim3(256), 0, st, p1, p2, nt, C, chunk, o1,
+                           o2);
+        q1 = o1; q2 = o2; nb = nch;
+    }
+    float* c1 = coef;
+    float* c2 = coef + (size_t)G * C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
+                       dbeta, c1, c2);
+    const size_t total4 = (size_t)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dz, (const float*)nullptr, y,
+                       total4, sh, Mg, C, gamma, mean, rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, dy,
+                       (float*)nullptr);
+    return io_check_launch("bn_bwd_from_tiles");
+}
+
 static int bn_rows_per_block(int Mg, int G, int* nb) {
     int want = 1024 / (G > 0 ? G : 1);
     if (want < 1) want = 1;

@@ -85,7 +85,8 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
 }
 
 int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
-                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st) {
+                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st, const IoBwStats* bw) {
+    IO_REQUIRE(!bw || stride == 1, IO_ERR_SHAPE, "dgrad: fused BN-backward reductions need a stride-1 convolution");
     for (int ph = 0; ph < stride; ++ph)
         for (int pw = 0; pw < stride; ++pw) {
             IoConvGeom g = io_geom_dgrad(N, H, W, Cin, Cout, R, S, stride, pad, ph, pw);
@@ -93,7 +94,7 @@ int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, 
             // a lattice class no tap reaches keeps its values when accumulating in place -- unless a ReLU
             // mask has to be applied to them
             if ((g.Th == 0 || g.Tw == 0) && add == dx && !mask) continue;
-            int rc = io_launch_conv_nt(g, dy, wt, dx, add, mask, 0, st);
+            int rc = io_launch_conv_nt(g, dy, wt, dx, add, mask, 0, st, nullptr, nullptr, bw);
             if (rc) return rc;
         }
     return IO_OK;

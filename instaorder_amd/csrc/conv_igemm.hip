@@ -17,6 +17,7 @@
 // accumulators), register-staged double buffering (global loads of tile k+1 fly under the 64
 // MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.
 #include <stdlib.h>
+#include <string.h>
 
 #include "io_common.h"
 
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                                                          const float* __restrict__ add,
                                                          const float* __restrict__ mask, int ntn, unsigned in_bytes,
                                                          unsigned w_bytes, unsigned out_bytes,
-                                                         float* __restrict__ st_mean, float* __restrict__ st_m2) {
+                                                         float* __restrict__ st_mean, float* __restrict__ st_m2,
+                                                         IoBwStats bw) {
     constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
@@ -291,6 +293,20 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out, out_bytes);
     const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? add : out, out_bytes);
     const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mask ? mask : out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc(bw.y ? bw.y : out, out_bytes);
+    float bw_mu[TJ], bw_rs[TJ], bw_sc[TJ], bw_sh[TJ], bw_s1[TJ], bw_s2[TJ];
+    if (bw.y) {
+        const int gcol = (m0 / bw.Mg) * g.Co + n0 + wn * (BN / WN) + (lane & 31);   // group is uniform per tile
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            bw_mu[j] = bw.mean[gcol + j * 32];
+            bw_rs[j] = bw.rstd[gcol + j * 32];
+            bw_sc[j] = bw.mscale ? bw.mscale[gcol + j * 32] : 0.f;
+            bw_sh[j] = bw.mscale ? bw.mshift[gcol + j * 32] : 0.f;
+            bw_s1[j] = 0.f;
+            bw_s2[j] = 0.f;
+        }
+    }
     const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * 4u;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -331,6 +347,26 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
             }
         }
+        if (bw.y) {
+            // BN-backward reductions of the producer BN of this gradient tensor (see IoBwStats)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rs_bwy, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (bw.mscale) v = __builtin_fmaf(yv[r] - bw_mu[j], bw_sc[j], bw_sh[j]) > 0.f ? v : 0.f;
+                    acc[i][j][r] = v;
+                    const float vv = rowb[r] == kInvalidOff ? 0.f : v;
+                    bw_s1[j] += vv;
+                    bw_s2[j] += vv * ((yv[r] - bw_mu[j]) * bw_rs[j]);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -338,6 +374,30 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 const float v = acc[i][j][r];      // (bit_cast straight from the vector element miscompiles)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out,
                                                       rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0);
+            }
+        }
+    }
+    if (bw.y) {
+        __syncthreads();
+        float* red = smem;                   // [2 sums][2 row-waves][BN]
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const float a = bw_s1[j] + __shfl_xor(bw_s1[j], 32, 64);
+            const float b = bw_s2[j] + __shfl_xor(bw_s2[j], 32, 64);
+            if (lane < 32) {
+                const int cl = wn * (BN / WN) + j * 32 + lane;
+                red[wm * BN + cl] = a;
+                red[2 * BN + wm * BN + cl] = b;
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int cl = wn * (BN / WN) + j * 32 + lane;
+                const size_t o = (size_t)mt * g.Co + n0 + cl;
+                bw.p1[o] = red[cl] + red[BN + cl];
+                bw.p2[o] = red[2 * BN + cl] + red[3 * BN + cl];
             }
         }
     }
@@ -603,7 +663,15 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out, const float* add,
-                      const float* mask, int stem, hipStream_t st, float* st_mean, float* st_m2) {
+                      const float* mask, int stem, hipStream_t st, float* st_mean, float* st_m2,
+                      const IoBwStats* bw) {
+    IoBwStats bws;
+    memset(&bws, 0, sizeof(bws));
+    if (bw) {
+        bws = *bw;
+        IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg % 128 == 0, IO_ERR_SHAPE,
+                   "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group");
+    }
     IO_REQUIRE((st_mean == nullptr) == (st_m2 == nullptr), IO_ERR_SHAPE, "conv_nt: statistics outputs come in pairs");
     IO_REQUIRE(!st_mean || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && !add && !mask), IO_ERR_SHAPE,
                "conv_nt: fused statistics need a plain dense forward convolution");
@@ -641,7 +709,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2);                         \
+                           mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);                    \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");

@@ -58,10 +58,24 @@ static inline void io_geom_finish(IoConvGeom& g) {
     g.fd_wo = io_fastdiv(g.Wo);
 }
 
+// Optional epilogue of a data-gradient launch: the BN-backward reductions of the BN layer that produced the
+// tensor this gradient belongs to (sum dz, sum dz*xhat per 128-row tile and channel), so the separate reduce
+// pass over (dz, y) disappears.  y: that BN's input (the conv output); mean/rstd (+ optional scale/shift to
+// recompute the ReLU mask from y) are its [G][C] tables; Mg rows per group (a multiple of 128).
+struct IoBwStats {
+    const float* y;
+    const float *mean, *rstd, *mscale, *mshift;
+    float *p1, *p2;     // [M/128][C] tile partials
+    int Mg;
+};
+
 // internal launchers shared between the C ABI and the network executor
 int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,
                       const float* add, const float* mask, int stem, hipStream_t st, float* st_mean = nullptr,
-                      float* st_m2 = nullptr);
+                      float* st_m2 = nullptr, const IoBwStats* bw = nullptr);
+int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, int M, int C, int G,
+                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                         float* dy, float* coef, hipStream_t st);
 constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics
 int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
@@ -73,7 +87,8 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
 IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
 int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
-                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st);
+                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,
+                 const IoBwStats* bw = nullptr);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench / profiling) ----
 enum IoProfClass {

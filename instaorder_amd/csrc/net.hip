@@ -332,10 +332,47 @@ int conv_wgrad(const Ctx& c, const ConvL& L, const float* x, const float* dy, in
 }
 
 int conv_dgrad(const Ctx& c, const ConvL& L, const float* dy, float* dx, const float* add, const float* mask,
-               int H) {
+               int H, const IoBwStats* bw = nullptr) {
     float* wt = c.buf(c.plan.wt);
     IO_TRY(io_filter_transpose(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, c.st));
-    return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st);
+    return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st, bw);
+}
+
+bool tiles_ok(const Ctx& c, int M) { return (M / c.G) % kIoStatTileRows == 0; }
+
+IoBwStats bw_for(const Ctx& c, const BnL& b, const float* y, int M, bool mask_from_y) {
+    Tables t = c.tables(b);
+    IoBwStats bw;
+    bw.y = y;
+    bw.mean = t.mean;
+    bw.rstd = t.rstd;
+    bw.mscale = mask_from_y ? t.scale : nullptr;
+    bw.mshift = mask_from_y ? t.shift : nullptr;
+    bw.p1 = c.buf(c.plan.tile_mean);     // the forward's tile-partial scratch is free during the backward
+    bw.p2 = c.buf(c.plan.tile_m2);
+    bw.Mg = M / c.G;
+    return bw;
+}
+
+int bn_back_tiles(const Ctx& c, const BnL& b, const float* dz, const float* y, int M, float* dy) {
+    Tables t = c.tables(b);
+    return io_bn_bwd_from_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), dz, y, M, b.C, c.G,
+                                c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off, dy,
+                                c.buf(c.plan.coef), c.st);
+}
+
+// data gradient of conv L (-> dx, the gradient of relu(bn(y))), then the backward of that BN (-> dyb).
+// With a stride-1 conv the BN-backward reductions ride in the conv epilogue (which also applies the ReLU
+// mask recomputed from y), and only the apply pass remains.
+int dgrad_then_bn(const Ctx& c, const ConvL& L, const float* dy, float* dx, int H, const BnL& b, const float* y,
+                  int M, float* dyb) {
+    if (L.stride == 1 && tiles_ok(c, M)) {
+        IoBwStats bw = bw_for(c, b, y, M, true);
+        IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
+        return bn_back_tiles(c, b, dx, y, M, dyb);
+    }
+    IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H));
+    return bn_back(c, b, dx, 1, nullptr, y, M, dyb, nullptr);
 }
 
 int run_backward(Ctx& c, const float* dlogits, const float* x8) {
@@ -366,6 +403,7 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         int H = H1;
         for (size_t i = 0; i < nb; ++i) { Hin[i] = H; H /= net->blocks[i].stride; }
     }
+    bool have_tiles = false;    // BN-backward partial sums of the current block's bn3 already produced?
     for (size_t ii = nb; ii-- > 0;) {
         const Block& b = net->blocks[ii];
         const BlockBufs& bb = p.blk[ii];
@@ -376,17 +414,28 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         // whose gradient is not masked here)
         const float* xmask = ii == 0 ? nullptr : xin;
         // bn3: Gd holds dz = d(out) * [out > 0]; dy3 -> Ga
-        IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.buf(bb.y3), Mout, Ga, nullptr));
+        if (have_tiles)
+            IO_TRY(bn_back_tiles(c, b.b3, Gd, c.buf(bb.y3), Mout, Ga));
+        else
+            IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.buf(bb.y3), Mout, Ga, nullptr));
+        have_tiles = false;
         IO_TRY(conv_wgrad(c, b.c3, c.buf(bb.a2), Ga, Ho));
-        IO_TRY(conv_dgrad(c, b.c3, Ga, Gb, nullptr, nullptr, Ho));
-        IO_TRY(bn_back(c, b.b2, Gb, 1, nullptr, c.buf(bb.y2), Mout, Gc, nullptr));
+        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.buf(bb.y2), Mout, Gc));
         IO_TRY(conv_wgrad(c, b.c2, c.buf(bb.a1), Gc, H));
-        IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, nullptr, H));
-        IO_TRY(bn_back(c, b.b1, Ga, 1, nullptr, c.buf(bb.y1), Min, Gb, nullptr));
+        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.buf(bb.y1), Min, Gb));
         IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
-        // d(x_in) = dgrad(conv1) + identity path; the mask is idempotent, so with a downsample branch it is
-        // applied by both kernels (the strided one only touches its own output lattice)
-        IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, xmask, H));
+        // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
+        // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
+        // the previous block's bn3.  With one, the mask is idempotent and is applied by both kernels (the
+        // strided one only touches its own output lattice).
+        if (!b.down && ii > 0 && tiles_ok(c, Min)) {
+            const Block& pb = net->blocks[ii - 1];
+            IoBwStats bw = bw_for(c, pb.b3, c.buf(p.blk[ii - 1].y3), Min, false);
+            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, Gd, xmask, H, &bw));
+            have_tiles = true;
+        } else {
+            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, xmask, H));
+        }
         if (b.down) {
             IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
