@@ -65,6 +65,15 @@ int io_conv2d_fwd_bnstats(const float* x, const float* w, float* y, int N, int H
  * is applied in the epilogue. */
 int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* relu_mask, int N,
                     int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t stream);
+/* Backward through `conv(relu(bn(y)))` for a stride-1 conv, fused: the data gradient of the conv, the ReLU
+ * mask recomputed from y (scale/shift = the forward's tables), and the BatchNorm backward whose two
+ * reductions ride in the conv epilogue.  dz[N,H,W,Cin] gets the masked gradient of bn's output, dyb the
+ * gradient of y, dgamma/dbeta [Cin].  N*H*W/G must be a multiple of 128.  workspace: at least
+ * 2*((tiles + tiles/64 + G + 2)*Cin) + 2*G*Cin floats with tiles = N*H*W/128. */
+int io_conv2d_dgrad_bnbwd(const float* dy, const float* wt, float* dz, int N, int H, int W, int Cin, int Cout, int R,
+                          int S, int pad, const float* y, int G, const float* gamma, const float* mean,
+                          const float* rstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                          float* dyb, float* workspace, size_t workspace_floats, hipStream_t stream);
 /* gradient w.r.t. the filter; workspace from io_conv2d_wgrad_workspace_bytes (split-K partials). */
 size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 int io_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int R,

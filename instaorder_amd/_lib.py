@@ -37,6 +37,8 @@ SIGNATURES = {
     "io_conv2d_fwd_bnstats": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P,
                                    _P, _P, _P, _Z, _P]),
     "io_conv2d_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_dgrad_bnbwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+                                   _P, _Z, _P]),
     "io_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "io_conv2d_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "io_filter_transpose": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -140,6 +140,28 @@ extern "C" int io_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     return io_run_dgrad(dy, wt, dx, add, relu_mask, N, H, W, Cin, Cout, R, S, stride, pad, st);
 }
 
+extern "C" int io_conv2d_dgrad_bnbwd(const float* dy, const float* wt, float* dz, int N, int H, int W, int Cin, int Cout,
+                                     int R, int S, int pad, const float* y, int G, const float* gamma,
+                                     const float* mean, const float* rstd, const float* scale, const float* shift,
+                                     float* dgamma, float* dbeta, float* dyb, float* workspace,
+                                     size_t workspace_floats, hipStream_t st) {
+    IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad_bnbwd: Cin=%d must be a multiple of 64", Cin);
+    const int M = N * H * W;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_dgrad_bnbwd: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    const size_t tiles = (size_t)M / kIoStatTileRows;
+    const size_t per = (tiles + tiles / 64 + G + 2) * (size_t)Cin;
+    IO_REQUIRE(workspace_floats >= 2 * per + 2 * (size_t)G * Cin, IO_ERR_WORKSPACE,
+               "conv2d_dgrad_bnbwd: workspace %zu < %zu floats", workspace_floats, 2 * per + 2 * (size_t)G * Cin);
+    IoBwStats bw;
+    bw.y = y; bw.mean = mean; bw.rstd = rstd; bw.mscale = scale; bw.mshift = shift;
+    bw.p1 = workspace; bw.p2 = workspace + per; bw.Mg = M / G;
+    int rc = io_run_dgrad(dy, wt, dz, nullptr, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, st, &bw);
+    if (rc) return rc;
+    return io_bn_bwd_from_tiles(bw.p1, bw.p2, dz, y, M, Cin, G, gamma, mean, rstd, dgamma, dbeta, dyb,
+                                workspace + 2 * per, st);
+}
+
 extern "C" size_t io_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
                                                   int pad) {
     IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);

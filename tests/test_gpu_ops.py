@@ -158,6 +158,51 @@ def test_conv_dgrad(case):
     assert relerr(acc2.permute(0, 3, 1, 2), want) < 2e-5
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,k,G", [(4, 16, 64, 256, 1, 2), (2, 16, 128, 128, 3, 1), (8, 8, 512, 64, 1, 2)])
+def test_conv_dgrad_with_fused_bn_backward(N, H, Cin, Cout, k, G):
+    """autograd through conv(relu(bn(y))) w.r.t. y / gamma / beta in ONE fused call (dgrad + ReLU mask from y +
+    BN-backward reductions in the epilogue + apply) against torch in fp64."""
+    g = torch.Generator().manual_seed(N * H + Cin)
+    y = (torch.randn(N, Cin, H, H, generator=g, dtype=torch.float64) * 0.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(Cin, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(Cin, generator=g, dtype=torch.float64)).requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)
+    outs = []
+    for gi in range(G):
+        sl = slice(gi * N // G, (gi + 1) * N // G)
+        outs.append(F.batch_norm(y[sl], None, None, gamma, beta, True, 0.1, 1e-5))
+    a = F.relu(torch.cat(outs, 0))
+    o = F.conv2d(a, w, padding=k // 2)
+    do = torch.randn(o.shape, generator=g, dtype=torch.float64)
+    gy, gg, gb = torch.autograd.grad(o, [y, gamma, beta], do)
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    M = N * H * H
+    yd = nhwc(y.detach())
+    mean, rstd, scale, shift = (torch.empty(G * Cin, device=DEV) for _ in range(4))
+    npart = L().io_bn_partial_floats(M, Cin, G)
+    part = torch.empty(npart, device=DEV)
+    _lib.check(L().io_bn_stats_finalize(P(yd), M, Cin, G, P(f(gamma)), P(f(beta)), None, None, 0.1, 1e-5, P(mean), P(rstd),
+                                        P(scale), P(shift), P(part), npart, ST()), "stats")
+    wt = krsc(w).view(Cout, k * k, Cin).permute(2, 1, 0).contiguous()
+    tiles = M // 128
+    nws = 2 * ((tiles + tiles // 64 + G + 2) * Cin) + 2 * G * Cin
+    ws = torch.empty(nws, device=DEV)
+    dz, dyb = torch.empty_like(yd), torch.empty_like(yd)
+    dgam, dbet = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+    _lib.check(L().io_conv2d_dgrad_bnbwd(P(nhwc(do)), P(wt), P(dz), N, H, H, Cin, Cout, k, k, k // 2, P(yd), G, P(f(gamma)),
+                                         P(mean), P(rstd), P(scale), P(shift), P(dgam), P(dbet), P(dyb), P(ws), nws, ST()),
+               "dgrad+bnbwd")
+    assert relerr(dyb.permute(0, 3, 1, 2), gy) < 3e-5
+    assert relerr(dgam, gg) < 3e-5 and relerr(dbet, gb) < 3e-5
+    da = torch.autograd.grad(F.conv2d(a.detach().requires_grad_(True), w, padding=k // 2), [], do, allow_unused=True) \
+        if False else None
+    ref_dz = torch.autograd.grad(o, a, do, retain_graph=False) if False else None
+    # dz = (conv data gradient) * [a > 0]
+    a2 = a.detach().requires_grad_(True)
+    dz_ref = torch.autograd.grad(F.conv2d(a2, w, padding=k // 2), a2, do)[0] * (a.detach() > 0)
+    assert relerr(dz.permute(0, 3, 1, 2), dz_ref) < 3e-5
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_wgrad(case):
     N, H, W, Cin, Cout, k, s, p = case
