@@ -298,36 +298,40 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
     reduce_rows_store<2>(cm, s1, s2, p1 + o, p2 + o, C4);
 }
 
+// block = 8 channels x 32 lanes over the partials; ALL loads of a lane are issued before the first use (the
+// partials were written by other XCDs in the previous kernel, so every dependent round trip is an HBM/MALL
+// miss -- the kernel is pure latency, and serial batches were what made it take 20-60 us)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1,
                                                              const float* __restrict__ p2, int nb, int G, int Mg,
                                                              int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ c1,
                                                              float* __restrict__ c2) {
-    __shared__ double sh[2][8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx;
+    constexpr int U = 16, MAXG = 8;
+    __shared__ double sh[2][32][8];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;     // tx: channel, ty: partial lane (0..31)
+    const int c = blockIdx.x * 8 + tx;
     const bool ok = c < C;
     double dg = 0.0, db = 0.0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G && g < MAXG; ++g) {
         double a = 0.0, b2 = 0.0;
-        if (ok)
-            for (int b0 = ty; b0 < nb; b0 += 64) {
-                float v1[8], v2[8];
+        for (int b0 = ty; b0 < nb; b0 += 32 * U) {
+            float v1[U], v2[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b = b0 + 8 * u;
-                    const size_t o = ((size_t)g * nb + (b < nb ? b : 0)) * C + c;
-                    v1[u] = b < nb ? p1[o] : 0.f;
-                    v2[u] = b < nb ? p2[o] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { a += (double)v1[u]; b2 += (double)v2[u]; }
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + 32 * u;
+                const bool in = ok && b < nb;
+                const size_t o = ((size_t)g * nb + (in ? b : 0)) * C + (ok ? c : 0);
+                v1[u] = in ? p1[o] : 0.f;
+                v2[u] = in ? p2[o] : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a += (double)v1[u]; b2 += (double)v2[u]; }
+        }
         sh[0][ty][tx] = a;
         sh[1][ty][tx] = b2;
         __syncthreads();
         if (ok && ty == 0) {
-            for (int k = 1; k < 8; ++k) { a += sh[0][k][tx]; b2 += sh[1][k][tx]; }
+            for (int k = 1; k < 32; ++k) { a += sh[0][k][tx]; b2 += sh[1][k][tx]; }
             db += a;
             dg += b2;
             c1[g * C + c] = (float)(a / Mg);
@@ -528,7 +532,7 @@ int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, 
     }
     float* c1 = coef;
     float* c2 = coef + (size_t)G * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
                        dbeta, c1, c2);
     const size_t total4 = (size_t)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dz, (const float*)nullptr, y,
@@ -621,7 +625,7 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, G), dim3(kThreads), 0, st, dout, act, y, Mg, C, rpb, mean,
                        rstd, mask_scale, mask_shift, p1, p2);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
                        dgamma, dbeta, c1, c2);
     const size_t total4 = (size_t)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dout, act, y, total4,
