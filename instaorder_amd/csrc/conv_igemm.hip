@@ -16,7 +16,6 @@
 // per SIMD busy: 128x128x32 block tile, 4 waves in 2x2, 2x2 MFMA tiles per wave (4 independent
 // accumulators), register-staged double buffering (global loads of tile k+1 fly under the 64
 // MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.
-#include <stdlib.h>
 #include <string.h>
 
 #include "io_common.h"
@@ -51,17 +50,9 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
-// predicated 16-byte load without a branch: invalid lanes read the (always mapped) tensor base and
-// are zeroed afterwards, so the loads stay straight-line code the scheduler can hoist and overlap
-__device__ __forceinline__ f32x4 ld4_if(const float* base, size_t off, bool ok) {
-    const f32x4 v = ld4(base + (ok ? off : 0));
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return ok ? v : z;
-}
-
 // ------------------------------------------------------------------------------------------
-// NT kernel.  NW waves per block share one 128 x BN tile: NW = 4 -> 2x2 waves of 64 x BN/2,
-// NW = 8 -> 2x4 waves of 64 x BN/4 (more waves per SIMD to cover HBM latency, smaller fragments).
+// NT kernel.  NW waves per block share one 128 x BN tile: NW = 4 -> 2x2 waves of 64 x BN/2 (what is
+// launched); NW = 8 -> 2x4 waves of 64 x BN/4 measured identical (the kernel is not latency bound).
 // ------------------------------------------------------------------------------------------
 template <int BN, bool STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
@@ -692,9 +683,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
     const size_t lds = (size_t)2 * (128 + bn) * 36 * sizeof(float);
-    static const int nw_env = getenv("IO_NT_WAVES") ? atoi(getenv("IO_NT_WAVES")) : 0;
-    const int nw = (nw_env == 8 && bn == 128 && !stem) ? 8 : 4;
-    dim3 grid((unsigned)tiles), block(nw * 64);
+    dim3 grid((unsigned)tiles), block(kThreads);
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
@@ -714,8 +703,6 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
         IO_LAUNCH_NT(64, true, 4);
-    } else if (bn == 128 && nw == 8) {
-        IO_LAUNCH_NT(128, false, 8);
     } else if (bn == 128) {
         IO_LAUNCH_NT(128, false, 4);
     } else {

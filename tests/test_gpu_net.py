@@ -503,3 +503,17 @@ def test_use_rgb_false_and_ordernet_ext():
     b2["depth_order"] = lab.numpy()
     logs, _ = orc.train_step(state, {}, b2, "OrderNet", 0.0, 0.0)
     assert abs(float(out["loss"]) - float(logs["loss"])) < FWD_TOL * float(logs["loss"])
+
+
+def test_synthetic_val_accuracy_within_0p1_pp():
+    """'val order accuracy within 0.1 pp': occlusion recall/precision/F1 and depth WHDR of the HIP path vs the
+    reference-pinned oracle on a seeded synthetic validation set (no dataset / checkpoint exists offline)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("synthetic_val", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "synthetic_val.py"))
+    sv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sv)
+    delta, flips = sv.run(n_images=12, n_inst=5, S=128, verbose=True)
+    for k, v in delta.items():
+        assert abs(v) <= 0.1, (k, v)
