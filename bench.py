@@ -118,6 +118,10 @@ def main():
                             dev["is_overlap"], dev["occ_order"])
         return model.step()
 
+    # per-kernel HIP-event timing needs eager launches; with --no-prof the step is replayed from a hipGraph
+    # (identical kernels; only matters when the step is launch-bound, i.e. at small per-GPU batches)
+    if not args.no_prof:
+        model._use_graph = False
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -149,6 +153,7 @@ def main():
         "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, fp32, fwd+bwd+SGD "
                                "(BASELINE.json configs[1])" % (args.algo, B, S, S),
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
+                   "hip_graph": bool(model._use_graph and model._graph is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
                        args.backend, model.net.flat_grads.numel())},
         "achieved_tflops_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12,

@@ -36,11 +36,7 @@ def broadcast_params(model):
     (distributed_utils.py:34-37 broadcasts each state_dict entry)."""
     net = _net_of(model)
     if hasattr(net, "flat_params"):
-        broadcast_flat([net.flat_params, net.flat_running])
-        cnt = torch.stack([node._buffers["num_batches_tracked"] for _, node in net._bn_nodes])
-        dist.broadcast(cnt, 0)
-        for i, (_, node) in enumerate(net._bn_nodes):
-            node._buffers["num_batches_tracked"].copy_(cnt[i])
+        broadcast_flat([net.flat_params, net.flat_running, net._nbt])
     else:
         for p in model.state_dict().values():
             dist.broadcast(p, 0)

@@ -136,13 +136,24 @@ def sgd_momentum(params, grads, buf, lr, momentum, weight_decay):
                                           float(momentum), float(weight_decay), _stream()), "io_sgd_momentum")
 
 
+_prof_on = False
+
+
+def prof_active():
+    return _prof_on
+
+
 def prof_begin():
     """Start HIP-event timing of every library launch (per kernel class, on the launch stream)."""
+    global _prof_on
     _lib.check(_lib.lib().io_prof_begin(), "io_prof_begin")
+    _prof_on = True
 
 
 def prof_end():
     """Stop and return {class name: dict(launches, total_ms, flops, bytes)} (synchronises)."""
+    global _prof_on
+    _prof_on = False
     arr = (_lib.ProfEntry * 32)()
     n = _lib.lib().io_prof_end(arr, 32)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),

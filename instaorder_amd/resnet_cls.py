@@ -75,6 +75,7 @@ class ResNet(nn.Module):
         self._flat = torch.zeros(self.plan.param_floats, dtype=torch.float32, device=dev)
         self._flat_grad = torch.zeros_like(self._flat)
         self._running = torch.zeros(self.plan.running_floats, dtype=torch.float32, device=dev)
+        self._nbt = None            # num_batches_tracked of every BN layer, one int64 vector (one add per step)
         self._pool = _WorkspacePool()
         self._eval_ws = None
         self._param_list = []
@@ -121,15 +122,17 @@ class ResNet(nn.Module):
 
     def _bind_views(self):
         self._grad_views = []
+        if self._nbt is None:
+            self._nbt = torch.zeros(len(self._bn_nodes), dtype=torch.long, device=self._flat.device)
         for t, p in self._param_list:
             p.data = self._view(self._flat, t)
             gv = self._view(self._flat_grad, t)
             self._grad_views.append(gv)
-        for t, node in self._bn_nodes:
+        for i, (t, node) in enumerate(self._bn_nodes):
             C, ro = t["shape"][0], t["running_offset"]
             node._buffers["running_mean"] = self._running[ro:ro + C]
             node._buffers["running_var"] = self._running[ro + C:ro + 2 * C]
-            node._buffers["num_batches_tracked"] = node._buffers["num_batches_tracked"].to(self._flat.device)
+            node._buffers["num_batches_tracked"] = self._nbt[i]
 
     def _apply(self, fn, *args, **kwargs):
         # move / cast the flat buffers, then re-create every view (module.cuda(), .to(), .float())
@@ -139,8 +142,7 @@ class ResNet(nn.Module):
         self._flat = new_flat.contiguous()
         self._flat_grad = fn(self._flat_grad).contiguous()
         self._running = fn(self._running).contiguous()
-        for t, node in self._bn_nodes:
-            node._buffers["num_batches_tracked"] = fn(node._buffers["num_batches_tracked"])
+        self._nbt = fn(self._nbt).contiguous()
         self._bind_views()
         self._eval_ws = None
         self._pool = _WorkspacePool()
@@ -165,7 +167,7 @@ class ResNet(nn.Module):
             for t, node in self._bn_nodes:
                 node._buffers["running_mean"].zero_()
                 node._buffers["running_var"].fill_(1.0)
-                node._buffers["num_batches_tracked"].zero_()
+            self._nbt.zero_()
 
     # ---- flat access for the fused optimiser / data-parallel helpers ----------------------------
     @property
@@ -187,8 +189,7 @@ class ResNet(nn.Module):
             p.grad = gv
 
     def bump_batches_tracked(self, k):
-        for t, node in self._bn_nodes:
-            node._buffers["num_batches_tracked"] += k
+        self._nbt += k
 
     # ---- execution -------------------------------------------------------------------------------
     def _run_forward(self, x8, N, S, G, training):

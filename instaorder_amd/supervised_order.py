@@ -12,6 +12,8 @@ into ONE batch of 2B samples that the engine normalises as two independent Batch
 gradient come from one HIP kernel, the backward is ``io_net_backward``, the gradient exchange is one
 flat all-reduce and the update one fused SGD launch -- with no host synchronisation in between.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,10 +41,27 @@ class _OrderBase(SingleStageModel):
             raise ValueError("use_rgb=%s needs backbone_param.in_channels=%d, got %d"
                              % (self.use_rgb, want, self.net.in_channels))
         self._x8 = None
+        # hipGraph replay of forward + loss + backward (the ~800 launches of a step): pays off when the step
+        # is launch-bound (small per-GPU batches, e.g. the reference recipe's 32 pairs/GPU); IO_NO_GRAPH=1 disables
+        self._use_graph = os.environ.get("IO_NO_GRAPH", "0") != "1"
+        self._graph = None
+        self._graph_key = None
+        self._seen_key = None
+        self._static = {}
         if load_pretrain is not None:
             self.load_pretrain(load_pretrain)
 
     # -- inputs ------------------------------------------------------------------------------------
+    def _static_copy(self, name, t):
+        """Labels live in persistent device tensors so that a captured step can be replayed."""
+        cur = self._static.get(name)
+        if cur is None or cur.shape != t.shape or cur.dtype != t.dtype or cur.device != t.device:
+            cur = torch.empty_like(t)
+            self._static[name] = cur
+            self._graph = None
+        cur.copy_(t)
+        return cur
+
     def _set_images(self, rgb, modal1, modal2):
         self.rgb = _dev(rgb, torch.float32).contiguous()
         self.modal1 = _dev(modal1, torch.float32).contiguous()
@@ -50,6 +69,7 @@ class _OrderBase(SingleStageModel):
         B = self.rgb.shape[0]
         if self._x8 is None or self._x8.shape[0] != 2 * B or self._x8.shape[1:3] != self.rgb.shape[2:]:
             self._x8 = None
+            self._graph = None
         self._x8 = engine.pack_pair_directions(self.rgb if self.use_rgb else None, self.modal1, self.modal2,
                                                self._x8)
         self.B = B
@@ -85,17 +105,44 @@ class _OrderBase(SingleStageModel):
         logs = self._logs(losses)
         return (logs if logs is not None else {}), {"loss": losses[0]}
 
+    def _fwd_loss_bwd(self, N, S):
+        net = self.net
+        logits, ws = net._run_forward(self._x8, N, S, 2, True)
+        losses, dlogits = self._loss(logits, True, True)
+        net._run_backward(self._x8, dlogits, N, S, 2, ws)
+        return logits, losses, ws
+
     def step(self):
         net = self.net
         if not net.training:
             raise RuntimeError("step() needs switch_to('train')")
         N = 2 * self.B
         S = self._x8.shape[1]
-        logits, ws = net._run_forward(self._x8, N, S, 2, True)
+        key = (N, S, self._x8.data_ptr(), net.flat_params.data_ptr())
+        if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
+            self._graph.replay()
+            logits, losses = self._graph_out
+        elif self._use_graph and self._seen_key == key and not engine.prof_active():
+            # second step with this shape (the first ran eagerly and warmed every kernel): capture, then run it
+            try:
+                ws_keep = None
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    logits, losses, ws_keep = self._fwd_loss_bwd(N, S)
+                self._graph, self._graph_key, self._graph_out, self._graph_ws = g, key, (logits, losses), ws_keep
+                g.replay()
+            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
+                self._use_graph = False
+                self._graph = None
+                print("instaorder_amd: hipGraph capture disabled (%s)" % ex)
+                logits, losses, ws = self._fwd_loss_bwd(N, S)
+                net._pool.give(ws)
+        else:
+            logits, losses, ws = self._fwd_loss_bwd(N, S)
+            net._pool.give(ws)
+            self._seen_key = key
         self.last_logits = logits
-        losses, dlogits = self._loss(logits, True, True)
-        net._run_backward(self._x8, dlogits, N, S, 2, ws)
-        net._pool.give(ws)
         if self.world_size > 1:
             distributed_utils.average_gradients(self.model)
         net.attach_grads()
@@ -120,7 +167,7 @@ class InstaOrderNet_o(_OrderBase):
         self._set_images(rgb, modal1, modal2)
         self.occ_order1 = _dev(occ_order, torch.float32)
         self.occ_order2 = _mirror_occ(self.occ_order1)
-        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+        self._occ_t = self._static_copy("occ", torch.cat([self.occ_order1, self.occ_order2], 0))
 
     def _loss_args(self, training):
         return dict(occ_target=self._occ_t)
@@ -138,11 +185,11 @@ class InstaOrderNet_od(_OrderBase):
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
         self.count = _dev(count)
-        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
+        self.is_overlap = self._static_copy("ovl", _dev(is_overlap, torch.long).contiguous())
         self.occ_order1 = _dev(occ_order, torch.float32)
         self.occ_order2 = _mirror_occ(self.occ_order1)
-        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
-        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0).contiguous()
+        self._occ_t = self._static_copy("occ", torch.cat([self.occ_order1, self.occ_order2], 0))
+        self._dep_t = self._static_copy("dep", torch.cat([self.depth_order1, self.depth_order2], 0))
 
     def _loss_args(self, training):
         return dict(occ_target=self._occ_t, depth_target=self._dep_t, is_overlap=self.is_overlap,
@@ -166,8 +213,8 @@ class InstaOrderNet_d(_OrderBase):
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
         self.count = _dev(count)
-        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
-        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0).contiguous()
+        self.is_overlap = self._static_copy("ovl", _dev(is_overlap, torch.long).contiguous())
+        self._dep_t = self._static_copy("dep", torch.cat([self.depth_order1, self.depth_order2], 0))
 
     def _loss_args(self, training):
         if training:
@@ -190,7 +237,7 @@ class OrderNet(_OrderBase):
         self._set_images(rgb, modal1, modal2)
         self.occ_order1 = _dev(occ_order, torch.long)
         self.occ_order2 = _mirror_classes(self.occ_order1)
-        self._dep_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+        self._dep_t = self._static_copy("dep", torch.cat([self.occ_order1, self.occ_order2], 0))
 
     def _loss_args(self, training):
         return dict(depth_target=self._dep_t)
