@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR_TRAIN = 64.27e9      # 2 x (3 x 10.882 - 0.514) GFLOP, conv+FC MACs x 2
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -73,6 +74,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--algo", default="InstaOrderNet_o")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="fp32 = BASELINE configs[1] (default, "
+                    "the headline); bf16 = configs[2]: bf16 activations / GEMM operands, fp32 accumulate and weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -99,7 +102,7 @@ def main():
     nc = {"InstaOrderNet_o": 2, "InstaOrderNet_od": [2, 3]}[args.algo]
     cfg = dict(algo=args.algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
                backbone_param=dict(in_channels=5, num_classes=nc), use_rgb=True, overlap_weight=0.1,
-               distinct_weight=0.9)
+               distinct_weight=0.9, dtype=args.dtype)
     model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
     sd = synthetic.make_state_dict(1, 5, nc, prefix="module.")          # reference-init statistics
     model.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -149,9 +152,10 @@ def main():
     result = {
         "metric": "instance-pairs/sec (fwd+bwd)", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, fp32, fwd+bwd+SGD "
-                               "(BASELINE.json configs[1])" % (args.algo, B, S, S),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, %s, fwd+bwd+SGD "
+                               "(BASELINE.json configs[%d])" % (args.algo, B, S, S, args.dtype,
+                                                                1 if args.dtype == "fp32" else 2),
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
                    "hip_graph": bool(model._use_graph and model._graph is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
@@ -160,6 +164,8 @@ def main():
         "mfma_frac_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12
         / (world * PEAK_FP32_MFMA_TFLOPS),
     }
+    if args.dtype == "bf16":      # mixed: fwd/dgrad on the bf16 MFMA, wgrad on the fp32 MFMA -- no single peak applies
+        result["mfma_frac_whole_step"] = None
     if prof:
         tot_ms = sum(v["total_ms"] for v in prof.values())
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
@@ -173,8 +179,12 @@ def main():
                 traffic = tj["bytes_per_launch_corrected"]
         except Exception:
             pass
-        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+        # the wgrad kernel runs the fp32 MFMA in both modes; the NT kernel (fwd / dgrad) follows --dtype
+        peak = PEAK_BF16_MFMA_TFLOPS if (args.dtype == "bf16" and "wgrad" not in name) else PEAK_FP32_MFMA_TFLOPS
+        if args.dtype == "bf16":
+            traffic = None
+        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": peak,
+                              "unit": "TFLOP/s", "frac": tfl / peak, "traffic": traffic,
                               "launches": d["launches"], "avg_launch_ms": avg_ms,
                               "flops_per_launch": d["flops"] / d["launches"],
                               "share_of_gpu_time": d["total_ms"] / tot_ms}

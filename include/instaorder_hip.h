@@ -165,6 +165,10 @@ int io_net_tensor_info(const io_net* net, int i, io_tensor_info* out);
 int io_net_num_logits(const io_net* net);
 /* bytes of workspace needed for a forward(/backward) of N samples of size S x S */
 size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training);
+/* Byte offset, inside a TRAINING workspace of that shape, of an activation the forward pass keeps (for layer-wise
+ * parity checks against resnet_cls.py:203-222): which = 0 conv1 output [N,S/2,S/2,64], 1 relu(bn1(.)), 2 max-pool
+ * output [N,S/4,S/4,64], 3+i output of bottleneck i (0..15), NHWC, element type = the net's dtype.  -1 on error. */
+long io_net_activation_offset(const io_net* net, int N, int S, int which);
 /* x8[N,S,S,8] -> logits[N][K].  training != 0: batch statistics in G groups, running stats updated,
  * activations kept in `workspace` for io_net_backward. */
 int io_net_forward(io_net* net, const float* params, float* running, const float* x8, int N, int S, int G,
@@ -173,6 +177,38 @@ int io_net_forward(io_net* net, const float* params, float* running, const float
  * training io_net_forward with the same x8 / N / S / G / workspace. */
 int io_net_backward(io_net* net, const float* params, float* grads, const float* x8, const float* dlogits, int N,
                     int S, int G, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* ---- bf16 configuration (BASELINE configs[2], [3]) ------------------------------------------------------
+ * dtype 0 = fp32 (everything above), 1 = bf16: activations, activation gradients and GEMM operands are bf16
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulate); parameters and their gradients, BatchNorm statistics, losses and
+ * the optimiser stay fp32; the 5-channel stem reads the fp32 packed input.  The `_dt` entry points are the
+ * storage-typed forms of the functions of the same name; `void*` tensors have the element type `dtype` says. */
+#define IO_DTYPE_F32 0
+#define IO_DTYPE_BF16 1
+int io_net_set_dtype(io_net* net, int dtype);
+int io_net_get_dtype(const io_net* net);
+int io_conv2d_fwd_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                     int stride, int pad, int dtype_in, int dtype_out, hipStream_t stream);
+int io_conv2d_dgrad_dt(const void* dy, const void* wt, void* dx, const void* add, const void* relu_mask, int N, int H,
+                       int W, int Cin, int Cout, int R, int S, int stride, int pad, int dtype, hipStream_t stream);
+int io_conv2d_wgrad_dt(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
+                       int stride, int pad, void* workspace, size_t workspace_bytes, int dtype_in, int dtype_dy,
+                       hipStream_t stream);
+/* fp32 master filter [Cout][taps][Cin] -> GEMM operand of `dtype`: a plain cast (transpose = 0, bf16 only) or the
+ * transposed filter [Cin][taps][Cout] the data gradient reads (transpose = 1). */
+int io_filter_prepare(const float* w, int Cout, int taps, int Cin, void* dst, int transpose, int dtype,
+                      hipStream_t stream);
+int io_bn_stats_finalize_dt(const void* y, int M, int C, int G, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                            float* rstd, float* scale, float* shift, float* partial, size_t partial_floats, int dtype,
+                            hipStream_t stream);
+int io_bn_apply_dt(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
+                   const float* shift, const void* identity, const float* mean2, const float* scale2,
+                   const float* shift2, int relu, void* out, int dtype, hipStream_t stream);
+int io_bn_bwd_dt(const void* dout, const void* act, const float* mask_scale, const float* mask_shift, const void* y,
+                 int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                 float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef, int dtype,
+                 hipStream_t stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of

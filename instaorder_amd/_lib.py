@@ -62,8 +62,18 @@ SIGNATURES = {
     "io_net_tensor_info": (_I, [_P, _I, C.POINTER(TensorInfo)]),
     "io_net_num_logits": (_I, [_P]),
     "io_net_workspace_bytes": (_Z, [_P, _I, _I, _I]),
+    "io_net_activation_offset": (_L, [_P, _I, _I, _I]),
     "io_net_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "io_net_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "io_net_set_dtype": (_I, [_P, _I]),
+    "io_net_get_dtype": (_I, [_P]),
+    "io_conv2d_fwd_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_dgrad_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_conv2d_wgrad_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _I, _P]),
+    "io_filter_prepare": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "io_bn_stats_finalize_dt": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "io_bn_apply_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "io_bn_bwd_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "io_prof_begin": (_I, []),
     "io_prof_end": (_I, [C.POINTER(ProfEntry), _I]),
 }

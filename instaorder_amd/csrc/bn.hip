@@ -15,8 +15,9 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 4 consecutive elements <-> float4, for fp32 and bf16 tensors alike (tables / partials are always fp32)
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p) { return io_ldv(p); }
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v) { io_stv(p, v); }
 
 // BN affine output; the SAME expression is used by the forward apply and by the backward kernels that
 // recompute the ReLU mask from y, so the mask bit is reproduced exactly
@@ -72,14 +73,15 @@ __device__ __forceinline__ void reduce_rows_store(const ColMap& cm, f32x4 (&s0)[
 // with pivot = the block's first row (per channel): conv outputs whose |mean| >> std would otherwise
 // lose the variance in E[x^2] - E[x]^2.  Partials: sum d, sum d^2, pivot, per (g, b, c); merged in
 // fp64 with the pairwise (Chan) update -- the same robustness as the reference's two-pass CPU kernel.
-__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, int Mg, int C, int rpb,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict__ x, int Mg, int C, int rpb,
                                                            float* __restrict__ psum, float* __restrict__ psq,
                                                            float* __restrict__ ppiv) {
     const int C4 = C >> 2;
     const ColMap cm = col_map(C4);
     const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
-    const float* xg = x + (size_t)g * Mg * C;
+    const T* xg = x + (size_t)g * Mg * C;
     f32x4 s[2], ss[2], pv[2];
     for (int i = 0; i < 2; ++i) {
         s[i] = 0.f; ss[i] = 0.f; pv[i] = 0.f;
@@ -212,10 +214,10 @@ __global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, c
 struct BnTab {
     const float *mean, *scale, *shift;
 };
-template <int MODE>   // 0 none, 1 identity tensor, 2 second BN (downsample branch)
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, size_t total4, int c4shift,
-                                                           int Mg, int sg, BnTab t, const float* __restrict__ idt,
-                                                           BnTab t2, int relu, float* __restrict__ out) {
+template <int MODE, typename T>   // MODE 0 none, 1 identity tensor, 2 second BN (downsample branch)
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ y, size_t total4, int c4shift,
+                                                           int Mg, int sg, BnTab t, const T* __restrict__ idt,
+                                                           BnTab t2, int relu, T* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int c4mask = (1 << c4shift) - 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -237,9 +239,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
 // ---- backward ----------------------------------------------------------------------------------
 // dz = dout * [act > 0] (act may be null: no ReLU behind this BN), xhat = (y - mean) * rstd
 // partial sums of dz and dz*xhat per (group, block, channel)
-__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __restrict__ dout,
-                                                                const float* __restrict__ act,
-                                                                const float* __restrict__ y, int Mg, int C, int rpb,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __restrict__ dout,
+                                                                const T* __restrict__ act,
+                                                                const T* __restrict__ y, int Mg, int C, int rpb,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd,
                                                                 const float* __restrict__ mscale,
@@ -346,8 +349,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // dy = gamma*rstd*(dz - c1 - xhat*c2); optionally also stores dz (may alias dout)
-__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ act,
-                                                               const float* __restrict__ y, size_t total4,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* dout, const T* __restrict__ act,
+                                                               const T* __restrict__ y, size_t total4,
                                                                int c4shift, int Mg, int C,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ mean,
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* dou
                                                                const float* __restrict__ c2,
                                                                const float* __restrict__ mscale,
                                                                const float* __restrict__ mshift,
-                                                               float* __restrict__ dy, float* dz_out) {
+                                                               T* __restrict__ dy, T* dz_out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int c4mask = (1 << c4shift) - 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -510,15 +514,15 @@ __global__ __launch_bounds__(256) void bn_sum_tiles_kernel(const float* __restri
 // BN backward when sum(dz), sum(dz*xhat) per (128-row tile, channel) were already produced by the epilogue of
 // the kernel that wrote dz (IoBwStats): merge the tile partials, finalize, apply.  dz is already masked.
 // p1/p2 need room for (tiles + tiles/64 + G) * C floats each.
-int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, int M, int C, int G,
+int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, int M, int C, int G,
                          const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                         float* dy, float* coef, hipStream_t st) {
+                         void* dy, float* coef, hipStream_t st, int dt) {
     const int sh = ilog2_exact(C / 4);
     IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd_from_tiles: C=%d unsupported", C);
     IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
                "bn_bwd_from_tiles: rows per group must be a multiple of %d", kIoStatTileRows);
     const int Mg = M / G, nt = Mg / kIoStatTileRows;
-    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * 3.0, st);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C * 3.0, st);
     const float* q1 = p1;
     const float* q2 = p2;
     int nb = nt;
@@ -535,9 +539,14 @@ int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
                        dbeta, c1, c2);
     const size_t total4 = (size_t)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dz, (const float*)nullptr, y,
-                       total4, sh, Mg, C, gamma, mean, rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, dy,
-                       (float*)nullptr);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,
+                           (const bf16_t*)dz, (const bf16_t*)nullptr, (const bf16_t*)y, total4, sh, Mg, C, gamma, mean,
+                           rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, (bf16_t*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,
+                           (const float*)dz, (const float*)nullptr, (const float*)y, total4, sh, Mg, C, gamma, mean,
+                           rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, (float*)dy, (float*)nullptr);
     return io_check_launch("bn_bwd_from_tiles");
 }
 
@@ -557,10 +566,10 @@ extern "C" size_t io_bn_partial_floats(int M, int C, int G) {
     return (size_t)3 * G * nb * C;
 }
 
-extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
-                                    float* running_mean, float* running_var, float momentum, float eps,
-                                    float* mean, float* rstd, float* scale, float* shift, float* partial,
-                                    size_t partial_floats, hipStream_t st) {
+int io_bn_stats_finalize_t(const void* y, int M, int C, int G, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                           float* rstd, float* scale, float* shift, float* partial, size_t partial_floats,
+                           hipStream_t st, int dt) {
     IO_REQUIRE(C % 4 == 0 && C <= 2048 && ilog2_exact(C / 4) >= 0, IO_ERR_SHAPE, "bn_stats: C=%d unsupported", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_stats: M=%d not divisible by G=%d", M, G);
     IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_stats: partial too small");
@@ -570,11 +579,24 @@ extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const f
     float* psum = partial;
     float* psq = partial + (size_t)G * nb * C;
     float* ppiv = partial + (size_t)2 * G * nb * C;
-    IoProfScope prof(IO_PROF_BN_STATS, 0.0, 4.0 * M * C, st);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, G), dim3(kThreads), 0, st, y, Mg, C, rpb, psum, psq, ppiv);
+    IoProfScope prof(IO_PROF_BN_STATS, 0.0, (double)io_dtype_bytes(dt) * M * C, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb, G), dim3(kThreads), 0, st, (const bf16_t*)y, Mg, C, rpb,
+                           psum, psq, ppiv);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb, G), dim3(kThreads), 0, st, (const float*)y, Mg, C, rpb,
+                           psum, psq, ppiv);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(io_cdiv(C, 32)), dim3(256), 0, st, psum, psq, ppiv, nb, rpb, G, Mg,
                        C, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
     return io_check_launch("bn_stats_finalize");
+}
+
+extern "C" int io_bn_stats_finalize(const float* y, int M, int C, int G, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps,
+                                    float* mean, float* rstd, float* scale, float* shift, float* partial,
+                                    size_t partial_floats, hipStream_t st) {
+    return io_bn_stats_finalize_t(y, M, C, G, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd,
+                                  scale, shift, partial, partial_floats, st, IO_F32);
 }
 
 extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
@@ -585,30 +607,45 @@ extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, 
     return io_check_launch("bn_eval_prepare");
 }
 
-extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* mean,
-                           const float* scale, const float* shift, const float* identity, const float* mean2,
-                           const float* scale2, const float* shift2, int relu, float* out, hipStream_t st) {
+int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
+                  const float* shift, const void* identity, const float* mean2, const float* scale2,
+                  const float* shift2, int relu, void* out, hipStream_t st, int dt) {
     const int sh = ilog2_exact(C / 4);
     IO_REQUIRE(C % 4 == 0 && sh >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be 4*2^k", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_apply: M=%d not divisible by G=%d", M, G);
     const size_t total4 = (size_t)M * (C / 4);
     const int Mg = M / G, sg = per_group_tables ? C : 0;
     dim3 grid(ew_blocks(total4)), block(kThreads);
-    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 4.0 * M * C * (identity ? 3.0 : 2.0), st);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, (double)io_dtype_bytes(dt) * M * C * (identity ? 3.0 : 2.0), st);
     const BnTab t{mean, scale, shift}, t2{mean2, scale2, shift2};
-    if (identity && scale2)
-        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
-    else if (identity)
-        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, y, total4, sh, Mg, sg, t, identity, t2, relu, out);
+    const int mode = (identity && scale2) ? 2 : (identity ? 1 : 0);
+#define IO_BN_APPLY(MODE_, T_)                                                                                     \
+    hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_>), grid, block, 0, st, (const T_*)y, total4, sh, Mg, sg, t,      \
+                       (const T_*)identity, t2, relu, (T_*)out)
+    if (dt == IO_BF16) {
+        if (mode == 2) IO_BN_APPLY(2, bf16_t);
+        else if (mode == 1) IO_BN_APPLY(1, bf16_t);
+        else IO_BN_APPLY(0, bf16_t);
+    } else {
+        if (mode == 2) IO_BN_APPLY(2, float);
+        else if (mode == 1) IO_BN_APPLY(1, float);
+        else IO_BN_APPLY(0, float);
+    }
+#undef IO_BN_APPLY
     return io_check_launch("bn_apply");
 }
 
-extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_scale, const float* mask_shift,
-                         const float* y, int M, int C, int G, const float* gamma, const float* mean,
-                         const float* rstd, float* dgamma, float* dbeta, float* dy, float* dz_out, float* partial,
-                         size_t partial_floats, float* coef, hipStream_t st) {
+extern "C" int io_bn_apply(const float* y, int M, int C, int G, int per_group_tables, const float* mean,
+                           const float* scale, const float* shift, const float* identity, const float* mean2,
+                           const float* scale2, const float* shift2, int relu, float* out, hipStream_t st) {
+    return io_bn_apply_t(y, M, C, G, per_group_tables, mean, scale, shift, identity, mean2, scale2, shift2, relu, out,
+                         st, IO_F32);
+}
+
+int io_bn_bwd_t(const void* dout, const void* act, const float* mask_scale, const float* mask_shift, const void* y,
+                int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef,
+                hipStream_t st, int dt) {
     IO_REQUIRE(!(act && mask_scale), IO_ERR_SHAPE, "bn_bwd: give the activation OR the mask tables, not both");
     IO_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), IO_ERR_SHAPE, "bn_bwd: mask tables come in pairs");
     const int sh = ilog2_exact(C / 4);
@@ -622,13 +659,29 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_
     float* p2 = partial + (size_t)G * nb * C;
     float* c1 = coef;
     float* c2 = coef + (size_t)G * C;
-    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, G), dim3(kThreads), 0, st, dout, act, y, Mg, C, rpb, mean,
-                       rstd, mask_scale, mask_shift, p1, p2);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,
-                       dgamma, dbeta, c1, c2);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0,
+                     (double)io_dtype_bytes(dt) * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
     const size_t total4 = (size_t)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dout, act, y, total4,
-                       sh, Mg, C, gamma, mean, rstd, c1, c2, mask_scale, mask_shift, dy, dz_out);
+#define IO_BN_BWD(T_)                                                                                               \
+    do {                                                                                                            \
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T_>, dim3(nb, G), dim3(kThreads), 0, st, (const T_*)dout,           \
+                           (const T_*)act, (const T_*)y, Mg, C, rpb, mean, rstd, mask_scale, mask_shift, p1, p2);   \
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,     \
+                           dgamma, dbeta, c1, c2);                                                                  \
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,                 \
+                           (const T_*)dout, (const T_*)act, (const T_*)y, total4, sh, Mg, C, gamma, mean, rstd, c1, \
+                           c2, mask_scale, mask_shift, (T_*)dy, (T_*)dz_out);                                       \
+    } while (0)
+    if (dt == IO_BF16) IO_BN_BWD(bf16_t);
+    else IO_BN_BWD(float);
+#undef IO_BN_BWD
     return io_check_launch("bn_bwd");
+}
+
+extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_scale, const float* mask_shift,
+                         const float* y, int M, int C, int G, const float* gamma, const float* mean,
+                         const float* rstd, float* dgamma, float* dbeta, float* dy, float* dz_out, float* partial,
+                         size_t partial_floats, float* coef, hipStream_t st) {
+    return io_bn_bwd_t(dout, act, mask_scale, mask_shift, y, M, C, G, gamma, mean, rstd, dgamma, dbeta, dy, dz_out,
+                       partial, partial_floats, coef, st, IO_F32);
 }

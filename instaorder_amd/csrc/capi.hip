@@ -84,8 +84,9 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
     return g;
 }
 
-int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
-                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st, const IoBwStats* bw) {
+int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
+                 int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st, const IoBwStats* bw,
+                 int dt) {
     IO_REQUIRE(!bw || stride == 1, IO_ERR_SHAPE, "dgrad: fused BN-backward reductions need a stride-1 convolution");
     for (int ph = 0; ph < stride; ++ph)
         for (int pw = 0; pw < stride; ++pw) {
@@ -94,7 +95,7 @@ int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, 
             // a lattice class no tap reaches keeps its values when accumulating in place -- unless a ReLU
             // mask has to be applied to them
             if ((g.Th == 0 || g.Tw == 0) && add == dx && !mask) continue;
-            int rc = io_launch_conv_nt(g, dy, wt, dx, add, mask, 0, st, nullptr, nullptr, bw);
+            int rc = io_launch_conv_nt(g, dy, wt, dx, add, mask, 0, st, nullptr, nullptr, bw, dt, dt);
             if (rc) return rc;
         }
     return IO_OK;
@@ -241,4 +242,55 @@ extern "C" int io_prof_end(io_prof_entry* out, int max_entries) {
     for (int c = 0; c < IO_PROF_NCLASS && n < max_entries; ++c)
         if (acc[c].launches > 0) out[n++] = acc[c];
     return n;
+}
+
+// ---- storage-typed variants (dtype: 0 = fp32, 1 = bf16 activations / operands; see IoDType) ------------------
+extern "C" int io_conv2d_fwd_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
+                                int S, int stride, int pad, int dtype_in, int dtype_out, hipStream_t st) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, Cin == 8, st, nullptr, nullptr, nullptr, dtype_in,
+                             dtype_out);
+}
+
+extern "C" int io_conv2d_dgrad_dt(const void* dy, const void* wt, void* dx, const void* add, const void* relu_mask,
+                                  int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  int dtype, hipStream_t st) {
+    IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad: Cin=%d must be a multiple of 64", Cin);
+    return io_run_dgrad(dy, wt, dx, add, relu_mask, N, H, W, Cin, Cout, R, S, stride, pad, st, nullptr, dtype);
+}
+
+extern "C" int io_conv2d_wgrad_dt(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                                  int R, int S, int stride, int pad, void* ws, size_t ws_bytes, int dtype_in,
+                                  int dtype_dy, hipStream_t st) {
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    return io_launch_conv_wgrad(g, x, dy, dw, (float*)ws, ws_bytes, Cin == 8, st, dtype_in, dtype_dy);
+}
+
+extern "C" int io_filter_prepare(const float* w, int Cout, int taps, int Cin, void* dst, int transpose, int dtype,
+                                 hipStream_t st) {
+    return io_filter_prepare_t(w, Cout, taps, Cin, dst, transpose, st, dtype);
+}
+
+extern "C" int io_bn_stats_finalize_dt(const void* y, int M, int C, int G, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps,
+                                       float* mean, float* rstd, float* scale, float* shift, float* partial,
+                                       size_t partial_floats, int dtype, hipStream_t st) {
+    return io_bn_stats_finalize_t(y, M, C, G, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale,
+                                  shift, partial, partial_floats, st, dtype);
+}
+
+extern "C" int io_bn_apply_dt(const void* y, int M, int C, int G, int per_group_tables, const float* mean,
+                              const float* scale, const float* shift, const void* identity, const float* mean2,
+                              const float* scale2, const float* shift2, int relu, void* out, int dtype,
+                              hipStream_t st) {
+    return io_bn_apply_t(y, M, C, G, per_group_tables, mean, scale, shift, identity, mean2, scale2, shift2, relu, out,
+                         st, dtype);
+}
+
+extern "C" int io_bn_bwd_dt(const void* dout, const void* act, const float* mask_scale, const float* mask_shift,
+                            const void* y, int M, int C, int G, const float* gamma, const float* mean,
+                            const float* rstd, float* dgamma, float* dbeta, void* dy, void* dz_out, float* partial,
+                            size_t partial_floats, float* coef, int dtype, hipStream_t st) {
+    return io_bn_bwd_t(dout, act, mask_scale, mask_shift, y, M, C, G, gamma, mean, rstd, dgamma, dbeta, dy, dz_out,
+                       partial, partial_floats, coef, st, dtype);
 }

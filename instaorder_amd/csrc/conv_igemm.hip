@@ -43,26 +43,62 @@ __device__ __forceinline__ int fdiv(int n, IoFastDiv f) {
 // (kInvalidOff, or rows beyond M) returns zeros in hardware -- no 64-bit address arithmetic, no selects.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
+// 4 consecutive elements at byte offset `off`, widened to fp32 (filter-gradient kernel: fp32 MFMA on bf16 data)
+template <typename T> __device__ __forceinline__ f32x4 bldv(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ f32x4 bldv<float>(__amdgpu_buffer_rsrc_t r, unsigned off) { return bld4(r, off); }
+template <> __device__ __forceinline__ f32x4 bldv<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, q[0] << 16);
+    v[1] = __builtin_bit_cast(float, q[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, q[1] << 16);
+    v[3] = __builtin_bit_cast(float, q[1] & 0xffff0000u);
+    return v;
+}
+// one element
+template <typename T> __device__ __forceinline__ float ld_el(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ float ld_el<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+template <> __device__ __forceinline__ float ld_el<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return io_bf2f(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+}
+template <typename T> __device__ __forceinline__ void st_el(float v, __amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ void st_el<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+template <> __device__ __forceinline__ void st_el<bf16_t>(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, 0, 0);
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------
 // NT kernel.  NW waves per block share one 128 x BN tile: NW = 4 -> 2x2 waves of 64 x BN/2 (what is
 // launched); NW = 8 -> 2x4 waves of 64 x BN/4 measured identical (the kernel is not latency bound).
 // ------------------------------------------------------------------------------------------
-template <int BN, bool STEM, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const float* __restrict__ in,
-                                                         const float* __restrict__ wgt, float* __restrict__ out,
-                                                         const float* __restrict__ add,
-                                                         const float* __restrict__ mask, int ntn, unsigned in_bytes,
+// TA: storage type of the operands (in, wgt): float -> v_mfma_f32_32x32x2_f32, bf16 -> v_mfma_f32_32x32x16_bf16.
+// A k-tile row is always 128 bytes (32 floats or 64 bf16) and a lane always moves 16-byte chunks, so the LDS
+// image, the addressing and the fragment reads are byte-for-byte the same in both modes.  TO: storage type of
+// out / add / mask / bw.y (the fp32 stem writes bf16 activations in bf16 mode).
+template <typename TA, typename TO, int BN, bool STEM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
+                                                         const TA* __restrict__ wgt, TO* __restrict__ out,
+                                                         const TO* __restrict__ add,
+                                                         const TO* __restrict__ mask, int ntn, unsigned in_bytes,
                                                          unsigned w_bytes, unsigned out_bytes,
                                                          float* __restrict__ st_mean, float* __restrict__ st_m2,
                                                          IoBwStats bw) {
-    constexpr int BM = 128, BK = 32, LDT = BK + 4, NT = NW * 64;
+    constexpr int ES = sizeof(TA), OS = sizeof(TO);
+    constexpr int VE = 16 / ES;             // elements per 16-byte chunk
+    constexpr int BM = 128, BK = 128 / ES, LDT = 32 + 4, NT = NW * 64;   // LDT in 4-byte words
+    static_assert(!STEM || ES == 4, "the 5-channel stem runs on fp32 operands");
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
     constexpr int AR = (BM * 8) / NT;       // A rows loaded per thread (8 float4 per row)
@@ -100,11 +136,12 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
         const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
         hi0[j] = ho * g.is;
         wi0[j] = wo * g.is;
-        rowv[j] = (unsigned)(((n * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * 4)) * 4u;
+        rowv[j] = (unsigned)(((n * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
     }
     unsigned wv[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * g.Ci + (STEM ? 0 : kq * 4)) * 4u;
+    for (int j = 0; j < BR; ++j)
+        wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
     const bool nopad = g.Th == 1 && g.Tw == 1 && g.dh0 == 0 && g.dw0 == 0 && g.is == 1 && g.Hi >= g.Ho &&
                        g.Wi >= g.Wo;   // 1x1 stride-1: a row is valid for every k-tile or for none
 
@@ -129,8 +166,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
             dh = g.dh0 + g.dhs * th;
             dw = g.dw0 + g.dws * tw;
             const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
-            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cc * BK) * 4u;
-            woff = (unsigned)(widx * g.Ci + cc * BK) * 4u;
+            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cc * BK) * (unsigned)ES;
+            woff = (unsigned)(widx * g.Ci + cc * BK) * (unsigned)ES;
         }
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
@@ -189,14 +226,25 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
 #pragma unroll
         for (int j = 0; j < TJ; ++j) b[j] = ld4(bl + j * 32 * LDT);
     };
+    // one fragment read (16 B per lane and tile) feeds 4 fp32 MFMAs (k = 2 each) or 1 bf16 MFMA (k = 16)
     auto mma16 = [&](const f32x4 (&a)[TI], const f32x4 (&b)[TJ]) {
+        if constexpr (ES == 4) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][tt], b[j][tt], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][tt], b[j][tt], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                        __builtin_bit_cast(bf16x8, b[j]), acc[i][j],
+                                                                        0, 0, 0);
+        }
     };
 
     f32x4 fa[TI], fb[TJ];
@@ -282,9 +330,9 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
     // before the stores.
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? add : out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mask ? mask : out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc(bw.y ? bw.y : out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? (const void*)add : (const void*)out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mask ? (const void*)mask : (const void*)out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc(bw.y ? bw.y : (const void*)out, out_bytes);
     float bw_mu[TJ], bw_rs[TJ], bw_sc[TJ], bw_sh[TJ], bw_s1[TJ], bw_s2[TJ];
     if (bw.y) {
         const int gcol = (m0 / bw.Mg) * g.Co + n0 + wn * (BN / WN) + (lane & 31);   // group is uniform per tile
@@ -298,7 +346,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
             bw_s2[j] = 0.f;
         }
     }
-    const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * 4u;
+    const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
+    constexpr unsigned JS = 32u * OS;     // byte step between a lane's column blocks
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         unsigned rowb[16];
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 pix = (n * g.outH + (ho * g.os + g.ooh)) * g.outW + (wo * g.os + g.oow);
             }
-            rowb[r] = ok ? (unsigned)(pix * g.Co) * 4u + colb : kInvalidOff;
+            rowb[r] = ok ? (unsigned)(pix * g.Co) * (unsigned)OS + colb : kInvalidOff;
         }
         if (add) {
 #pragma unroll
@@ -320,8 +369,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 float av[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rs_add, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
+                    av[r] = ld_el<TO>(rs_add, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * JS);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
             }
@@ -332,8 +380,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 float mv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    mv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rs_mask, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
+                    mv[r] = ld_el<TO>(rs_mask, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * JS);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
             }
@@ -345,8 +392,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
                 float yv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    yv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rs_bwy, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0));
+                    yv[r] = ld_el<TO>(rs_bwy, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * JS);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r];
@@ -363,8 +409,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const float v = acc[i][j][r];      // (bit_cast straight from the vector element miscompiles)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out,
-                                                      rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * 128u, 0, 0);
+                st_el<TO>(v, rs_out, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * JS);
             }
         }
     }
@@ -397,9 +442,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const fl
 // ------------------------------------------------------------------------------------------
 // TN (weight gradient) kernel
 // ------------------------------------------------------------------------------------------
-template <int BMO, int BNC, bool STEM>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const float* __restrict__ in,
-                                                             const float* __restrict__ dy,
+// TX / TDY: storage of the conv input and of dY.  The arithmetic is fp32 MFMA in both modes: bf16 operands are
+// widened when they are staged (the reduction index m is the slow dimension of both operands, so bf16 MFMA
+// fragments -- 8 consecutive m per lane -- would need a transposed LDS image; the bf16 configuration is HBM
+// bound, not MFMA bound, so round 1 keeps the exact-fp32 reduction here).
+template <typename TX, typename TDY, int BMO, int BNC, bool STEM>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
+                                                             const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int kps,
                                                              unsigned in_bytes, unsigned dy_bytes) {
     constexpr int BKM = 32;
@@ -466,14 +515,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int m = mb + ra0 + SA * j;
-            ra[j] = bld4(rs_dy, (unsigned)(m * g.Co + o0 + qa * 4) * 4u);   // m >= M: past the end -> 0
+            ra[j] = bldv<TDY>(rs_dy, (unsigned)(m * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int m = mb + rb0 + SB * j;
             unsigned off;
             if (lin) {
-                off = (unsigned)(m * g.Ci + coff) * 4u;
+                off = (unsigned)(m * g.Ci + coff) * (unsigned)sizeof(TX);
             } else {
                 bool ok = tapok && m < M;
                 const int mm = ok ? m : 0;
@@ -481,9 +530,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 const int hi = ho * g.is + dh, wi = wo * g.is + dw;
                 ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * 4u : kInvalidOff;
+                off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * (unsigned)sizeof(TX) : kInvalidOff;
             }
-            rb[j] = bld4(rs_in, off);
+            rb[j] = bldv<TX>(rs_in, off);
         }
     };
     auto store_tile = [&](int buf) {
@@ -653,9 +702,9 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     return (size_t)p.splits * g.Co * g.wT * g.Ci * sizeof(float);
 }
 
-int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out, const float* add,
-                      const float* mask, int stem, hipStream_t st, float* st_mean, float* st_m2,
-                      const IoBwStats* bw) {
+int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
+                      const void* mask, int stem, hipStream_t st, float* st_mean, float* st_m2,
+                      const IoBwStats* bw, int dt_in, int dt_out) {
     IoBwStats bws;
     memset(&bws, 0, sizeof(bws));
     if (bw) {
@@ -667,15 +716,16 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     IO_REQUIRE(!st_mean || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && !add && !mask), IO_ERR_SHAPE,
                "conv_nt: fused statistics need a plain dense forward convolution");
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_nt: Co=%d must be a multiple of 64", g.Co);
+    const int es = io_dtype_bytes(dt_in), os = io_dtype_bytes(dt_out);
     if (stem)
-        IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): Ci=%d must be 8 (5 channels padded)", g.Ci);
+        IO_REQUIRE(g.Ci == 8 && dt_in == IO_F32, IO_ERR_SHAPE, "conv_nt(stem): needs fp32 input with Ci=8 (5 padded)");
     else
-        IO_REQUIRE(g.Ci % 32 == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of 32", g.Ci);
+        IO_REQUIRE(g.Ci % (128 / es) == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of %d", g.Ci, 128 / es);
     const long M = (long)g.N * g.Ho * g.Wo;
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
-    const double in_b = 4.0 * g.N * g.Hi * g.Wi * g.Ci, w_b = 4.0 * g.Co * g.wT * g.Ci;
+    const double in_b = (double)es * g.N * g.Hi * g.Wi * g.Ci, w_b = (double)es * g.Co * g.wT * g.Ci;
     IO_REQUIRE(in_b < 4.0e9 && w_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: operand larger than 4 GB (32-bit offsets)");
-    const double out_b = 4.0 * g.N * g.outH * g.outW * g.Co;
+    const double out_b = (double)os * g.N * g.outH * g.outW * g.Co;
     IO_REQUIRE(out_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: output larger than 4 GB (32-bit offsets)");
     const unsigned in_bytes = (unsigned)in_b, w_bytes = (unsigned)w_b, out_bytes = (unsigned)out_b;
     const int bn = (g.Co % 128 == 0) ? 128 : 64;
@@ -688,37 +738,45 @@ int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, fl
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
-                     4.0 * ((double)M * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred), st);
-#define IO_LAUNCH_NT(BN_, STEM_, NW_)                                                                        \
+                     (double)os * M * g.Co + (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred), st);
+#define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_)                                                                   \
     do {                                                                                                     \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<BN_, STEM_, NW_>,                          \
+            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>,                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + BN_) * 36 * 4); \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<BN_, STEM_, NW_>), grid, block, lds, st, g, in, wgt, out, add,    \
-                           mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);                    \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>), grid, block, lds, st, g,               \
+                           (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add, (const TO_*)mask,    \
+                           ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);                          \
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
-        IO_LAUNCH_NT(64, true, 4);
-    } else if (bn == 128) {
-        IO_LAUNCH_NT(128, false, 4);
+        if (dt_out == IO_BF16) IO_LAUNCH_NT(float, bf16_t, 64, true);
+        else IO_LAUNCH_NT(float, float, 64, true);
+    } else if (dt_in == IO_BF16) {
+        IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
+        if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, false);
+        else IO_LAUNCH_NT(bf16_t, bf16_t, 64, false);
     } else {
-        IO_LAUNCH_NT(64, false, 4);
+        IO_REQUIRE(dt_out == IO_F32, IO_ERR_SHAPE, "conv_nt: fp32 operands write fp32 outputs (except the stem)");
+        if (bn == 128) IO_LAUNCH_NT(float, float, 128, false);
+        else IO_LAUNCH_NT(float, float, 64, false);
     }
 #undef IO_LAUNCH_NT
     return io_check_launch("conv_nt");
 }
 
-int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, float* dw, float* partial,
-                         size_t partial_bytes, int stem, hipStream_t st) {
+int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, float* dw, float* partial,
+                         size_t partial_bytes, int stem, hipStream_t st, int dt_in, int dt_dy) {
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_wgrad: Co=%d must be a multiple of 64", g.Co);
     if (stem)
-        IO_REQUIRE(g.Ci == 8 && g.Co == 64, IO_ERR_SHAPE, "conv_wgrad(stem): need Ci=8, Co=64");
+        IO_REQUIRE(g.Ci == 8 && g.Co == 64 && dt_in == IO_F32, IO_ERR_SHAPE,
+                   "conv_wgrad(stem): need fp32 input with Ci=8, Co=64");
     else
-        IO_REQUIRE(g.Ci % 64 == 0, IO_ERR_SHAPE, "conv_wgrad: Ci=%d must be a multiple of 64", g.Ci);
+        IO_REQUIRE(g.Ci % 64 == 0 && dt_in == dt_dy, IO_ERR_SHAPE,
+                   "conv_wgrad: Ci=%d must be a multiple of 64 (and one storage type)", g.Ci);
     IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW, IO_ERR_SHAPE, "conv_wgrad: dY must be dense");
     WgradPlan p = plan_wgrad(g, stem);
     const size_t need = io_conv_wgrad_partial_bytes(g, stem);
@@ -726,29 +784,37 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, 
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     float* dst = p.splits == 1 ? dw : partial;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(kThreads);
-    const double in_b = 4.0 * g.N * g.Hi * g.Wi * g.Ci, dy_b = 4.0 * g.N * g.Ho * g.Wo * g.Co;
+    const double in_b = (double)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
+    const double dy_b = (double)io_dtype_bytes(dt_dy) * g.N * g.Ho * g.Wo * g.Co;
     IO_REQUIRE(in_b < 4.0e9 && dy_b < 4.0e9, IO_ERR_SHAPE, "conv_wgrad: operand larger than 4 GB (32-bit offsets)");
     const unsigned in_bytes = (unsigned)in_b, dy_bytes = (unsigned)dy_b;
     const double Md = (double)g.N * g.Ho * g.Wo;
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_WGRAD_STEM : IO_PROF_WGRAD, 2.0 * Md * g.Co * kred,
-                     4.0 * (Md * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred), st);
-#define IO_LAUNCH_WG(BMO_, BNC_, STEM_)                                                                   \
-    do {                                                                                                  \
-        const size_t lds = (size_t)2 * 32 * (BMO_ + BNC_) * sizeof(float);                                \
-        hipLaunchKernelGGL((conv_wgrad_kernel<BMO_, BNC_, STEM_>), grid, block, lds, st, g, in, dy, dst,  \
-                           p.ntile_c, p.kps, in_bytes, dy_bytes);                                         \
+                     io_dtype_bytes(dt_dy) * Md * g.Co + io_dtype_bytes(dt_in) * (double)g.N * g.Hi * g.Wi * g.Ci +
+                         4.0 * g.Co * kred, st);
+#define IO_LAUNCH_WG(TX_, TDY_, BMO_, BNC_, STEM_)                                                              \
+    do {                                                                                                        \
+        const size_t lds = (size_t)2 * 32 * (BMO_ + BNC_) * sizeof(float);                                      \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, STEM_>), grid, block, lds, st, g,          \
+                           (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.kps, in_bytes, dy_bytes);         \
     } while (0)
-    if (stem)
-        IO_LAUNCH_WG(64, 64, true);
-    else if (p.bmo == 128 && p.bnc == 128)
-        IO_LAUNCH_WG(128, 128, false);
-    else if (p.bmo == 128)
-        IO_LAUNCH_WG(128, 64, false);
-    else if (p.bnc == 128)
-        IO_LAUNCH_WG(64, 128, false);
-    else
-        IO_LAUNCH_WG(64, 64, false);
+#define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
+    do {                                                                               \
+        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 128, false);    \
+        else if (p.bmo == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 64, false);                \
+        else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, false);                \
+        else IO_LAUNCH_WG(TX_, TDY_, 64, 64, false);                                   \
+    } while (0)
+    if (stem) {
+        if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, true);
+        else IO_LAUNCH_WG(float, float, 64, 64, true);
+    } else if (dt_in == IO_BF16) {
+        IO_LAUNCH_WG_SHAPES(bf16_t, bf16_t);
+    } else {
+        IO_LAUNCH_WG_SHAPES(float, float);
+    }
+#undef IO_LAUNCH_WG_SHAPES
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;

@@ -22,6 +22,40 @@ static inline int io_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short bf16_t;          // bfloat16 storage (activations / activation gradients in bf16 mode)
+
+// storage type of activation-like tensors.  fp32: everything as in the reference.  bf16: activations, their
+// gradients and the GEMM operands are bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); parameters, their
+// gradients, BatchNorm statistics, losses and the optimiser stay fp32.
+enum IoDType { IO_F32 = 0, IO_BF16 = 1 };
+static inline int io_dtype_bytes(int dt) { return dt == IO_BF16 ? 2 : 4; }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float io_bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ bf16_t io_f2bf(float f) {      // round to nearest even (NaN stays NaN)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+// 4 consecutive elements <-> float4
+__device__ __forceinline__ f32x4 io_ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 io_ldv(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, r.x << 16);
+    v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r.y << 16);
+    v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void io_stv(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void io_stv(bf16_t* p, f32x4 v) {
+    uint2 r;
+    r.x = (unsigned)io_f2bf(v[0]) | ((unsigned)io_f2bf(v[1]) << 16);
+    r.y = (unsigned)io_f2bf(v[2]) | ((unsigned)io_f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+#endif
 
 // exact n / d for 0 <= n < 2^31 by multiply-high: q = umulhi(n, magic) >> shift (shift < 0: d == 1)
 struct IoFastDiv {
@@ -63,32 +97,57 @@ static inline void io_geom_finish(IoConvGeom& g) {
 // pass over (dz, y) disappears.  y: that BN's input (the conv output); mean/rstd (+ optional scale/shift to
 // recompute the ReLU mask from y) are its [G][C] tables; Mg rows per group (a multiple of 128).
 struct IoBwStats {
-    const float* y;
+    const void* y;       // same storage type as the gradient tensor being written
     const float *mean, *rstd, *mscale, *mshift;
     float *p1, *p2;     // [M/128][C] tile partials
     int Mg;
 };
 
 // internal launchers shared between the C ABI and the network executor
-int io_launch_conv_nt(const IoConvGeom& g, const float* in, const float* wgt, float* out,
-                      const float* add, const float* mask, int stem, hipStream_t st, float* st_mean = nullptr,
-                      float* st_m2 = nullptr, const IoBwStats* bw = nullptr);
-int io_bn_bwd_from_tiles(float* p1, float* p2, const float* dz, const float* y, int M, int C, int G,
+// dt_in: storage of `in` and `wgt`; dt_out: storage of out / add / mask / bw.y
+int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
+                      const void* mask, int stem, hipStream_t st, float* st_mean = nullptr,
+                      float* st_m2 = nullptr, const IoBwStats* bw = nullptr, int dt_in = IO_F32,
+                      int dt_out = IO_F32);
+int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, int M, int C, int G,
                          const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                         float* dy, float* coef, hipStream_t st);
+                         void* dy, float* coef, hipStream_t st, int dt = IO_F32);
+// storage-typed internals behind the fp32 C entry points of the same name (dt: IoDType of the tensors)
+int io_bn_stats_finalize_t(const void* y, int M, int C, int G, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                           float* rstd, float* scale, float* shift, float* partial, size_t partial_floats,
+                           hipStream_t st, int dt);
+int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
+                  const float* shift, const void* identity, const float* mean2, const float* scale2,
+                  const float* shift2, int relu, void* out, hipStream_t st, int dt);
+int io_bn_bwd_t(const void* dout, const void* act, const float* mask_scale, const float* mask_shift, const void* y,
+                int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef,
+                hipStream_t st, int dt);
+int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt);
+int io_maxpool_bwd_t(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, hipStream_t st, int dt);
+int io_avgpool_fc_fwd_t(const void* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
+                        const float* w1, const float* b1, int K1, float* pooled, float* logits, hipStream_t st,
+                        int dt);
+int io_avgpool_fc_bwd_t(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
+                        const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
+                        float* db1, hipStream_t st, int dt);
+// fp32 master filter -> filter of storage type dt, either as is (transpose = 0) or as W^T [C][T][O]
+int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int transpose, hipStream_t st, int dt);
 constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics
 int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* mean, float* rstd, float* scale, float* shift, hipStream_t st);
-int io_launch_conv_wgrad(const IoConvGeom& g, const float* in, const float* dy, float* dw,
-                         float* partial, size_t partial_bytes, int stem, hipStream_t st);
+// dt_in: storage of `in` (the conv input), dt_dy: storage of dY; dW and the partials are fp32
+int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, float* dw, float* partial,
+                         size_t partial_bytes, int stem, hipStream_t st, int dt_in = IO_F32, int dt_dy = IO_F32);
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
 
 IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
-int io_run_dgrad(const float* dy, const float* wt, float* dx, const float* add, const float* mask, int N, int H,
+int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,
-                 const IoBwStats* bw = nullptr);
+                 const IoBwStats* bw = nullptr, int dt = IO_F32);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench / profiling) ----
 enum IoProfClass {

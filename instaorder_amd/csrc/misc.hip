@@ -6,8 +6,12 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p) { return io_ldv(p); }
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v) { io_stv(p, v); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return io_bf2f(*p); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = io_f2bf(v); }
 
 int ew_blocks(size_t n) {
     size_t b = (n + kThreads - 1) / kThreads;
@@ -41,8 +45,9 @@ __global__ __launch_bounds__(kThreads) void pack_planes_kernel(PackArgs a, int n
 // ---- max-pool 3x3 stride 2 pad 1 (resnet_cls.py:144), NHWC -----------------------------------
 // idx keeps, per output element, which of the 9 window taps won (first maximum in (kh,kw) scan
 // order, as the PyTorch CPU kernel); one byte per element, 4 channels packed per uint32.
-__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
-                                                              int C, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W,
+                                                              int C, T* __restrict__ out,
                                                               uint32_t* __restrict__ idx) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
     const size_t total = (size_t)N * Ho * Wo * C4;
@@ -75,9 +80,10 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ dy,
                                                               const uint32_t* __restrict__ idx, int N, int H, int W,
-                                                              int C, float* __restrict__ dx) {
+                                                              int C, T* __restrict__ dx) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
     const size_t total = (size_t)N * H * W * C4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __re
 
 // ---- global average pool + FC heads (resnet_cls.py:152-160, 214-222) ----------------------------
 // one block per sample: pooled[n][c] = mean_p x[n][p][c]; logits[n][k] = pooled . W[k] + b[k]
-__global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const float* __restrict__ x, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const T* __restrict__ x, int HW, int C,
                                                              const float* __restrict__ w0,
                                                              const float* __restrict__ b0, int K0,
                                                              const float* __restrict__ w1,
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const float* __res
     extern __shared__ float sp[];   // C floats + 8*4 reduction slots
     const int n = blockIdx.x, C4 = C >> 2;
     const float inv = 1.f / (float)HW;
-    const float* xn = x + (size_t)n * HW * C;
+    const T* xn = x + (size_t)n * HW * C;
     for (int q = threadIdx.x; q < C4; q += blockDim.x) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int p = 0; p < HW; ++p) s += ld4(xn + (size_t)p * C + q * 4);
@@ -149,11 +156,12 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_kernel(const float* __res
 }
 
 // d_x[n][p][c] = (sum_k dlogits[n][k] W[k][c]) / HW
+template <typename T>
 __global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const float* __restrict__ dlogits,
                                                                       const float* __restrict__ w0, int K0,
                                                                       const float* __restrict__ w1, int K1, int HW,
-                                                                      int C, const float* __restrict__ mask,
-                                                                      float* __restrict__ dx) {
+                                                                      int C, const T* __restrict__ mask,
+                                                                      T* __restrict__ dx) {
     const int n = blockIdx.x, K = K0 + K1;
     const float inv = 1.f / (float)HW;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const flo
         s *= inv;
         for (int p = 0; p < HW; ++p) {
             const size_t o = ((size_t)n * HW + p) * C + c;
-            dx[o] = (!mask || mask[o] > 0.f) ? s : 0.f;
+            st1(dx + o, (!mask || ld1(mask + o) > 0.f) ? s : 0.f);
         }
     }
 }
@@ -296,21 +304,31 @@ __global__ __launch_bounds__(kThreads) void sgd_momentum_kernel(float* __restric
     }
 }
 
-// ---- filter transpose  W[O][T][C] -> Wt[C][T][O]  (operand of the data-gradient GEMM) ------------
-__global__ void filter_transpose_kernel(const float* __restrict__ w, int O, int T, int C, float* __restrict__ wt) {
+// ---- filter transpose  W[O][T][C] -> Wt[C][T][O]  (operand of the data-gradient GEMM); the source is the
+// fp32 master filter, the destination has the GEMM operand type (bf16 in bf16 mode) --------------------
+template <typename T>
+__global__ void filter_transpose_kernel(const float* __restrict__ w, int O, int T_, int C, T* __restrict__ wt) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z;
     const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         const int o = o0 + r, c = c0 + tx;
-        tile[r][tx] = (o < O && c < C) ? w[((size_t)o * T + t) * C + c] : 0.f;
+        tile[r][tx] = (o < O && c < C) ? w[((size_t)o * T_ + t) * C + c] : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int c = c0 + r, o = o0 + tx;
-        if (c < C && o < O) wt[((size_t)c * T + t) * O + o] = tile[tx][r];
+        if (c < C && o < O) st1(wt + ((size_t)c * T_ + t) * O + o, tile[tx][r]);
     }
+}
+
+// fp32 -> bf16 copy (operand copies of the fp32 master filters)
+__global__ __launch_bounds__(kThreads) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        st4(dst + i * 4, ld4(src + i * 4));
 }
 
 }  // namespace
@@ -329,48 +347,87 @@ extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* samp
     return io_check_launch("pack_planes");
 }
 
-extern "C" int io_maxpool_fwd(const float* x, int N, int H, int W, int C, float* out, uint32_t* idx,
-                              hipStream_t st) {
+int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt) {
     IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
     const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 4.0 * N * H * W * C * 1.3125, st);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, x, N, H, W, C, out, idx);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, (double)io_dtype_bytes(dt) * N * H * W * C * 1.3125, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const bf16_t*)x,
+                           N, H, W, C, (bf16_t*)out, idx);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const float*)x, N,
+                           H, W, C, (float*)out, idx);
     return io_check_launch("maxpool_fwd");
+}
+
+extern "C" int io_maxpool_fwd(const float* x, int N, int H, int W, int C, float* out, uint32_t* idx,
+                              hipStream_t st) {
+    return io_maxpool_fwd_t(x, N, H, W, C, out, idx, st, IO_F32);
+}
+
+int io_maxpool_bwd_t(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, hipStream_t st,
+                     int dt) {
+    IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
+    const size_t total = (size_t)N * H * W * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, (double)io_dtype_bytes(dt) * N * H * W * C * 1.3125, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const bf16_t*)dy,
+                           idx, N, H, W, C, (bf16_t*)dx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const float*)dy,
+                           idx, N, H, W, C, (float*)dx);
+    return io_check_launch("maxpool_bwd");
 }
 
 extern "C" int io_maxpool_bwd(const float* dy, const uint32_t* idx, int N, int H, int W, int C, float* dx,
                               hipStream_t st) {
-    IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
-    const size_t total = (size_t)N * H * W * (C / 4);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 4.0 * N * H * W * C * 1.3125, st);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, dy, idx, N, H, W, C, dx);
-    return io_check_launch("maxpool_bwd");
+    return io_maxpool_bwd_t(dy, idx, N, H, W, C, dx, st, IO_F32);
+}
+
+int io_avgpool_fc_fwd_t(const void* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
+                        const float* w1, const float* b1, int K1, float* pooled, float* logits, hipStream_t st,
+                        int dt) {
+    IO_REQUIRE(C % 4 == 0 && K0 >= 1 && K1 >= 0, IO_ERR_SHAPE, "avgpool_fc: C=%d K0=%d K1=%d", C, K0, K1);
+    const size_t lds = (size_t)(C + 32) * sizeof(float);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * N * C * (K0 + K1), (double)io_dtype_bytes(dt) * N * HW * C, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(avgpool_fc_kernel<bf16_t>, dim3(N), dim3(kThreads), lds, st, (const bf16_t*)x, HW, C, w0, b0,
+                           K0, w1, b1, K1, pooled, logits);
+    else
+        hipLaunchKernelGGL(avgpool_fc_kernel<float>, dim3(N), dim3(kThreads), lds, st, (const float*)x, HW, C, w0, b0,
+                           K0, w1, b1, K1, pooled, logits);
+    return io_check_launch("avgpool_fc_fwd");
 }
 
 extern "C" int io_avgpool_fc_fwd(const float* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
                                  const float* w1, const float* b1, int K1, float* pooled, float* logits,
                                  hipStream_t st) {
-    IO_REQUIRE(C % 4 == 0 && K0 >= 1 && K1 >= 0, IO_ERR_SHAPE, "avgpool_fc: C=%d K0=%d K1=%d", C, K0, K1);
-    const size_t lds = (size_t)(C + 32) * sizeof(float);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * N * C * (K0 + K1), 4.0 * N * HW * C, st);
-    hipLaunchKernelGGL(avgpool_fc_kernel, dim3(N), dim3(kThreads), lds, st, x, HW, C, w0, b0, K0, w1, b1, K1, pooled,
-                       logits);
-    return io_check_launch("avgpool_fc_fwd");
+    return io_avgpool_fc_fwd_t(x, N, HW, C, w0, b0, K0, w1, b1, K1, pooled, logits, st, IO_F32);
 }
 
-extern "C" int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0,
-                                 int K0, const float* w1, int K1, const float* relu_mask, float* dx, float* dw0,
-                                 float* db0, float* dw1, float* db1, hipStream_t st) {
+int io_avgpool_fc_bwd_t(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
+                        const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
+                        float* db1, hipStream_t st, int dt) {
     const int K = K0 + K1;
-    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, 4.0 * N * HW * C, st);
-    hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1, HW, C,
-                       relu_mask, dx);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, (double)io_dtype_bytes(dt) * N * HW * C, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<bf16_t>, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1,
+                           HW, C, (const bf16_t*)relu_mask, (bf16_t*)dx);
+    else
+        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<float>, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1,
+                           HW, C, (const float*)relu_mask, (float*)dx);
     hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K0), dim3(kThreads), 0, st, dlogits, pooled,
                        N, C, K, 0, K0, dw0, db0);
     if (K1 > 0)
         hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K1), dim3(kThreads), 0, st, dlogits,
                            pooled, N, C, K, K0, K1, dw1, db1);
     return io_check_launch("avgpool_fc_bwd");
+}
+
+extern "C" int io_avgpool_fc_bwd(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0,
+                                 int K0, const float* w1, int K1, const float* relu_mask, float* dx, float* dw0,
+                                 float* db0, float* dw1, float* db1, hipStream_t st) {
+    return io_avgpool_fc_bwd_t(dlogits, pooled, N, HW, C, w0, K0, w1, K1, relu_mask, dx, dw0, db0, dw1, db1, st, IO_F32);
 }
 
 extern "C" int io_order_loss(const float* logits, int N, int B, int Kocc, int Kdep, const float* occ_target,
@@ -397,9 +454,22 @@ extern "C" int io_sgd_momentum(float* params, const float* grads, float* momentu
     return io_check_launch("sgd_momentum");
 }
 
+int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int transpose, hipStream_t st, int dt) {
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, (4.0 + io_dtype_bytes(dt)) * O * T * C, st);
+    if (transpose) {
+        dim3 grid(io_cdiv(C, 32), io_cdiv(O, 32), T);
+        if (dt == IO_BF16)
+            hipLaunchKernelGGL(filter_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, w, O, T, C, (bf16_t*)dst);
+        else
+            hipLaunchKernelGGL(filter_transpose_kernel<float>, grid, dim3(256), 0, st, w, O, T, C, (float*)dst);
+    } else {
+        IO_REQUIRE(dt == IO_BF16 && ((size_t)O * T * C) % 4 == 0, IO_ERR_SHAPE, "filter_prepare: nothing to do");
+        const size_t n4 = (size_t)O * T * C / 4;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_blocks(n4)), dim3(kThreads), 0, st, w, (bf16_t*)dst, n4);
+    }
+    return io_check_launch("filter_prepare");
+}
+
 extern "C" int io_filter_transpose(const float* w, int O, int T, int C, float* wt, hipStream_t st) {
-    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 8.0 * O * T * C, st);
-    hipLaunchKernelGGL(filter_transpose_kernel, dim3(io_cdiv(C, 32), io_cdiv(O, 32), T), dim3(256), 0, st, w, O, T,
-                       C, wt);
-    return io_check_launch("filter_transpose");
+    return io_filter_prepare_t(w, O, T, C, wt, 1, st, IO_F32);
 }

@@ -39,6 +39,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct io_net {
+    int dtype = IO_F32;       // storage of activations / activation gradients / GEMM operands (IoDType)
     int in_ch, n_heads, head_dims[2];
     ConvL stem;
     BnL bn1;
@@ -109,6 +110,7 @@ struct Plan {
     size_t tile_mean, tile_m2;   // fused-statistics partials written by the conv epilogue (training)
     size_t gbuf[5];      // gradient scratch (training only)
     size_t wt, wg_partial, wg_partial_bytes;
+    size_t wop;          // bf16 mode: operand copy of the whole flat parameter buffer (same element offsets)
     size_t total;
 };
 
@@ -126,7 +128,9 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     Arena a;
     const int H0 = S / 2, H1 = S / 4;
     const size_t f = sizeof(float);
-    const size_t maxact = (size_t)N * H0 * H0 * 64 * f;   // == N*H1*H1*256*f, the largest activations
+    const size_t e = (size_t)io_dtype_bytes(net->dtype);   // activation element size
+    const size_t maxact = (size_t)N * H0 * H0 * 64 * e;   // == N*H1*H1*256*e, the largest activations
+    p.wop = net->dtype == IO_BF16 ? a.take((size_t)net->param_floats * sizeof(bf16_t)) : 0;
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
     p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
@@ -143,20 +147,20 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     if (training) {
         p.y0 = a.take(maxact);
         p.a0 = a.take(maxact);
-        p.p0 = a.take((size_t)N * H1 * H1 * 64 * f);
+        p.p0 = a.take((size_t)N * H1 * H1 * 64 * e);
         p.idx0 = a.take((size_t)N * H1 * H1 * 16 * sizeof(uint32_t));
         int H = H1;
         for (size_t i = 0; i < net->blocks.size(); ++i) {
             const Block& b = net->blocks[i];
             const int Ho = H / b.stride;
             BlockBufs& bb = p.blk[i];
-            bb.y1 = a.take((size_t)N * H * H * b.planes * f);
-            bb.a1 = a.take((size_t)N * H * H * b.planes * f);
-            bb.y2 = a.take((size_t)N * Ho * Ho * b.planes * f);
-            bb.a2 = a.take((size_t)N * Ho * Ho * b.planes * f);
-            bb.y3 = a.take((size_t)N * Ho * Ho * b.planes * 4 * f);
-            bb.yd = b.down ? a.take((size_t)N * Ho * Ho * b.planes * 4 * f) : 0;
-            bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * f);
+            bb.y1 = a.take((size_t)N * H * H * b.planes * e);
+            bb.a1 = a.take((size_t)N * H * H * b.planes * e);
+            bb.y2 = a.take((size_t)N * Ho * Ho * b.planes * e);
+            bb.a2 = a.take((size_t)N * Ho * Ho * b.planes * e);
+            bb.y3 = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
+            bb.yd = b.down ? a.take((size_t)N * Ho * Ho * b.planes * 4 * e) : 0;
+            bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
             H = Ho;
         }
         for (int i = 0; i < 5; ++i) p.gbuf[i] = a.take(maxact);
@@ -176,7 +180,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
                 IoConvGeom g = io_geom_fwd(N, Hin, Hin, c.cin, c.cout, c.k, c.k, c.stride, c.pad);
                 const size_t need = io_conv_wgrad_partial_bytes(g, 0);
                 if (need > wg) wg = need;
-                const size_t wsz = (size_t)c.cout * c.k * c.k * c.cin * f;
+                const size_t wsz = (size_t)c.cout * c.k * c.k * c.cin * e;
                 if (wsz > wtmax) wtmax = wsz;
             }
             H /= b.stride;
@@ -225,7 +229,14 @@ struct Ctx {
     hipStream_t st;
     std::vector<long> chan_prefix;
 
-    float* buf(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    float* buf(size_t off) const { return reinterpret_cast<float*>(ws + off); }   // fp32 scratch / tables
+    void* act(size_t off) const { return ws + off; }                               // activation-typed tensors
+    int dt() const { return net->dtype; }
+    // GEMM operand view of a filter: the fp32 master itself, or its bf16 copy made at the start of the pass
+    const void* wop(long w_off) const {
+        return net->dtype == IO_BF16 ? (const void*)(reinterpret_cast<const bf16_t*>(ws + plan.wop) + w_off)
+                                     : (const void*)(params + w_off);
+    }
     Tables tables(const BnL& b) const {
         float* base = buf(plan.tables) + (size_t)4 * kMaxGroups * chan_prefix[b.index];
         const size_t gs = (size_t)kMaxGroups * b.C;
@@ -233,14 +244,16 @@ struct Ctx {
     }
 };
 
-int conv_fwd(const Ctx& c, const ConvL& L, const float* x, float* y, int H, bool stats = false) {
+int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
-    return io_launch_conv_nt(g, x, c.params + L.w_off, y, nullptr, nullptr, L.cin_store == 8, c.st,
-                             stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr);
+    const bool stem = L.cin_store == 8;      // the stem always reads the fp32 packed input and fp32 filter
+    return io_launch_conv_nt(g, x, stem ? (const void*)(c.params + L.w_off) : c.wop(L.w_off), y, nullptr, nullptr, stem,
+                             c.st, stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
+                             nullptr, stem ? IO_F32 : c.dt(), c.dt());
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
-int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M, bool from_tiles = false) {
+int bn_prepare(const Ctx& c, const BnL& b, const void* y, int M, bool from_tiles = false) {
     Tables t = c.tables(b);
     if (c.training && from_tiles)
         return io_bn_finalize_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), M, b.C, c.G,
@@ -248,23 +261,23 @@ int bn_prepare(const Ctx& c, const BnL& b, const float* y, int M, bool from_tile
                                     c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
                                     t.shift, c.st);
     if (c.training)
-        return io_bn_stats_finalize(y, M, b.C, c.G, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
-                                    c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
-                                    t.shift, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.st);
+        return io_bn_stats_finalize_t(y, M, b.C, c.G, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
+                                      c.running + b.run_off + b.C, kBnMomentum, kBnEps, t.mean, t.rstd, t.scale,
+                                      t.shift, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.st, c.dt());
     return io_bn_eval_prepare(b.C, c.params + b.g_off, c.params + b.b_off, c.running + b.run_off,
                               c.running + b.run_off + b.C, kBnEps, t.mean, t.scale, t.shift, c.st);
 }
 
 // conv followed by the statistics of its output; the statistics ride in the conv epilogue whenever a
 // 128-row tile never straddles two BN groups
-int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const float* x, float* y, int Hin, int Mout) {
+int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout) {
     const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
     IO_TRY(conv_fwd(c, L, x, y, Hin, fuse));
     return bn_prepare(c, b, y, Mout, fuse);
 }
 
-int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, const BnL* b2, int relu,
-           float* out) {
+int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, const BnL* b2, int relu,
+           void* out) {
     Tables t = c.tables(b);
     const float *m2 = nullptr, *s2 = nullptr, *h2 = nullptr;
     if (b2) {
@@ -274,73 +287,76 @@ int bn_act(const Ctx& c, const BnL& b, const float* y, int M, const float* idt, 
         h2 = t2.shift;
     }
     // tables are laid out with a group stride of C (training) -- eval uses one shared row
-    return io_bn_apply(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.mean, t.scale, t.shift, idt, m2, s2,
-                       h2, relu, out, c.st);
+    return io_bn_apply_t(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.mean, t.scale, t.shift, idt, m2, s2,
+                         h2, relu, out, c.st, c.dt());
 }
 
 int run_forward(Ctx& c, const float* x8, float* logits) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
     const int H0 = c.S / 2, H1 = c.S / 4;
+    if (c.dt() == IO_BF16)      // bf16 GEMM operands: one cast of the whole flat fp32 parameter buffer
+        IO_TRY(io_filter_prepare_t(c.params, 1, 1, (int)net->param_floats, c.act(p.wop), 0, c.st, IO_BF16));
     // stem
-    IO_TRY(conv_bn(c, net->stem, net->bn1, x8, c.buf(p.y0), c.S, c.N * H0 * H0));
-    IO_TRY(bn_act(c, net->bn1, c.buf(p.y0), c.N * H0 * H0, nullptr, nullptr, 1, c.buf(p.a0)));
-    IO_TRY(io_maxpool_fwd(c.buf(p.a0), c.N, H0, H0, 64, c.buf(p.p0),
-                          c.training ? reinterpret_cast<uint32_t*>(c.ws + p.idx0) : nullptr, c.st));
-    const float* x = c.buf(p.p0);
+    IO_TRY(conv_bn(c, net->stem, net->bn1, x8, c.act(p.y0), c.S, c.N * H0 * H0));
+    IO_TRY(bn_act(c, net->bn1, c.act(p.y0), c.N * H0 * H0, nullptr, nullptr, 1, c.act(p.a0)));
+    IO_TRY(io_maxpool_fwd_t(c.act(p.a0), c.N, H0, H0, 64, c.act(p.p0),
+                            c.training ? reinterpret_cast<uint32_t*>(c.ws + p.idx0) : nullptr, c.st, c.dt()));
+    const void* x = c.act(p.p0);
     int H = H1;
     for (size_t i = 0; i < net->blocks.size(); ++i) {
         const Block& b = net->blocks[i];
         const BlockBufs& bb = p.blk[i];
         const int Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
-        IO_TRY(conv_bn(c, b.c1, b.b1, x, c.buf(bb.y1), H, Min));
-        IO_TRY(bn_act(c, b.b1, c.buf(bb.y1), Min, nullptr, nullptr, 1, c.buf(bb.a1)));
-        IO_TRY(conv_bn(c, b.c2, b.b2, c.buf(bb.a1), c.buf(bb.y2), H, Mout));
-        IO_TRY(bn_act(c, b.b2, c.buf(bb.y2), Mout, nullptr, nullptr, 1, c.buf(bb.a2)));
-        IO_TRY(conv_bn(c, b.c3, b.b3, c.buf(bb.a2), c.buf(bb.y3), Ho, Mout));
+        IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
+        IO_TRY(bn_act(c, b.b1, c.act(bb.y1), Min, nullptr, nullptr, 1, c.act(bb.a1)));
+        IO_TRY(conv_bn(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.y2), H, Mout));
+        IO_TRY(bn_act(c, b.b2, c.act(bb.y2), Mout, nullptr, nullptr, 1, c.act(bb.a2)));
+        IO_TRY(conv_bn(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.y3), Ho, Mout));
         if (b.down) {
-            IO_TRY(conv_bn(c, b.cd, b.bd, x, c.buf(bb.yd), H, Mout));
-            IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, c.buf(bb.yd), &b.bd, 1, c.buf(bb.out)));
+            IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
+            IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
         } else {
-            IO_TRY(bn_act(c, b.b3, c.buf(bb.y3), Mout, x, nullptr, 1, c.buf(bb.out)));
+            IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, x, nullptr, 1, c.act(bb.out)));
         }
-        x = c.buf(bb.out);
+        x = c.act(bb.out);
         H = Ho;
     }
     const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
     const float* b1 = net->n_heads > 1 ? c.params + net->fcb_off[1] : nullptr;
-    IO_TRY(io_avgpool_fc_fwd(x, c.N, H * H, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
-                             net->head_dims[0], w1, b1, net->n_heads > 1 ? net->head_dims[1] : 0, c.buf(p.pooled),
-                             logits, c.st));
+    IO_TRY(io_avgpool_fc_fwd_t(x, c.N, H * H, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
+                               net->head_dims[0], w1, b1, net->n_heads > 1 ? net->head_dims[1] : 0, c.buf(p.pooled),
+                               logits, c.st, c.dt()));
     return IO_OK;
 }
 
 // mask: 0 = no ReLU behind this BN, 1 = recompute relu(bn(y)) > 0 from y, 2 = read the stored activation
-int bn_back(const Ctx& c, const BnL& b, const float* dout, int mask, const float* act, const float* y, int M,
-            float* dy, float* dz_out) {
+int bn_back(const Ctx& c, const BnL& b, const void* dout, int mask, const void* act, const void* y, int M,
+            void* dy, void* dz_out) {
     Tables t = c.tables(b);
-    return io_bn_bwd(dout, mask == 2 ? act : nullptr, mask == 1 ? t.scale : nullptr, mask == 1 ? t.shift : nullptr,
-                     y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off, dy,
-                     dz_out, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.buf(c.plan.coef), c.st);
+    return io_bn_bwd_t(dout, mask == 2 ? act : nullptr, mask == 1 ? t.scale : nullptr, mask == 1 ? t.shift : nullptr,
+                       y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off, dy,
+                       dz_out, c.buf(c.plan.bn_partial), c.plan.bn_partial_floats, c.buf(c.plan.coef), c.st, c.dt());
 }
 
-int conv_wgrad(const Ctx& c, const ConvL& L, const float* x, const float* dy, int H) {
+int conv_wgrad(const Ctx& c, const ConvL& L, const void* x, const void* dy, int H) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
-    return io_launch_conv_wgrad(g, x, dy, c.grads + L.w_off, c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes,
-                                L.cin_store == 8, c.st);
+    const bool stem = L.cin_store == 8;
+    return io_launch_conv_wgrad(g, x, dy, c.grads + L.w_off, c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes, stem,
+                                c.st, stem ? IO_F32 : c.dt(), c.dt());
 }
 
-int conv_dgrad(const Ctx& c, const ConvL& L, const float* dy, float* dx, const float* add, const float* mask,
+int conv_dgrad(const Ctx& c, const ConvL& L, const void* dy, void* dx, const void* add, const void* mask,
                int H, const IoBwStats* bw = nullptr) {
-    float* wt = c.buf(c.plan.wt);
-    IO_TRY(io_filter_transpose(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, c.st));
-    return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st, bw);
+    void* wt = c.act(c.plan.wt);
+    IO_TRY(io_filter_prepare_t(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, 1, c.st, c.dt()));
+    return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st, bw, c.dt());
 }
 
 bool tiles_ok(const Ctx& c, int M) { return (M / c.G) % kIoStatTileRows == 0; }
 
-IoBwStats bw_for(const Ctx& c, const BnL& b, const float* y, int M, bool mask_from_y) {
+IoBwStats bw_for(const Ctx& c, const BnL& b, const void* y, int M, bool mask_from_y) {
     Tables t = c.tables(b);
     IoBwStats bw;
     bw.y = y;
@@ -354,18 +370,18 @@ IoBwStats bw_for(const Ctx& c, const BnL& b, const float* y, int M, bool mask_fr
     return bw;
 }
 
-int bn_back_tiles(const Ctx& c, const BnL& b, const float* dz, const float* y, int M, float* dy) {
+int bn_back_tiles(const Ctx& c, const BnL& b, const void* dz, const void* y, int M, void* dy) {
     Tables t = c.tables(b);
     return io_bn_bwd_from_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), dz, y, M, b.C, c.G,
                                 c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off, dy,
-                                c.buf(c.plan.coef), c.st);
+                                c.buf(c.plan.coef), c.st, c.dt());
 }
 
 // data gradient of conv L (-> dx, the gradient of relu(bn(y))), then the backward of that BN (-> dyb).
 // With a stride-1 conv the BN-backward reductions ride in the conv epilogue (which also applies the ReLU
 // mask recomputed from y), and only the apply pass remains.
-int dgrad_then_bn(const Ctx& c, const ConvL& L, const float* dy, float* dx, int H, const BnL& b, const float* y,
-                  int M, float* dyb) {
+int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H, const BnL& b, const void* y,
+                  int M, void* dyb) {
     if (L.stride == 1 && tiles_ok(c, M)) {
         IoBwStats bw = bw_for(c, b, y, M, true);
         IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
@@ -378,11 +394,11 @@ int dgrad_then_bn(const Ctx& c, const ConvL& L, const float* dy, float* dx, int 
 int run_backward(Ctx& c, const float* dlogits, const float* x8) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
-    float* Gd = c.buf(p.gbuf[0]);
-    float* Ge = c.buf(p.gbuf[1]);
-    float* Ga = c.buf(p.gbuf[2]);
-    float* Gb = c.buf(p.gbuf[3]);
-    float* Gc = c.buf(p.gbuf[4]);
+    void* Gd = c.act(p.gbuf[0]);
+    void* Ge = c.act(p.gbuf[1]);
+    void* Ga = c.act(p.gbuf[2]);
+    void* Gb = c.act(p.gbuf[3]);
+    void* Gc = c.act(p.gbuf[4]);
     const int H0 = c.S / 2, H1 = c.S / 4;
     // spatial size of the last stage
     int Hlast = H1;
@@ -392,11 +408,11 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
     // Gradients of block outputs are kept ALREADY MASKED by that output's ReLU: whoever writes the last
     // contribution to d(out) applies [out > 0] in its epilogue (here: the pooling backward; below: the
     // data-gradient kernels), so the BN backward of the block needs neither the activation nor a mask pass.
-    IO_TRY(io_avgpool_fc_bwd(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
-                             net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0,
-                             c.buf(p.blk[nb - 1].out), Gd, c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
-                             net->n_heads > 1 ? c.grads + net->fcw_off[1] : nullptr,
-                             net->n_heads > 1 ? c.grads + net->fcb_off[1] : nullptr, c.st));
+    IO_TRY(io_avgpool_fc_bwd_t(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
+                               net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0,
+                               c.act(p.blk[nb - 1].out), Gd, c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
+                               net->n_heads > 1 ? c.grads + net->fcw_off[1] : nullptr,
+                               net->n_heads > 1 ? c.grads + net->fcb_off[1] : nullptr, c.st, c.dt()));
     // per-block input resolution
     std::vector<int> Hin(nb);
     {
@@ -409,20 +425,20 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         const BlockBufs& bb = p.blk[ii];
         const int H = Hin[ii], Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
-        const float* xin = ii == 0 ? c.buf(p.p0) : c.buf(p.blk[ii - 1].out);
+        const void* xin = ii == 0 ? c.act(p.p0) : c.act(p.blk[ii - 1].out);
         // the block input is the previous block's post-ReLU output (for block 0 it is the max-pool output,
         // whose gradient is not masked here)
-        const float* xmask = ii == 0 ? nullptr : xin;
+        const void* xmask = ii == 0 ? nullptr : xin;
         // bn3: Gd holds dz = d(out) * [out > 0]; dy3 -> Ga
         if (have_tiles)
-            IO_TRY(bn_back_tiles(c, b.b3, Gd, c.buf(bb.y3), Mout, Ga));
+            IO_TRY(bn_back_tiles(c, b.b3, Gd, c.act(bb.y3), Mout, Ga));
         else
-            IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.buf(bb.y3), Mout, Ga, nullptr));
+            IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.act(bb.y3), Mout, Ga, nullptr));
         have_tiles = false;
-        IO_TRY(conv_wgrad(c, b.c3, c.buf(bb.a2), Ga, Ho));
-        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.buf(bb.y2), Mout, Gc));
-        IO_TRY(conv_wgrad(c, b.c2, c.buf(bb.a1), Gc, H));
-        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.buf(bb.y1), Min, Gb));
+        IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
+        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, Gc));
+        IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
+        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.act(bb.y1), Min, Gb));
         IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
         // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
@@ -430,22 +446,22 @@ int run_backward(Ctx& c, const float* dlogits, const float* x8) {
         // strided one only touches its own output lattice).
         if (!b.down && ii > 0 && tiles_ok(c, Min)) {
             const Block& pb = net->blocks[ii - 1];
-            IoBwStats bw = bw_for(c, pb.b3, c.buf(p.blk[ii - 1].y3), Min, false);
+            IoBwStats bw = bw_for(c, pb.b3, c.act(p.blk[ii - 1].y3), Min, false);
             IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, Gd, xmask, H, &bw));
             have_tiles = true;
         } else {
             IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, xmask, H));
         }
         if (b.down) {
-            IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.buf(bb.yd), Mout, Ga, nullptr));
+            IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.act(bb.yd), Mout, Ga, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
             IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, xmask, H));
         }
-        float* t = Gd; Gd = Ge; Ge = t;
+        void* t = Gd; Gd = Ge; Ge = t;
     }
     // Gd = d(maxpool output)
-    IO_TRY(io_maxpool_bwd(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st));
-    IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.buf(p.y0), c.N * H0 * H0, Ga, nullptr));
+    IO_TRY(io_maxpool_bwd_t(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st, c.dt()));
+    IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.act(p.y0), c.N * H0 * H0, Ga, nullptr));
     // stem filter gradient only: the network input needs no data gradient
     IO_TRY(conv_wgrad(c, net->stem, x8, Ga, c.S));
     return IO_OK;
@@ -522,6 +538,12 @@ extern "C" io_net* io_net_create(int in_channels, int n_heads, const int* head_d
 }
 
 extern "C" void io_net_destroy(io_net* net) { delete net; }
+extern "C" int io_net_set_dtype(io_net* net, int dtype) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "io_net_set_dtype: unknown dtype %d", dtype);
+    net->dtype = dtype;
+    return IO_OK;
+}
+extern "C" int io_net_get_dtype(const io_net* net) { return net->dtype; }
 extern "C" long io_net_param_floats(const io_net* net) { return net->param_floats; }
 extern "C" long io_net_running_floats(const io_net* net) { return net->running_floats; }
 extern "C" int io_net_num_tensors(const io_net* net) { return (int)net->tensors.size(); }
@@ -544,6 +566,18 @@ static int check_shape(int N, int S, int G) {
 extern "C" size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training) {
     if (check_shape(N, S, 1)) return 0;
     return make_plan(net, N, S, training != 0).total;
+}
+
+extern "C" long io_net_activation_offset(const io_net* net, int N, int S, int which) {
+    if (check_shape(N, S, 1)) return -1;
+    const Plan p = make_plan(net, N, S, true);
+    const int nb = (int)net->blocks.size();
+    if (which == 0) return (long)p.y0;
+    if (which == 1) return (long)p.a0;
+    if (which == 2) return (long)p.p0;
+    if (which >= 3 && which < 3 + nb) return (long)p.blk[which - 3].out;
+    io_set_error("io_net_activation_offset: which=%d (0..%d)", which, 2 + nb);
+    return -1;
 }
 
 static void fill_ctx(Ctx& c, io_net* net, const float* params, float* running, float* grads, int N, int S, int G,

@@ -28,14 +28,20 @@ class Net(object):
     """Plan of resnet50_cls(in_channels, num_classes) -- mirrors models/backbone/resnet_cls.py:259-268.
     Creating it needs no GPU (it only lays out the flat parameter buffer)."""
 
-    def __init__(self, in_channels=5, num_classes=2):
+    DTYPES = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+    def __init__(self, in_channels=5, num_classes=2, dtype="fp32"):
         self.lib = _lib.lib()
+        if dtype not in self.DTYPES:
+            raise ValueError("dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+        self.dtype = "bf16" if self.DTYPES[dtype] else "fp32"
         heads = list(num_classes) if isinstance(num_classes, (list, tuple)) else [int(num_classes)]
         self.head_dims = heads
         arr = (C.c_int * len(heads))(*heads)
         self.handle = self.lib.io_net_create(int(in_channels), len(heads), arr)
         if not self.handle:
             raise RuntimeError("io_net_create failed: " + _lib.last_error())
+        _lib.check(self.lib.io_net_set_dtype(self.handle, self.DTYPES[dtype]), "io_net_set_dtype")
         self.in_channels = int(in_channels)
         self.param_floats = int(self.lib.io_net_param_floats(self.handle))
         self.running_floats = int(self.lib.io_net_running_floats(self.handle))
@@ -63,6 +69,12 @@ class Net(object):
         if n == 0:
             raise RuntimeError("io_net_workspace_bytes: " + _lib.last_error())
         return n
+
+    def activation_offset(self, N, S, which):
+        off = int(self.lib.io_net_activation_offset(self.handle, int(N), int(S), int(which)))
+        if off < 0:
+            raise RuntimeError("io_net_activation_offset: " + _lib.last_error())
+        return off
 
     def forward(self, params, running, x8, N, S, G, training, ws, logits):
         _lib.require_gpu()

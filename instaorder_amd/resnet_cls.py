@@ -65,9 +65,13 @@ class _NetFunction(torch.autograd.Function):
 
 
 class ResNet(nn.Module):
-    def __init__(self, in_channels=5, num_classes=2, device=None):
+    def __init__(self, in_channels=5, num_classes=2, device=None, dtype="fp32"):
+        """dtype='bf16' (not in the reference, which is fp32 only): activations, their gradients and the GEMM
+        operands are bf16 on the device (BASELINE configs[2], [3]); parameters, gradients, BN statistics and the
+        module's inputs / outputs stay fp32, so the API and checkpoints are unchanged."""
         super(ResNet, self).__init__()
-        self.plan = engine.Net(in_channels, num_classes)
+        self.plan = engine.Net(in_channels, num_classes, dtype)
+        self.dtype = self.plan.dtype
         self.in_channels = in_channels
         self.is_occ_and_depth = isinstance(num_classes, (list, tuple))
         self.head_dims = list(num_classes) if self.is_occ_and_depth else [int(num_classes)]

@@ -25,7 +25,8 @@ class SingleStageModel(object):
         arch = params["backbone_arch"]
         if arch not in _BACKBONES:
             raise KeyError("unknown backbone_arch '{}' (have: {})".format(arch, sorted(_BACKBONES)))
-        net = _BACKBONES[arch](**params["backbone_param"])
+        # `dtype` is this package's one extension of the config surface: 'fp32' (reference behaviour) | 'bf16'
+        net = _BACKBONES[arch](dtype=params.get("dtype", "fp32"), **params["backbone_param"])
         common_utils.init_weights(net, init_type="xavier")
         if torch.cuda.is_available():
             net.cuda()
