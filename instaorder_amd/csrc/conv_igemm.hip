@@ -442,10 +442,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // ------------------------------------------------------------------------------------------
 // TN (weight gradient) kernel
 // ------------------------------------------------------------------------------------------
-// TX / TDY: storage of the conv input and of dY.  The arithmetic is fp32 MFMA in both modes: bf16 operands are
-// widened when they are staged (the reduction index m is the slow dimension of both operands, so bf16 MFMA
-// fragments -- 8 consecutive m per lane -- would need a transposed LDS image; the bf16 configuration is HBM
-// bound, not MFMA bound, so round 1 keeps the exact-fp32 reduction here).
+// fp32 MFMA.  TX / TDY: storage of the conv input and of dY; bf16 operands are widened when they are staged (used
+// for the stem in bf16 mode: fp32 packed input x bf16 dY; all other bf16 convs run conv_wgrad_bf16_kernel below).
 template <typename TX, typename TDY, int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
@@ -636,6 +634,174 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN kernel on the bf16 MFMA (bf16 mode, every conv but the fp32 stem)
+// ------------------------------------------------------------------------------------------
+// dW[o][tap][c] = sum_m dY[m][o] * X[gather(m, tap)][c].  v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE values of the
+// reduction index per lane, but m is the slow index of both operands in memory.  So the staging pass transposes:
+// a thread fetches an 8(m) x 8(channel) block with eight 16-byte row loads, interleaves the 16-bit halves with 32
+// v_perm_b32 (the dword-level part of the transpose is register renaming) and writes eight 16-byte LDS rows of an
+// image [channel][64 m] -- byte for byte the image the NT kernel builds ([row][64 k], 36-word pitch), so the fragment
+// reads, the MFMA stream and the software pipeline are the NT kernel's.  Thread -> block mapping: m-group fastest
+// (8 lanes cover 8 m-groups of one channel group): the LDS writes of a wave then hit all 64 banks 4 lanes deep (the
+// b128 minimum) and each global row still gets 128 contiguous bytes from 8 lanes.
+// Grid: 1-D, XCD-remapped so that the blocks of one m-range (all taps / channel tiles of a split) share an L2.
+template <int BMO, int BNC>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
+                                                                  const bf16_t* __restrict__ dy,
+                                                                  float* __restrict__ dst, int ntile_c, int tiles,
+                                                                  int kps, unsigned in_bytes, unsigned dy_bytes) {
+    constexpr int BKM = 64, LDT = 36;
+    constexpr int TI = BMO / 64, TJ = BNC / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                      // [2][BMO][LDT]
+    float* sB = smem + 2 * BMO * LDT;      // [2][BNC][LDT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = g.Ho * g.Wo;
+    const int M = g.N * HoWo;
+    const int T = g.Th * g.Tw;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int per_o = T * ntile_c;
+    const int ot = tile / per_o, rem0 = tile - ot * per_o;
+    const int o0 = ot * BMO;
+    const int tap = rem0 / ntile_c;
+    const int c0 = (rem0 - tap * ntile_c) * BNC;
+    const int th = tap / g.Tw, tw = tap - th * g.Tw;
+    const int dh = g.dh0 + g.dhs * th, dw = g.dw0 + g.dws * tw;
+    const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
+
+    // staging role (wave-uniform): threads [0, BMO) move dY blocks, [BMO, BMO + BNC) move X blocks
+    const bool role_a = wave * 64 < BMO;
+    const bool role_b = !role_a && wave * 64 < BMO + BNC;
+    const int blk = role_a ? tid : tid - BMO;
+    const int mg = blk & 7, cg = blk >> 3;
+
+    const int nkt = (M + BKM - 1) / BKM;
+    const int kt0 = split * kps;
+    const int kt1 = min(kt0 + kps, nkt);
+
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
+    const bool lin = T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+    u32x4 rr[8];
+    auto load_tile = [&](int kt) {
+        const int mrow = kt * BKM + mg * 8;
+        if (role_a) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)     // rows past M lie past the end of dY -> zeros
+                rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (unsigned)((mrow + r) * g.Co + o0 + cg * 8) * 2u, 0, 0);
+        } else if (role_b) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int m = mrow + r;
+                unsigned off;
+                if (lin) {
+                    off = (unsigned)(m * g.Ci + c0 + cg * 8) * 2u;
+                } else {
+                    bool ok = m < M;
+                    const int mm = ok ? m : 0;
+                    const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                    const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+                    const int hi = ho * g.is + dh, wi = wo * g.is + dw;
+                    ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                    off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + c0 + cg * 8) * 2u : kInvalidOff;
+                }
+                rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (role_a || role_b) {
+            float* base = (role_a ? sA + buf * BMO * LDT : sB + buf * BNC * LDT) + cg * 8 * LDT + mg * 4;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                // channel c of the block: halves (c & 1) of dword (c >> 1) of the eight rows, rows pairwise packed
+                const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_perm(rr[2 * j + 1][c >> 1], rr[2 * j][c >> 1], sel);
+                *reinterpret_cast<u32x4*>(base + c * LDT) = v;
+            }
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_off = (wm * (BMO / 2) + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int b_off = (wn * (BNC / 2) + (lane & 31)) * LDT + (lane >> 5) * 4;
+    auto read_frags = [&](int buf, int kk, f32x4 (&a)[TI], f32x4 (&b)[TJ]) {
+        const float* al = sA + buf * BMO * LDT + a_off + kk * 8;
+        const float* bl = sB + buf * BNC * LDT + b_off + kk * 8;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) a[i] = ld4(al + i * 32 * LDT);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[j] = ld4(bl + j * 32 * LDT);
+    };
+    auto mma = [&](const f32x4 (&a)[TI], const f32x4 (&b)[TJ]) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                    __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    };
+
+    f32x4 fa[TI], fb[TJ];
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    if (kt0 < kt1) read_frags(0, 0, fa, fb);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            f32x4 na[TI], nb[TJ];
+            read_frags(buf, kk + 1, na, nb);
+            mma(fa, fb);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = na[i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+        }
+        store_tile(buf ^ 1);
+        __syncthreads();
+        f32x4 na[TI], nb[TJ];
+        read_frags(buf ^ 1, 0, na, nb);
+        mma(fa, fb);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[i] = na[i];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+    }
+
+    const size_t wrow = (size_t)g.wT * g.Ci;
+    float* base = dst + (size_t)split * g.Co * wrow;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int cl = wn * (BNC / 2) + j * 32 + (lane & 31);
+                base[(size_t)o * wrow + (size_t)widx * g.Ci + c0 + cl] = acc[i][j][r];
+            }
+        }
+}
+
 // dst[i] = sum_z partial[z][i]: block = 32 float4 columns x 8 split lanes (8 loads in flight per lane),
 // fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
@@ -783,6 +949,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     float* dst = p.splits == 1 ? dw : partial;
+    int splits = p.splits;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(kThreads);
     const double in_b = (double)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
     const double dy_b = (double)io_dtype_bytes(dt_dy) * g.N * g.Ho * g.Wo * g.Co;
@@ -810,7 +977,28 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, true);
         else IO_LAUNCH_WG(float, float, 64, 64, true);
     } else if (dt_in == IO_BF16) {
-        IO_LAUNCH_WG_SHAPES(bf16_t, bf16_t);
+        // 64-row k-tiles; the split count can only shrink, so the fp32 plan's partial buffer is large enough
+        const int nkt64 = io_cdiv((long)Md, 64), kps64 = io_cdiv(p.kps, 2);
+        splits = io_cdiv(nkt64, kps64);
+        dst = splits == 1 ? dw : partial;
+        dim3 grid1((unsigned)(p.tiles * splits));
+#define IO_LAUNCH_WGB(BMO_, BNC_)                                                                                \
+    do {                                                                                                         \
+        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                       \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_>), grid1, block, lds, st, g, (const bf16_t*)in,    \
+                           (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes, dy_bytes);               \
+    } while (0)
+        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGB(128, 128);
+        else if (p.bmo == 128) IO_LAUNCH_WGB(128, 64);
+        else if (p.bnc == 128) IO_LAUNCH_WGB(64, 128);
+        else IO_LAUNCH_WGB(64, 64);
+#undef IO_LAUNCH_WGB
     } else {
         IO_LAUNCH_WG_SHAPES(float, float);
     }
@@ -818,10 +1006,10 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
-    if (p.splits > 1) {
+    if (splits > 1) {
         const size_t n4 = (size_t)g.Co * g.wT * g.Ci / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
-                           p.splits);
+                           splits);
         rc = io_check_launch("splitk_reduce");
     }
     return rc;
