@@ -447,8 +447,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 template <typename TX, typename TDY, int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
-                                                             float* __restrict__ dst, int ntile_c, int kps,
-                                                             unsigned in_bytes, unsigned dy_bytes) {
+                                                             float* __restrict__ dst, int ntile_c, int tiles,
+                                                             int kps, unsigned in_bytes, unsigned dy_bytes) {
     constexpr int BKM = 32;
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     constexpr int QA = BMO / 4, QB = BNC / 4;          // float4 per tile row
@@ -465,10 +465,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const int M = g.N * HoWo;
     const int T = g.Th * g.Tw;
 
-    // tile decode: blockIdx.x -> (o tile, tap, channel tile)
+    // 1-D grid, XCD-remapped: the blocks of one m-range (all taps / channel tiles of a split) share an L2.
+    // tile decode: tile -> (o tile, tap, channel tile)
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
     const int per_o = STEM ? ntile_c : T * ntile_c;
-    const int ot = blockIdx.x / per_o;
-    const int rem0 = blockIdx.x - ot * per_o;
+    const int ot = tile / per_o;
+    const int rem0 = tile - ot * per_o;
     const int o0 = ot * BMO;
     int tap = 0, c0;
     if (STEM) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     }
 
     const int nkt = (M + BKM - 1) / BKM;
-    const int kt0 = blockIdx.y * kps;
+    const int kt0 = split * kps;
     const int kt1 = min(kt0 + kps, nkt);
 
     // 32-bit byte offsets through buffer descriptors; rows past M fall off the end of dY / In and read 0.
@@ -508,6 +511,27 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
     const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     f32x4 ra[RA], rb[RB];
+    // The gather offsets of a k-tile are computed one iteration ahead of its loads (`prep`), so that the loads
+    // themselves are the first thing a loop iteration issues and have the whole MFMA stream to land under.
+    unsigned offb[RB];
+    auto prep = [&](int kt) {
+        const int mb = kt * BKM;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int m = mb + rb0 + SB * j;
+            if (lin) {
+                offb[j] = (unsigned)(m * g.Ci + coff) * (unsigned)sizeof(TX);
+            } else {
+                bool ok = tapok && m < M;
+                const int mm = ok ? m : 0;
+                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+                const int hi = ho * g.is + dh, wi = wo * g.is + dw;
+                ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                offb[j] = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * (unsigned)sizeof(TX) : kInvalidOff;
+            }
+        }
+    };
     auto load_tile = [&](int kt) {
         const int mb = kt * BKM;
 #pragma unroll
@@ -516,22 +540,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
             ra[j] = bldv<TDY>(rs_dy, (unsigned)(m * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int m = mb + rb0 + SB * j;
-            unsigned off;
-            if (lin) {
-                off = (unsigned)(m * g.Ci + coff) * (unsigned)sizeof(TX);
-            } else {
-                bool ok = tapok && m < M;
-                const int mm = ok ? m : 0;
-                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
-                const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
-                const int hi = ho * g.is + dh, wi = wo * g.is + dw;
-                ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * (unsigned)sizeof(TX) : kInvalidOff;
-            }
-            rb[j] = bldv<TX>(rs_in, off);
-        }
+        for (int j = 0; j < RB; ++j) rb[j] = bldv<TX>(rs_in, offb[j]);
     };
     auto store_tile = [&](int buf) {
         float* a = sA + buf * BKM * BMO + ra0 * BMO + qa * 4;
@@ -576,14 +585,18 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     };
     float fa[4][TI], fb[4][TJ];
     if (kt0 < kt1) {
+        prep(kt0);
         load_tile(kt0);
         store_tile(0);
+        prep(kt0 + 1 < kt1 ? kt0 + 1 : kt0);
     }
     __syncthreads();
     if (kt0 < kt1) read_frags(0, 0, fa, fb);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
         load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
+        __builtin_amdgcn_sched_barrier(0);
+        prep(kt + 2 < kt1 ? kt + 2 : kt);           // rows past M read zeros anyway; clamp keeps it branch-free
 #pragma unroll
         for (int grp = 0; grp < 3; ++grp) {
             float na[4][TI], nb[4][TJ];
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 
     // epilogue: rows = output channel o, cols = input channel (or flattened stem column)
     const size_t wrow = (size_t)g.wT * g.Ci;
-    float* base = dst + (size_t)blockIdx.y * g.Co * wrow;
+    float* base = dst + (size_t)split * g.Co * wrow;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -851,7 +864,9 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
         p.tiles = (g.Co / p.bmo) * g.Th * g.Tw * p.ntile_c;
     }
     const int nkt = io_cdiv(M, 32);
-    int want = io_cdiv(1024, p.tiles);          // ~4 resident block-waves over 256 CUs
+    // 2 blocks fit a CU (LDS), so 512 run at once: fill at most two full rounds -- one block more than that would
+    // cost a third, almost empty round (a 3x3 conv with 36 tiles: 29 splits = 1044 blocks ran 25 % slower than 28)
+    int want = 1024 / p.tiles;
     int maxs = nkt / 8 > 0 ? nkt / 8 : 1;       // at least 8 k-tiles (256 rows) per split
     p.splits = want < maxs ? want : maxs;
     if (p.splits < 1) p.splits = 1;
@@ -950,7 +965,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     float* dst = p.splits == 1 ? dw : partial;
     int splits = p.splits;
-    dim3 grid((unsigned)p.tiles, (unsigned)p.splits), block(kThreads);
+    dim3 grid((unsigned)(p.tiles * p.splits)), block(kThreads);
     const double in_b = (double)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
     const double dy_b = (double)io_dtype_bytes(dt_dy) * g.N * g.Ho * g.Wo * g.Co;
     IO_REQUIRE(in_b < 4.0e9 && dy_b < 4.0e9, IO_ERR_SHAPE, "conv_wgrad: operand larger than 4 GB (32-bit offsets)");
@@ -964,7 +979,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     do {                                                                                                        \
         const size_t lds = (size_t)2 * 32 * (BMO_ + BNC_) * sizeof(float);                                      \
         hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, STEM_>), grid, block, lds, st, g,          \
-                           (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.kps, in_bytes, dy_bytes);         \
+                           (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes, dy_bytes); \
     } while (0)
 #define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
     do {                                                                               \
