@@ -169,24 +169,28 @@ size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training);
  * parity checks against resnet_cls.py:203-222): which = 0 conv1 output [N,S/2,S/2,64], 1 relu(bn1(.)), 2 max-pool
  * output [N,S/4,S/4,64], 3+i output of bottleneck i (0..15), NHWC, element type = the net's dtype.  -1 on error. */
 long io_net_activation_offset(const io_net* net, int N, int S, int which);
-/* x8[N,S,S,8] -> logits[N][K].  training != 0: batch statistics in G groups, running stats updated,
- * activations kept in `workspace` for io_net_backward. */
-int io_net_forward(io_net* net, const float* params, float* running, const float* x8, int N, int S, int G,
+/* x8[N,S,S,8] (element type = the net's dtype: float, or bf16 after io_net_set_dtype(net, 1)) -> logits[N][K].
+ * training != 0: batch statistics in G groups, running stats updated, activations kept in `workspace` for
+ * io_net_backward. */
+int io_net_forward(io_net* net, const float* params, float* running, const void* x8, int N, int S, int G,
                    int training, void* workspace, size_t workspace_bytes, float* logits, hipStream_t stream);
 /* gradient of every parameter into grads (same layout as params; fully overwritten).  Must follow a
  * training io_net_forward with the same x8 / N / S / G / workspace. */
-int io_net_backward(io_net* net, const float* params, float* grads, const float* x8, const float* dlogits, int N,
+int io_net_backward(io_net* net, const float* params, float* grads, const void* x8, const float* dlogits, int N,
                     int S, int G, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* ---- bf16 configuration (BASELINE configs[2], [3]) ------------------------------------------------------
  * dtype 0 = fp32 (everything above), 1 = bf16: activations, activation gradients and GEMM operands are bf16
  * (v_mfma_f32_32x32x16_bf16, fp32 accumulate); parameters and their gradients, BatchNorm statistics, losses and
- * the optimiser stay fp32; the 5-channel stem reads the fp32 packed input.  The `_dt` entry points are the
- * storage-typed forms of the functions of the same name; `void*` tensors have the element type `dtype` says. */
+ * the optimiser stay fp32; the packed network input x8 is bf16 as well (masks are exact, the normalised image
+ * rounds to 8 bits of mantissa).  The `_dt` entry points are the storage-typed forms of the functions of the same
+ * name; `void*` tensors have the element type `dtype` says. */
 #define IO_DTYPE_F32 0
 #define IO_DTYPE_BF16 1
 int io_net_set_dtype(io_net* net, int dtype);
 int io_net_get_dtype(const io_net* net);
+int io_pack_planes_nhwc8_dt(const float* const* planes, const long* sample_strides, int nplanes, int N, int H, int W,
+                            void* out, int dtype, hipStream_t stream);
 int io_conv2d_fwd_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                      int stride, int pad, int dtype_in, int dtype_out, hipStream_t stream);
 int io_conv2d_dgrad_dt(const void* dy, const void* wt, void* dx, const void* add, const void* relu_mask, int N, int H,

@@ -67,6 +67,7 @@ SIGNATURES = {
     "io_net_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "io_net_set_dtype": (_I, [_P, _I]),
     "io_net_get_dtype": (_I, [_P]),
+    "io_pack_planes_nhwc8_dt": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "io_conv2d_fwd_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "io_conv2d_dgrad_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "io_conv2d_wgrad_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _I, _P]),

@@ -245,6 +245,12 @@ extern "C" int io_prof_end(io_prof_entry* out, int max_entries) {
 }
 
 // ---- storage-typed variants (dtype: 0 = fp32, 1 = bf16 activations / operands; see IoDType) ------------------
+extern "C" int io_pack_planes_nhwc8_dt(const float* const* planes, const long* sample_strides, int nplanes, int N,
+                                       int H, int W, void* out, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "pack: unknown dtype %d", dtype);
+    return io_pack_planes_t(planes, sample_strides, nplanes, N, H, W, out, st, dtype);
+}
+
 extern "C" int io_conv2d_fwd_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
                                 int S, int stride, int pad, int dtype_in, int dtype_out, hipStream_t st) {
     IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     constexpr int ES = sizeof(TA), OS = sizeof(TO);
     constexpr int VE = 16 / ES;             // elements per 16-byte chunk
     constexpr int BM = 128, BK = 128 / ES, LDT = 32 + 4, NT = NW * 64;   // LDT in 4-byte words
-    static_assert(!STEM || ES == 4, "the 5-channel stem runs on fp32 operands");
+    constexpr int CPT = ES / 2;             // stem: 16-byte chunks per 8-channel tap (fp32 2, bf16 1)
+    constexpr int TPT = 8 / CPT;            // stem: taps per k-tile
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
     constexpr int AR = (BM * 8) / NT;       // A rows loaded per thread (8 float4 per row)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     const int M = g.N * HoWo;
     const int lr = tid >> 3, kq = tid & 7;
     const int nkc = STEM ? 1 : g.Ci / BK;
-    const int nk = STEM ? (g.wT + 3) / 4 : g.Th * g.Tw * nkc;
+    const int nk = STEM ? (g.wT + TPT - 1) / TPT : g.Th * g.Tw * nkc;
 
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
     // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
@@ -155,13 +156,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
         unsigned aoff, woff;     // wave-uniform for the regular path
         bool tapok = true;
         if (STEM) {
-            const int tap = kt * 4 + (kq >> 1);
+            const int tap = kt * TPT + kq / CPT;
             tapok = tap < g.wT;
             const int r = tap / g.S, s = tap - r * g.S;
             dh = g.dh0 + g.dhs * r;
             dw = g.dw0 + g.dws * s;
-            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + (kq & 1) * 4) * 4u;
-            woff = (unsigned)((tapok ? tap : 0) * g.Ci + (kq & 1) * 4) * 4u;
+            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + (kq % CPT) * VE) * (unsigned)ES;
+            woff = (unsigned)((tapok ? tap : 0) * g.Ci + (kq % CPT) * VE) * (unsigned)ES;
         } else {
             dh = g.dh0 + g.dhs * th;
             dw = g.dw0 + g.dws * tw;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 // (8 lanes cover 8 m-groups of one channel group): the LDS writes of a wave then hit all 64 banks 4 lanes deep (the
 // b128 minimum) and each global row still gets 128 contiguous bytes from 8 lanes.
 // Grid: 1-D, XCD-remapped so that the blocks of one m-range (all taps / channel tiles of a split) share an L2.
-template <int BMO, int BNC>
+template <int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
                                                                   const bf16_t* __restrict__ dy,
                                                                   float* __restrict__ dst, int ntile_c, int tiles,
@@ -679,27 +680,44 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / tiles, tile = logical - split * tiles;
-    const int per_o = T * ntile_c;
-    const int ot = tile / per_o, rem0 = tile - ot * per_o;
-    const int o0 = ot * BMO;
-    const int tap = rem0 / ntile_c;
-    const int c0 = (rem0 - tap * ntile_c) * BNC;
-    const int th = tap / g.Tw, tw = tap - th * g.Tw;
-    const int dh = g.dh0 + g.dhs * th, dw = g.dw0 + g.dws * tw;
-    const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
-
     // staging role (wave-uniform): threads [0, BMO) move dY blocks, [BMO, BMO + BNC) move X blocks
     const bool role_a = wave * 64 < BMO;
     const bool role_b = !role_a && wave * 64 < BMO + BNC;
     const int blk = role_a ? tid : tid - BMO;
     const int mg = blk & 7, cg = blk >> 3;
 
+    // tile -> (o tile, tap, channel tile); stem: the columns are the flattened (tap, 8 channels) axis, so each
+    // 8-column group of a thread is one tap of its own
+    const int per_o = STEM ? ntile_c : T * ntile_c;
+    const int ot = tile / per_o, rem0 = tile - ot * per_o;
+    const int o0 = ot * BMO;
+    int c0, dh, dw, widx, xcol;
+    bool tapok = true;
+    if (STEM) {
+        c0 = rem0 * BNC;
+        const int tp = (c0 >> 3) + cg;
+        tapok = tp < g.wT;
+        const int r = tp / g.S, sx = tp - r * g.S;
+        dh = g.dh0 + g.dhs * r;
+        dw = g.dw0 + g.dws * sx;
+        widx = 0;
+        xcol = 0;
+    } else {
+        const int tap = rem0 / ntile_c;
+        c0 = (rem0 - tap * ntile_c) * BNC;
+        const int th = tap / g.Tw, tw = tap - th * g.Tw;
+        dh = g.dh0 + g.dhs * th;
+        dw = g.dw0 + g.dws * tw;
+        widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
+        xcol = c0 + cg * 8;
+    }
+
     const int nkt = (M + BKM - 1) / BKM;
     const int kt0 = split * kps;
     const int kt1 = min(kt0 + kps, nkt);
 
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
-    const bool lin = T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+    const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     u32x4 rr[8];
     auto load_tile = [&](int kt) {
         const int mrow = kt * BKM + mg * 8;
@@ -713,15 +731,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
                 const int m = mrow + r;
                 unsigned off;
                 if (lin) {
-                    off = (unsigned)(m * g.Ci + c0 + cg * 8) * 2u;
+                    off = (unsigned)(m * g.Ci + xcol) * 2u;
                 } else {
-                    bool ok = m < M;
+                    bool ok = tapok && m < M;
                     const int mm = ok ? m : 0;
                     const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
                     const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                     const int hi = ho * g.is + dh, wi = wo * g.is + dw;
                     ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                    off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + c0 + cg * 8) * 2u : kInvalidOff;
+                    off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + xcol) * 2u : kInvalidOff;
                 }
                 rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
             }
@@ -810,7 +828,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int cl = wn * (BNC / 2) + j * 32 + (lane & 31);
-                base[(size_t)o * wrow + (size_t)widx * g.Ci + c0 + cl] = acc[i][j][r];
+                if (STEM) {
+                    if (c0 + cl < (int)wrow) base[(size_t)o * wrow + c0 + cl] = acc[i][j][r];
+                } else {
+                    base[(size_t)o * wrow + (size_t)widx * g.Ci + c0 + cl] = acc[i][j][r];
+                }
             }
         }
 }
@@ -899,7 +921,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_nt: Co=%d must be a multiple of 64", g.Co);
     const int es = io_dtype_bytes(dt_in), os = io_dtype_bytes(dt_out);
     if (stem)
-        IO_REQUIRE(g.Ci == 8 && dt_in == IO_F32, IO_ERR_SHAPE, "conv_nt(stem): needs fp32 input with Ci=8 (5 padded)");
+        IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): needs the packed input with Ci=8 (5 padded)");
     else
         IO_REQUIRE(g.Ci % (128 / es) == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of %d", g.Ci, 128 / es);
     const long M = (long)g.N * g.Ho * g.Wo;
@@ -934,8 +956,14 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     } while (0)
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
-        if (dt_out == IO_BF16) IO_LAUNCH_NT(float, bf16_t, 64, true);
-        else IO_LAUNCH_NT(float, float, 64, true);
+        if (dt_in == IO_BF16) {
+            IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
+            IO_LAUNCH_NT(bf16_t, bf16_t, 64, true);
+        } else if (dt_out == IO_BF16) {
+            IO_LAUNCH_NT(float, bf16_t, 64, true);
+        } else {
+            IO_LAUNCH_NT(float, float, 64, true);
+        }
     } else if (dt_in == IO_BF16) {
         IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
         if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, false);
@@ -953,8 +981,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                          size_t partial_bytes, int stem, hipStream_t st, int dt_in, int dt_dy) {
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_wgrad: Co=%d must be a multiple of 64", g.Co);
     if (stem)
-        IO_REQUIRE(g.Ci == 8 && g.Co == 64 && dt_in == IO_F32, IO_ERR_SHAPE,
-                   "conv_wgrad(stem): need fp32 input with Ci=8, Co=64");
+        IO_REQUIRE(g.Ci == 8 && g.Co == 64 && (dt_in == IO_F32 || dt_dy == IO_BF16), IO_ERR_SHAPE,
+                   "conv_wgrad(stem): need Ci=8, Co=64 (and bf16 dY with a bf16 input)");
     else
         IO_REQUIRE(g.Ci % 64 == 0 && dt_in == dt_dy, IO_ERR_SHAPE,
                    "conv_wgrad: Ci=%d must be a multiple of 64 (and one storage type)", g.Ci);
@@ -988,7 +1016,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, false);                \
         else IO_LAUNCH_WG(TX_, TDY_, 64, 64, false);                                   \
     } while (0)
-    if (stem) {
+    if (stem && dt_in == IO_F32) {
         if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, true);
         else IO_LAUNCH_WG(float, float, 64, 64, true);
     } else if (dt_in == IO_BF16) {
@@ -997,22 +1025,24 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         splits = io_cdiv(nkt64, kps64);
         dst = splits == 1 ? dw : partial;
         dim3 grid1((unsigned)(p.tiles * splits));
-#define IO_LAUNCH_WGB(BMO_, BNC_)                                                                                \
+#define IO_LAUNCH_WGB(BMO_, BNC_, STEM_)                                                                         \
     do {                                                                                                         \
         const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                       \
         static bool attr_done = false;                                                                           \
         if (!attr_done) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_>,                           \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
             attr_done = true;                                                                                    \
         }                                                                                                        \
-        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_>), grid1, block, lds, st, g, (const bf16_t*)in,    \
-                           (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes, dy_bytes);               \
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_>), grid1, block, lds, st, g,                \
+                           (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes,       \
+                           dy_bytes);                                                                            \
     } while (0)
-        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGB(128, 128);
-        else if (p.bmo == 128) IO_LAUNCH_WGB(128, 64);
-        else if (p.bnc == 128) IO_LAUNCH_WGB(64, 128);
-        else IO_LAUNCH_WGB(64, 64);
+        if (stem) IO_LAUNCH_WGB(64, 64, true);
+        else if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGB(128, 128, false);
+        else if (p.bmo == 128) IO_LAUNCH_WGB(128, 64, false);
+        else if (p.bnc == 128) IO_LAUNCH_WGB(64, 128, false);
+        else IO_LAUNCH_WGB(64, 64, false);
 #undef IO_LAUNCH_WGB
     } else {
         IO_LAUNCH_WG_SHAPES(float, float);

@@ -132,6 +132,8 @@ int io_avgpool_fc_fwd_t(const void* x, int N, int HW, int C, const float* w0, co
 int io_avgpool_fc_bwd_t(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
                         const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
                         float* db1, hipStream_t st, int dt);
+int io_pack_planes_t(const float* const* planes, const long* sample_strides, int nplanes, int N, int H, int W,
+                     void* out, hipStream_t st, int dt);
 // fp32 master filter -> filter of storage type dt, either as is (transpose = 0) or as W^T [C][T][O]
 int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int transpose, hipStream_t st, int dt);
 constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics

@@ -26,8 +26,9 @@ struct PackArgs {
     const float* plane[5];
     long stride[5];   // floats between consecutive samples of that plane
 };
+template <typename T>
 __global__ __launch_bounds__(kThreads) void pack_planes_kernel(PackArgs a, int nplanes, int N, int HW,
-                                                              float* __restrict__ out) {
+                                                              T* __restrict__ out) {
     const size_t total = (size_t)N * HW;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(kThreads) void pack_planes_kernel(PackArgs a, int n
         for (int c = 0; c < 5; ++c) v[c] = c < nplanes ? a.plane[c][n * a.stride[c] + p] : 0.f;
         v[5] = v[6] = v[7] = 0.f;
         const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-        st4(out + i * 8, lo);
-        st4(out + i * 8 + 4, hi);
+        io_stv(out + i * 8, lo);
+        io_stv(out + i * 8 + 4, hi);
     }
 }
 
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(kThreads) void cast_bf16_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* sample_strides, int nplanes, int N,
-                                    int H, int W, float* out, hipStream_t st) {
+int io_pack_planes_t(const float* const* planes, const long* sample_strides, int nplanes, int N, int H, int W,
+                     void* out, hipStream_t st, int dt) {
     IO_REQUIRE(nplanes >= 1 && nplanes <= 5, IO_ERR_SHAPE, "pack: nplanes=%d (1..5)", nplanes);
     PackArgs a;
     for (int c = 0; c < 5; ++c) {
@@ -342,9 +343,19 @@ extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* samp
         a.stride[c] = c < nplanes ? sample_strides[c] : 0;
     }
     const size_t total = (size_t)N * H * W;
-    IoProfScope prof(IO_PROF_PACK, 0.0, 4.0 * total * (nplanes + 8.0), st);
-    hipLaunchKernelGGL(pack_planes_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, a, nplanes, N, H * W, out);
+    IoProfScope prof(IO_PROF_PACK, 0.0, (double)total * (4.0 * nplanes + 8.0 * io_dtype_bytes(dt)), st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(pack_planes_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, a, nplanes, N,
+                           H * W, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(pack_planes_kernel<float>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, a, nplanes, N, H * W,
+                           (float*)out);
     return io_check_launch("pack_planes");
+}
+
+extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* sample_strides, int nplanes, int N,
+                                    int H, int W, float* out, hipStream_t st) {
+    return io_pack_planes_t(planes, sample_strides, nplanes, N, H, W, out, st, IO_F32);
 }
 
 int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt) {

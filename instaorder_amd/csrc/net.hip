@@ -246,10 +246,10 @@ struct Ctx {
 
 int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
-    const bool stem = L.cin_store == 8;      // the stem always reads the fp32 packed input and fp32 filter
-    return io_launch_conv_nt(g, x, stem ? (const void*)(c.params + L.w_off) : c.wop(L.w_off), y, nullptr, nullptr, stem,
-                             c.st, stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
-                             nullptr, stem ? IO_F32 : c.dt(), c.dt());
+    const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
+    return io_launch_conv_nt(g, x, c.wop(L.w_off), y, nullptr, nullptr, stem, c.st,
+                             stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr, nullptr,
+                             c.dt(), c.dt());
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
@@ -291,7 +291,7 @@ int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, co
                          h2, relu, out, c.st, c.dt());
 }
 
-int run_forward(Ctx& c, const float* x8, float* logits) {
+int run_forward(Ctx& c, const void* x8, float* logits) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
     const int H0 = c.S / 2, H1 = c.S / 4;
@@ -344,7 +344,7 @@ int conv_wgrad(const Ctx& c, const ConvL& L, const void* x, const void* dy, int 
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;
     return io_launch_conv_wgrad(g, x, dy, c.grads + L.w_off, c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes, stem,
-                                c.st, stem ? IO_F32 : c.dt(), c.dt());
+                                c.st, c.dt(), c.dt());
 }
 
 int conv_dgrad(const Ctx& c, const ConvL& L, const void* dy, void* dx, const void* add, const void* mask,
@@ -391,7 +391,7 @@ int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H,
     return bn_back(c, b, dx, 1, nullptr, y, M, dyb, nullptr);
 }
 
-int run_backward(Ctx& c, const float* dlogits, const float* x8) {
+int run_backward(Ctx& c, const float* dlogits, const void* x8) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
     void* Gd = c.act(p.gbuf[0]);
@@ -605,7 +605,7 @@ static void fill_ctx(Ctx& c, io_net* net, const float* params, float* running, f
     for (int i = 0; i < net->n_bn; ++i) { c.chan_prefix[i] = acc; acc += Cs[i]; }
 }
 
-extern "C" int io_net_forward(io_net* net, const float* params, float* running, const float* x8, int N, int S,
+extern "C" int io_net_forward(io_net* net, const float* params, float* running, const void* x8, int N, int S,
                               int G, int training, void* ws, size_t ws_bytes, float* logits, hipStream_t st) {
     IO_TRY(check_shape(N, S, G));
     IO_REQUIRE(training || G == 1, IO_ERR_SHAPE, "eval forward uses running statistics: G must be 1");
@@ -616,7 +616,7 @@ extern "C" int io_net_forward(io_net* net, const float* params, float* running, 
     return run_forward(c, x8, logits);
 }
 
-extern "C" int io_net_backward(io_net* net, const float* params, float* grads, const float* x8,
+extern "C" int io_net_backward(io_net* net, const float* params, float* grads, const void* x8,
                                const float* dlogits, int N, int S, int G, void* ws, size_t ws_bytes,
                                hipStream_t st) {
     IO_TRY(check_shape(N, S, G));

@@ -89,28 +89,35 @@ class Net(object):
                                             _stream()), "io_net_backward")
 
 
+TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
 def pack_planes(planes, strides, N, H, W, out):
-    """planes: list of (tensor, element offset) giving channel 0.. of sample 0; strides: floats between
-    samples.  Writes out[N,H,W,8] (torch.cat + NCHW->NHWC + pad, supervised_order.py:537)."""
+    """planes: list of (fp32 tensor, element offset) giving channel 0.. of sample 0; strides: floats between
+    samples.  Writes out[N,H,W,8] (torch.cat + NCHW->NHWC + pad, supervised_order.py:537); ``out`` is fp32 or
+    bf16 -- the storage type of the network that will read it."""
     _lib.require_gpu()
     n = len(planes)
     pa = (C.c_void_p * n)(*[t.data_ptr() + 4 * off for t, off in planes])
     sa = (C.c_long * n)(*[int(s) for s in strides])
-    _lib.check(_lib.lib().io_pack_planes_nhwc8(pa, sa, n, int(N), int(H), int(W), _ptr(out), _stream()),
-               "io_pack_planes_nhwc8")
+    if out.dtype not in (torch.float32, torch.bfloat16) or not out.is_contiguous():
+        raise ValueError("pack_planes: out must be a contiguous fp32 or bf16 tensor")
+    _lib.check(_lib.lib().io_pack_planes_nhwc8_dt(pa, sa, n, int(N), int(H), int(W), _ptr(out),
+                                                  1 if out.dtype == torch.bfloat16 else 0, _stream()),
+               "io_pack_planes_nhwc8_dt")
 
 
-def pack_nchw(x, out=None):
-    """x[N,C<=5,H,W] (NCHW fp32) -> [N,H,W,8]."""
+def pack_nchw(x, out=None, dtype="fp32"):
+    """x[N,C<=5,H,W] (NCHW fp32) -> [N,H,W,8] of ``dtype``."""
     _dev_f32(x, "x")
     N, Cc, H, W = x.shape
     if out is None:
-        out = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, H, W, 8), device=x.device, dtype=TORCH_DTYPE[dtype])
     pack_planes([(x, c * H * W) for c in range(Cc)], [Cc * H * W] * Cc, N, H, W, out)
     return out
 
 
-def pack_pair_directions(rgb, modal1, modal2, out=None):
+def pack_pair_directions(rgb, modal1, modal2, out=None, dtype="fp32"):
     """Both mask orders of a pair batch in one buffer: rows [0,B) = (modal1, modal2, rgb), rows
     [B,2B) = (modal2, modal1, rgb) -- the two model calls of supervised_order.py:537-538.  ``rgb=None``
     is the reference's ``use_rgb=False`` form (masks only)."""
@@ -119,7 +126,7 @@ def pack_pair_directions(rgb, modal1, modal2, out=None):
             _dev_f32(t, nme)
     B, _, H, W = modal1.shape
     if out is None:
-        out = torch.empty((2 * B, H, W, 8), device=modal1.device, dtype=torch.float32)
+        out = torch.empty((2 * B, H, W, 8), device=modal1.device, dtype=TORCH_DTYPE[dtype])
     HW = H * W
     rgbp = [(rgb, c * HW) for c in range(3)] if rgb is not None else []
     st = [HW, HW] + [3 * HW] * len(rgbp)

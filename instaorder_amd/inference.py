@@ -104,7 +104,7 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
             ii = torch.tensor([a for a, _ in chunk], device=dev)
             jj = torch.tensor([b for _, b in chunk], device=dev)
             mi, mj = masks[ii].contiguous(), masks[jj].contiguous()
-            x8 = torch.empty((2 * p, S, S, 8), device=dev)
+            x8 = torch.empty((2 * p, S, S, 8), device=dev, dtype=engine.TORCH_DTYPE[net.dtype])
             rgbp = [(rgb, c * HW) for c in range(3)]
             engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[:p])
             engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[p:])

@@ -225,6 +225,9 @@ class ResNet(nn.Module):
         N, S = x8.shape[0], x8.shape[1]
         if x8.shape[2] != S:
             raise ValueError("square inputs only, got %s" % (tuple(x8.shape),))
+        if x8.dtype != engine.TORCH_DTYPE[self.dtype] or not x8.is_contiguous():
+            raise ValueError("packed input must be contiguous %s (the net's storage type), got %s"
+                             % (self.dtype, x8.dtype))
         if self.training:
             if torch.is_grad_enabled():
                 params = [p for _, p in self._param_list]
@@ -247,7 +250,7 @@ class ResNet(nn.Module):
             raise ValueError("expected [B,%d,H,W], got %s" % (self.in_channels, tuple(x.shape)))
         if not x.is_cuda:
             raise RuntimeError("instaorder_amd: input must be on the GPU; there is no CPU fallback")
-        x8 = engine.pack_nchw(x.contiguous().float())
+        x8 = engine.pack_nchw(x.contiguous().float(), dtype=self.dtype)
         return self.split_heads(self.forward_packed(x8, 1))
 
 

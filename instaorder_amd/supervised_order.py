@@ -71,7 +71,7 @@ class _OrderBase(SingleStageModel):
             self._x8 = None
             self._graph = None
         self._x8 = engine.pack_pair_directions(self.rgb if self.use_rgb else None, self.modal1, self.modal2,
-                                               self._x8)
+                                               self._x8, dtype=self.net.dtype)
         self.B = B
 
     # -- loss plumbing -------------------------------------------------------------------------------

@@ -63,6 +63,35 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     assert relerr(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2), gw) < 2e-5   # fp32 accumulate of exact products
 
 
+def test_stem_bf16_fwd_wgrad_and_pack():
+    """7x7 stride-2 stem on the packed 8-channel bf16 input (resnet_cls.py:140): forward and filter gradient on the
+    bf16 MFMA, plus the packing kernel writing bf16."""
+    from instaorder_amd import engine
+    N, H = 3, 40
+    g = torch.Generator().manual_seed(5)
+    x5 = torch.randn(N, 5, H, H, generator=g)
+    x8d = engine.pack_nchw(x5.cuda(), dtype="bf16")
+    assert x8d.dtype == torch.bfloat16 and x8d.shape == (N, H, H, 8)
+    ref8 = torch.cat([x5, torch.zeros(N, 3, H, H)], 1).bfloat16()
+    assert torch.equal(x8d.cpu(), ref8.permute(0, 2, 3, 1).contiguous())
+    x = ref8.double().requires_grad_(True)
+    w = bf(torch.randn(64, 8, 7, 7, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=3)
+    Ho = y.shape[2]
+    dy = bf(torch.randn(y.shape, generator=g))
+    gw, = torch.autograd.grad(y, [w], dy)
+    wb = w.detach().permute(0, 2, 3, 1).contiguous().bfloat16().cuda()          # [64][49][8]
+    yd = torch.empty(N, Ho, Ho, 64, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L().io_conv2d_fwd_dt(P(x8d), P(wb), P(yd), N, H, H, 8, 64, 7, 7, 2, 3, BF, BF, ST()), "stem fwd")
+    assert relerr(yd.float().permute(0, 3, 1, 2), y.detach()) < 6e-3
+    dyd = to_bf_dev(dy.permute(0, 2, 3, 1))
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, H, H, 8, 64, 7, 7, 2, 3)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.empty(64, 49, 8, device=DEV)
+    _lib.check(L().io_conv2d_wgrad_dt(P(x8d), P(dyd), P(dw), N, H, H, 8, 64, 7, 7, 2, 3, P(ws), nb, BF, BF, ST()), "stem wgrad")
+    assert relerr(dw.view(64, 7, 7, 8).permute(0, 3, 1, 2), gw) < 2e-5
+
+
 @pytest.mark.parametrize("N,H,C,G", [(4, 8, 64, 2), (4, 8, 256, 1), (6, 4, 2048, 2)])
 def test_batchnorm_bf16(N, H, C, G):
     g = torch.Generator().manual_seed(C)

@@ -40,12 +40,11 @@ def main():
             sd[k] = sd[k] * g3
     b = synthetic.make_pair_batch(980, N, S)
     x = torch.cat([torch.from_numpy(b[k]) for k in ("modal1", "modal2", "rgb")], 1).cuda()
-    x8 = engine.pack_nchw(x)
     res = {}
     for dt in ("fp32", "bf16"):
         net = ResNet(5, 2, dtype=dt).cuda()
         net.load_state_dict(sd)
-        res[dt] = acts(net, x8, N, S, G)
+        res[dt] = acts(net, engine.pack_nchw(x, dtype=dt), N, S, G)
     la, a = res["fp32"]
     lb, bb = res["bf16"]
     for i, (p, q) in enumerate(zip(a, bb)):
