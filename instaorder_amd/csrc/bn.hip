@@ -28,6 +28,48 @@ __device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 mean, f32x4 scale, f32
     return r;
 }
 
+// One 16-byte chunk of a storage-typed tensor = VEC consecutive channels (4 fp32 / 8 bf16), held as NV float4.
+// The streaming (apply) kernels move whole chunks so that a bf16 lane issues the same 16-byte accesses as fp32.
+template <typename T> struct Chunk {
+    static constexpr int VEC = 16 / (int)sizeof(T), NV = VEC / 4;
+    f32x4 v[NV];
+};
+__device__ __forceinline__ Chunk<float> ldc(const float* p) {
+    Chunk<float> c;
+    c.v[0] = *reinterpret_cast<const f32x4*>(p);
+    return c;
+}
+__device__ __forceinline__ Chunk<bf16_t> ldc(const bf16_t* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    Chunk<bf16_t> c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c.v[k >> 1][(k & 1) * 2] = __builtin_bit_cast(float, w[k] << 16);
+        c.v[k >> 1][(k & 1) * 2 + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+    }
+    return c;
+}
+__device__ __forceinline__ void stc(float* p, const Chunk<float>& c) { *reinterpret_cast<f32x4*>(p) = c.v[0]; }
+__device__ __forceinline__ void stc(bf16_t* p, const Chunk<bf16_t>& c) {
+    uint4 r;
+    r.x = (unsigned)io_f2bf(c.v[0][0]) | ((unsigned)io_f2bf(c.v[0][1]) << 16);
+    r.y = (unsigned)io_f2bf(c.v[0][2]) | ((unsigned)io_f2bf(c.v[0][3]) << 16);
+    r.z = (unsigned)io_f2bf(c.v[1][0]) | ((unsigned)io_f2bf(c.v[1][1]) << 16);
+    r.w = (unsigned)io_f2bf(c.v[1][2]) | ((unsigned)io_f2bf(c.v[1][3]) << 16);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+// per-channel table entries for the channels of one chunk
+template <int NV> struct Tab {
+    f32x4 v[NV];
+};
+template <int NV> __device__ __forceinline__ Tab<NV> ldt(const float* p) {
+    Tab<NV> t;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) t.v[k] = *reinterpret_cast<const f32x4*>(p + 4 * k);
+    return t;
+}
+
 struct ColMap {
     int TX, TY, tx, ty, nq;   // column threads, row lanes, my coords, quads per thread
 };
@@ -214,25 +256,54 @@ __global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, c
 struct BnTab {
     const float *mean, *scale, *shift;
 };
+// Grid (x, G): blockIdx.y is the BN group, the x blocks grid-stride over the group's chunks with a stride that is a
+// multiple of the chunks per row -- so a thread keeps ONE channel chunk for its whole life and its table entries
+// are loaded once; the loop body is nothing but 4 independent chunk loads per tensor, the arithmetic and the stores.
 template <int MODE, typename T>   // MODE 0 none, 1 identity tensor, 2 second BN (downsample branch)
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ y, size_t total4, int c4shift,
-                                                           int Mg, int sg, BnTab t, const T* __restrict__ idt,
-                                                           BnTab t2, int relu, T* __restrict__ out) {
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ y, size_t per_group, int cvmask,
+                                                           int sg, BnTab t, const T* __restrict__ idt, BnTab t2,
+                                                           int relu, T* __restrict__ out) {
+    constexpr int VEC = Chunk<T>::VEC, NV = Chunk<T>::NV, U = 4;
+    const int g = blockIdx.y;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const int c4mask = (1 << c4shift) - 1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const int q = (int)(i & c4mask);
-        const size_t row = i >> c4shift;
-        const int g = (int)(row / Mg);
-        const int co = g * sg + q * 4;
-        f32x4 v = bn_affine(ld4(y + i * 4), ld4(t.mean + co), ld4(t.scale + co), ld4(t.shift + co));
-        if (MODE == 1) v += ld4(idt + i * 4);
-        if (MODE == 2) v += bn_affine(ld4(idt + i * 4), ld4(t2.mean + co), ld4(t2.scale + co), ld4(t2.shift + co));
-        if (relu) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int co = g * sg + (int)(i & (size_t)cvmask) * VEC;
+    const Tab<NV> mu = ldt<NV>(t.mean + co), sc = ldt<NV>(t.scale + co), sh = ldt<NV>(t.shift + co);
+    Tab<NV> mu2 = mu, sc2 = sc, sh2 = sh;
+    if (MODE == 2) {
+        mu2 = ldt<NV>(t2.mean + co);
+        sc2 = ldt<NV>(t2.scale + co);
+        sh2 = ldt<NV>(t2.shift + co);
+    }
+    const size_t base = (size_t)g * per_group;
+    for (; i < per_group; i += U * stride) {
+        Chunk<T> a[U], b[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < per_group) {
+                a[u] = ldc(y + (base + j) * VEC);
+                if (MODE != 0) b[u] = ldc(idt + (base + j) * VEC);
+            }
         }
-        st4(out + i * 4, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < per_group) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    f32x4 v = bn_affine(a[u].v[k], mu.v[k], sc.v[k], sh.v[k]);
+                    if (MODE == 1) v += b[u].v[k];
+                    if (MODE == 2) v += bn_affine(b[u].v[k], mu2.v[k], sc2.v[k], sh2.v[k]);
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    a[u].v[k] = v;
+                }
+                stc(out + (base + j) * VEC, a[u]);
+            }
+        }
     }
 }
 
@@ -348,12 +419,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-// dy = gamma*rstd*(dz - c1 - xhat*c2); optionally also stores dz (may alias dout)
+// dy = gamma*rstd*(dz - c1 - xhat*c2); optionally also stores dz (may alias dout).  Same launch geometry as
+// bn_apply_kernel: one channel chunk per thread, every per-channel coefficient in registers.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* dout, const T* __restrict__ act,
-                                                               const T* __restrict__ y, size_t total4,
-                                                               int c4shift, int Mg, int C,
-                                                               const float* __restrict__ gamma,
+                                                               const T* __restrict__ y, size_t per_group,
+                                                               int cvmask, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ rstd,
                                                                const float* __restrict__ c1,
@@ -361,26 +432,66 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* dout, c
                                                                const float* __restrict__ mscale,
                                                                const float* __restrict__ mshift,
                                                                T* __restrict__ dy, T* dz_out) {
+    constexpr int VEC = Chunk<T>::VEC, NV = Chunk<T>::NV, U = 4;
+    const int g = blockIdx.y;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const int c4mask = (1 << c4shift) - 1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const int q = (int)(i & c4mask);
-        const size_t row = i >> c4shift;
-        const int g = (int)(row / Mg);
-        const int co = g * C + q * 4;
-        f32x4 d = ld4(dout + i * 4);
-        const f32x4 yv = ld4(y + i * 4), muv = ld4(mean + co);
-        if (act || mscale) {
-            const f32x4 a = act ? ld4(act + i * 4) : bn_affine(yv, muv, ld4(mscale + co), ld4(mshift + co));
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(i & (size_t)cvmask) * VEC, co = g * C + q;
+    const Tab<NV> mu = ldt<NV>(mean + co), rs = ldt<NV>(rstd + co), k1 = ldt<NV>(c1 + co), k2 = ldt<NV>(c2 + co);
+    Tab<NV> gr = ldt<NV>(gamma + q), msc = mu, msh = mu;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = a[k] > 0.f ? d[k] : 0.f;
-        }
-        const f32x4 rs = ld4(rstd + co);
-        const f32x4 xh = (yv - muv) * rs;
-        const f32x4 r = (d - ld4(c1 + co) - xh * ld4(c2 + co)) * (ld4(gamma + q * 4) * rs);
-        if (dz_out) st4(dz_out + i * 4, d);
-        st4(dy + i * 4, r);
+    for (int k = 0; k < NV; ++k) gr.v[k] *= rs.v[k];
+    if (mscale) {
+        msc = ldt<NV>(mscale + co);
+        msh = ldt<NV>(mshift + co);
     }
+    const size_t base = (size_t)g * per_group;
+    for (; i < per_group; i += U * stride) {
+        Chunk<T> d[U], yv[U], av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < per_group) {
+                d[u] = ldc(dout + (base + j) * VEC);
+                yv[u] = ldc(y + (base + j) * VEC);
+                if (act) av[u] = ldc(act + (base + j) * VEC);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * stride;
+            if (j < per_group) {
+                Chunk<T> r;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    f32x4 dd = d[u].v[k];
+                    if (act || mscale) {
+                        const f32x4 a = act ? av[u].v[k] : bn_affine(yv[u].v[k], mu.v[k], msc.v[k], msh.v[k]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dd[e] = a[e] > 0.f ? dd[e] : 0.f;
+                    }
+                    const f32x4 xh = (yv[u].v[k] - mu.v[k]) * rs.v[k];
+                    r.v[k] = (dd - k1.v[k] - xh * k2.v[k]) * gr.v[k];
+                    d[u].v[k] = dd;
+                }
+                if (dz_out) stc(dz_out + (base + j) * VEC, d[u]);
+                stc(dy + (base + j) * VEC, r);
+            }
+        }
+    }
+}
+
+// launch geometry of the two streaming kernels above: x blocks times G groups.  The grid stride (x blocks * 256
+// chunks) must be a multiple of the chunks per row (<= 512) -- any even block count -- and should NOT be a power of
+// two: a thread's 4 chunks in flight would sit exactly 2^k bytes apart, on the same HBM channel.
+static int stream_blocks(size_t per_group, int cv, int G) {
+    size_t want = (per_group + (size_t)kThreads * 4 - 1) / ((size_t)kThreads * 4);   // 4 chunks per thread and trip
+    size_t cap = 8192 / (size_t)(G > 0 ? G : 1);
+    if (want > cap) want = cap;
+    int b = (int)(want & ~(size_t)1);
+    if (b < 2) b = 2;
+    if (b >= 6 && ((b / 2) & 1) == 0) b -= 2;      // 2 * odd
+    return b;
 }
 
 int ilog2_exact(int v) {
@@ -538,15 +649,17 @@ int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, in
     float* c2 = coef + (size_t)G * C;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
                        dbeta, c1, c2);
-    const size_t total4 = (size_t)M * (C / 4);
+    const int vec = 16 / io_dtype_bytes(dt), cv = C / vec;
+    const size_t per_group = (size_t)Mg * cv;
+    dim3 agrid(stream_blocks(per_group, cv, G), G);
     if (dt == IO_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,
-                           (const bf16_t*)dz, (const bf16_t*)nullptr, (const bf16_t*)y, total4, sh, Mg, C, gamma, mean,
-                           rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, (bf16_t*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(kThreads), 0, st, (const bf16_t*)dz,
+                           (const bf16_t*)nullptr, (const bf16_t*)y, per_group, cv - 1, C, gamma, mean, rstd, c1, c2,
+                           (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, (bf16_t*)nullptr);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,
-                           (const float*)dz, (const float*)nullptr, (const float*)y, total4, sh, Mg, C, gamma, mean,
-                           rstd, c1, c2, (const float*)nullptr, (const float*)nullptr, (float*)dy, (float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, agrid, dim3(kThreads), 0, st, (const float*)dz,
+                           (const float*)nullptr, (const float*)y, per_group, cv - 1, C, gamma, mean, rstd, c1, c2,
+                           (const float*)nullptr, (const float*)nullptr, (float*)dy, (float*)nullptr);
     return io_check_launch("bn_bwd_from_tiles");
 }
 
@@ -610,17 +723,17 @@ extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, 
 int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
                   const float* shift, const void* identity, const float* mean2, const float* scale2,
                   const float* shift2, int relu, void* out, hipStream_t st, int dt) {
-    const int sh = ilog2_exact(C / 4);
-    IO_REQUIRE(C % 4 == 0 && sh >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be 4*2^k", C);
+    const int vec = 16 / io_dtype_bytes(dt);
+    IO_REQUIRE(C % vec == 0 && ilog2_exact(C / vec) >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be %d*2^k", C, vec);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_apply: M=%d not divisible by G=%d", M, G);
-    const size_t total4 = (size_t)M * (C / 4);
-    const int Mg = M / G, sg = per_group_tables ? C : 0;
-    dim3 grid(ew_blocks(total4)), block(kThreads);
+    const int Mg = M / G, sg = per_group_tables ? C : 0, cv = C / vec;
+    const size_t per_group = (size_t)Mg * cv;
+    dim3 grid(stream_blocks(per_group, cv, G), G), block(kThreads);
     IoProfScope prof(IO_PROF_BN_APPLY, 0.0, (double)io_dtype_bytes(dt) * M * C * (identity ? 3.0 : 2.0), st);
     const BnTab t{mean, scale, shift}, t2{mean2, scale2, shift2};
     const int mode = (identity && scale2) ? 2 : (identity ? 1 : 0);
 #define IO_BN_APPLY(MODE_, T_)                                                                                     \
-    hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_>), grid, block, 0, st, (const T_*)y, total4, sh, Mg, sg, t,      \
+    hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_>), grid, block, 0, st, (const T_*)y, per_group, cv - 1, sg, t,   \
                        (const T_*)identity, t2, relu, (T_*)out)
     if (dt == IO_BF16) {
         if (mode == 2) IO_BN_APPLY(2, bf16_t);
@@ -661,16 +774,18 @@ int io_bn_bwd_t(const void* dout, const void* act, const float* mask_scale, cons
     float* c2 = coef + (size_t)G * C;
     IoProfScope prof(IO_PROF_BN_BWD, 0.0,
                      (double)io_dtype_bytes(dt) * M * C * ((act ? 6.0 : 4.0) + 1.0 + (dz_out ? 1.0 : 0.0)), st);
-    const size_t total4 = (size_t)M * (C / 4);
+    const int vec = 16 / io_dtype_bytes(dt), cv = C / vec;
+    const size_t per_group = (size_t)Mg * cv;
+    dim3 agrid(stream_blocks(per_group, cv, G), G);
 #define IO_BN_BWD(T_)                                                                                               \
     do {                                                                                                            \
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<T_>, dim3(nb, G), dim3(kThreads), 0, st, (const T_*)dout,           \
                            (const T_*)act, (const T_*)y, Mg, C, rpb, mean, rstd, mask_scale, mask_shift, p1, p2);   \
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C,     \
                            dgamma, dbeta, c1, c2);                                                                  \
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st,                 \
-                           (const T_*)dout, (const T_*)act, (const T_*)y, total4, sh, Mg, C, gamma, mean, rstd, c1, \
-                           c2, mask_scale, mask_shift, (T_*)dy, (T_*)dz_out);                                       \
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, agrid, dim3(kThreads), 0, st, (const T_*)dout,                  \
+                           (const T_*)act, (const T_*)y, per_group, cv - 1, C, gamma, mean, rstd, c1, c2,           \
+                           mask_scale, mask_shift, (T_*)dy, (T_*)dz_out);                                           \
     } while (0)
     if (dt == IO_BF16) IO_BN_BWD(bf16_t);
     else IO_BN_BWD(float);
