@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates the measurement artefacts under gpurun_out/ on the GPU box (1x MI355X):
+#   bench_n1.json            the default bench line (fp32, configs[1]) incl. roofline + cpu_baseline
+#   bench_n1_bf16.json       the bf16 configuration (configs[2] shape at 256 pairs)
+#   kernel_stats_raw.csv     rocprofv3 --kernel-trace --stats of the same bench command
+#   traffic_*.txt            PMC HBM traffic of the dominant kernel (separate passes, see collect_traffic.sh)
+# tools/make_profiles.py (run in the repo afterwards) turns them into profiles/rNN_*.
+# usage: bash tools/refresh_profiles.sh
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_n1_bf16.json 2>> $O/bench_n1.err
+python3 bench.py --no-prof --no-cpu-baseline > $O/bench_n1_graph.json 2>> $O/bench_n1.err
+python3 bench.py --no-prof --no-cpu-baseline --dtype bf16 > $O/bench_n1_bf16_graph.json 2>> $O/bench_n1.err
+cd /tmp
+rm -rf /tmp/kt
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
+cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats_raw.csv
+cd $R
+bash tools/collect_traffic.sh > $O/traffic.log 2>&1
+tail -3 $O/bench_n1.err
