@@ -21,6 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FLOP_PER_PAIR_FWD = 21.76e9        # 2 passes x 10.882 GFLOP
 FLOP_PER_PAIR_TRAIN = 64.27e9      # 2 x (3 x 10.882 - 0.514) GFLOP, conv+FC MACs x 2
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16 dense peak
@@ -76,6 +77,9 @@ def main():
     ap.add_argument("--algo", default="InstaOrderNet_o")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="fp32 = BASELINE configs[1] (default, "
                     "the headline); bf16 = configs[2]: bf16 activations / GEMM operands, fp32 accumulate and weights")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "infer"], help="train = fwd+bwd+SGD (the "
+                    "BASELINE metric, default); fwd = both directional passes + loss in training mode (batch "
+                    "statistics), no backward; infer = the same in eval mode (inference.py's forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -106,7 +110,7 @@ def main():
     model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
     sd = synthetic.make_state_dict(1, 5, nc, prefix="module.")          # reference-init statistics
     model.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    model.switch_to("train")
+    model.switch_to("eval" if args.mode == "infer" else "train")
 
     # synthetic pair batch; a small seeded block tiled to B to keep host set-up short
     base = synthetic.make_pair_batch(1000 + rank, min(B, 32), S)
@@ -119,6 +123,8 @@ def main():
         else:
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["depth_order"], dev["count"],
                             dev["is_overlap"], dev["occ_order"])
+        if args.mode != "train":
+            return model.forward_only()[1]
         return model.step()
 
     # per-kernel HIP-event timing needs eager launches; with --no-prof the step is replayed from a hipGraph
@@ -149,20 +155,23 @@ def main():
         dt = float(tt.item())
     pairs_per_s = world * B * args.steps / dt
 
+    flop_per_pair = (FLOP_PER_PAIR_TRAIN if args.mode == "train" else FLOP_PER_PAIR_FWD) * (S / 256.0) ** 2
     result = {
-        "metric": "instance-pairs/sec (fwd+bwd)", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
+        "metric": "instance-pairs/sec (fwd+bwd)" if args.mode == "train" else "instance-pairs/sec (%s)" % args.mode,
+        "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, %s, fwd+bwd+SGD "
+        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, %s, %s "
                                "(BASELINE.json configs[%d])" % (args.algo, B, S, S, args.dtype,
+                                                                {"train": "fwd+bwd+SGD", "fwd": "forward+loss, train mode",
+                                                                 "infer": "forward+loss, eval mode"}[args.mode],
                                                                 1 if args.dtype == "fp32" else 2),
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
                    "hip_graph": bool(model._use_graph and model._graph is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
                        args.backend, model.net.flat_grads.numel())},
-        "achieved_tflops_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12,
-        "mfma_frac_whole_step": pairs_per_s * FLOP_PER_PAIR_TRAIN * (S / 256.0) ** 2 / 1e12
-        / (world * PEAK_FP32_MFMA_TFLOPS),
+        "achieved_tflops_whole_step": pairs_per_s * flop_per_pair / 1e12,
+        "mfma_frac_whole_step": pairs_per_s * flop_per_pair / 1e12 / (world * PEAK_FP32_MFMA_TFLOPS),
     }
     if args.dtype == "bf16":      # mixed: fwd/dgrad on the bf16 MFMA, wgrad on the fp32 MFMA -- no single peak applies
         result["mfma_frac_whole_step"] = None
@@ -194,7 +203,7 @@ def main():
                 "gbs": v["bytes"] / (v["total_ms"] * 1e-3) / 1e9}
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
         result["cpu_baseline"] = cpu_baseline(sd, S)
     if rank == 0:
         print(json.dumps(result))

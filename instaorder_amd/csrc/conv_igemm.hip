@@ -941,7 +941,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
-                     (double)os * M * g.Co + (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred), st);
+                     (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + (bw ? 1.0 : 0.0)) +
+                         (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
+                     st);
 #define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_)                                                                   \
     do {                                                                                                     \
         static bool attr_done = false;                                                                       \

@@ -22,6 +22,12 @@ for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_n1_bf16.json", "ben
     if os.path.exists(os.path.join(G, src)):
         json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (rnd, dst)), "w"), indent=1)
 
+for m in ("fwd", "infer"):
+    for d in ("fp32", "bf16"):
+        src = os.path.join(G, "bench_%s_%s.json" % (m, d))
+        if os.path.exists(src):
+            json.dump(last_json(src), open(os.path.join(P, "%s_bench_%s_%s.json" % (rnd, m, d)), "w"), indent=1)
+
 raw = os.path.join(G, "kernel_stats_raw.csv")
 if os.path.exists(raw):
     csv.field_size_limit(1 << 30)

@@ -15,6 +15,9 @@ python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_n1_bf16.json 2>> $O/bench_n1.err
 python3 bench.py --no-prof --no-cpu-baseline > $O/bench_n1_graph.json 2>> $O/bench_n1.err
 python3 bench.py --no-prof --no-cpu-baseline --dtype bf16 > $O/bench_n1_bf16_graph.json 2>> $O/bench_n1.err
+for m in fwd infer; do for d in fp32 bf16; do
+  python3 bench.py --mode $m --dtype $d --steps 10 --warmup 3 --no-cpu-baseline 2>> $O/bench_n1.err | tail -1 > $O/bench_${m}_${d}.json
+done; done
 cd /tmp
 rm -rf /tmp/kt
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
