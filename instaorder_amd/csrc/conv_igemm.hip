@@ -46,6 +46,13 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+// Descriptor over the tail of a tensor that starts `base` bytes in: a block addresses only the samples its tile
+// touches, relative to the first of them, so 32-bit offsets never limit the size of the whole tensor (activations of
+// 1024-pair batches exceed 4 GiB).  num_records saturates at 2^32-1; kInvalidOff stays out of range either way.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_at(const void* p, size_t base, size_t total) {
+    const size_t rest = total > base ? total - base : 0;
+    return make_rsrc(static_cast<const char*>(p) + base, rest > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)rest);
+}
 __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
@@ -91,8 +98,8 @@ template <typename TA, typename TO, int BN, bool STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
-                                                         const TO* __restrict__ mask, int ntn, unsigned in_bytes,
-                                                         unsigned w_bytes, unsigned out_bytes,
+                                                         const TO* __restrict__ mask, int ntn, size_t in_bytes,
+                                                         unsigned w_bytes, size_t out_bytes,
                                                          float* __restrict__ st_mean, float* __restrict__ st_m2,
                                                          IoBwStats bw) {
     constexpr int ES = sizeof(TA), OS = sizeof(TO);
@@ -124,7 +131,10 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
     // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
     // unit returns zeros.
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_w = make_rsrc(wgt, w_bytes);
+    const int n_lo = fdiv(m0, g.fd_howo);        // first sample of this tile: every offset below is relative to it
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * ES),
+                                                      in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wgt, w_bytes);
     unsigned rowv[AR];
     int hi0[AR], wi0[AR];
     bool rvalid[AR];
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
         const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
         hi0[j] = ho * g.is;
         wi0[j] = wo * g.is;
-        rowv[j] = (unsigned)(((n * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
+        rowv[j] = (unsigned)((((n - n_lo) * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
     }
     unsigned wv[BR];
 #pragma unroll
@@ -330,10 +340,12 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     // their stores are dropped and their `add` loads return 0); the `add` variant issues all its loads
     // before the stores.
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_add = make_rsrc(add ? (const void*)add : (const void*)out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mask ? (const void*)mask : (const void*)out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc(bw.y ? bw.y : (const void*)out, out_bytes);
+    const int opix_lo = n_lo * g.outH * g.outW;           // < 2^31: it is a pixel count, not a byte count
+    const size_t out_base = (size_t)opix_lo * (size_t)(g.Co * OS);
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_at(out, out_base, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = make_rsrc_at(add ? (const void*)add : (const void*)out, out_base, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc_at(mask ? (const void*)mask : (const void*)out, out_base, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc_at(bw.y ? bw.y : (const void*)out, out_base, out_bytes);
     float bw_mu[TJ], bw_rs[TJ], bw_sc[TJ], bw_sh[TJ], bw_s1[TJ], bw_s2[TJ];
     if (bw.y) {
         const int gcol = (m0 / bw.Mg) * g.Co + n0 + wn * (BN / WN) + (lane & 31);   // group is uniform per tile
@@ -356,13 +368,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const bool ok = m < M;
-            int pix = ok ? m : 0;
+            int pix = ok ? m : m0;
             if (!dense) {
                 const int n = fdiv(pix, g.fd_howo), rem = pix - n * HoWo;
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 pix = (n * g.outH + (ho * g.os + g.ooh)) * g.outW + (wo * g.os + g.oow);
             }
-            rowb[r] = ok ? (unsigned)(pix * g.Co) * (unsigned)OS + colb : kInvalidOff;
+            rowb[r] = ok ? (unsigned)((pix - opix_lo) * g.Co) * (unsigned)OS + colb : kInvalidOff;
         }
         if (add) {
 #pragma unroll
@@ -449,7 +461,7 @@ template <typename TX, typename TDY, int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int tiles,
-                                                             int kps, unsigned in_bytes, unsigned dy_bytes) {
+                                                             int kps, size_t in_bytes, size_t dy_bytes) {
     constexpr int BKM = 32;
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     constexpr int QA = BMO / 4, QB = BNC / 4;          // float4 per tile row
@@ -507,9 +519,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const int kt0 = split * kps;
     const int kt1 = min(kt0 + kps, nkt);
 
-    // 32-bit byte offsets through buffer descriptors; rows past M fall off the end of dY / In and read 0.
+    // 32-bit byte offsets through buffer descriptors that start at this split's first row (dY) / first sample
+    // (In); rows past M fall off the end of dY / In and read 0.
     // `lin`: 1x1 stride-1 (the gathered pixel of row m is pixel m): no per-k-tile decoding at all.
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
+    const int mfirst = min(kt0 * BKM, M - 1);
+    const int n_lo = fdiv(mfirst, g.fd_howo);
+    const int ipix_lo = n_lo * g.Hi * g.Wi;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)ipix_lo * (size_t)(g.Ci * (int)sizeof(TX)), in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc_at(dy, (size_t)mfirst * (size_t)(g.Co * (int)sizeof(TDY)), dy_bytes);
     const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     f32x4 ra[RA], rb[RB];
     // The gather offsets of a k-tile are computed one iteration ahead of its loads (`prep`), so that the loads
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
         for (int j = 0; j < RB; ++j) {
             const int m = mb + rb0 + SB * j;
             if (lin) {
-                offb[j] = (unsigned)(m * g.Ci + coff) * (unsigned)sizeof(TX);
+                offb[j] = (unsigned)((m - ipix_lo) * g.Ci + coff) * (unsigned)sizeof(TX);
             } else {
                 bool ok = tapok && m < M;
                 const int mm = ok ? m : 0;
@@ -529,7 +546,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 const int hi = ho * g.is + dh, wi = wo * g.is + dw;
                 ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                offb[j] = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * (unsigned)sizeof(TX) : kInvalidOff;
+                offb[j] = ok ? (unsigned)((((n - n_lo) * g.Hi + hi) * g.Wi + wi) * g.Ci + coff) * (unsigned)sizeof(TX)
+                             : kInvalidOff;
             }
         }
     };
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int m = mb + ra0 + SA * j;
-            ra[j] = bldv<TDY>(rs_dy, (unsigned)(m * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
+            ra[j] = bldv<TDY>(rs_dy, (unsigned)((m - mfirst) * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) rb[j] = bldv<TX>(rs_in, offb[j]);
@@ -664,7 +682,7 @@ template <int BMO, int BNC, bool STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
                                                                   const bf16_t* __restrict__ dy,
                                                                   float* __restrict__ dst, int ntile_c, int tiles,
-                                                                  int kps, unsigned in_bytes, unsigned dy_bytes) {
+                                                                  int kps, size_t in_bytes, size_t dy_bytes) {
     constexpr int BKM = 64, LDT = 36;
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -716,7 +734,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
     const int kt0 = split * kps;
     const int kt1 = min(kt0 + kps, nkt);
 
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in, in_bytes), rs_dy = make_rsrc(dy, dy_bytes);
+    const int mfirst = min(kt0 * BKM, M - 1);    // descriptors start at this split's first row / first sample
+    const int n_lo = fdiv(mfirst, g.fd_howo);
+    const int ipix_lo = n_lo * g.Hi * g.Wi;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)ipix_lo * (size_t)(g.Ci * 2), in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc_at(dy, (size_t)mfirst * (size_t)(g.Co * 2), dy_bytes);
     const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     u32x4 rr[8];
     auto load_tile = [&](int kt) {
@@ -724,14 +746,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
         if (role_a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)     // rows past M lie past the end of dY -> zeros
-                rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (unsigned)((mrow + r) * g.Co + o0 + cg * 8) * 2u, 0, 0);
+                rr[r] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_dy, (unsigned)((mrow + r - mfirst) * g.Co + o0 + cg * 8) * 2u, 0, 0);
         } else if (role_b) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int m = mrow + r;
                 unsigned off;
                 if (lin) {
-                    off = (unsigned)(m * g.Ci + xcol) * 2u;
+                    off = (unsigned)((m - ipix_lo) * g.Ci + xcol) * 2u;
                 } else {
                     bool ok = tapok && m < M;
                     const int mm = ok ? m : 0;
@@ -739,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
                     const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                     const int hi = ho * g.is + dh, wi = wo * g.is + dw;
                     ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                    off = ok ? (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.Ci + xcol) * 2u : kInvalidOff;
+                    off = ok ? (unsigned)((((n - n_lo) * g.Hi + hi) * g.Wi + wi) * g.Ci + xcol) * 2u : kInvalidOff;
                 }
                 rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
             }
@@ -926,11 +949,17 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(g.Ci % (128 / es) == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of %d", g.Ci, 128 / es);
     const long M = (long)g.N * g.Ho * g.Wo;
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
-    const double in_b = (double)es * g.N * g.Hi * g.Wi * g.Ci, w_b = (double)es * g.Co * g.wT * g.Ci;
-    IO_REQUIRE(in_b < 4.0e9 && w_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: operand larger than 4 GB (32-bit offsets)");
-    const double out_b = (double)os * g.N * g.outH * g.outW * g.Co;
-    IO_REQUIRE(out_b < 4.0e9, IO_ERR_SHAPE, "conv_nt: output larger than 4 GB (32-bit offsets)");
-    const unsigned in_bytes = (unsigned)in_b, w_bytes = (unsigned)w_b, out_bytes = (unsigned)out_b;
+    // whole tensors may exceed 4 GiB (descriptors are rebased per tile); what a tile spans -- the samples of 128
+    // consecutive rows, relative to the first -- must fit 32-bit byte offsets, and pixel counts must fit an int
+    const double w_b = (double)es * g.Co * g.wT * g.Ci;
+    const double span = 128.0 / ((double)g.Ho * g.Wo) + 2.0;
+    IO_REQUIRE(w_b < 4.0e9 && span * es * g.Hi * g.Wi * g.Ci < 4.0e9 && span * os * g.outH * g.outW * g.Co < 4.0e9,
+               IO_ERR_SHAPE, "conv_nt: filter or per-tile sample span larger than 4 GB (32-bit offsets)");
+    IO_REQUIRE((double)g.N * g.Hi * g.Wi < 2.0e9 && (double)g.N * g.outH * g.outW < 2.0e9, IO_ERR_SHAPE,
+               "conv_nt: more than 2^31 pixels");
+    const size_t in_bytes = (size_t)es * g.N * g.Hi * g.Wi * g.Ci;
+    const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
+    const unsigned w_bytes = (unsigned)w_b;
     const int bn = (g.Co % 128 == 0) ? 128 : 64;
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
@@ -996,10 +1025,16 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     float* dst = p.splits == 1 ? dw : partial;
     int splits = p.splits;
     dim3 grid((unsigned)(p.tiles * p.splits)), block(kThreads);
-    const double in_b = (double)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
-    const double dy_b = (double)io_dtype_bytes(dt_dy) * g.N * g.Ho * g.Wo * g.Co;
-    IO_REQUIRE(in_b < 4.0e9 && dy_b < 4.0e9, IO_ERR_SHAPE, "conv_wgrad: operand larger than 4 GB (32-bit offsets)");
-    const unsigned in_bytes = (unsigned)in_b, dy_bytes = (unsigned)dy_b;
+    // descriptors are rebased per split: what one split spans must fit 32-bit offsets, not the whole tensors
+    const size_t in_bytes = (size_t)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
+    const size_t dy_bytes = (size_t)io_dtype_bytes(dt_dy) * g.N * g.Ho * g.Wo * g.Co;
+    {
+        const double rows = (double)p.kps * 32.0 + 64.0, samples = rows / ((double)g.Ho * g.Wo) + 2.0;
+        IO_REQUIRE(rows * g.Co * io_dtype_bytes(dt_dy) < 4.0e9 &&
+                       samples * g.Hi * g.Wi * g.Ci * io_dtype_bytes(dt_in) < 4.0e9 &&
+                       (double)g.N * g.Hi * g.Wi < 2.0e9,
+                   IO_ERR_SHAPE, "conv_wgrad: one split spans more than 4 GB (32-bit offsets)");
+    }
     const double Md = (double)g.N * g.Ho * g.Wo;
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(stem ? IO_PROF_WGRAD_STEM : IO_PROF_WGRAD, 2.0 * Md * g.Co * kred,

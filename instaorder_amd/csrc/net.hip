@@ -559,7 +559,8 @@ static int check_shape(int N, int S, int G) {
     IO_REQUIRE(S >= 32 && S % 32 == 0, IO_ERR_SHAPE, "input size S=%d must be a multiple of 32", S);
     IO_REQUIRE(N >= 1 && G >= 1 && G <= kMaxGroups && N % G == 0, IO_ERR_SHAPE, "N=%d G=%d (G<=%d, G | N)", N, G,
                kMaxGroups);
-    IO_REQUIRE((double)N * S * S * 16.0 < 1.0e9, IO_ERR_SHAPE, "N=%d x S=%d: activations exceed 4 GB (32-bit offsets)", N, S);
+    // tensors may exceed 4 GiB (the kernels address them tile by tile); row and pixel counts must fit an int
+    IO_REQUIRE((double)N * S * S < 2.0e9, IO_ERR_SHAPE, "N=%d x S=%d: more than 2^31 input pixels", N, S);
     return IO_OK;
 }
 

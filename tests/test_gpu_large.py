@@ -1,0 +1,102 @@
+"""Tensors larger than 4 GiB (1024 pairs per GPU in bf16 = 2048 samples, 4 GiB per layer-1
+activation): the GEMM kernels address activations tile by tile through rebased buffer descriptors, so only what one
+tile / split spans has to fit 32-bit offsets.  These cases put the first and the last samples of an over-4-GiB
+tensor through the kernels and compare them with small launches on the same data."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ALGO_CLASSES, synthetic
+from instaorder_amd import _lib
+from test_gpu_ops import L, P, ST
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _need(gib):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gib * 2 ** 30:
+        pytest.skip("needs %d GiB of free HBM" % gib)
+
+
+def test_conv_over_4gib_fp32():
+    _need(24)
+    N, H, C = 1100, 128, 64                       # 18.0 M rows x 64 ch x 4 B = 4.6 GB in, 4.6 GB out
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, H, H, C, device=DEV, generator=g)
+    assert x.numel() * 4 > 2 ** 32
+    w = torch.randn(C, 9, C, device=DEV, generator=g) * 0.05
+    y = torch.empty(N, H, H, C, device=DEV)
+    _lib.check(L().io_conv2d_fwd(P(x), P(w), P(y), N, H, H, C, C, 3, 3, 1, 1, ST()), "fwd")
+    for lo in (0, 547, N - 3):                    # first, one straddling the 4 GiB line, last
+        xs = x[lo:lo + 3].contiguous()
+        ys = torch.empty(3, H, H, C, device=DEV)
+        _lib.check(L().io_conv2d_fwd(P(xs), P(w), P(ys), 3, H, H, C, C, 3, 3, 1, 1, ST()), "fwd small")
+        assert torch.equal(ys, y[lo:lo + 3]), "samples %d.." % lo
+    # filter gradient: the reduction runs over all 18 M rows; compare with the sum of two half-batch launches
+    dy = torch.randn(N, H, H, C, device=DEV, generator=g)
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, H, H, C, C, 3, 3, 1, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.empty(C, 9, C, device=DEV)
+    _lib.check(L().io_conv2d_wgrad(P(x), P(dy), P(dw), N, H, H, C, C, 3, 3, 1, 1, P(ws), nb, ST()), "wgrad")
+    half = N // 2
+    acc = torch.zeros(C, 9, C, device=DEV, dtype=torch.float64)
+    for lo, n in ((0, half), (half, N - half)):
+        xs, ds = x[lo:lo + n].contiguous(), dy[lo:lo + n].contiguous()
+        d2 = torch.empty(C, 9, C, device=DEV)
+        nb2 = L().io_conv2d_wgrad_workspace_bytes(n, H, H, C, C, 3, 3, 1, 1)
+        ws2 = torch.empty(max(nb2, 16), dtype=torch.uint8, device=DEV)
+        _lib.check(L().io_conv2d_wgrad(P(xs), P(ds), P(d2), n, H, H, C, C, 3, 3, 1, 1, P(ws2), nb2, ST()), "wgrad half")
+        acc += d2.double()
+    err = float((dw.double() - acc).norm() / acc.norm())
+    assert err < 1e-5, err
+    # data gradient
+    wt = torch.empty(C, 9, C, device=DEV)
+    _lib.check(L().io_filter_transpose(P(w), C, 9, C, P(wt), ST()), "wt")
+    dx = torch.empty(N, H, H, C, device=DEV)
+    _lib.check(L().io_conv2d_dgrad(P(dy), P(wt), P(dx), None, None, N, H, H, C, C, 3, 3, 1, 1, ST()), "dgrad")
+    for lo in (0, N - 2):
+        ds = dy[lo:lo + 2].contiguous()
+        dxs = torch.empty(2, H, H, C, device=DEV)
+        _lib.check(L().io_conv2d_dgrad(P(ds), P(wt), P(dxs), None, None, 2, H, H, C, C, 3, 3, 1, 1, ST()), "dgrad small")
+        assert torch.equal(dxs, dx[lo:lo + 2])
+
+
+def test_config3_1024_pairs_bf16_step():
+    """BASELINE configs[2]: InstaOrderNet_od, bf16, 1024 pairs (2048 samples) of 256x256 on ONE GPU: ~125 GiB of
+    workspace, layer-1 activations of exactly 4 GiB.  Eval-mode logits of the big batch must equal those of a
+    64-sample launch on the same images bit for bit (per-sample independence), and a training step must run."""
+    _need(170)
+    import instaorder_amd as ia
+    algo, B, S = "InstaOrderNet_od", 1024, 256
+    cfg = dict(algo=algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype="bf16",
+               backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    sd = synthetic.make_state_dict(11, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    base = synthetic.make_pair_batch(77, 32, S)
+    reps = B // 32
+    t = {k: torch.from_numpy(np.concatenate([v] * reps, 0)).cuda() for k, v in base.items()}
+    # distinct samples across the batch: scale the image by a per-sample factor
+    scale = torch.linspace(0.5, 1.5, B, device=DEV).view(B, 1, 1, 1)
+    t["rgb"] = t["rgb"] * scale
+    m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+    m.switch_to("eval")
+    m.forward_only(ret_loss=False)
+    big = m.last_logits.clone()                     # [2B, 5]: rows [0,B) first direction, [B,2B) second
+    assert big.shape == (2 * B, 5) and torch.isfinite(big).all()
+    for lo in (0, B - 32):
+        m.set_input(t["rgb"][lo:lo + 32], t["modal1"][lo:lo + 32], t["modal2"][lo:lo + 32], t["depth_order"][lo:lo + 32],
+                    t["count"][lo:lo + 32], t["is_overlap"][lo:lo + 32], t["occ_order"][lo:lo + 32])
+        m.forward_only(ret_loss=False)
+        small = m.last_logits
+        assert torch.equal(small[:32], big[lo:lo + 32]) and torch.equal(small[32:], big[B + lo:B + lo + 32])
+    m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+    m.switch_to("train")
+    logs, out = m.step()
+    loss = float(out["loss"])
+    assert np.isfinite(loss) and 0.5 < loss < 20.0, loss
+    gn = float(m.net.flat_grads.norm())
+    assert np.isfinite(gn) and gn > 0
