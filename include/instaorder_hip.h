@@ -214,6 +214,42 @@ int io_bn_bwd_dt(const void* dout, const void* act, const float* mask_scale, con
                  float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef, int dtype,
                  hipStream_t stream);
 
+/* ---- operators of the MiDaS branch (InstaDepthNet_od / _d: midas/midas_net.py:116-212, midas/blocks.py:71-195) ----
+ * NHWC fp32.  Grouped 3x3 convolution of the ResNeXt-101 32x8d encoder (resnet_cls.py:309-320, `groups=32`): the
+ * filter w[C][cg][R*S] (OIHW, cg = C/groups input channels per group, cg | 64) is expanded by io_gconv_pack to two
+ * block-diagonal operands over 64-channel windows -- wc[C][R*S][64] for the forward, wtc[C][R*S][64] for the data
+ * gradient -- and the filter gradient comes back in the wc layout (io_gconv_unpack_grad extracts [C][cg][R*S]). */
+int io_gconv_pack(const float* w, int C, int cg, int taps, float* wc, float* wtc, hipStream_t stream);
+int io_gconv_unpack_grad(const float* dwc, int C, int cg, int taps, float* dw, hipStream_t stream);
+int io_gconv2d_fwd(const float* x, const float* wc, float* y, int N, int H, int W, int C, int R, int S, int stride,
+                   int pad, hipStream_t stream);
+int io_gconv2d_dgrad(const float* dy, const float* wtc, float* dx, int N, int H, int W, int C, int R, int S, int stride,
+                     int pad, hipStream_t stream);
+size_t io_gconv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int R, int S, int stride, int pad);
+int io_gconv2d_wgrad(const float* x, const float* dy, float* dwc, int N, int H, int W, int C, int R, int S, int stride,
+                     int pad, void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* nn.functional.interpolate(scale_factor=2, mode='bilinear', align_corners=...) (midas/blocks.py:111-113, 186-188):
+ * x[N,H,W,C] -> out[N,2H,2W,C]; bwd is its exact adjoint dy[N,2H,2W,C] -> dx[N,H,W,C]. */
+int io_upsample2x_bilinear_fwd(const float* x, int N, int H, int W, int C, int align_corners, float* out,
+                               hipStream_t stream);
+int io_upsample2x_bilinear_bwd(const float* dy, int N, int H, int W, int C, int align_corners, float* dx,
+                               hipStream_t stream);
+/* out[M][C] = [relu](x + bias) (bias may be NULL; out may alias x): conv bias / nn.ReLU of midas/blocks.py:121-160 */
+int io_bias_act(const float* x, const float* bias, int M, int C, int relu, float* out, hipStream_t stream);
+/* dx = dy * [act > 0] (dx may alias dy) */
+int io_relu_bwd(const float* dy, const float* act, size_t n, float* dx, hipStream_t stream);
+int io_add(const float* a, const float* b, size_t n, float* out, hipStream_t stream);
+/* out[c] = sum_m x[m][c] (bias gradient); C must divide 256; partial: io_colsum_partial_floats(M, C) floats */
+size_t io_colsum_partial_floats(int M, int C);
+int io_colsum(const float* x, int M, int C, float* out, float* partial, size_t partial_floats, hipStream_t stream);
+/* nn.Conv2d(C, 1, 1) [+ nn.ReLU] (midas_net.py:139-140): out[m] = act(b + sum_c x[m*pitch + c] * w[c]); the input may
+ * carry padding channels (pitch >= C, <= 64).  bwd: dx[M][pitch] (zero in the padding channels), dw[C], db[1];
+ * partial: io_colsum_partial_floats(M, C) floats. */
+int io_head1_fwd(const float* x, int M, int pitch, int C, const float* w, const float* b, int relu, float* out,
+                 hipStream_t stream);
+int io_head1_bwd(const float* dy, const float* out, const float* x, int M, int pitch, int C, const float* w, int relu,
+                 float* dx, float* dw, float* db, float* partial, size_t partial_floats, hipStream_t stream);
+
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of
  * classes written.  flops / bytes are the ALGORITHMIC figures of the timed launches. */

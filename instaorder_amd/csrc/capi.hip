@@ -86,11 +86,12 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
 
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st, const IoBwStats* bw,
-                 int dt) {
+                 int dt, int gw) {
     IO_REQUIRE(!bw || stride == 1, IO_ERR_SHAPE, "dgrad: fused BN-backward reductions need a stride-1 convolution");
     for (int ph = 0; ph < stride; ++ph)
         for (int pw = 0; pw < stride; ++pw) {
             IoConvGeom g = io_geom_dgrad(N, H, W, Cin, Cout, R, S, stride, pad, ph, pw);
+            g.gw = gw;
             if (g.Ho <= 0 || g.Wo <= 0) continue;
             // a lattice class no tap reaches keeps its values when accumulating in place -- unless a ReLU
             // mask has to be applied to them

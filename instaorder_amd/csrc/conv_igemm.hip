@@ -125,7 +125,10 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     const int HoWo = g.Ho * g.Wo;
     const int M = g.N * HoWo;
     const int lr = tid >> 3, kq = tid & 7;
-    const int nkc = STEM ? 1 : g.Ci / BK;
+    // grouped (block-diagonal) mode: this tile's output channels read the gw input channels starting at n0
+    const int kw = g.gw ? g.gw : g.Ci;           // filter row length per tap
+    const int cbase = g.gw ? n0 : 0;             // first input channel of the k range
+    const int nkc = STEM ? 1 : kw / BK;
     const int nk = STEM ? (g.wT + TPT - 1) / TPT : g.Th * g.Tw * nkc;
 
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     unsigned wv[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-        wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
+        wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * kw + (STEM ? 0 : kq * VE)) * (unsigned)ES;
     const bool nopad = g.Th == 1 && g.Tw == 1 && g.dh0 == 0 && g.dw0 == 0 && g.is == 1 && g.Hi >= g.Ho &&
                        g.Wi >= g.Wo;   // 1x1 stride-1: a row is valid for every k-tile or for none
 
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
             dh = g.dh0 + g.dhs * th;
             dw = g.dw0 + g.dws * tw;
             const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
-            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cc * BK) * (unsigned)ES;
-            woff = (unsigned)(widx * g.Ci + cc * BK) * (unsigned)ES;
+            aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cbase + cc * BK) * (unsigned)ES;
+            woff = (unsigned)(widx * kw + cc * BK) * (unsigned)ES;
         }
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
         c0 = rem0 * BNC;                 // column in the flattened (tap, 8 channels) axis
     } else {
         tap = rem0 / ntile_c;
-        c0 = (rem0 - tap * ntile_c) * BNC;
+        c0 = g.gw ? o0 : (rem0 - tap * ntile_c) * BNC;      // grouped: only the diagonal (o tile == c tile)
     }
     const int qa = tid % QA, ra0 = tid / QA;
     const int qb = tid % QB, rb0 = tid / QB;
@@ -646,7 +649,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     }
 
     // epilogue: rows = output channel o, cols = input channel (or flattened stem column)
-    const size_t wrow = (size_t)g.wT * g.Ci;
+    const int kwid = g.gw ? g.gw : g.Ci;          // filter row length per tap (grouped: the window)
+    const size_t wrow = (size_t)g.wT * kwid;
     float* base = dst + (size_t)split * g.Co * wrow;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
                     const int col = c0 + cl;
                     if (col < (int)wrow) base[(size_t)o * wrow + col] = acc[i][j][r];
                 } else {
-                    base[(size_t)o * wrow + (size_t)widx * g.Ci + c0 + cl] = acc[i][j][r];
+                    base[(size_t)o * wrow + (size_t)widx * kwid + (g.gw ? 0 : c0) + cl] = acc[i][j][r];
                 }
             }
         }
@@ -903,6 +907,10 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
         p.bnc = 64;
         p.ntile_c = io_cdiv((long)g.wT * g.Ci, 64);
         p.tiles = (g.Co / p.bmo) * p.ntile_c;
+    } else if (g.gw) {
+        p.bmo = p.bnc = g.gw;
+        p.ntile_c = 1;
+        p.tiles = (g.Co / p.bmo) * g.Th * g.Tw;
     } else {
         p.bnc = (g.Ci % 128 == 0) ? 128 : 64;
         p.ntile_c = g.Ci / p.bnc;
@@ -925,7 +933,7 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     WgradPlan p = plan_wgrad(g, stem);
     if (p.splits == 1) return 0;
-    return (size_t)p.splits * g.Co * g.wT * g.Ci * sizeof(float);
+    return (size_t)p.splits * g.Co * g.wT * (g.gw ? g.gw : g.Ci) * sizeof(float);
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
@@ -951,7 +959,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
     // whole tensors may exceed 4 GiB (descriptors are rebased per tile); what a tile spans -- the samples of 128
     // consecutive rows, relative to the first -- must fit 32-bit byte offsets, and pixel counts must fit an int
-    const double w_b = (double)es * g.Co * g.wT * g.Ci;
+    const double w_b = (double)es * g.Co * g.wT * (g.gw ? g.gw : g.Ci);
     const double span = 128.0 / ((double)g.Ho * g.Wo) + 2.0;
     IO_REQUIRE(w_b < 4.0e9 && span * es * g.Hi * g.Wi * g.Ci < 4.0e9 && span * os * g.outH * g.outW * g.Co < 4.0e9,
                IO_ERR_SHAPE, "conv_nt: filter or per-tile sample span larger than 4 GB (32-bit offsets)");
@@ -960,14 +968,16 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const size_t in_bytes = (size_t)es * g.N * g.Hi * g.Wi * g.Ci;
     const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
     const unsigned w_bytes = (unsigned)w_b;
-    const int bn = (g.Co % 128 == 0) ? 128 : 64;
+    const int bn = g.gw ? g.gw : ((g.Co % 128 == 0) ? 128 : 64);
+    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co && dt_in == IO_F32), IO_ERR_SHAPE,
+               "conv_nt: grouped mode needs a 64-channel window, Ci == Co, fp32");
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
     const size_t lds = (size_t)2 * (128 + bn) * 36 * sizeof(float);
     dim3 grid((unsigned)tiles), block(kThreads);
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
-    const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
+    const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + (bw ? 1.0 : 0.0)) +
@@ -1018,6 +1028,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         IO_REQUIRE(g.Ci % 64 == 0 && dt_in == dt_dy, IO_ERR_SHAPE,
                    "conv_wgrad: Ci=%d must be a multiple of 64 (and one storage type)", g.Ci);
     IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW, IO_ERR_SHAPE, "conv_wgrad: dY must be dense");
+    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co && dt_in == IO_F32), IO_ERR_SHAPE,
+               "conv_wgrad: grouped mode needs a 64-channel window, Ci == Co, fp32");
     WgradPlan p = plan_wgrad(g, stem);
     const size_t need = io_conv_wgrad_partial_bytes(g, stem);
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,
@@ -1036,7 +1048,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                    IO_ERR_SHAPE, "conv_wgrad: one split spans more than 4 GB (32-bit offsets)");
     }
     const double Md = (double)g.N * g.Ho * g.Wo;
-    const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * g.Ci;
+    const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_WGRAD_STEM : IO_PROF_WGRAD, 2.0 * Md * g.Co * kred,
                      io_dtype_bytes(dt_dy) * Md * g.Co + io_dtype_bytes(dt_in) * (double)g.N * g.Hi * g.Wi * g.Ci +
                          4.0 * g.Co * kred, st);
@@ -1089,7 +1101,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
     if (splits > 1) {
-        const size_t n4 = (size_t)g.Co * g.wT * g.Ci / 4;
+        const size_t n4 = (size_t)g.Co * g.wT * (g.gw ? g.gw : g.Ci) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
                            splits);
         rc = io_check_launch("splitk_reduce");

@@ -1,0 +1,377 @@
+// Operators the MiDaS branch (InstaDepthNet_od / _d) needs on top of the ResNet-50 path:
+//   * grouped 3x3 convolution of ResNeXt-101 32x8d (resnet_cls.py:309-320 via midas/blocks.py:85-87), run by the
+//     implicit-GEMM kernels as a block-diagonal convolution over 64-channel windows (IoConvGeom::gw): the filter
+//     [C][cg][3][3] is expanded to [C][9][64] (zeros outside the group), so the waste is 64 / cg of a small layer
+//     instead of C / cg of a dense emulation;
+//   * bilinear x2 up-sampling, align_corners True (FeatureFusionBlock, midas/blocks.py:186-190) and False
+//     (Interpolate in output_conv, midas/blocks.py:97-118), forward and exact adjoint (gather form, deterministic);
+//   * bias (+ReLU), ReLU backward, add, column sums (bias gradients) for the biased 3x3 convolutions of the decoder
+//     (midas/blocks.py:121-160, midas_net.py:134-141);
+//   * the final 1x1 convolution to ONE channel (+ReLU) and its backward.
+// All tensors NHWC fp32.
+#include "io_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+int ew_blocks(size_t n) {
+    size_t b = (n + kThreads - 1) / kThreads;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+// ---- grouped filter <-> block-diagonal windows ---------------------------------------------------------------
+// w [C][cg][T] (OIHW with T = R*S taps).  wc [C][T][64]: row o holds, for its 64-channel window wb = 64*(o/64), the
+// taps of input channel wb + cl (zero unless that channel is in o's group).  wtc [C][T][64]: the same for the data
+// gradient, row = INPUT channel c, column = output channel wb + cl.
+__global__ __launch_bounds__(kThreads) void gconv_pack_kernel(const float* __restrict__ w, int C, int cg, int T,
+                                                             float* __restrict__ wc, float* __restrict__ wtc) {
+    const size_t total = (size_t)C * T * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cl = (int)(i & 63);
+        const int tap = (int)((i >> 6) % T);
+        const int o = (int)(i / ((size_t)T * 64));
+        const int other = (o & ~63) + cl;
+        const bool same = (other / cg) == (o / cg);
+        wc[i] = same ? w[((size_t)o * cg + other % cg) * T + tap] : 0.f;
+        wtc[i] = same ? w[((size_t)other * cg + o % cg) * T + tap] : 0.f;
+    }
+}
+
+// dw [C][cg][T] <- dwc [C][T][64] (entries outside the group are gradients of structural zeros: dropped)
+__global__ __launch_bounds__(kThreads) void gconv_unpack_kernel(const float* __restrict__ dwc, int C, int cg, int T,
+                                                               float* __restrict__ dw) {
+    const size_t total = (size_t)C * cg * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % T);
+        const int cil = (int)((i / T) % cg);
+        const int o = (int)(i / ((size_t)T * cg));
+        const int ci = (o / cg) * cg + cil;
+        dw[i] = dwc[((size_t)o * T + tap) * 64 + (ci - (o & ~63))];
+    }
+}
+
+// ---- bilinear x2 ----------------------------------------------------------------------------------------------
+// source index of nn.functional.interpolate(scale_factor=2, mode='bilinear'): align_corners -> dst*(H-1)/(2H-1);
+// otherwise max(0.5*(dst+0.5)-0.5, 0)
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, int H, int align) {
+    const int OH = 2 * H;
+    float src;
+    if (align) {
+        const float sc = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+        src = sc * (float)dst;
+    } else {
+        src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+    }
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > H - 1) l.i0 = H - 1;
+    l.i1 = l.i0 + (l.i0 < H - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+__global__ __launch_bounds__(kThreads) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                                 int C4, int align, float* __restrict__ out) {
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)N * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % C4);
+        size_t t = i / C4;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const Lerp lh = lerp_of(oh, H, align), lw = lerp_of(ow, W, align);
+        const f32x4* xp = reinterpret_cast<const f32x4*>(x) + (size_t)n * H * W * C4 + q;
+        const f32x4 a = xp[((size_t)lh.i0 * W + lw.i0) * C4], b = xp[((size_t)lh.i0 * W + lw.i1) * C4];
+        const f32x4 c = xp[((size_t)lh.i1 * W + lw.i0) * C4], d = xp[((size_t)lh.i1 * W + lw.i1) * C4];
+        // same association as PyTorch's CPU kernel: h0lambda*(w0lambda*a + w1lambda*b) + h1lambda*(...)
+        reinterpret_cast<f32x4*>(out)[i] = lh.w0 * (lw.w0 * a + lw.w1 * b) + lh.w1 * (lw.w0 * c + lw.w1 * d);
+    }
+}
+
+// exact adjoint in gather form: input pixel (h, w) collects from every output pixel whose stencil touches it
+__global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W,
+                                                                 int C4, int align, float* __restrict__ dx) {
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % C4);
+        size_t t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4* dp = reinterpret_cast<const f32x4*>(dy) + (size_t)n * OH * OW * C4 + q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int oh0 = max(0, 2 * h - 3), oh1 = min(OH - 1, 2 * h + 4);
+        const int ow0 = max(0, 2 * w - 3), ow1 = min(OW - 1, 2 * w + 4);
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            const Lerp lh = lerp_of(oh, H, align);
+            const float wh = (lh.i0 == h ? lh.w0 : 0.f) + (lh.i1 == h ? lh.w1 : 0.f);
+            if (wh == 0.f) continue;
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const Lerp lw = lerp_of(ow, W, align);
+                const float ww = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
+                if (ww == 0.f) continue;
+                acc += (wh * ww) * dp[((size_t)oh * OW + ow) * C4];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = acc;
+    }
+}
+
+// ---- elementwise ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bias_act_kernel(const float* x, const float* __restrict__ bias, size_t total4,
+                                                           int C4, int relu, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        if (bias) v += reinterpret_cast<const f32x4*>(bias)[i % C4];
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const float* dy, const float* __restrict__ act, size_t total4,
+                                                           float* dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void add_kernel(const float* a, const float* b, size_t total4, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+// ---- column sums: out[c] = sum_m x[m][c] (bias gradients), two levels, fixed order ---------------------------------
+// block b sums rows [b*rpb, ...) into partial[b][C]; thread = (column tx = tid % C, row lane ty = tid / C)
+__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* __restrict__ x, int M, int C, int rpb,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[kThreads];
+    const int TY = kThreads / C, tx = threadIdx.x % C, ty = threadIdx.x / C;
+    const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, M);
+    float s = 0.f;
+    for (int r = r0 + ty; r < r1; r += TY) s += x[(size_t)r * C + tx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0) {
+        for (int k = 1; k < TY; ++k) s += red[k * C + tx];
+        partial[(size_t)blockIdx.x * C + tx] = s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nb, int stride, int C,
+                                    float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)partial[(size_t)b * stride + c];
+    out[c] = (float)s;
+}
+
+// ---- 1x1 convolution to one channel (+ReLU), midas_net.py:139-140 ---------------------------------------------------
+// out[m] = act(b + sum_c x[m*pitch + c] * w[c]); one thread per row (C <= 64 floats, contiguous)
+__global__ __launch_bounds__(kThreads) void head1_fwd_kernel(const float* __restrict__ x, int M, int pitch, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            int relu, float* __restrict__ out) {
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < (size_t)M; m += (size_t)gridDim.x * blockDim.x) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(x + m * pitch);
+        float s = b ? b[0] : 0.f;
+        for (int q = 0; q < C / 4; ++q) {
+            const f32x4 v = xp[q], ww = reinterpret_cast<const f32x4*>(w)[q];
+            s += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
+        }
+        out[m] = (relu && s < 0.f) ? 0.f : s;
+    }
+}
+
+// dz = dy * [out > 0]; dx[m][c] = dz * w[c] (zero in the padding channels C..pitch); partial[b][C+1] = block sums of
+// dz * x[m][c] and of dz
+__global__ __launch_bounds__(kThreads) void head1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                            const float* __restrict__ x, int M, int pitch, int C,
+                                                            const float* __restrict__ w, int relu, int rpb,
+                                                            float* __restrict__ dx, float* __restrict__ partial) {
+    __shared__ float red[kThreads];
+    const int TXN = 64;                                  // column lanes (>= C, padded)
+    const int TY = kThreads / TXN, tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
+    const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, M);
+    const float wc = tx < C ? w[tx] : 0.f;
+    float s = 0.f, sb = 0.f;
+    for (int r = r0 + ty; r < r1; r += TY) {
+        float dz = dy[r];
+        if (relu && !(out[r] > 0.f)) dz = 0.f;
+        if (tx < pitch) dx[(size_t)r * pitch + tx] = dz * wc;
+        if (tx < C) s += dz * x[(size_t)r * pitch + tx];
+        sb += dz;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0) {
+        for (int k = 1; k < TY; ++k) s += red[k * TXN + tx];
+        if (tx < C) partial[(size_t)blockIdx.x * (C + 1) + tx] = s;
+    }
+    __syncthreads();
+    red[threadIdx.x] = sb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < TY; ++k) t += red[k * TXN];
+        partial[(size_t)blockIdx.x * (C + 1) + C] = t;
+    }
+}
+
+int rows_per_block(int M, int* nb) {
+    int want = 1024;
+    int rpb = (M + want - 1) / want;
+    if (rpb < 64) rpb = 64;
+    *nb = (M + rpb - 1) / rpb;
+    return rpb;
+}
+
+}  // namespace
+
+extern "C" int io_gconv_pack(const float* w, int C, int cg, int taps, float* wc, float* wtc, hipStream_t st) {
+    IO_REQUIRE(C % 64 == 0 && cg >= 1 && cg <= 64 && 64 % cg == 0, IO_ERR_SHAPE,
+               "gconv_pack: C=%d must be a multiple of 64 and the group width %d must divide 64", C, cg);
+    const size_t total = (size_t)C * taps * 64;
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 12.0 * total, st);
+    hipLaunchKernelGGL(gconv_pack_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, w, C, cg, taps, wc, wtc);
+    return io_check_launch("gconv_pack");
+}
+
+extern "C" int io_gconv_unpack_grad(const float* dwc, int C, int cg, int taps, float* dw, hipStream_t st) {
+    IO_REQUIRE(C % 64 == 0 && cg >= 1 && cg <= 64 && 64 % cg == 0, IO_ERR_SHAPE, "gconv_unpack_grad: C=%d cg=%d", C, cg);
+    const size_t total = (size_t)C * cg * taps;
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 8.0 * total, st);
+    hipLaunchKernelGGL(gconv_unpack_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, dwc, C, cg, taps, dw);
+    return io_check_launch("gconv_unpack_grad");
+}
+
+static IoConvGeom gconv_geom(int N, int H, int W, int C, int R, int S, int stride, int pad) {
+    IoConvGeom g = io_geom_fwd(N, H, W, C, C, R, S, stride, pad);
+    g.gw = 64;
+    return g;
+}
+
+extern "C" int io_gconv2d_fwd(const float* x, const float* wc, float* y, int N, int H, int W, int C, int R, int S,
+                              int stride, int pad, hipStream_t st) {
+    return io_launch_conv_nt(gconv_geom(N, H, W, C, R, S, stride, pad), x, wc, y, nullptr, nullptr, 0, st);
+}
+
+extern "C" int io_gconv2d_dgrad(const float* dy, const float* wtc, float* dx, int N, int H, int W, int C, int R, int S,
+                                int stride, int pad, hipStream_t st) {
+    return io_run_dgrad(dy, wtc, dx, nullptr, nullptr, N, H, W, C, C, R, S, stride, pad, st, nullptr, IO_F32, 64);
+}
+
+extern "C" size_t io_gconv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int R, int S, int stride, int pad) {
+    return io_conv_wgrad_partial_bytes(gconv_geom(N, H, W, C, R, S, stride, pad), 0);
+}
+
+extern "C" int io_gconv2d_wgrad(const float* x, const float* dy, float* dwc, int N, int H, int W, int C, int R, int S,
+                                int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+    return io_launch_conv_wgrad(gconv_geom(N, H, W, C, R, S, stride, pad), x, dy, dwc, (float*)ws, ws_bytes, 0, st);
+}
+
+extern "C" int io_upsample2x_bilinear_fwd(const float* x, int N, int H, int W, int C, int align_corners, float* out,
+                                          hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
+    const size_t total = (size_t)N * 4 * H * W * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 20.0 * N * H * W * C, st);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, x, N, H, W, C / 4,
+                       align_corners, out);
+    return io_check_launch("upsample2x_fwd");
+}
+
+extern "C" int io_upsample2x_bilinear_bwd(const float* dy, int N, int H, int W, int C, int align_corners, float* dx,
+                                          hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
+    const size_t total = (size_t)N * H * W * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 20.0 * N * H * W * C, st);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, dy, N, H, W, C / 4,
+                       align_corners, dx);
+    return io_check_launch("upsample2x_bwd");
+}
+
+extern "C" int io_bias_act(const float* x, const float* bias, int M, int C, int relu, float* out, hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && M > 0, IO_ERR_SHAPE, "bias_act: M=%d C=%d", M, C);
+    const size_t total4 = (size_t)M * (C / 4);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 8.0 * M * C, st);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, x, bias, total4, C / 4, relu, out);
+    return io_check_launch("bias_act");
+}
+
+extern "C" int io_relu_bwd(const float* dy, const float* act, size_t n, float* dx, hipStream_t st) {
+    IO_REQUIRE(n % 4 == 0 && n > 0, IO_ERR_SHAPE, "relu_bwd: n=%zu", n);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 12.0 * n, st);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, dy, act, n / 4, dx);
+    return io_check_launch("relu_bwd");
+}
+
+extern "C" int io_add(const float* a, const float* b, size_t n, float* out, hipStream_t st) {
+    IO_REQUIRE(n % 4 == 0 && n > 0, IO_ERR_SHAPE, "add: n=%zu", n);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 12.0 * n, st);
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, a, b, n / 4, out);
+    return io_check_launch("add");
+}
+
+extern "C" size_t io_colsum_partial_floats(int M, int C) {
+    int nb;
+    rows_per_block(M, &nb);
+    return (size_t)nb * (C + 1);
+}
+
+extern "C" int io_colsum(const float* x, int M, int C, float* out, float* partial, size_t partial_floats,
+                         hipStream_t st) {
+    IO_REQUIRE(C >= 1 && C <= kThreads && kThreads % C == 0 && M > 0, IO_ERR_SHAPE, "colsum: C=%d must divide %d", C,
+               kThreads);
+    int nb;
+    const int rpb = rows_per_block(M, &nb);
+    IO_REQUIRE(partial_floats >= (size_t)nb * C, IO_ERR_WORKSPACE, "colsum: workspace %zu < %zu floats", partial_floats,
+               (size_t)nb * C);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C, st);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kThreads), 0, st, x, M, C, rpb, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C, C, out);
+    return io_check_launch("colsum");
+}
+
+extern "C" int io_head1_fwd(const float* x, int M, int pitch, int C, const float* w, const float* b, int relu,
+                            float* out, hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && C <= 64 && pitch % 4 == 0 && pitch >= C && pitch <= 64 && M > 0, IO_ERR_SHAPE,
+               "head1: C=%d pitch=%d (C <= pitch <= 64, multiples of 4)", C, pitch);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * M * C, 4.0 * M * (pitch + 1), st);
+    hipLaunchKernelGGL(head1_fwd_kernel, dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, st, x, M, pitch, C, w, b, relu,
+                       out);
+    return io_check_launch("head1_fwd");
+}
+
+extern "C" int io_head1_bwd(const float* dy, const float* out, const float* x, int M, int pitch, int C, const float* w,
+                            int relu, float* dx, float* dw, float* db, float* partial, size_t partial_floats,
+                            hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && C <= 64 && pitch % 4 == 0 && pitch >= C && pitch <= 64 && M > 0, IO_ERR_SHAPE,
+               "head1: C=%d pitch=%d (C <= pitch <= 64, multiples of 4)", C, pitch);
+    int nb;
+    const int rpb = rows_per_block(M, &nb);
+    IO_REQUIRE(partial_floats >= (size_t)nb * (C + 1), IO_ERR_WORKSPACE, "head1_bwd: workspace %zu < %zu floats",
+               partial_floats, (size_t)nb * (C + 1));
+    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * M * C, 4.0 * M * (2.0 * pitch + 2), st);
+    hipLaunchKernelGGL(head1_bwd_kernel, dim3(nb), dim3(kThreads), 0, st, dy, out, x, M, pitch, C, w, relu, rpb, dx,
+                       partial);
+    // the per-block sums are [nb][C+1]: column sums give dw[0..C) and db
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C + 1, C, dw);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, st, partial + C, nb, C + 1, 1, db);
+    return io_check_launch("head1_bwd");
+}

@@ -85,6 +85,8 @@ struct IoConvGeom {
     int dh0, dhs, dw0, dws;   // dh = dh0 + dhs*th ; dw = dw0 + dws*tw
     int r0, rs, s0, ss;       // filter tap (r,s) = (r0+rs*th, s0+ss*tw)
     int S, wT;           // filter width S and total taps wT=R*S: weights [Co][wT][Ci]
+    int gw;              // 0: dense.  > 0: grouped convolution run as a block-diagonal one: output channels
+                         // [t*gw, (t+1)*gw) read only input channels [t*gw, (t+1)*gw); weights [Co][wT][gw]
     IoFastDiv fd_howo, fd_wo;   // division by Ho*Wo and by Wo (filled by io_geom_finish)
 };
 static inline void io_geom_finish(IoConvGeom& g) {
@@ -149,7 +151,7 @@ IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,
-                 const IoBwStats* bw = nullptr, int dt = IO_F32);
+                 const IoBwStats* bw = nullptr, int dt = IO_F32, int gw = 0);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench / profiling) ----
 enum IoProfClass {

@@ -1,0 +1,117 @@
+"""Kernels of the MiDaS branch against fp64 torch ops: grouped 3x3 convolution of ResNeXt
+(forward / data gradient / filter gradient through the block-diagonal window form), bilinear x2 (both align_corners
+modes, forward + adjoint), bias / ReLU / add / column sums, and the one-channel head."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from instaorder_amd import _lib
+from test_gpu_ops import L, P, ST, nhwc, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(t):
+    return t.float().to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("C,cg,H,stride", [(256, 8, 12, 1), (512, 16, 10, 2), (1024, 32, 6, 1), (2048, 64, 6, 2),
+                                           (128, 4, 9, 1)])
+def test_grouped_conv3x3(C, cg, H, stride):
+    N, groups = 3, C // cg
+    g = torch.Generator().manual_seed(C + cg)
+    x = torch.randn(N, C, H, H, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(C, cg, 3, 3, generator=g, dtype=torch.float64) / np.sqrt(9 * cg)).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=1, groups=groups)
+    Ho = y.shape[2]
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    wd = dev(w.detach().reshape(C, cg, 9))
+    wc = torch.empty(C, 9, 64, device=DEV)
+    wtc = torch.empty(C, 9, 64, device=DEV)
+    _lib.check(L().io_gconv_pack(P(wd), C, cg, 9, P(wc), P(wtc), ST()), "pack")
+    xd = dev(x.detach().permute(0, 2, 3, 1))
+    yd = torch.empty(N, Ho, Ho, C, device=DEV)
+    _lib.check(L().io_gconv2d_fwd(P(xd), P(wc), P(yd), N, H, H, C, 3, 3, stride, 1, ST()), "fwd")
+    assert relerr(yd.permute(0, 3, 1, 2), y.detach()) < 2e-6
+    dyd = dev(dy.permute(0, 2, 3, 1))
+    dxd = torch.empty(N, H, H, C, device=DEV)
+    _lib.check(L().io_gconv2d_dgrad(P(dyd), P(wtc), P(dxd), N, H, H, C, 3, 3, stride, 1, ST()), "dgrad")
+    assert relerr(dxd.permute(0, 3, 1, 2), gx) < 2e-6
+    nb = L().io_gconv2d_wgrad_workspace_bytes(N, H, H, C, 3, 3, stride, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dwc = torch.empty(C, 9, 64, device=DEV)
+    _lib.check(L().io_gconv2d_wgrad(P(xd), P(dyd), P(dwc), N, H, H, C, 3, 3, stride, 1, P(ws), nb, ST()), "wgrad")
+    dw = torch.empty(C, cg, 9, device=DEV)
+    _lib.check(L().io_gconv_unpack_grad(P(dwc), C, cg, 9, P(dw), ST()), "unpack")
+    assert relerr(dw.view(C, cg, 3, 3), gw) < 2e-6
+
+
+@pytest.mark.parametrize("align", [0, 1])
+@pytest.mark.parametrize("N,H,W,C", [(2, 6, 6, 256), (1, 3, 5, 8), (2, 1, 4, 64)])
+def test_upsample2x_bilinear(N, H, W, C, align):
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=bool(align))
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gx, = torch.autograd.grad(y, [x], dy)
+    xd = dev(x.detach().permute(0, 2, 3, 1))
+    out = torch.empty(N, 2 * H, 2 * W, C, device=DEV)
+    _lib.check(L().io_upsample2x_bilinear_fwd(P(xd), N, H, W, C, align, P(out), ST()), "up fwd")
+    assert relerr(out.permute(0, 3, 1, 2), y.detach()) < 1e-6
+    dx = torch.empty(N, H, W, C, device=DEV)
+    _lib.check(L().io_upsample2x_bilinear_bwd(P(dev(dy.permute(0, 2, 3, 1))), N, H, W, C, align, P(dx), ST()), "up bwd")
+    assert relerr(dx.permute(0, 3, 1, 2), gx) < 1e-6
+
+
+def test_bias_relu_add_colsum():
+    M, C = 3000, 128
+    g = torch.Generator().manual_seed(1)
+    x, b = torch.randn(M, C, generator=g), torch.randn(C, generator=g)
+    xd, bd = dev(x), dev(b)
+    out = torch.empty(M, C, device=DEV)
+    _lib.check(L().io_bias_act(P(xd), P(bd), M, C, 1, P(out), ST()), "bias_act")
+    assert torch.equal(out.cpu(), torch.relu(x + b))
+    _lib.check(L().io_bias_act(P(xd), None, M, C, 1, P(out), ST()), "relu")
+    assert torch.equal(out.cpu(), torch.relu(x))
+    dy = torch.randn(M, C, generator=g)
+    dx = torch.empty(M, C, device=DEV)
+    _lib.check(L().io_relu_bwd(P(dev(dy)), P(out), M * C, P(dx), ST()), "relu_bwd")
+    assert torch.equal(dx.cpu(), dy * (x > 0))
+    _lib.check(L().io_add(P(xd), P(dev(dy)), M * C, P(dx), ST()), "add")
+    assert torch.equal(dx.cpu(), x + dy)
+    for Cc in (32, 128, 256):
+        v = torch.randn(M, Cc, generator=g)
+        npart = L().io_colsum_partial_floats(M, Cc)
+        part = torch.empty(npart, device=DEV)
+        s = torch.empty(Cc, device=DEV)
+        _lib.check(L().io_colsum(P(dev(v)), M, Cc, P(s), P(part), npart, ST()), "colsum")
+        assert relerr(s, v.double().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_head_one_channel(relu):
+    M, C, pitch = 5000, 32, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, pitch, generator=g, dtype=torch.float64)
+    w = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(1, generator=g, dtype=torch.float64).requires_grad_(True)
+    xr = x[:, :C].clone().requires_grad_(True)
+    z = xr @ w + b
+    y = torch.relu(z) if relu else z
+    dy = torch.randn(M, generator=g, dtype=torch.float64)
+    gx, gw, gb = torch.autograd.grad(y, [xr, w, b], dy)
+    xd = dev(x)
+    out = torch.empty(M, device=DEV)
+    _lib.check(L().io_head1_fwd(P(xd), M, pitch, C, P(dev(w.detach())), P(dev(b.detach())), relu, P(out), ST()), "head fwd")
+    assert relerr(out, y.detach()) < 1e-6
+    npart = L().io_colsum_partial_floats(M, C)
+    part = torch.empty(npart, device=DEV)
+    dx = torch.full((M, pitch), 7.0, device=DEV)
+    dw, db = torch.empty(C, device=DEV), torch.empty(1, device=DEV)
+    _lib.check(L().io_head1_bwd(P(dev(dy)), P(out), P(xd), M, pitch, C, P(dev(w.detach())), relu, P(dx), P(dw), P(db), P(part),
+                                npart, ST()), "head bwd")
+    assert relerr(dx[:, :C], gx) < 1e-6 and float(dx[:, C:].abs().max()) == 0.0
+    assert relerr(dw, gw) < 1e-5 and relerr(db, gb) < 1e-5
