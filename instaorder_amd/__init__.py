@@ -3,6 +3,7 @@
 Public surface mirrors the reference's ``models`` / ``utils`` packages for this path:
 
     from instaorder_amd import InstaOrderNet_o, InstaOrderNet_od, InstaOrderNet_d, OrderNet
+    from instaorder_amd import InstaDepthNet_od, InstaDepthNet_d       # MiDaS-based nets (midas_net.py)
     from instaorder_amd import backbone            # backbone.resnet50_cls
     from instaorder_amd import utils               # DistModule, average_gradients, StepLRScheduler, ...
 
@@ -16,7 +17,8 @@ from . import synthetic  # noqa: F401  (numpy only)
 
 def __getattr__(name):
     # lazy: keeps `import instaorder_amd.synthetic` usable where torch/ctypes setup is unwanted
-    if name in ("InstaOrderNet_o", "InstaOrderNet_od", "InstaOrderNet_d", "OrderNet"):
+    if name in ("InstaOrderNet_o", "InstaOrderNet_od", "InstaOrderNet_d", "OrderNet", "InstaDepthNet_od",
+                "InstaDepthNet_d"):
         from . import supervised_order
         return getattr(supervised_order, name)
     if name == "SingleStageModel":

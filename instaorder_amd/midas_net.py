@@ -1,0 +1,261 @@
+"""MI355X-native InstaDepthNet_od / InstaDepthNet_d -- host-side mirror of midas/midas_net.py:14-212 and
+midas/blocks.py:5-195 (BASELINE configs[4]).
+
+Same constructor surface, same ``forward(img, mask1, mask2) -> (disp[B,H,W], depth_order[B,3], occ_order[B,2] | None)``
+and the same ``state_dict`` keys / OIHW shapes as the reference modules (including the duplicate keys the reference
+gets from re-using ``conv1`` / ``bn1`` inside ``layer1 = nn.Sequential(conv1, bn1, relu, maxpool, layer1)``), so
+checkpoints interchange.  The arithmetic is ``instaorder_amd.ops`` (HIP kernels, NHWC fp32) op by op: the ResNeXt-101
+32x8d encoder with its grouped 3x3 convolutions, the RefineNet decoder, and the two ResNet-50 order branches with
+feature injection.  The encoder of ``torch.hub``'s ``resnext101_32x8d_wsl`` is torchvision's ResNeXt-101 32x8d, i.e.
+the reference's own ``resnext101_32x8d`` (resnet_cls.py:309-320).
+
+Reference quirk kept on purpose: ``ResidualConvUnit`` applies an IN-PLACE ReLU to its input (midas/blocks.py:151), so
+its skip connection adds relu(x), not x.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import common_utils, ops
+
+__all__ = ["InstaDepthNet_od", "InstaDepthNet_d"]
+
+
+class Conv2d(nn.Module):
+    """Parameter holder with nn.Conv2d's names, shapes and default init; computation in ops.conv2d (+ bias)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=False, groups=1, co_pad=False):
+        super(Conv2d, self).__init__()
+        self.stride, self.padding, self.groups, self.co_pad = stride, padding, groups, co_pad
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(cin // groups * k * k)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, relu=False):
+        y = ops.conv2d(x, self.weight, self.stride, self.padding, self.groups, self.co_pad)
+        if self.bias is not None or relu:
+            y = ops.bias_act(y, self.bias, relu)
+        return y
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, c):
+        super(BatchNorm2d, self).__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+
+    def forward(self, x, relu=False, identity=None):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
+                              identity)
+
+
+class _Fn(nn.Module):
+    """Parameter-free stage of an nn.Sequential (keeps the reference's child indices)."""
+
+    def __init__(self, fn):
+        super(_Fn, self).__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x)
+
+
+class Bottleneck(nn.Module):
+    """resnet_cls.py:75-116 with groups / base_width."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64):
+        super(Bottleneck, self).__init__()
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = Conv2d(inplanes, width, 1)
+        self.bn1 = BatchNorm2d(width)
+        self.conv2 = Conv2d(width, width, 3, stride, 1, groups=groups)
+        self.bn2 = BatchNorm2d(width)
+        self.conv3 = Conv2d(width, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        identity = x
+        if self.downsample is not None:
+            identity = self.downsample[1](self.downsample[0](x))
+        return self.bn3(self.conv3(out), relu=True, identity=identity)
+
+
+def _make_layer(inplanes, planes, blocks, stride, groups, base_width):
+    downsample = None
+    if stride != 1 or inplanes != planes * 4:
+        downsample = nn.Sequential(Conv2d(inplanes, planes * 4, 1, stride), BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, downsample, groups, base_width)]
+    for _ in range(1, blocks):
+        layers.append(Bottleneck(planes * 4, planes, 1, None, groups, base_width))
+    return nn.Sequential(*layers)
+
+
+class _Trunk(nn.Module):
+    """The four stages of a (grouped) ResNet as midas/blocks.py:71-82 arranges them:
+    layer1 = Sequential(conv1, bn1, relu, maxpool, layer1), layer2..4.  ``conv1`` / ``bn1`` / ``fc`` are also
+    registered at top level when ``keep_stem_names`` (the reference's do_net / oo_net / gdo_net keep them)."""
+
+    def __init__(self, in_channels, layers, groups, base_width, keep_stem_names, num_classes=None):
+        super(_Trunk, self).__init__()
+        conv1 = Conv2d(in_channels, 64, 7, 2, 3)
+        bn1 = BatchNorm2d(64)
+        if keep_stem_names:
+            self.conv1, self.bn1 = conv1, bn1
+        l1 = _make_layer(64, 64, layers[0], 1, groups, base_width)
+        self.layer1 = nn.Sequential(conv1, bn1, _Fn(lambda x: x), _Fn(ops.max_pool_3x3s2), l1)
+        self.layer2 = _make_layer(256, 128, layers[1], 2, groups, base_width)
+        self.layer3 = _make_layer(512, 256, layers[2], 2, groups, base_width)
+        self.layer4 = _make_layer(1024, 512, layers[3], 2, groups, base_width)
+        if num_classes is not None:
+            self.fc = nn.Linear(2048, num_classes)      # present (unused) in the reference's order branches
+        for m in self.modules():                          # resnet_cls.py:162-167
+            if isinstance(m, Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def run_layer1(self, x8):
+        seq = self.layer1
+        y = seq[1](seq[0](x8), relu=True)
+        return seq[4](seq[3](y))
+
+
+class ResidualConvUnit(nn.Module):
+    """midas/blocks.py:121-160 (skip connection carries relu(x): the reference's ReLU is in-place)."""
+
+    def __init__(self, features):
+        super(ResidualConvUnit, self).__init__()
+        self.conv1 = Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv2 = Conv2d(features, features, 3, 1, 1, bias=True)
+
+    def forward(self, x):
+        r = ops.relu(x)
+        out = self.conv1(r, relu=True)
+        out = self.conv2(out)
+        return ops.add(out, r)
+
+
+class FeatureFusionBlock(nn.Module):
+    """midas/blocks.py:163-195."""
+
+    def __init__(self, features):
+        super(FeatureFusionBlock, self).__init__()
+        self.resConfUnit1 = ResidualConvUnit(features)
+        self.resConfUnit2 = ResidualConvUnit(features)
+
+    def forward(self, *xs):
+        output = xs[0]
+        if len(xs) == 2:
+            output = ops.add(output, self.resConfUnit1(xs[1]))
+        output = self.resConfUnit2(output)
+        return ops.upsample2x(output, True)
+
+
+class _Scratch(nn.Module):
+    pass
+
+
+class _InstaDepthBase(nn.Module):
+    def __init__(self, path=None, features=256, non_negative=True):
+        super(_InstaDepthBase, self).__init__()
+        # encoder: ResNeXt-101 32x8d (midas/blocks.py:5-8, 85-87)
+        self.pretrained = _Trunk(3, [3, 4, 23, 3], 32, 8, keep_stem_names=False)
+        self.scratch = _Scratch()
+        for i, c in enumerate([256, 512, 1024, 2048]):                       # midas/blocks.py:19-45
+            setattr(self.scratch, "layer%d_rn" % (i + 1), Conv2d(c, features, 3, 1, 1))
+        for i in (4, 3, 2, 1):
+            setattr(self.scratch, "refinenet%d" % i, FeatureFusionBlock(features))
+        self.non_negative = non_negative
+        self.scratch.output_conv = nn.Sequential(                              # midas_net.py:134-141
+            Conv2d(features, 128, 3, 1, 1, bias=True),
+            _Fn(lambda x: ops.upsample2x(x, False)),
+            Conv2d(128, 32, 3, 1, 1, bias=True, co_pad=True),
+            _Fn(lambda x: x),
+            Conv2d(32, 1, 1, 1, 0, bias=True),
+            _Fn(lambda x: x),
+        )
+        if path:
+            self.load(path)
+
+    def load(self, path):
+        """midas/base_model.py:5-15."""
+        parameters = torch.load(path, map_location=torch.device("cpu"))
+        if "optimizer" in parameters:
+            parameters = parameters["model"]
+        self.load_state_dict(parameters, strict=False)
+
+    def _order_branch(self, net, fc, x8m, l1, l2, l3):
+        f1 = net.run_layer1(x8m)
+        f2 = net.layer2(ops.add(f1, l1))
+        f3 = net.layer3(ops.add(f2, l2))
+        f4 = net.layer4(ops.add(f3, l3))
+        return ops.avgpool_fc(f4, fc.weight, fc.bias)
+
+    def _encode_decode(self, img):
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise ValueError("expected img [B,3,H,W], got %s" % (tuple(img.shape),))
+        if not img.is_cuda:
+            raise RuntimeError("instaorder_amd: input must be on the GPU; there is no CPU fallback")
+        p, s = self.pretrained, self.scratch
+        x8 = ops.nhwc_from_nchw(img.float(), pad_to=8)
+        l1 = p.run_layer1(x8)
+        l2 = p.layer2(l1)
+        l3 = p.layer3(l2)
+        l4 = p.layer4(l3)
+        path4 = s.refinenet4(s.layer4_rn(l4))
+        path3 = s.refinenet3(path4, s.layer3_rn(l3))
+        path2 = s.refinenet2(path3, s.layer2_rn(l2))
+        path1 = s.refinenet1(path2, s.layer1_rn(l1))
+        oc = s.output_conv
+        y = oc[0](path1)
+        y = oc[1](y)
+        y = oc[2](y, relu=True)                         # 32 real + 32 zero channels
+        disp = ops.head1(y, oc[4].weight, oc[4].bias, self.non_negative)
+        return disp, (l1, l2, l3)
+
+
+class InstaDepthNet_od(_InstaDepthBase):
+    """midas_net.py:116-212: disparity + depth-order head + occlusion-order head."""
+
+    def __init__(self, path=None, features=256, depth_num_classes=3, occ_num_classes=2, non_negative=True):
+        super(InstaDepthNet_od, self).__init__(path, features, non_negative)
+        self.do_net = _Trunk(2, [3, 4, 6, 3], 1, 64, keep_stem_names=True, num_classes=depth_num_classes)
+        self.depth_fc = nn.Linear(2048, depth_num_classes)
+        self.oo_net = _Trunk(2, [3, 4, 6, 3], 1, 64, keep_stem_names=True, num_classes=occ_num_classes)
+        self.occ_fc = nn.Linear(2048, occ_num_classes)
+        common_utils.init_weights(self.do_net, init_type="xavier")
+        common_utils.init_weights(self.oo_net, init_type="xavier")
+
+    def forward(self, img, mask1, mask2):
+        disp, (l1, l2, l3) = self._encode_decode(img)
+        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8)
+        depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
+        occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
+        return disp, depth_order, occ_order
+
+
+class InstaDepthNet_d(_InstaDepthBase):
+    """midas_net.py:14-113: disparity + geometric depth-order head."""
+
+    def __init__(self, path=None, features=256, depth_num_classes=3, occ_num_classes=2, non_negative=True):
+        super(InstaDepthNet_d, self).__init__(path, features, non_negative)
+        self.gdo_net = _Trunk(2, [3, 4, 6, 3], 1, 64, keep_stem_names=True, num_classes=3)
+        self.fc = nn.Linear(2048, depth_num_classes)
+        common_utils.init_weights(self.gdo_net, init_type="xavier")
+
+    def forward(self, img, mask1, mask2):
+        disp, (l1, l2, l3) = self._encode_decode(img)
+        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8)
+        depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+        return disp, depth_order, None

@@ -1,0 +1,380 @@
+"""Operator layer for graphs the fixed ResNet-50 executor (io_net_*) does not cover -- today the MiDaS branch
+(InstaDepthNet_od / _d, midas/midas_net.py:116-212).  Every function is a ``torch.autograd.Function`` whose forward
+and backward are launches of libinstaorder_hip.so on **NHWC fp32** tensors; torch supplies memory, streams and the
+autograd tape only.  Filters are taken in the reference's OIHW layout (what ``state_dict`` holds) and re-laid out to
+the kernels' [Cout][taps][Cin] once per call.
+
+There is no CPU path: inputs must live on an MI355X.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+__all__ = ["conv2d", "batch_norm", "max_pool_3x3s2", "avgpool_fc", "upsample2x", "bias_act", "relu", "add", "head1",
+           "nhwc_from_nchw", "nchw_from_nhwc"]
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _L():
+    _lib.require_gpu()
+    return _lib.lib()
+
+
+def _chk(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError("instaorder_amd.ops: %s must be a contiguous fp32 tensor on the GPU (no CPU fallback)" % name)
+
+
+def nhwc_from_nchw(x, pad_to=None):
+    """[N,C,H,W] -> contiguous [N,H,W,C'] (C' = pad_to, zero filled, for the 8-channel stems)."""
+    N, Cc, H, W = x.shape
+    if pad_to is not None and pad_to != Cc:
+        out = torch.zeros((N, H, W, pad_to), device=x.device, dtype=x.dtype)
+        out[..., :Cc] = x.permute(0, 2, 3, 1)
+        return out
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw_from_nhwc(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ---- convolution -------------------------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    """Dense convolution (models/backbone/resnet_cls.py:23-31, midas/blocks.py:27-38, 133-139).  x[N,H,W,Ci'] where
+    Ci' >= Ci is the stored channel count (8 for the 3- / 2-channel stems); w OIHW [Co,Ci,R,S].  Output channels are
+    padded to a multiple of 64 when `co_pad` (the 128 -> 32 convolution of output_conv): the extra channels are 0."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, co_pad):
+        _chk(x, "x")
+        N, H, W_, Cs = x.shape
+        Co, Ci, R, S = w.shape
+        Cop = ((Co + 63) // 64) * 64 if co_pad else Co
+        wk = torch.zeros((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
+        wk[:Co, :, :Ci] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Ci)
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
+        y = torch.empty((N, Ho, Wo, Cop), device=x.device, dtype=torch.float32)
+        _lib.check(_L().io_conv2d_fwd(_p(x), _p(wk), _p(y), N, H, W_, Cs, Cop, R, S, stride, pad, _st()), "io_conv2d_fwd")
+        ctx.save_for_backward(x, wk)
+        ctx.geom = (N, H, W_, Cs, Cop, Co, Ci, R, S, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wk = ctx.saved_tensors
+        N, H, W_, Cs, Cop, Co, Ci, R, S, stride, pad = ctx.geom
+        dy = dy.contiguous()
+        L = _L()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if Cs == 8:
+                raise RuntimeError("ops.conv2d: no data gradient for the packed 8-channel stem input")
+            wt = torch.empty((Cs, R * S, Cop), device=x.device, dtype=torch.float32)
+            _lib.check(L.io_filter_transpose(_p(wk), Cop, R * S, Cs, _p(wt), _st()), "io_filter_transpose")
+            dx = torch.empty_like(x)
+            _lib.check(L.io_conv2d_dgrad(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Cop, R, S, stride, pad, _st()),
+                       "io_conv2d_dgrad")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Cop, R, S, stride, pad))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
+            dwk = torch.empty((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
+            _lib.check(L.io_conv2d_wgrad(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Cop, R, S, stride, pad, _p(ws), nb, _st()),
+                       "io_conv2d_wgrad")
+            dw = dwk[:Co, :, :Ci].reshape(Co, R, S, Ci).permute(0, 3, 1, 2).contiguous()
+        return dx, dw, None, None, None
+
+
+class _GroupedConv(torch.autograd.Function):
+    """Grouped 3x3 convolution of ResNeXt (resnet_cls.py:23-26 with groups=32): w OIHW [C, C/groups, R, S]."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        _chk(x, "x")
+        N, H, W_, Cc = x.shape
+        Co, cg, R, S = w.shape
+        if Co != Cc:
+            raise ValueError("grouped conv: Cin must equal Cout")
+        L = _L()
+        wc = torch.empty((Cc, R * S, 64), device=x.device, dtype=torch.float32)
+        wtc = torch.empty_like(wc)
+        _lib.check(L.io_gconv_pack(_p(w.detach().contiguous()), Cc, cg, R * S, _p(wc), _p(wtc), _st()), "io_gconv_pack")
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
+        y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(L.io_gconv2d_fwd(_p(x), _p(wc), _p(y), N, H, W_, Cc, R, S, stride, pad, _st()), "io_gconv2d_fwd")
+        ctx.save_for_backward(x, wtc)
+        ctx.geom = (N, H, W_, Cc, cg, R, S, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wtc = ctx.saved_tensors
+        N, H, W_, Cc, cg, R, S, stride, pad = ctx.geom
+        dy = dy.contiguous()
+        L = _L()
+        dx = torch.empty_like(x)
+        _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wtc), _p(dx), N, H, W_, Cc, R, S, stride, pad, _st()), "io_gconv2d_dgrad")
+        nb = int(L.io_gconv2d_wgrad_workspace_bytes(N, H, W_, Cc, R, S, stride, pad))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
+        dwc = torch.empty((Cc, R * S, 64), device=x.device, dtype=torch.float32)
+        _lib.check(L.io_gconv2d_wgrad(_p(x), _p(dy), _p(dwc), N, H, W_, Cc, R, S, stride, pad, _p(ws), nb, _st()),
+                   "io_gconv2d_wgrad")
+        dw = torch.empty((Cc, cg, R, S), device=x.device, dtype=torch.float32)
+        _lib.check(L.io_gconv_unpack_grad(_p(dwc), Cc, cg, R * S, _p(dw), _st()), "io_gconv_unpack_grad")
+        return dx, dw, None, None
+
+
+def conv2d(x, w, stride=1, pad=0, groups=1, co_pad=False):
+    if groups == 1:
+        return _Conv.apply(x, w, stride, pad, co_pad)
+    if w.shape[0] // groups != w.shape[1]:
+        raise ValueError("grouped conv: expected [C, C/groups, R, S] filters")
+    return _GroupedConv.apply(x, w, stride, pad)
+
+
+# ---- BatchNorm (+ residual add) (+ ReLU) ---------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    """nn.BatchNorm2d (+ `out += identity`) (+ nn.ReLU) of resnet_cls.py:96-116.  Training: batch statistics, running
+    estimates advanced in place (momentum 0.1, unbiased variance); eval: running estimates."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, identity):
+        _chk(x, "x")
+        L = _L()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        dev = x.device
+        mean, rstd, scale, shift = (torch.empty(Cc, device=dev) for _ in range(4))
+        if training:
+            npart = int(L.io_bn_partial_floats(M, Cc, 1))
+            part = torch.empty(npart, device=dev)
+            _lib.check(L.io_bn_stats_finalize(_p(x), M, Cc, 1, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
+                                              _p(running_var), 0.1, 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift), _p(part),
+                                              npart, _st()), "io_bn_stats_finalize")
+        else:
+            _lib.check(L.io_bn_eval_prepare(Cc, _p(gamma.detach()), _p(beta.detach()), _p(running_mean), _p(running_var),
+                                            1e-5, _p(mean), _p(scale), _p(shift), _st()), "io_bn_eval_prepare")
+            rstd = scale / gamma.detach()
+        out = torch.empty_like(x)
+        _lib.check(L.io_bn_apply(_p(x), M, Cc, 1, 0, _p(mean), _p(scale), _p(shift), _p(identity), None, None, None,
+                                 int(relu), _p(out), _st()), "io_bn_apply")
+        ctx.save_for_backward(x, out, gamma, mean, rstd)
+        ctx.cfg = (M, Cc, bool(relu), identity is not None, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, gamma, mean, rstd = ctx.saved_tensors
+        M, Cc, relu, has_id, training = ctx.cfg
+        if not training:
+            raise RuntimeError("ops.batch_norm: backward through eval-mode BatchNorm is not implemented")
+        L = _L()
+        dout = dout.contiguous()
+        dev = x.device
+        npart = int(L.io_bn_partial_floats(M, Cc, 1))
+        part = torch.empty(npart, device=dev)
+        coef = torch.empty(2 * Cc, device=dev)
+        dgamma, dbeta = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        dx = torch.empty_like(x)
+        dz = torch.empty_like(x) if has_id else None          # gradient of the pre-ReLU sum = gradient of `identity`
+        _lib.check(L.io_bn_bwd(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, 1, _p(gamma.detach()), _p(mean),
+                               _p(rstd), _p(dgamma), _p(dbeta), _p(dx), _p(dz), _p(part), npart, _p(coef), _st()),
+                   "io_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, dz
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, relu=False, identity=None):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, relu, identity)
+
+
+# ---- pooling / heads --------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "x")
+        N, H, W_, Cc = x.shape
+        Ho, Wo = (H + 1) // 2, (W_ + 1) // 2
+        out = torch.empty((N, Ho, Wo, Cc), device=x.device)
+        idx = torch.empty((N, Ho, Wo, Cc // 4), dtype=torch.int32, device=x.device)
+        _lib.check(_L().io_maxpool_fwd(_p(x), N, H, W_, Cc, _p(out), _p(idx), _st()), "io_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, H, W_, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, H, W_, Cc = ctx.geom
+        dx = torch.empty((N, H, W_, Cc), device=dy.device)
+        _lib.check(_L().io_maxpool_bwd(_p(dy.contiguous()), _p(idx), N, H, W_, Cc, _p(dx), _st()), "io_maxpool_bwd")
+        return dx
+
+
+def max_pool_3x3s2(x):
+    """nn.MaxPool2d(3, 2, 1) (resnet_cls.py:144)."""
+    return _MaxPool.apply(x)
+
+
+class _AvgPoolFc(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) + flatten + nn.Linear (midas_net.py:195-197, 205-207)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(x, "x")
+        N, H, W_, Cc = x.shape
+        K = w.shape[0]
+        pooled = torch.empty((N, Cc), device=x.device)
+        logits = torch.empty((N, K), device=x.device)
+        wd, bd = w.detach().contiguous(), b.detach().contiguous()
+        _lib.check(_L().io_avgpool_fc_fwd(_p(x), N, H * W_, Cc, _p(wd), _p(bd), K, None, None, 0, _p(pooled), _p(logits),
+                                          _st()), "io_avgpool_fc_fwd")
+        ctx.save_for_backward(pooled, wd)
+        ctx.geom = (N, H, W_, Cc, K)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pooled, wd = ctx.saved_tensors
+        N, H, W_, Cc, K = ctx.geom
+        dx = torch.empty((N, H, W_, Cc), device=pooled.device)
+        dw, db = torch.empty((K, Cc), device=pooled.device), torch.empty(K, device=pooled.device)
+        _lib.check(_L().io_avgpool_fc_bwd(_p(dlogits.contiguous()), _p(pooled), N, H * W_, Cc, _p(wd), K, None, 0, None,
+                                          _p(dx), _p(dw), _p(db), None, None, _st()), "io_avgpool_fc_bwd")
+        return dx, dw, db
+
+
+def avgpool_fc(x, w, b):
+    return _AvgPoolFc.apply(x, w, b)
+
+
+# ---- decoder pieces -----------------------------------------------------------------------------------------------------
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, align):
+        _chk(x, "x")
+        N, H, W_, Cc = x.shape
+        out = torch.empty((N, 2 * H, 2 * W_, Cc), device=x.device)
+        _lib.check(_L().io_upsample2x_bilinear_fwd(_p(x), N, H, W_, Cc, int(align), _p(out), _st()), "io_upsample2x_fwd")
+        ctx.geom = (N, H, W_, Cc, int(align))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, Cc, align = ctx.geom
+        dx = torch.empty((N, H, W_, Cc), device=dy.device)
+        _lib.check(_L().io_upsample2x_bilinear_bwd(_p(dy.contiguous()), N, H, W_, Cc, align, _p(dx), _st()),
+                   "io_upsample2x_bwd")
+        return dx, None
+
+
+def upsample2x(x, align_corners):
+    """nn.functional.interpolate(scale_factor=2, mode='bilinear', align_corners=...) (midas/blocks.py:111-113, 186-188)."""
+    return _Upsample.apply(x, align_corners)
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, relu):
+        _chk(x, "x")
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        out = torch.empty_like(x)
+        bd = None
+        if bias is not None:
+            bd = bias.detach()
+            if bd.numel() != Cc:                       # padded output channels carry no bias
+                bd = torch.cat([bd, torch.zeros(Cc - bd.numel(), device=x.device)])
+        _lib.check(_L().io_bias_act(_p(x), _p(bd), M, Cc, int(relu), _p(out), _st()), "io_bias_act")
+        ctx.save_for_backward(out)
+        ctx.cfg = (M, Cc, bool(relu), None if bias is None else bias.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        out, = ctx.saved_tensors
+        M, Cc, relu, nbias = ctx.cfg
+        L = _L()
+        dy = dy.contiguous()
+        dx = dy
+        if relu:
+            dx = torch.empty_like(dy)
+            _lib.check(L.io_relu_bwd(_p(dy), _p(out), dy.numel(), _p(dx), _st()), "io_relu_bwd")
+        db = None
+        if nbias is not None:
+            npart = int(L.io_colsum_partial_floats(M, Cc))
+            part = torch.empty(npart, device=dy.device)
+            dbf = torch.empty(Cc, device=dy.device)
+            _lib.check(L.io_colsum(_p(dx), M, Cc, _p(dbf), _p(part), npart, _st()), "io_colsum")
+            db = dbf[:nbias].clone()
+        return dx, db, None
+
+
+def bias_act(x, bias=None, relu=False):
+    """[relu](x + bias): the bias of a biased nn.Conv2d and / or nn.ReLU (midas/blocks.py:133-160)."""
+    return _BiasAct.apply(x, bias, relu)
+
+
+def relu(x):
+    return _BiasAct.apply(x, None, True)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, "a")
+        _chk(b, "b")
+        out = torch.empty_like(a)
+        _lib.check(_L().io_add(_p(a), _p(b), a.numel(), _p(out), _st()), "io_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Head1(torch.autograd.Function):
+    """nn.Conv2d(C, 1, 1) [+ nn.ReLU] on an input that may carry padding channels (midas_net.py:139-140)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _chk(x, "x")
+        N, H, W_, pitch = x.shape
+        Cc = w.numel()
+        M = N * H * W_
+        out = torch.empty((N, H, W_), device=x.device)
+        wd, bd = w.detach().reshape(-1).contiguous(), b.detach().reshape(-1).contiguous()
+        _lib.check(_L().io_head1_fwd(_p(x), M, pitch, Cc, _p(wd), _p(bd), int(relu), _p(out), _st()), "io_head1_fwd")
+        ctx.save_for_backward(x, out, wd)
+        ctx.cfg = (M, pitch, Cc, int(relu), tuple(w.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, out, wd = ctx.saved_tensors
+        M, pitch, Cc, relu, wshape = ctx.cfg
+        L = _L()
+        npart = int(L.io_colsum_partial_floats(M, Cc))
+        part = torch.empty(npart, device=x.device)
+        dx = torch.empty_like(x)
+        dw, db = torch.empty(Cc, device=x.device), torch.empty(1, device=x.device)
+        _lib.check(L.io_head1_bwd(_p(dy.contiguous()), _p(out), _p(x), M, pitch, Cc, _p(wd), relu, _p(dx), _p(dw), _p(db),
+                                  _p(part), npart, _st()), "io_head1_bwd")
+        return dx, dw.view(wshape), db, None
+
+
+def head1(x, w, b, relu):
+    return _Head1.apply(x, w, b, relu)

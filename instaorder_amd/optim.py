@@ -76,3 +76,71 @@ class FusedSGD(torch.optim.Optimizer):
                     mb = st.get("momentum_buffer")
                     if mb is not None:
                         self._views[int(i)].copy_(mb)
+
+
+class FlatSGD(torch.optim.Optimizer):
+    """Momentum-SGD for an ordinary module tree (the MiDaS branch): the parameters are moved into ONE flat fp32
+    buffer (each ``nn.Parameter`` becomes a view of it), so the update is the same single HIP launch as FusedSGD;
+    the gradients autograd produced per tensor are gathered into a flat buffer first (that buffer is also what the
+    data-parallel all-reduce runs on).  torch.optim.SGD semantics / state_dict layout as above."""
+
+    def __init__(self, module, lr, momentum=0.9, weight_decay=0.0):
+        params = []
+        seen = set()
+        for p in module.parameters():
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                params.append(p)
+        defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False)
+        super(FlatSGD, self).__init__(params, defaults)
+        self._params = params
+        n = sum(((p.numel() + 63) // 64) * 64 for p in params)
+        dev = params[0].device
+        self.flat_params = torch.zeros(n, device=dev)
+        self.flat_grads = torch.zeros(n, device=dev)
+        self._buf = torch.zeros(n, device=dev)
+        self._spans = []
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_params[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_params[off:off + k].view(p.shape)
+                self._spans.append((off, k))
+                off += ((k + 63) // 64) * 64
+
+    def gather_grads(self):
+        """Per-tensor autograd gradients -> the flat gradient buffer (missing gradients count as zero)."""
+        with torch.no_grad():
+            for p, (off, k) in zip(self._params, self._spans):
+                if p.grad is None:
+                    self.flat_grads[off:off + k].zero_()
+                else:
+                    self.flat_grads[off:off + k].copy_(p.grad.reshape(-1))
+        return self.flat_grads
+
+    @torch.no_grad()
+    def step(self, closure=None, gathered=False):
+        g = self.param_groups[0]
+        if not gathered:
+            self.gather_grads()
+        engine.sgd_momentum(self.flat_params, self.flat_grads, self._buf, g["lr"], g["momentum"], g["weight_decay"])
+        return None
+
+    def state_dict(self):
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self._params)))
+        state = {i: {"momentum_buffer": self._buf[off:off + k].view(p.shape).detach().clone()}
+                 for i, (p, (off, k)) in enumerate(zip(self._params, self._spans))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        with torch.no_grad():
+            for i, st in sd["state"].items():
+                mb = st.get("momentum_buffer")
+                if mb is not None:
+                    off, k = self._spans[int(i)]
+                    self._buf[off:off + k].copy_(mb.reshape(-1))

@@ -3,16 +3,15 @@
 Builds the backbone named by ``params['backbone_arch']`` with ``params['backbone_param']``, applies
 the xavier(0.02) initialisation, places it on the GPU, wraps it (DistModule / FixModule), creates the
 optimiser (``.optim`` is a torch.optim.Optimizer whose lr the scheduler rewrites) and provides the
-checkpoint I/O.  Only the ResNet order networks are in scope; the MiDaS-based
-InstaDepthNet_* variants are the "next" row and raise NotImplementedError.
+checkpoint I/O.  ``InstaDepthNet_od`` / ``InstaDepthNet_d`` build the MiDaS-based nets of midas_net.py.
 """
 import os
 
 import torch
 import torch.distributed as dist
 
-from . import common_utils, distributed_utils, resnet_cls
-from .optim import FusedSGD
+from . import common_utils, distributed_utils, midas_net, resnet_cls
+from .optim import FlatSGD, FusedSGD
 
 _BACKBONES = {"resnet50_cls": resnet_cls.resnet50_cls}
 
@@ -20,14 +19,16 @@ _BACKBONES = {"resnet50_cls": resnet_cls.resnet50_cls}
 class SingleStageModel(object):
     def __init__(self, params, dist_model=False):
         if params["algo"] in ("InstaDepthNet_od", "InstaDepthNet_d"):
-            raise NotImplementedError("{}: MiDaS backbone is outside the MI355X hot path built so far"
-                                      .format(params["algo"]))
-        arch = params["backbone_arch"]
-        if arch not in _BACKBONES:
-            raise KeyError("unknown backbone_arch '{}' (have: {})".format(arch, sorted(_BACKBONES)))
-        # `dtype` is this package's one extension of the config surface: 'fp32' (reference behaviour) | 'bf16'
-        net = _BACKBONES[arch](dtype=params.get("dtype", "fp32"), **params["backbone_param"])
-        common_utils.init_weights(net, init_type="xavier")
+            # single_stage_model.py:17-22: the MiDaS-based nets take only the (optional) pretrained MiDaS weights
+            cls = midas_net.InstaDepthNet_od if params["algo"] == "InstaDepthNet_od" else midas_net.InstaDepthNet_d
+            net = cls(params.get("pretrained_weight"), non_negative=True)
+        else:
+            arch = params["backbone_arch"]
+            if arch not in _BACKBONES:
+                raise KeyError("unknown backbone_arch '{}' (have: {})".format(arch, sorted(_BACKBONES)))
+            # `dtype` is this package's one extension of the config surface: 'fp32' (reference behaviour) | 'bf16'
+            net = _BACKBONES[arch](dtype=params.get("dtype", "fp32"), **params["backbone_param"])
+            common_utils.init_weights(net, init_type="xavier")
         if torch.cuda.is_available():
             net.cuda()
         if dist_model:
@@ -38,7 +39,9 @@ class SingleStageModel(object):
             self.world_size = 1
         self.net = net
 
-        if params["optim"] == "SGD":
+        if params["optim"] == "SGD" and not hasattr(net, "flat_params"):
+            self.optim = FlatSGD(self.model, lr=params["lr"], momentum=0.9, weight_decay=params["weight_decay"])
+        elif params["optim"] == "SGD":
             self.optim = FusedSGD(self.model, lr=params["lr"], momentum=0.9,
                                   weight_decay=params["weight_decay"])
         elif params["optim"] == "Adam":

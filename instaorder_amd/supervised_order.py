@@ -241,3 +241,169 @@ class OrderNet(_OrderBase):
 
     def _loss_args(self, training):
         return dict(depth_target=self._dep_t)
+
+
+# ---- MiDaS-based nets (supervised_order.py:97-367 of the reference) --------------------------------------------------
+def _erode_cross(m):
+    """scipy.ndimage.binary_erosion with its default 3x3 cross structuring element and border_value 0
+    (supervised_order.py:156-157), on a [B,H,W] bool tensor."""
+    z = torch.zeros_like(m)
+    up, down, left, right = z.clone(), z.clone(), z.clone(), z.clone()
+    up[:, 1:] = m[:, :-1]
+    down[:, :-1] = m[:, 1:]
+    left[:, :, 1:] = m[:, :, :-1]
+    right[:, :, :-1] = m[:, :, 1:]
+    return m & up & down & left & right
+
+
+class _DepthBase(SingleStageModel):
+    """Shared machinery of InstaDepthNet_od / InstaDepthNet_d: two directional passes of the MiDaS-based net
+    (HIP operators, instaorder_amd.ops), order-head losses through io_order_loss, and the two disparity losses --
+    edge-aware smoothness (differentiable) and the disparity-order count (a pure count: no gradient, exactly as in
+    the reference) -- as small device-side tensor programs on the [B,1,H,W] disparity maps."""
+    HAS_OCC = False
+
+    def __init__(self, params, load_pretrain=None, dist_model=False):
+        super(_DepthBase, self).__init__(params, dist_model)
+        self.params = params
+        self.use_rgb = params.get("use_rgb", False)
+
+    # inputs ----------------------------------------------------------------------------------------------------------
+    def _set_common(self, rgb, modal1, modal2, depth_order, count, is_overlap):
+        self.rgb = _dev(rgb, torch.float32).contiguous()
+        self.modal1 = _dev(modal1, torch.float32).contiguous()
+        self.modal2 = _dev(modal2, torch.float32).contiguous()
+        self.depth_order1 = _dev(depth_order, torch.long)
+        self.depth_order2 = _mirror_classes(self.depth_order1)
+        self.count = _dev(count)
+        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
+        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0)
+        self.B = self.rgb.shape[0]
+
+    # losses ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def min_max_norm(disp):
+        mn = disp.min(2, True)[0].min(3, True)[0]
+        mx = disp.max(2, True)[0].max(3, True)[0]
+        return (disp - mn) / (mx + 1e-7)
+
+    def get_smooth_loss(self, disp, img):
+        """supervised_order.py:214-235."""
+        disp = self.min_max_norm(disp)
+        mean_disp = disp.mean(2, True).mean(3, True)
+        disp = disp / (mean_disp + 1e-7)
+        gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+        gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+        gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+        giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+        return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
+
+    def _disp_order_count(self, disp1, disp2):
+        """supervised_order.py:152-173 (no gradient flows through these counts in the reference either)."""
+        with torch.no_grad():
+            e1 = _erode_cross(self.modal1[:, 0] != 0)
+            e2 = _erode_cross(self.modal2[:, 0] != 0)
+            total = torch.zeros((), device=disp1.device, dtype=torch.float32)
+            distinct = (self.is_overlap == 0)
+            d1, d2 = disp1[:, 0], disp2[:, 0]
+            # the reference's .max()/.min() of an empty selection would raise; pairs with an empty eroded mask are
+            # skipped here
+            for bb in torch.nonzero(distinct).flatten().tolist():
+                a, b = e1[bb], e2[bb]
+                if not (bool(a.any()) and bool(b.any())):
+                    continue
+                order = int(self.depth_order1[bb])
+                if order not in (0, 1):
+                    continue
+                le = order == self._LE_ORDER
+                for d, flip in ((d1[bb], False), (d2[bb], True)):
+                    use_le = le != flip
+                    if use_le:
+                        total += (d[a] <= d[b].max()).sum() + (d[a].min() <= d[b]).sum()
+                    else:
+                        total += (d[a] >= d[b].max()).sum() + (d[a].min() >= d[b]).sum()
+            return total / float(disp1.shape[2] * disp1.shape[3])
+
+    _LE_ORDER = 0     # both reference classes use `<=` on disp1 when depth_order1 == 0 (supervised_order.py:158-162, 289-293)
+
+    def _run(self, training):
+        net = self.model
+        disp1, dep1, occ1 = net(self.rgb, self.modal1, self.modal2)
+        disp2, dep2, occ2 = net(self.rgb, self.modal2, self.modal1)
+        return disp1.unsqueeze(1), disp2.unsqueeze(1), dep1, dep2, occ1, occ2
+
+    def _losses(self, outs, want_grad):
+        disp1, disp2, dep1, dep2, occ1, occ2 = outs
+        inv = 1.0 / self.world_size
+        p = self.params
+        B = self.B
+        dep = torch.cat([dep1, dep2], 0).contiguous()
+        l_ov, g_ov = engine.order_loss(dep, B, 0, 3, depth_target=self._dep_t, is_overlap=self.is_overlap,
+                                       overlap_weight=p["overlap_weight"], distinct_weight=0.0, inv_world=inv,
+                                       want_grad=want_grad)
+        l_di, g_di = engine.order_loss(dep, B, 0, 3, depth_target=self._dep_t, is_overlap=self.is_overlap,
+                                       overlap_weight=0.0, distinct_weight=p["distinct_weight"], inv_world=inv,
+                                       want_grad=want_grad)
+        loss_overlap, loss_distinct = l_ov[0], l_di[0]
+        heads = [(dep, (g_ov + g_di) if want_grad else None)]
+        loss_occ = 0
+        if self.HAS_OCC and p["occ_order_weight"] != 0:
+            occ = torch.cat([occ1, occ2], 0).contiguous()
+            l_oc, g_oc = engine.order_loss(occ, B, 2, 0, occ_target=self._occ_t, inv_world=inv, want_grad=want_grad)
+            loss_occ = l_oc[0]
+            heads.append((occ, g_oc))
+        loss_smooth = 0
+        if p["smooth_weight"] != 0:
+            loss_smooth = (self.get_smooth_loss(disp1, self.rgb) + self.get_smooth_loss(disp2, self.rgb)) \
+                * p["smooth_weight"] * inv
+        loss_disp_order = 0
+        if p["dorder_weight"] != 0:
+            loss_disp_order = self._disp_order_count(disp1, disp2) * p["dorder_weight"] * inv
+        loss = loss_overlap + loss_distinct + loss_occ + loss_smooth + loss_disp_order
+        logs = {"loss_overlap": loss_overlap, "loss_distinct": loss_distinct}
+        if self.HAS_OCC:
+            logs["loss_occ"] = loss_occ
+        logs["loss_smooth"] = loss_smooth
+        logs["loss_disp_order"] = loss_disp_order
+        return logs, loss, heads, loss_smooth
+
+    # API -------------------------------------------------------------------------------------------------------------
+    def forward_only(self, ret_loss=True):
+        with torch.no_grad():
+            outs = self._run(False)
+            logs, loss, _, _ = self._losses(outs, False)
+        return logs, {"loss": loss}
+
+    def step(self):
+        outs = self._run(True)
+        logs, loss, heads, loss_smooth = self._losses(outs, True)
+        self.optim.zero_grad()
+        roots, grads = [h for h, _ in heads], [g for _, g in heads]
+        if torch.is_tensor(loss_smooth) and loss_smooth.requires_grad:
+            roots.append(loss_smooth)
+            grads.append(torch.ones_like(loss_smooth))
+        torch.autograd.backward(roots, grads)
+        flat = self.optim.gather_grads()
+        if self.world_size > 1:
+            distributed_utils.allreduce_flat(flat)
+        self.optim.step(gathered=True)
+        return logs, {"loss": loss.detach() if torch.is_tensor(loss) else loss}
+
+
+class InstaDepthNet_od(_DepthBase):
+    """supervised_order.py:97-235: disparity + depth order + occlusion order."""
+    HAS_OCC = True
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None,
+                  occ_order=None):
+        self._set_common(rgb, modal1, modal2, depth_order, count, is_overlap)
+        self.occ_order1 = _dev(occ_order, torch.float32)
+        self.occ_order2 = _mirror_occ(self.occ_order1)
+        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+
+
+class InstaDepthNet_d(_DepthBase):
+    """supervised_order.py:239-367: disparity + depth order."""
+
+    def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None):
+        self._set_common(rgb, modal1, modal2, depth_order, count, is_overlap)

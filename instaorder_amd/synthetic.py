@@ -180,3 +180,49 @@ def image_mode_inputs(image, modal, input_size):
     rgb = image.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0)
     rgb = ((rgb - mean) / std)[None]
     return rgb.astype(np.float32), modal.astype(np.float32)
+
+
+# ---- MiDaS-based nets (InstaDepthNet_od / _d) -----------------------------------------------------------------------
+def make_spec_state_dict(seed, spec, prefix=""):
+    """Seeded, well-conditioned values for an arbitrary module: ``spec`` is a list of (key, shape, alias_of) in
+    ``state_dict`` order, alias_of = the first key that shares the tensor (the order branches of InstaDepthNet_*
+    expose conv1 / bn1 under two names) or None.  Filters: N(0, sqrt(2 / fan_in)); the last BatchNorm of every
+    bottleneck (``bn3``) gets weight ~ 0.2 so that rounding noise adds up instead of multiplying through 33 + 16
+    blocks; other BN weights ~ N(1, 0.05); BN biases / conv biases ~ N(0, 0.05); running_mean ~
+    N(0, 0.1), running_var ~ U(0.5, 1.5).  Every tensor has its own RandomState(seed, crc32(key))."""
+    import zlib
+    out = {}
+    for key, shape, alias in spec:
+        if alias is not None:
+            out[prefix + key] = out[prefix + alias]
+            continue
+        rng = np.random.RandomState([seed & 0x7FFFFFFF, zlib.crc32(key.encode()) & 0x7FFFFFFF])
+        shape = tuple(shape)
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            v = np.zeros(shape, dtype=np.int64)
+        elif leaf == "running_mean":
+            v = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif leaf == "running_var":
+            v = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif len(shape) == 2:
+            v = (rng.standard_normal(shape) * np.sqrt(1.0 / shape[1])).astype(np.float32)
+        elif leaf == "weight":          # BatchNorm weight
+            centre = 0.2 if ".bn3." in "." + key else 1.0
+            v = (centre + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+        else:                           # biases
+            v = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        out[prefix + key] = v
+    return out
+
+
+def make_depth_batch(seed, B, S):
+    """Inputs of InstaDepthNet_*.set_input: the pair batch plus what the disparity losses look at (masks with an
+    interior after erosion, is_overlap with both values present)."""
+    b = make_pair_batch(seed, B, S)
+    b["is_overlap"] = (np.arange(B) % 2).astype(np.int64)
+    b["depth_order"] = (np.arange(B) % 3).astype(np.int64)
+    return b

@@ -380,6 +380,82 @@ def case_decisions(tag):
     print(tag, np.array(res_o)[:4].tolist(), np.array(res_od)[:4].tolist())
 
 
+# ---- MiDaS-based nets -----------------------------------------------------------------------------
+DEPTH_LOSS_WEIGHTS = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1,
+                          occ_order_weight=1.0)
+
+
+def case_depthnet(algo, S, B, seed, tag):
+    """InstaDepthNet_od / _d of the unmodified reference: torch.hub.load (network fetch of the un-vendored WSL
+    ResNeXt, midas/blocks.py:85-87) is replaced by the reference's own resnext101_32x8d (same architecture,
+    SURVEY 8(c)); no pretrained MiDaS weights exist here, so weights are synthetic."""
+    from models.backbone import resnet_cls as ref_resnet
+    torch.hub.load = lambda repo, name, **kw: ref_resnet.resnext101_32x8d(in_channels=3)
+    import models
+    cfg = model_cfg(algo)
+    cfg["pretrained_weight"] = None
+    cfg.update(DEPTH_LOSS_WEIGHTS)
+    cfg["lr"] = 1e-3
+    m = getattr(models, algo)(cfg, dist_model=True)
+    ref_sd = m.model.state_dict()
+    first, spec = {}, []
+    for k, v in ref_sd.items():
+        kk = k[len("module."):]
+        ptr = v.data_ptr() if v.numel() else id(v)
+        alias = first.get(ptr) if v.dim() > 0 else None
+        if alias is None and v.dim() > 0:
+            first[ptr] = kk
+        spec.append((kk, tuple(v.shape), alias))
+    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    out = {"keys": np.array([k for k, _, _ in spec]),
+           "shapes": np.array([",".join(str(d) for d in sh) for _, sh, _ in spec]),
+           "aliases": np.array([a or "" for _, _, a in spec])}
+    batch = synthetic.make_depth_batch(seed + 100, B, S)
+    t = {k: torch.from_numpy(v.copy()) for k, v in batch.items()}
+
+    def feed():
+        if algo == "InstaDepthNet_od":
+            m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+        else:
+            m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"])
+
+    m.switch_to("eval")
+    with torch.no_grad():
+        d, dep, occ = m.model(t["rgb"], t["modal1"], t["modal2"])
+    out["eval_disp"], out["eval_dep"] = d.numpy(), dep.numpy()
+    if occ is not None:
+        out["eval_occ"] = occ.numpy()
+    feed()
+    logs, l = m.forward_only()
+    for k, v in logs.items():
+        out["evalfo_" + k] = np.float64(float(v))
+    out["evalfo_loss"] = np.float64(float(l["loss"]))
+    m.switch_to("train")
+    feed()
+    logs, l = m.step()
+    for k, v in logs.items():
+        out["step_" + k] = np.float64(float(v))
+    out["step_loss"] = np.float64(float(l["loss"]))
+    names, gn, gs = [], [], []
+    for k, p in m.model.named_parameters():
+        g = p.grad
+        a = (g if g is not None else torch.zeros_like(p)).detach().contiguous().view(-1).double().numpy()
+        names.append(k[len("module."):])
+        gn.append(np.sqrt((a * a).sum()))
+        gs.append(a[sample_idx(a.size)].astype(np.float32))
+    out["names"], out["grad_norms"], out["grad_samples"] = np.array(names), np.array(gn), np.stack(gs)
+    _, pn, ps = snapshot(m, "p")
+    out["step_param_norms"], out["step_param_samples"] = pn, ps
+    rm, rv, nb = snapshot(m, "bn")
+    out["step_running_mean"], out["step_running_var"], out["step_num_batches"] = rm, rv, nb
+    out["meta"] = np.array([S, B, seed])
+    out["lr"], out["weight_decay"] = np.float64(cfg["lr"]), np.float64(cfg["weight_decay"])
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, {k: float(v) for k, v in out.items() if k.startswith("step_loss") or k.startswith("evalfo_loss")},
+          "params", len(names), "state entries", len(spec))
+
+
 CASES = {
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),
     "od_S64_B6": lambda: case_train("InstaOrderNet_od", 64, 6, 12, 3, "od_S64_B6"),
@@ -394,6 +470,8 @@ CASES = {
     "plumbing_od": lambda: case_plumbing("InstaOrderNet_od", 19, 2, 4, 256, 6, "plumbing_od"),
     "scheduler": lambda: case_scheduler("scheduler"),
     "decisions": lambda: case_decisions("decisions"),
+    "depthnet_od_S64_B2": lambda: case_depthnet("InstaDepthNet_od", 64, 2, 31, "depthnet_od_S64_B2"),
+    "depthnet_d_S64_B2": lambda: case_depthnet("InstaDepthNet_d", 64, 2, 32, "depthnet_d_S64_B2"),
 }
 
 if __name__ == "__main__":

@@ -1,0 +1,99 @@
+"""MiDaS-based nets on the MI355X (instaorder_amd.midas_net over instaorder_amd.ops) against the goldens of the real
+reference (tests/golden/depthnet_*.npz) -- SURVEY 8(a) row a25 / BASELINE configs[4] at parity-test size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, rel_err, synthetic
+
+pytestmark = pytest.mark.gpu
+CASES = [("InstaDepthNet_od", "depthnet_od_S64_B2"), ("InstaDepthNet_d", "depthnet_d_S64_B2")]
+WEIGHTS = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1, occ_order_weight=1.0)
+
+
+def load(tag):
+    g = np.load(os.path.join(GOLDEN, tag + ".npz"), allow_pickle=False)
+    spec = [(str(k), tuple(int(d) for d in str(s).split(",") if d), (str(a) or None))
+            for k, s, a in zip(g["keys"], g["shapes"], g["aliases"])]
+    return g, spec
+
+
+def build(algo, g, spec):
+    import instaorder_amd as ia
+    S, B, seed = (int(v) for v in g["meta"])
+    cfg = dict(algo=algo, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), optim="SGD", pretrained_weight=None,
+               use_rgb=True, **WEIGHTS)
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    batch = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(seed + 100, B, S).items()}
+    return m, batch
+
+
+def feed(m, algo, t):
+    if algo == "InstaDepthNet_od":
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+    else:
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"])
+
+
+@pytest.mark.parametrize("algo,tag", CASES)
+def test_forward_and_losses_match_reference(algo, tag):
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("eval")
+    with torch.no_grad():
+        d, dep, occ = m.model(t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())
+    assert rel_err(d.cpu().numpy(), g["eval_disp"]) < 1e-3
+    assert rel_err(dep.cpu().numpy(), g["eval_dep"]) < 1e-3
+    if occ is not None:
+        assert rel_err(occ.cpu().numpy(), g["eval_occ"]) < 1e-3
+    feed(m, algo, t)
+    logs, l = m.forward_only()
+    for k, v in logs.items():
+        ref = float(g["evalfo_" + k])
+        assert abs(float(v) - ref) <= 2e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    assert abs(float(l["loss"]) - float(g["evalfo_loss"])) <= 2e-3 * abs(float(g["evalfo_loss"]))
+
+
+@pytest.mark.parametrize("algo,tag", CASES)
+def test_training_step_matches_reference(algo, tag):
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("train")
+    feed(m, algo, t)
+    before = m.optim.flat_params.clone()
+    logs, l = m.step()
+    for k, v in logs.items():
+        ref = float(g["step_" + k])
+        # the disparity-order term is a COUNT of pixel comparisons (steps of 1/S^2): allow a few flips
+        tol = 5e-3 if k == "loss_disp_order" else 2e-3
+        assert abs(float(v) - ref) <= tol * max(1.0, abs(ref)), (k, float(v), ref)
+    # gradients (gathered flat): per-tensor norms and the sampled elements the reference stored.  fp32 ReLU networks
+    # are ill-conditioned backward: a few percent per tensor, tight in aggregate.
+    names = [str(n) for n in g["names"]]
+    idx = (np.arange(64, dtype=np.int64) * 2654435761)
+    num = den = 0.0
+    bad = []
+    for n, (off, k), ref_norm, ref_s in zip(names, m.optim._spans, g["grad_norms"], g["grad_samples"]):
+        gr = m.optim.flat_grads[off:off + k].double().cpu().numpy()
+        got = float(np.sqrt((gr * gr).sum()))
+        if ref_norm > 1e-6 and abs(got - ref_norm) > 0.1 * ref_norm:
+            bad.append((n, got, float(ref_norm)))
+        s = gr[idx % max(k, 1)]
+        num += float(((s - ref_s.astype(np.float64)) ** 2).sum())
+        den += float((ref_s.astype(np.float64) ** 2).sum())
+    assert len(bad) <= len(names) // 50, bad[:8]
+    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    # the update: lr * (momentum buffer = grad + wd * p) applied to every parameter
+    delta = float((m.optim.flat_params - before).norm())
+    assert delta > 0
+    pn = np.array([float(m.optim.flat_params[off:off + k].double().norm()) for off, k in m.optim._spans])
+    assert np.allclose(pn, g["step_param_norms"], rtol=2e-4, atol=1e-6)
+    # BN running statistics after the two directional passes
+    rm = torch.cat([b.reshape(-1) for k, b in m.model.named_buffers() if k.endswith("running_mean")]).cpu().numpy()
+    assert rel_err(rm, g["step_running_mean"]) < 1e-3
+    nb = [int(b) for k, b in m.model.named_buffers() if k.endswith("num_batches_tracked")]
+    assert nb == [int(v) for v in g["step_num_batches"]]
