@@ -202,12 +202,13 @@ def test_label_mirroring():
 
 def test_package_surface():
     import instaorder_amd as ia
-    for name in ("InstaOrderNet_o", "InstaOrderNet_od", "InstaOrderNet_d", "OrderNet", "SingleStageModel"):
+    for name in ("InstaOrderNet_o", "InstaOrderNet_od", "InstaOrderNet_d", "OrderNet", "SingleStageModel",
+                 "InstaDepthNet_od", "InstaDepthNet_d"):
         assert callable(getattr(ia, name))
     assert callable(ia.backbone.resnet50_cls) and callable(ia.utils.average_gradients)
     assert callable(ia.utils.StepLRScheduler) and callable(ia.utils.DistModule) and callable(ia.utils.init_weights)
-    with pytest.raises(NotImplementedError):
-        ia.SingleStageModel({"algo": "InstaDepthNet_od"})
+    with pytest.raises(KeyError):
+        ia.SingleStageModel({"algo": "InstaOrderNet_o", "backbone_arch": "no_such_net", "backbone_param": {}})
 
 
 def test_product_never_imports_oracle():
