@@ -103,23 +103,36 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     B, S = args.batch, args.size
-    nc = {"InstaOrderNet_o": 2, "InstaOrderNet_od": [2, 3]}[args.algo]
-    cfg = dict(algo=args.algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
-               backbone_param=dict(in_channels=5, num_classes=nc), use_rgb=True, overlap_weight=0.1,
-               distinct_weight=0.9, dtype=args.dtype)
-    model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
-    sd = synthetic.make_state_dict(1, 5, nc, prefix="module.")          # reference-init statistics
-    model.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    depthnet = args.algo.startswith("InstaDepthNet")
+    if depthnet:
+        # BASELINE configs[4] (secondary workload): the MiDaS-based net, loss weights of the reference's own
+        # experiments/InstaOrder/InstaDepthNet_od/config.yaml, module-default initialisation
+        assert args.dtype == "fp32" and args.mode == "train", "InstaDepthNet_*: fp32 training step only"
+        cfg = dict(algo=args.algo, lr=1e-5, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True,
+                   overlap_weight=0.0, distinct_weight=0.0, dorder_weight=1.0, smooth_weight=0.1, occ_order_weight=0.0)
+        model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
+        sd = None
+    else:
+        nc = {"InstaOrderNet_o": 2, "InstaOrderNet_od": [2, 3]}[args.algo]
+        cfg = dict(algo=args.algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+                   backbone_param=dict(in_channels=5, num_classes=nc), use_rgb=True, overlap_weight=0.1,
+                   distinct_weight=0.9, dtype=args.dtype)
+        model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
+        sd = synthetic.make_state_dict(1, 5, nc, prefix="module.")          # reference-init statistics
+        model.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.switch_to("eval" if args.mode == "infer" else "train")
 
     # synthetic pair batch; a small seeded block tiled to B to keep host set-up short
-    base = synthetic.make_pair_batch(1000 + rank, min(B, 32), S)
+    base = (synthetic.make_depth_batch if depthnet else synthetic.make_pair_batch)(1000 + rank, min(B, 32), S)
     reps = (B + min(B, 32) - 1) // min(B, 32)
     dev = {k: torch.from_numpy(np.concatenate([v] * reps, 0)[:B]).cuda() for k, v in base.items()}
 
     def one_step():
         if args.algo == "InstaOrderNet_o":
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["occ_order"])
+        elif args.algo == "InstaDepthNet_d":
+            model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["depth_order"], dev["count"],
+                            dev["is_overlap"])
         else:
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["depth_order"], dev["count"],
                             dev["is_overlap"], dev["occ_order"])
@@ -129,7 +142,7 @@ def main():
 
     # per-kernel HIP-event timing needs eager launches; with --no-prof the step is replayed from a hipGraph
     # (identical kernels; only matters when the step is launch-bound, i.e. at small per-GPU batches)
-    if not args.no_prof:
+    if not args.no_prof and not depthnet:
         model._use_graph = False
     for _ in range(args.warmup):
         one_step()
@@ -156,20 +169,28 @@ def main():
     pairs_per_s = world * B * args.steps / dt
 
     flop_per_pair = (FLOP_PER_PAIR_TRAIN if args.mode == "train" else FLOP_PER_PAIR_FWD) * (S / 256.0) ** 2
+    if depthnet:
+        # 127.2 GMAC per sample and pass at 384^2 in the reference (two full passes per pair).  The
+        # pair mode runs the image-only encoder + decoder (127.2 - 2 x 12.24 GMAC of ResNet-50 branches) ONCE per
+        # pair and only the order branches twice; the rate below counts the work actually executed.
+        branches = 2 * 12.24e9 if args.algo == "InstaDepthNet_od" else 12.24e9
+        shared = 127.2e9 - 2 * 12.24e9
+        macs = (shared + 2 * branches) if model.PAIR_MODE else 2 * (shared + branches)
+        flop_per_pair = 3 * 2 * macs * (S / 384.0) ** 2
     result = {
         "metric": "instance-pairs/sec (fwd+bwd)" if args.mode == "train" else "instance-pairs/sec (%s)" % args.mode,
         "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": "%s ResNet-50, pair-batch %d per GPU at %dx%dx5, %s, %s "
+        "config": {"workload": "%s, pair-batch %d per GPU at %dx%dx5, %s, %s "
                                "(BASELINE.json configs[%d])" % (args.algo, B, S, S, args.dtype,
                                                                 {"train": "fwd+bwd+SGD", "fwd": "forward+loss, train mode",
                                                                  "infer": "forward+loss, eval mode"}[args.mode],
-                                                                1 if args.dtype == "fp32" else 2),
+                                                                4 if depthnet else (1 if args.dtype == "fp32" else 2)),
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "hip_graph": bool(model._use_graph and model._graph is not None),
+                   "hip_graph": bool(getattr(model, "_use_graph", False) and getattr(model, "_graph", None) is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
-                       args.backend, model.net.flat_grads.numel())},
+                       args.backend, (model.optim if depthnet else model.net).flat_grads.numel())},
         "achieved_tflops_whole_step": pairs_per_s * flop_per_pair / 1e12,
         "mfma_frac_whole_step": pairs_per_s * flop_per_pair / 1e12 / (world * PEAK_FP32_MFMA_TFLOPS),
     }
@@ -203,7 +224,7 @@ def main():
                 "gbs": v["bytes"] / (v["total_ms"] * 1e-3) / 1e9}
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train" and not depthnet:
         result["cpu_baseline"] = cpu_baseline(sd, S)
     if rank == 0:
         print(json.dumps(result))

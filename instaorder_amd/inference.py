@@ -52,6 +52,24 @@ def decide(logits1, logits2, kocc, kdep):
     return res
 
 
+def net_forward_InstaDepthNet(model, image, inmodal1, inmodal2):
+    """Reference signature (inference.py:107-137): one pair through InstaDepthNet_od / _d, both mask orders,
+    direction-averaged decisions.  image [1,3,H,W] normalised, inmodal* [H,W] arrays in {0,1}.
+    Returns (argidx_depth, is_1_over_2, is_2_over_1, disp1, disp2)."""
+    dev = next(model.model.parameters()).device
+    m1 = torch.as_tensor(np.asarray(inmodal1, dtype=np.float32), device=dev)[None, None]
+    m2 = torch.as_tensor(np.asarray(inmodal2, dtype=np.float32), device=dev)[None, None]
+    image = image.to(dev)
+    with torch.no_grad():
+        disp1, dep1, occ1 = model.model(image, m1, m2)
+        disp2, dep2, occ2 = model.model(image, m2, m1)
+        if occ1 is not None:
+            r = decide(torch.cat([occ1, dep1], 1), torch.cat([occ2, dep2], 1), 2, 3)
+            return int(r["depth"][0]), bool(r["i_over_j"][0]), bool(r["j_over_i"][0]), disp1, disp2
+        r = decide(dep1, dep2, 0, 3)
+    return int(r["depth"][0]), 0, 0, disp1, disp2
+
+
 def decision_margins(pair_logits, method):
     """Distance of each decision from its threshold (|p - 0.5| for the two occlusion directions, gap
     between the two largest averaged depth probabilities) -- used by parity tests to leave aside

@@ -42,6 +42,24 @@ class Conv2d(nn.Module):
         return y
 
 
+class _BnMode(object):
+    """How the BatchNorm layers account the current call (see ops.batch_norm): `groups` independent statistic groups
+    (the two mask orders batched into one call of an order branch) or `repeat` identical calls folded into one (the
+    shared encoder / decoder, which the reference runs once per mask order on the same image)."""
+    groups = 1
+    repeat = 1
+
+    def __init__(self, groups=1, repeat=1):
+        self.g, self.r = groups, repeat
+
+    def __enter__(self):
+        self.prev = (_BnMode.groups, _BnMode.repeat)
+        _BnMode.groups, _BnMode.repeat = self.g, self.r
+
+    def __exit__(self, *a):
+        _BnMode.groups, _BnMode.repeat = self.prev
+
+
 class BatchNorm2d(nn.Module):
     def __init__(self, c):
         super(BatchNorm2d, self).__init__()
@@ -53,9 +71,9 @@ class BatchNorm2d(nn.Module):
 
     def forward(self, x, relu=False, identity=None):
         if self.training:
-            self.num_batches_tracked += 1
+            self.num_batches_tracked += _BnMode.groups * _BnMode.repeat
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
-                              identity)
+                              identity, _BnMode.groups, _BnMode.repeat)
 
 
 class _Fn(nn.Module):
@@ -225,6 +243,13 @@ class _InstaDepthBase(nn.Module):
         return disp, (l1, l2, l3)
 
 
+def _pair_inputs(mask1, mask2, feats):
+    """Both mask orders as one 2B batch: rows [0,B) = (mask1, mask2), rows [B,2B) = (mask2, mask1); the injected
+    encoder features are the same for both."""
+    m = torch.cat([torch.cat([mask1, mask2], 1), torch.cat([mask2, mask1], 1)], 0).float()
+    return ops.nhwc_from_nchw(m, pad_to=8), tuple(torch.cat([f, f], 0) for f in feats)
+
+
 class InstaDepthNet_od(_InstaDepthBase):
     """midas_net.py:116-212: disparity + depth-order head + occlusion-order head."""
 
@@ -244,6 +269,20 @@ class InstaDepthNet_od(_InstaDepthBase):
         occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
         return disp, depth_order, occ_order
 
+    def forward_pair(self, img, mask1, mask2):
+        """Both directional calls of supervised_order.py:187-188 / 198-199 at once: the image-only encoder + decoder
+        run ONCE (their result is the same for both mask orders), the order branches see the two orders as one 2B
+        batch with per-order BatchNorm statistics.  Returns (disp[B,H,W], depth[2B,3], occ[2B,2]), rows [0,B) =
+        call (mask1, mask2), rows [B,2B) = call (mask2, mask1).  Same values, gradients and running statistics as the
+        two separate calls."""
+        with _BnMode(repeat=2):
+            disp, feats = self._encode_decode(img)
+        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats)
+        with _BnMode(groups=2):
+            depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
+            occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
+        return disp, depth_order, occ_order
+
 
 class InstaDepthNet_d(_InstaDepthBase):
     """midas_net.py:14-113: disparity + geometric depth-order head."""
@@ -258,4 +297,13 @@ class InstaDepthNet_d(_InstaDepthBase):
         disp, (l1, l2, l3) = self._encode_decode(img)
         x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8)
         depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+        return disp, depth_order, None
+
+    def forward_pair(self, img, mask1, mask2):
+        """See InstaDepthNet_od.forward_pair."""
+        with _BnMode(repeat=2):
+            disp, feats = self._encode_decode(img)
+        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats)
+        with _BnMode(groups=2):
+            depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None

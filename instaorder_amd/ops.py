@@ -145,56 +145,68 @@ def conv2d(x, w, stride=1, pad=0, groups=1, co_pad=False):
 # ---- BatchNorm (+ residual add) (+ ReLU) ---------------------------------------------------------------------------------
 class _BatchNorm(torch.autograd.Function):
     """nn.BatchNorm2d (+ `out += identity`) (+ nn.ReLU) of resnet_cls.py:96-116.  Training: batch statistics, running
-    estimates advanced in place (momentum 0.1, unbiased variance); eval: running estimates."""
+    estimates advanced in place (momentum 0.1, unbiased variance); eval: running estimates.
+    groups = G: the batch is G consecutive equal parts normalised with separate statistics, running estimates advanced
+    part by part -- exactly G sequential module calls on the parts (the two mask orders of a pair batch).
+    repeat = R: the module call is accounted R times (running estimates advanced R times with the same statistics):
+    the reference runs the shared encoder once per mask order on identical input."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, identity):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, identity, groups, repeat):
         _chk(x, "x")
         L = _L()
         Cc = x.shape[-1]
         M = x.numel() // Cc
         dev = x.device
-        mean, rstd, scale, shift = (torch.empty(Cc, device=dev) for _ in range(4))
+        G = int(groups) if training else 1
+        mean, rstd, scale, shift = (torch.empty(G * Cc, device=dev) for _ in range(4))
         if training:
-            npart = int(L.io_bn_partial_floats(M, Cc, 1))
+            npart = int(L.io_bn_partial_floats(M, Cc, G))
             part = torch.empty(npart, device=dev)
-            _lib.check(L.io_bn_stats_finalize(_p(x), M, Cc, 1, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
+            _lib.check(L.io_bn_stats_finalize(_p(x), M, Cc, G, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
                                               _p(running_var), 0.1, 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift), _p(part),
                                               npart, _st()), "io_bn_stats_finalize")
+            for _ in range(int(repeat) - 1):          # same statistics again (G == 1 when repeat > 1)
+                n = M // G
+                var_unb = (1.0 / (rstd * rstd) - 1e-5) * (float(n) / float(max(n - 1, 1)))
+                running_mean.mul_(0.9).add_(mean, alpha=0.1)
+                running_var.mul_(0.9).add_(var_unb, alpha=0.1)
         else:
             _lib.check(L.io_bn_eval_prepare(Cc, _p(gamma.detach()), _p(beta.detach()), _p(running_mean), _p(running_var),
                                             1e-5, _p(mean), _p(scale), _p(shift), _st()), "io_bn_eval_prepare")
             rstd = scale / gamma.detach()
         out = torch.empty_like(x)
-        _lib.check(L.io_bn_apply(_p(x), M, Cc, 1, 0, _p(mean), _p(scale), _p(shift), _p(identity), None, None, None,
-                                 int(relu), _p(out), _st()), "io_bn_apply")
+        _lib.check(L.io_bn_apply(_p(x), M, Cc, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
+                                 None, None, int(relu), _p(out), _st()), "io_bn_apply")
         ctx.save_for_backward(x, out, gamma, mean, rstd)
-        ctx.cfg = (M, Cc, bool(relu), identity is not None, bool(training))
+        ctx.cfg = (M, Cc, bool(relu), identity is not None, bool(training), G)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, out, gamma, mean, rstd = ctx.saved_tensors
-        M, Cc, relu, has_id, training = ctx.cfg
+        M, Cc, relu, has_id, training, G = ctx.cfg
         if not training:
             raise RuntimeError("ops.batch_norm: backward through eval-mode BatchNorm is not implemented")
         L = _L()
         dout = dout.contiguous()
         dev = x.device
-        npart = int(L.io_bn_partial_floats(M, Cc, 1))
+        npart = int(L.io_bn_partial_floats(M, Cc, G))
         part = torch.empty(npart, device=dev)
-        coef = torch.empty(2 * Cc, device=dev)
+        coef = torch.empty(2 * G * Cc, device=dev)
         dgamma, dbeta = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         dx = torch.empty_like(x)
         dz = torch.empty_like(x) if has_id else None          # gradient of the pre-ReLU sum = gradient of `identity`
-        _lib.check(L.io_bn_bwd(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, 1, _p(gamma.detach()), _p(mean),
+        _lib.check(L.io_bn_bwd(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, G, _p(gamma.detach()), _p(mean),
                                _p(rstd), _p(dgamma), _p(dbeta), _p(dx), _p(dz), _p(part), npart, _p(coef), _st()),
                    "io_bn_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, dz
+        return dx, dgamma, dbeta, None, None, None, None, dz, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, relu=False, identity=None):
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, relu, identity)
+def batch_norm(x, gamma, beta, running_mean, running_var, training, relu=False, identity=None, groups=1, repeat=1):
+    if repeat > 1 and groups > 1:
+        raise ValueError("batch_norm: repeat and groups are exclusive")
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, relu, identity, groups, repeat)
 
 
 # ---- pooling / heads --------------------------------------------------------------------------------------------------

@@ -326,8 +326,15 @@ class _DepthBase(SingleStageModel):
 
     _LE_ORDER = 0     # both reference classes use `<=` on disp1 when depth_order1 == 0 (supervised_order.py:158-162, 289-293)
 
+    PAIR_MODE = True      # False: two separate model calls, literally as supervised_order.py:187-188
+
     def _run(self, training):
         net = self.model
+        B = self.B
+        if self.PAIR_MODE:
+            disp, dep, occ = net.module.forward_pair(self.rgb, self.modal1, self.modal2)
+            d = disp.unsqueeze(1)
+            return d, d, dep[:B], dep[B:], (occ[:B] if occ is not None else None), (occ[B:] if occ is not None else None)
         disp1, dep1, occ1 = net(self.rgb, self.modal1, self.modal2)
         disp2, dep2, occ2 = net(self.rgb, self.modal2, self.modal1)
         return disp1.unsqueeze(1), disp2.unsqueeze(1), dep1, dep2, occ1, occ2

@@ -58,10 +58,14 @@ def test_forward_and_losses_match_reference(algo, tag):
     assert abs(float(l["loss"]) - float(g["evalfo_loss"])) <= 2e-3 * abs(float(g["evalfo_loss"]))
 
 
+@pytest.mark.parametrize("pair_mode", [True, False])
 @pytest.mark.parametrize("algo,tag", CASES)
-def test_training_step_matches_reference(algo, tag):
+def test_training_step_matches_reference(algo, tag, pair_mode):
+    """pair_mode False: two model calls per step, literally as the reference; True (default): the shared encoder /
+    decoder once + both mask orders batched through the order branches -- same losses, gradients, running statistics."""
     g, spec = load(tag)
     m, t = build(algo, g, spec)
+    m.PAIR_MODE = pair_mode
     m.switch_to("train")
     feed(m, algo, t)
     before = m.optim.flat_params.clone()
@@ -97,3 +101,17 @@ def test_training_step_matches_reference(algo, tag):
     assert rel_err(rm, g["step_running_mean"]) < 1e-3
     nb = [int(b) for k, b in m.model.named_buffers() if k.endswith("num_batches_tracked")]
     assert nb == [int(v) for v in g["step_num_batches"]]
+
+
+def test_net_forward_InstaDepthNet_decisions():
+    """inference.py:107-137 through the HIP path: decisions equal those computed from the golden's eval logits."""
+    from instaorder_amd import inference
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("eval")
+    i = 0
+    d, o12, o21, disp1, disp2 = inference.net_forward_InstaDepthNet(m, t["rgb"][i:i + 1], t["modal1"][i, 0].numpy(),
+                                                                    t["modal2"][i, 0].numpy())
+    assert disp1.shape == (1, 64, 64) and d in (0, 1, 2) and isinstance(o12, bool)
+    assert rel_err(disp1.cpu().numpy()[0], g["eval_disp"][i]) < 2e-3      # batch-1 eval == row i of the batch-2 golden
