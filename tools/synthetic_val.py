@@ -7,7 +7,7 @@ trained-like weights, BN running statistics warmed by train-mode passes, head ce
 sides of the thresholds, random ground-truth matrices.  Prints recall / precision / F1 (occlusion) and WHDR
 (depth) for both paths and their difference in percentage points.
 
-usage: python tools/synthetic_val.py [n_images] [n_inst] [S]
+usage: python tools/synthetic_val.py [n_images] [n_inst] [S] [bf16]
 """
 import os
 import sys
@@ -22,11 +22,11 @@ from instaorder_amd import synthetic
 from oracle import resnet_oracle as orc        # checker only
 
 
-def run(n_images=20, n_inst=5, S=256, seed=91, verbose=True):
+def run(n_images=20, n_inst=5, S=256, seed=91, verbose=True, dtype="fp32"):
     algo = "InstaOrderNet_od"
     cfg = dict(algo=algo, lr=1e-4, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
                backbone_param=dict(in_channels=5, num_classes=[2, 3]), use_rgb=True, overlap_weight=0.1,
-               distinct_weight=0.9)
+               distinct_weight=0.9, dtype=dtype)
     m = ia.InstaOrderNet_od(cfg, dist_model=False)
     sd = synthetic.make_state_dict(seed, 5, [2, 3], prefix="module.", style="kaiming")
     m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
@@ -61,13 +61,22 @@ def run(n_images=20, n_inst=5, S=256, seed=91, verbose=True):
         m.net.fc_depth.bias += med[2:].cuda()
     acc = {"hip": [], "oracle": []}
     flips = 0
+    flip_margins = []          # the oracle's own decision margin (probability units) wherever the two paths disagree
     for item, (z1, z2) in zip(items, ologits):
         z1, z2 = z1 + med, z2 + med
         d = infer.decide(z1, z2, 2, 3)
+        marg = infer.decision_margins(torch.cat([z1, z2], 1), algo)
         o_occ, o_dep = orc.order_matrices(n_inst, pairs, d["i_over_j"], d["j_over_i"], d["depth"])
         rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
         res = infer.infer_order_batched(m, torch.from_numpy(rgb), torch.from_numpy(masks), method=algo)
         flips += int((res["occ_order"] != o_occ).sum() + (res["depth_order"] != o_dep).sum())
+        for k, (i, j) in enumerate(pairs):
+            if res["occ_order"][i, j] != o_occ[i, j]:
+                flip_margins.append(float(marg["occ"][k, 0]))
+            if res["occ_order"][j, i] != o_occ[j, i]:
+                flip_margins.append(float(marg["occ"][k, 1]))
+            if res["depth_order"][i, j] != o_dep[i, j]:
+                flip_margins.append(float(marg["depth"][k]))
         for name, occ, dep in (("hip", res["occ_order"], res["depth_order"]), ("oracle", o_occ, o_dep)):
             prf = infer.eval_order_recall_precision_f1(occ, item["gt_occ"], 0)
             w = infer.eval_depth_order_whdr(dep, (item["gt_depth"], item["gt_overlap"], item["gt_count"]))
@@ -76,13 +85,16 @@ def run(n_images=20, n_inst=5, S=256, seed=91, verbose=True):
     mh = np.mean(np.asarray(acc["hip"]), 0)
     mo = np.mean(np.asarray(acc["oracle"]), 0)
     if verbose:
-        print("images %d x instances %d (pairs %d), S=%d, differing matrix entries: %d"
-              % (n_images, n_inst, n_images * len(pairs), S, flips))
+        print("%s: images %d x instances %d (pairs %d), S=%d, differing matrix entries: %d"
+              % (dtype, n_images, n_inst, n_images * len(pairs), S, flips))
         for n, a, b in zip(names, mh, mo):
             print("  %-10s HIP %8.3f   oracle %8.3f   delta %+.3f pp" % (n, a, b, a - b))
+        print("  decisions that differ: %d, largest oracle margin among them: %.2e (probability units)"
+              % (len(flip_margins), max(flip_margins) if flip_margins else 0.0))
+    run.flip_margins = flip_margins
     return dict(zip(names, (mh - mo).tolist())), flips
 
 
 if __name__ == "__main__":
-    a = [int(v) for v in sys.argv[1:]]
-    run(*(a + [20, 5, 256][len(a):]))
+    a = [int(v) for v in sys.argv[1:] if v.isdigit()]
+    run(*(a + [20, 5, 256][len(a):]), dtype="bf16" if "bf16" in sys.argv else "fp32")
