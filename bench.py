@@ -107,8 +107,9 @@ def main():
     if depthnet:
         # BASELINE configs[4] (secondary workload): the MiDaS-based net, loss weights of the reference's own
         # experiments/InstaOrder/InstaDepthNet_od/config.yaml, module-default initialisation
-        assert args.dtype == "fp32" and args.mode == "train", "InstaDepthNet_*: fp32 training step only"
+        assert args.mode == "train", "InstaDepthNet_*: training step only"
         cfg = dict(algo=args.algo, lr=1e-5, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True,
+                   dtype=args.dtype,
                    overlap_weight=0.0, distinct_weight=0.0, dorder_weight=1.0, smooth_weight=0.1, occ_order_weight=0.0)
         model = getattr(ia, args.algo)(cfg, dist_model=world > 1)
         sd = None

@@ -215,40 +215,53 @@ int io_bn_bwd_dt(const void* dout, const void* act, const float* mask_scale, con
                  hipStream_t stream);
 
 /* ---- operators of the MiDaS branch (InstaDepthNet_od / _d: midas/midas_net.py:116-212, midas/blocks.py:71-195) ----
- * NHWC fp32.  Grouped 3x3 convolution of the ResNeXt-101 32x8d encoder (resnet_cls.py:309-320, `groups=32`): the
- * filter w[C][cg][R*S] (OIHW, cg = C/groups input channels per group, cg | 64) is expanded by io_gconv_pack to two
+ * NHWC; `dtype` (IO_DTYPE_F32 | IO_DTYPE_BF16) is the element type of every `void*` tensor; parameters, their
+ * gradients, biases and reduction results stay float.
+ * Grouped 3x3 convolution of the ResNeXt-101 32x8d encoder (resnet_cls.py:309-320, `groups=32`): the filter
+ * w[C][cg][R*S] (OIHW, cg = C/groups input channels per group, cg | 64) is expanded by io_gconv_pack to two
  * block-diagonal operands over 64-channel windows -- wc[C][R*S][64] for the forward, wtc[C][R*S][64] for the data
- * gradient -- and the filter gradient comes back in the wc layout (io_gconv_unpack_grad extracts [C][cg][R*S]). */
-int io_gconv_pack(const float* w, int C, int cg, int taps, float* wc, float* wtc, hipStream_t stream);
+ * gradient -- and the filter gradient comes back (float) in the wc layout (io_gconv_unpack_grad extracts
+ * [C][cg][R*S]). */
+int io_gconv_pack(const float* w, int C, int cg, int taps, void* wc, void* wtc, int dtype, hipStream_t stream);
 int io_gconv_unpack_grad(const float* dwc, int C, int cg, int taps, float* dw, hipStream_t stream);
-int io_gconv2d_fwd(const float* x, const float* wc, float* y, int N, int H, int W, int C, int R, int S, int stride,
-                   int pad, hipStream_t stream);
-int io_gconv2d_dgrad(const float* dy, const float* wtc, float* dx, int N, int H, int W, int C, int R, int S, int stride,
-                     int pad, hipStream_t stream);
+int io_gconv2d_fwd(const void* x, const void* wc, void* y, int N, int H, int W, int C, int R, int S, int stride, int pad,
+                   int dtype, hipStream_t stream);
+int io_gconv2d_dgrad(const void* dy, const void* wtc, void* dx, int N, int H, int W, int C, int R, int S, int stride,
+                     int pad, int dtype, hipStream_t stream);
 size_t io_gconv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int R, int S, int stride, int pad);
-int io_gconv2d_wgrad(const float* x, const float* dy, float* dwc, int N, int H, int W, int C, int R, int S, int stride,
-                     int pad, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int io_gconv2d_wgrad(const void* x, const void* dy, float* dwc, int N, int H, int W, int C, int R, int S, int stride,
+                     int pad, void* workspace, size_t workspace_bytes, int dtype, hipStream_t stream);
 /* nn.functional.interpolate(scale_factor=2, mode='bilinear', align_corners=...) (midas/blocks.py:111-113, 186-188):
  * x[N,H,W,C] -> out[N,2H,2W,C]; bwd is its exact adjoint dy[N,2H,2W,C] -> dx[N,H,W,C]. */
-int io_upsample2x_bilinear_fwd(const float* x, int N, int H, int W, int C, int align_corners, float* out,
+int io_upsample2x_bilinear_fwd(const void* x, int N, int H, int W, int C, int align_corners, void* out, int dtype,
                                hipStream_t stream);
-int io_upsample2x_bilinear_bwd(const float* dy, int N, int H, int W, int C, int align_corners, float* dx,
+int io_upsample2x_bilinear_bwd(const void* dy, int N, int H, int W, int C, int align_corners, void* dx, int dtype,
                                hipStream_t stream);
 /* out[M][C] = [relu](x + bias) (bias may be NULL; out may alias x): conv bias / nn.ReLU of midas/blocks.py:121-160 */
-int io_bias_act(const float* x, const float* bias, int M, int C, int relu, float* out, hipStream_t stream);
+int io_bias_act(const void* x, const float* bias, int M, int C, int relu, void* out, int dtype, hipStream_t stream);
 /* dx = dy * [act > 0] (dx may alias dy) */
-int io_relu_bwd(const float* dy, const float* act, size_t n, float* dx, hipStream_t stream);
-int io_add(const float* a, const float* b, size_t n, float* out, hipStream_t stream);
+int io_relu_bwd(const void* dy, const void* act, size_t n, void* dx, int dtype, hipStream_t stream);
+int io_add(const void* a, const void* b, size_t n, void* out, int dtype, hipStream_t stream);
 /* out[c] = sum_m x[m][c] (bias gradient); C must divide 256; partial: io_colsum_partial_floats(M, C) floats */
 size_t io_colsum_partial_floats(int M, int C);
-int io_colsum(const float* x, int M, int C, float* out, float* partial, size_t partial_floats, hipStream_t stream);
-/* nn.Conv2d(C, 1, 1) [+ nn.ReLU] (midas_net.py:139-140): out[m] = act(b + sum_c x[m*pitch + c] * w[c]); the input may
- * carry padding channels (pitch >= C, <= 64).  bwd: dx[M][pitch] (zero in the padding channels), dw[C], db[1];
- * partial: io_colsum_partial_floats(M, C) floats. */
-int io_head1_fwd(const float* x, int M, int pitch, int C, const float* w, const float* b, int relu, float* out,
+int io_colsum(const void* x, int M, int C, float* out, float* partial, size_t partial_floats, int dtype,
+              hipStream_t stream);
+/* nn.Conv2d(C, 1, 1) [+ nn.ReLU] (midas_net.py:139-140): out[m] (float) = act(b + sum_c x[m*pitch + c] * w[c]); the
+ * input may carry padding channels (pitch >= C, <= 64).  bwd: dx[M][pitch] (zero in the padding channels), dw[C],
+ * db[1]; partial: io_colsum_partial_floats(M, C) floats. */
+int io_head1_fwd(const void* x, int M, int pitch, int C, const float* w, const float* b, int relu, float* out, int dtype,
                  hipStream_t stream);
-int io_head1_bwd(const float* dy, const float* out, const float* x, int M, int pitch, int C, const float* w, int relu,
-                 float* dx, float* dw, float* db, float* partial, size_t partial_floats, hipStream_t stream);
+int io_head1_bwd(const float* dy, const float* out, const void* x, int M, int pitch, int C, const float* w, int relu,
+                 void* dx, float* dw, float* db, float* partial, size_t partial_floats, int dtype, hipStream_t stream);
+/* storage-typed forms of io_maxpool_* / io_avgpool_fc_* (pooled / logits / parameter gradients stay float) */
+int io_maxpool_fwd_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int dtype, hipStream_t stream);
+int io_maxpool_bwd_dt(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, int dtype,
+                      hipStream_t stream);
+int io_avgpool_fc_fwd_dt(const void* x, int N, int HW, int C, const float* w0, const float* b0, int K0, const float* w1,
+                         const float* b1, int K1, float* pooled, float* logits, int dtype, hipStream_t stream);
+int io_avgpool_fc_bwd_dt(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0, int K0,
+                         const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
+                         float* db1, int dtype, hipStream_t stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of

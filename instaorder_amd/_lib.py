@@ -75,21 +75,25 @@ SIGNATURES = {
     "io_bn_stats_finalize_dt": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "io_bn_apply_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "io_bn_bwd_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
-    "io_gconv_pack": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "io_gconv_pack": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "io_gconv_unpack_grad": (_I, [_P, _I, _I, _I, _P, _P]),
-    "io_gconv2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "io_gconv2d_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_gconv2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "io_gconv2d_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "io_gconv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    "io_gconv2d_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "io_upsample2x_bilinear_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "io_upsample2x_bilinear_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "io_bias_act": (_I, [_P, _P, _I, _I, _I, _P, _P]),
-    "io_relu_bwd": (_I, [_P, _P, _Z, _P, _P]),
-    "io_add": (_I, [_P, _P, _Z, _P, _P]),
+    "io_gconv2d_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
+    "io_upsample2x_bilinear_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "io_upsample2x_bilinear_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "io_bias_act": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "io_relu_bwd": (_I, [_P, _P, _Z, _P, _I, _P]),
+    "io_add": (_I, [_P, _P, _Z, _P, _I, _P]),
     "io_colsum_partial_floats": (_Z, [_I, _I]),
-    "io_colsum": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
-    "io_head1_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
-    "io_head1_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "io_colsum": (_I, [_P, _I, _I, _P, _P, _Z, _I, _P]),
+    "io_head1_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "io_head1_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _Z, _I, _P]),
+    "io_maxpool_fwd_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "io_maxpool_bwd_dt": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "io_avgpool_fc_fwd_dt": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P]),
+    "io_avgpool_fc_bwd_dt": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "io_prof_begin": (_I, []),
     "io_prof_end": (_I, [C.POINTER(ProfEntry), _I]),
 }

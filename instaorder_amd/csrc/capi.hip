@@ -301,3 +301,30 @@ extern "C" int io_bn_bwd_dt(const void* dout, const void* act, const float* mask
     return io_bn_bwd_t(dout, act, mask_scale, mask_shift, y, M, C, G, gamma, mean, rstd, dgamma, dbeta, dy, dz_out,
                        partial, partial_floats, coef, st, dtype);
 }
+
+
+extern "C" int io_maxpool_fwd_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int dtype,
+                                 hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "maxpool: unknown dtype %d", dtype);
+    return io_maxpool_fwd_t(x, N, H, W, C, out, idx, st, dtype);
+}
+
+extern "C" int io_maxpool_bwd_dt(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, int dtype,
+                                 hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "maxpool: unknown dtype %d", dtype);
+    return io_maxpool_bwd_t(dy, idx, N, H, W, C, dx, st, dtype);
+}
+
+extern "C" int io_avgpool_fc_fwd_dt(const void* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
+                                    const float* w1, const float* b1, int K1, float* pooled, float* logits, int dtype,
+                                    hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "avgpool_fc: unknown dtype %d", dtype);
+    return io_avgpool_fc_fwd_t(x, N, HW, C, w0, b0, K0, w1, b1, K1, pooled, logits, st, dtype);
+}
+
+extern "C" int io_avgpool_fc_bwd_dt(const float* dlogits, const float* pooled, int N, int HW, int C, const float* w0,
+                                    int K0, const float* w1, int K1, const void* relu_mask, void* dx, float* dw0,
+                                    float* db0, float* dw1, float* db1, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "avgpool_fc: unknown dtype %d", dtype);
+    return io_avgpool_fc_bwd_t(dlogits, pooled, N, HW, C, w0, K0, w1, K1, relu_mask, dx, dw0, db0, dw1, db1, st, dtype);
+}

@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
         xcol = 0;
     } else {
         const int tap = rem0 / ntile_c;
-        c0 = (rem0 - tap * ntile_c) * BNC;
+        c0 = g.gw ? o0 : (rem0 - tap * ntile_c) * BNC;      // grouped: only the diagonal (o tile == c tile)
         const int th = tap / g.Tw, tw = tap - th * g.Tw;
         dh = g.dh0 + g.dhs * th;
         dw = g.dw0 + g.dws * tw;
@@ -845,7 +845,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
         for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
     }
 
-    const size_t wrow = (size_t)g.wT * g.Ci;
+    const int kwid = g.gw ? g.gw : g.Ci;
+    const size_t wrow = (size_t)g.wT * kwid;
     float* base = dst + (size_t)split * g.Co * wrow;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
                 if (STEM) {
                     if (c0 + cl < (int)wrow) base[(size_t)o * wrow + c0 + cl] = acc[i][j][r];
                 } else {
-                    base[(size_t)o * wrow + (size_t)widx * g.Ci + c0 + cl] = acc[i][j][r];
+                    base[(size_t)o * wrow + (size_t)widx * kwid + (g.gw ? 0 : c0) + cl] = acc[i][j][r];
                 }
             }
         }
@@ -969,8 +970,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
     const unsigned w_bytes = (unsigned)w_b;
     const int bn = g.gw ? g.gw : ((g.Co % 128 == 0) ? 128 : 64);
-    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co && dt_in == IO_F32), IO_ERR_SHAPE,
-               "conv_nt: grouped mode needs a 64-channel window, Ci == Co, fp32");
+    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co), IO_ERR_SHAPE,
+               "conv_nt: grouped mode needs a 64-channel window and Ci == Co");
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
@@ -1028,8 +1029,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         IO_REQUIRE(g.Ci % 64 == 0 && dt_in == dt_dy, IO_ERR_SHAPE,
                    "conv_wgrad: Ci=%d must be a multiple of 64 (and one storage type)", g.Ci);
     IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW, IO_ERR_SHAPE, "conv_wgrad: dY must be dense");
-    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co && dt_in == IO_F32), IO_ERR_SHAPE,
-               "conv_wgrad: grouped mode needs a 64-channel window, Ci == Co, fp32");
+    IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co), IO_ERR_SHAPE,
+               "conv_wgrad: grouped mode needs a 64-channel window and Ci == Co");
     WgradPlan p = plan_wgrad(g, stem);
     const size_t need = io_conv_wgrad_partial_bytes(g, stem);
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,

@@ -15,6 +15,11 @@ namespace {
 
 constexpr int kThreads = 256;
 
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return io_bf2f(*p); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = io_f2bf(v); }
+
 int ew_blocks(size_t n) {
     size_t b = (n + kThreads - 1) / kThreads;
     return (int)(b > 8192 ? 8192 : (b ? b : 1));
@@ -24,8 +29,9 @@ int ew_blocks(size_t n) {
 // w [C][cg][T] (OIHW with T = R*S taps).  wc [C][T][64]: row o holds, for its 64-channel window wb = 64*(o/64), the
 // taps of input channel wb + cl (zero unless that channel is in o's group).  wtc [C][T][64]: the same for the data
 // gradient, row = INPUT channel c, column = output channel wb + cl.
+template <typename T_>
 __global__ __launch_bounds__(kThreads) void gconv_pack_kernel(const float* __restrict__ w, int C, int cg, int T,
-                                                             float* __restrict__ wc, float* __restrict__ wtc) {
+                                                             T_* __restrict__ wc, T_* __restrict__ wtc) {
     const size_t total = (size_t)C * T * 64;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int cl = (int)(i & 63);
@@ -33,8 +39,8 @@ __global__ __launch_bounds__(kThreads) void gconv_pack_kernel(const float* __res
         const int o = (int)(i / ((size_t)T * 64));
         const int other = (o & ~63) + cl;
         const bool same = (other / cg) == (o / cg);
-        wc[i] = same ? w[((size_t)o * cg + other % cg) * T + tap] : 0.f;
-        wtc[i] = same ? w[((size_t)other * cg + o % cg) * T + tap] : 0.f;
+        st1(wc + i, same ? w[((size_t)o * cg + other % cg) * T + tap] : 0.f);
+        st1(wtc + i, same ? w[((size_t)other * cg + o % cg) * T + tap] : 0.f);
     }
 }
 
@@ -77,8 +83,9 @@ __device__ __forceinline__ Lerp lerp_of(int dst, int H, int align) {
     return l;
 }
 
-__global__ __launch_bounds__(kThreads) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
-                                                                 int C4, int align, float* __restrict__ out) {
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void upsample2x_fwd_kernel(const T_* __restrict__ x, int N, int H, int W,
+                                                                 int C4, int align, T_* __restrict__ out) {
     const int OH = 2 * H, OW = 2 * W;
     const size_t total = (size_t)N * OH * OW * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -89,17 +96,18 @@ __global__ __launch_bounds__(kThreads) void upsample2x_fwd_kernel(const float* _
         const int oh = (int)(t % OH);
         const int n = (int)(t / OH);
         const Lerp lh = lerp_of(oh, H, align), lw = lerp_of(ow, W, align);
-        const f32x4* xp = reinterpret_cast<const f32x4*>(x) + (size_t)n * H * W * C4 + q;
-        const f32x4 a = xp[((size_t)lh.i0 * W + lw.i0) * C4], b = xp[((size_t)lh.i0 * W + lw.i1) * C4];
-        const f32x4 c = xp[((size_t)lh.i1 * W + lw.i0) * C4], d = xp[((size_t)lh.i1 * W + lw.i1) * C4];
+        const T_* xp = x + ((size_t)n * H * W * C4 + q) * 4;
+        const f32x4 a = io_ldv(xp + ((size_t)lh.i0 * W + lw.i0) * C4 * 4), b = io_ldv(xp + ((size_t)lh.i0 * W + lw.i1) * C4 * 4);
+        const f32x4 c = io_ldv(xp + ((size_t)lh.i1 * W + lw.i0) * C4 * 4), d = io_ldv(xp + ((size_t)lh.i1 * W + lw.i1) * C4 * 4);
         // same association as PyTorch's CPU kernel: h0lambda*(w0lambda*a + w1lambda*b) + h1lambda*(...)
-        reinterpret_cast<f32x4*>(out)[i] = lh.w0 * (lw.w0 * a + lw.w1 * b) + lh.w1 * (lw.w0 * c + lw.w1 * d);
+        io_stv(out + i * 4, lh.w0 * (lw.w0 * a + lw.w1 * b) + lh.w1 * (lw.w0 * c + lw.w1 * d));
     }
 }
 
 // exact adjoint in gather form: input pixel (h, w) collects from every output pixel whose stencil touches it
-__global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W,
-                                                                 int C4, int align, float* __restrict__ dx) {
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const T_* __restrict__ dy, int N, int H, int W,
+                                                                 int C4, int align, T_* __restrict__ dx) {
     const int OH = 2 * H, OW = 2 * W;
     const size_t total = (size_t)N * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float* _
         t /= W;
         const int h = (int)(t % H);
         const int n = (int)(t / H);
-        const f32x4* dp = reinterpret_cast<const f32x4*>(dy) + (size_t)n * OH * OW * C4 + q;
+        const T_* dp = dy + ((size_t)n * OH * OW * C4 + q) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int oh0 = max(0, 2 * h - 3), oh1 = min(OH - 1, 2 * h + 4);
         const int ow0 = max(0, 2 * w - 3), ow1 = min(OW - 1, 2 * w + 4);
@@ -121,52 +129,56 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float* _
                 const Lerp lw = lerp_of(ow, W, align);
                 const float ww = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
                 if (ww == 0.f) continue;
-                acc += (wh * ww) * dp[((size_t)oh * OW + ow) * C4];
+                acc += (wh * ww) * io_ldv(dp + ((size_t)oh * OW + ow) * C4 * 4);
             }
         }
-        reinterpret_cast<f32x4*>(dx)[i] = acc;
+        io_stv(dx + i * 4, acc);
     }
 }
 
 // ---- elementwise ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void bias_act_kernel(const float* x, const float* __restrict__ bias, size_t total4,
-                                                           int C4, int relu, float* out) {
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void bias_act_kernel(const T_* x, const float* __restrict__ bias, size_t total4,
+                                                           int C4, int relu, T_* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 v = io_ldv(x + i * 4);
         if (bias) v += reinterpret_cast<const f32x4*>(bias)[i % C4];
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
         }
-        reinterpret_cast<f32x4*>(out)[i] = v;
+        io_stv(out + i * 4, v);
     }
 }
 
-__global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const float* dy, const float* __restrict__ act, size_t total4,
-                                                           float* dx) {
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const T_* dy, const T_* __restrict__ act, size_t total4,
+                                                           T_* dx) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-        const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
+        f32x4 g = io_ldv(dy + i * 4);
+        const f32x4 a = io_ldv(act + i * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
-        reinterpret_cast<f32x4*>(dx)[i] = g;
+        io_stv(dx + i * 4, g);
     }
 }
 
-__global__ __launch_bounds__(kThreads) void add_kernel(const float* a, const float* b, size_t total4, float* out) {
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void add_kernel(const T_* a, const T_* b, size_t total4, T_* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+        io_stv(out + i * 4, io_ldv(a + i * 4) + io_ldv(b + i * 4));
 }
 
 // ---- column sums: out[c] = sum_m x[m][c] (bias gradients), two levels, fixed order ---------------------------------
 // block b sums rows [b*rpb, ...) into partial[b][C]; thread = (column tx = tid % C, row lane ty = tid / C)
-__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* __restrict__ x, int M, int C, int rpb,
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const T_* __restrict__ x, int M, int C, int rpb,
                                                                  float* __restrict__ partial) {
     __shared__ float red[kThreads];
     const int TY = kThreads / C, tx = threadIdx.x % C, ty = threadIdx.x / C;
     const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, M);
     float s = 0.f;
-    for (int r = r0 + ty; r < r1; r += TY) s += x[(size_t)r * C + tx];
+    for (int r = r0 + ty; r < r1; r += TY) s += ld1(x + (size_t)r * C + tx);
     red[threadIdx.x] = s;
     __syncthreads();
     if (ty == 0) {
@@ -185,14 +197,15 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nb, i
 
 // ---- 1x1 convolution to one channel (+ReLU), midas_net.py:139-140 ---------------------------------------------------
 // out[m] = act(b + sum_c x[m*pitch + c] * w[c]); one thread per row (C <= 64 floats, contiguous)
-__global__ __launch_bounds__(kThreads) void head1_fwd_kernel(const float* __restrict__ x, int M, int pitch, int C,
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void head1_fwd_kernel(const T_* __restrict__ x, int M, int pitch, int C,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             int relu, float* __restrict__ out) {
     for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < (size_t)M; m += (size_t)gridDim.x * blockDim.x) {
-        const f32x4* xp = reinterpret_cast<const f32x4*>(x + m * pitch);
+        const T_* xp = x + m * pitch;
         float s = b ? b[0] : 0.f;
         for (int q = 0; q < C / 4; ++q) {
-            const f32x4 v = xp[q], ww = reinterpret_cast<const f32x4*>(w)[q];
+            const f32x4 v = io_ldv(xp + q * 4), ww = reinterpret_cast<const f32x4*>(w)[q];
             s += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
         }
         out[m] = (relu && s < 0.f) ? 0.f : s;
@@ -201,10 +214,11 @@ __global__ __launch_bounds__(kThreads) void head1_fwd_kernel(const float* __rest
 
 // dz = dy * [out > 0]; dx[m][c] = dz * w[c] (zero in the padding channels C..pitch); partial[b][C+1] = block sums of
 // dz * x[m][c] and of dz
+template <typename T_>
 __global__ __launch_bounds__(kThreads) void head1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
-                                                            const float* __restrict__ x, int M, int pitch, int C,
+                                                            const T_* __restrict__ x, int M, int pitch, int C,
                                                             const float* __restrict__ w, int relu, int rpb,
-                                                            float* __restrict__ dx, float* __restrict__ partial) {
+                                                            T_* __restrict__ dx, float* __restrict__ partial) {
     __shared__ float red[kThreads];
     const int TXN = 64;                                  // column lanes (>= C, padded)
     const int TY = kThreads / TXN, tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
@@ -214,8 +228,8 @@ __global__ __launch_bounds__(kThreads) void head1_bwd_kernel(const float* __rest
     for (int r = r0 + ty; r < r1; r += TY) {
         float dz = dy[r];
         if (relu && !(out[r] > 0.f)) dz = 0.f;
-        if (tx < pitch) dx[(size_t)r * pitch + tx] = dz * wc;
-        if (tx < C) s += dz * x[(size_t)r * pitch + tx];
+        if (tx < pitch) st1(dx + (size_t)r * pitch + tx, dz * wc);
+        if (tx < C) s += dz * ld1(x + (size_t)r * pitch + tx);
         sb += dz;
     }
     red[threadIdx.x] = s;
@@ -244,12 +258,26 @@ int rows_per_block(int M, int* nb) {
 
 }  // namespace
 
-extern "C" int io_gconv_pack(const float* w, int C, int cg, int taps, float* wc, float* wtc, hipStream_t st) {
+#define IO_DT_REQUIRE(dt_) IO_REQUIRE((dt_) == IO_F32 || (dt_) == IO_BF16, IO_ERR_SHAPE, "unknown dtype %d", (dt_))
+#define IO_BY_DTYPE(dt_, CALL_)          \
+    do {                                 \
+        if ((dt_) == IO_BF16) {          \
+            typedef bf16_t T_;           \
+            CALL_;                       \
+        } else {                         \
+            typedef float T_;            \
+            CALL_;                       \
+        }                                \
+    } while (0)
+
+extern "C" int io_gconv_pack(const float* w, int C, int cg, int taps, void* wc, void* wtc, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 64 == 0 && cg >= 1 && cg <= 64 && 64 % cg == 0, IO_ERR_SHAPE,
                "gconv_pack: C=%d must be a multiple of 64 and the group width %d must divide 64", C, cg);
     const size_t total = (size_t)C * taps * 64;
-    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 12.0 * total, st);
-    hipLaunchKernelGGL(gconv_pack_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, w, C, cg, taps, wc, wtc);
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, (4.0 + 2.0 * io_dtype_bytes(dt)) * total, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(gconv_pack_kernel<T_>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, w, C, cg,
+                                       taps, (T_*)wc, (T_*)wtc));
     return io_check_launch("gconv_pack");
 }
 
@@ -267,64 +295,77 @@ static IoConvGeom gconv_geom(int N, int H, int W, int C, int R, int S, int strid
     return g;
 }
 
-extern "C" int io_gconv2d_fwd(const float* x, const float* wc, float* y, int N, int H, int W, int C, int R, int S,
-                              int stride, int pad, hipStream_t st) {
-    return io_launch_conv_nt(gconv_geom(N, H, W, C, R, S, stride, pad), x, wc, y, nullptr, nullptr, 0, st);
+extern "C" int io_gconv2d_fwd(const void* x, const void* wc, void* y, int N, int H, int W, int C, int R, int S,
+                              int stride, int pad, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
+    return io_launch_conv_nt(gconv_geom(N, H, W, C, R, S, stride, pad), x, wc, y, nullptr, nullptr, 0, st, nullptr,
+                             nullptr, nullptr, dt, dt);
 }
 
-extern "C" int io_gconv2d_dgrad(const float* dy, const float* wtc, float* dx, int N, int H, int W, int C, int R, int S,
-                                int stride, int pad, hipStream_t st) {
-    return io_run_dgrad(dy, wtc, dx, nullptr, nullptr, N, H, W, C, C, R, S, stride, pad, st, nullptr, IO_F32, 64);
+extern "C" int io_gconv2d_dgrad(const void* dy, const void* wtc, void* dx, int N, int H, int W, int C, int R, int S,
+                                int stride, int pad, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
+    return io_run_dgrad(dy, wtc, dx, nullptr, nullptr, N, H, W, C, C, R, S, stride, pad, st, nullptr, dt, 64);
 }
 
 extern "C" size_t io_gconv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int R, int S, int stride, int pad) {
     return io_conv_wgrad_partial_bytes(gconv_geom(N, H, W, C, R, S, stride, pad), 0);
 }
 
-extern "C" int io_gconv2d_wgrad(const float* x, const float* dy, float* dwc, int N, int H, int W, int C, int R, int S,
-                                int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
-    return io_launch_conv_wgrad(gconv_geom(N, H, W, C, R, S, stride, pad), x, dy, dwc, (float*)ws, ws_bytes, 0, st);
+extern "C" int io_gconv2d_wgrad(const void* x, const void* dy, float* dwc, int N, int H, int W, int C, int R, int S,
+                                int stride, int pad, void* ws, size_t ws_bytes, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
+    return io_launch_conv_wgrad(gconv_geom(N, H, W, C, R, S, stride, pad), x, dy, dwc, (float*)ws, ws_bytes, 0, st, dt,
+                                dt);
 }
 
-extern "C" int io_upsample2x_bilinear_fwd(const float* x, int N, int H, int W, int C, int align_corners, float* out,
-                                          hipStream_t st) {
+extern "C" int io_upsample2x_bilinear_fwd(const void* x, int N, int H, int W, int C, int align_corners, void* out,
+                                          int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
     const size_t total = (size_t)N * 4 * H * W * (C / 4);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 20.0 * N * H * W * C, st);
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, x, N, H, W, C / 4,
-                       align_corners, out);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 5.0 * io_dtype_bytes(dt) * N * H * W * C, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(upsample2x_fwd_kernel<T_>, dim3(ew_blocks(total)), dim3(kThreads), 0, st,
+                                       (const T_*)x, N, H, W, C / 4, align_corners, (T_*)out));
     return io_check_launch("upsample2x_fwd");
 }
 
-extern "C" int io_upsample2x_bilinear_bwd(const float* dy, int N, int H, int W, int C, int align_corners, float* dx,
-                                          hipStream_t st) {
+extern "C" int io_upsample2x_bilinear_bwd(const void* dy, int N, int H, int W, int C, int align_corners, void* dx,
+                                          int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
     const size_t total = (size_t)N * H * W * (C / 4);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 20.0 * N * H * W * C, st);
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, st, dy, N, H, W, C / 4,
-                       align_corners, dx);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 5.0 * io_dtype_bytes(dt) * N * H * W * C, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(upsample2x_bwd_kernel<T_>, dim3(ew_blocks(total)), dim3(kThreads), 0, st,
+                                       (const T_*)dy, N, H, W, C / 4, align_corners, (T_*)dx));
     return io_check_launch("upsample2x_bwd");
 }
 
-extern "C" int io_bias_act(const float* x, const float* bias, int M, int C, int relu, float* out, hipStream_t st) {
+extern "C" int io_bias_act(const void* x, const float* bias, int M, int C, int relu, void* out, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 4 == 0 && M > 0, IO_ERR_SHAPE, "bias_act: M=%d C=%d", M, C);
     const size_t total4 = (size_t)M * (C / 4);
-    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 8.0 * M * C, st);
-    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, x, bias, total4, C / 4, relu, out);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 2.0 * io_dtype_bytes(dt) * M * C, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(bias_act_kernel<T_>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, (const T_*)x,
+                                       bias, total4, C / 4, relu, (T_*)out));
     return io_check_launch("bias_act");
 }
 
-extern "C" int io_relu_bwd(const float* dy, const float* act, size_t n, float* dx, hipStream_t st) {
+extern "C" int io_relu_bwd(const void* dy, const void* act, size_t n, void* dx, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(n % 4 == 0 && n > 0, IO_ERR_SHAPE, "relu_bwd: n=%zu", n);
-    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 12.0 * n, st);
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, dy, act, n / 4, dx);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 3.0 * io_dtype_bytes(dt) * n, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(relu_bwd_kernel<T_>, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, (const T_*)dy,
+                                       (const T_*)act, n / 4, (T_*)dx));
     return io_check_launch("relu_bwd");
 }
 
-extern "C" int io_add(const float* a, const float* b, size_t n, float* out, hipStream_t st) {
+extern "C" int io_add(const void* a, const void* b, size_t n, void* out, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(n % 4 == 0 && n > 0, IO_ERR_SHAPE, "add: n=%zu", n);
-    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 12.0 * n, st);
-    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, a, b, n / 4, out);
+    IoProfScope prof(IO_PROF_BN_APPLY, 0.0, 3.0 * io_dtype_bytes(dt) * n, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(add_kernel<T_>, dim3(ew_blocks(n / 4)), dim3(kThreads), 0, st, (const T_*)a,
+                                       (const T_*)b, n / 4, (T_*)out));
     return io_check_launch("add");
 }
 
@@ -334,42 +375,46 @@ extern "C" size_t io_colsum_partial_floats(int M, int C) {
     return (size_t)nb * (C + 1);
 }
 
-extern "C" int io_colsum(const float* x, int M, int C, float* out, float* partial, size_t partial_floats,
+extern "C" int io_colsum(const void* x, int M, int C, float* out, float* partial, size_t partial_floats, int dt,
                          hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C >= 1 && C <= kThreads && kThreads % C == 0 && M > 0, IO_ERR_SHAPE, "colsum: C=%d must divide %d", C,
                kThreads);
     int nb;
     const int rpb = rows_per_block(M, &nb);
     IO_REQUIRE(partial_floats >= (size_t)nb * C, IO_ERR_WORKSPACE, "colsum: workspace %zu < %zu floats", partial_floats,
                (size_t)nb * C);
-    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 4.0 * M * C, st);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kThreads), 0, st, x, M, C, rpb, partial);
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(colsum_partial_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, (const T_*)x, M, C, rpb,
+                                       partial));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C, C, out);
     return io_check_launch("colsum");
 }
 
-extern "C" int io_head1_fwd(const float* x, int M, int pitch, int C, const float* w, const float* b, int relu,
-                            float* out, hipStream_t st) {
+extern "C" int io_head1_fwd(const void* x, int M, int pitch, int C, const float* w, const float* b, int relu,
+                            float* out, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 4 == 0 && C <= 64 && pitch % 4 == 0 && pitch >= C && pitch <= 64 && M > 0, IO_ERR_SHAPE,
                "head1: C=%d pitch=%d (C <= pitch <= 64, multiples of 4)", C, pitch);
-    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * M * C, 4.0 * M * (pitch + 1), st);
-    hipLaunchKernelGGL(head1_fwd_kernel, dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, st, x, M, pitch, C, w, b, relu,
-                       out);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * M * C, (double)M * (io_dtype_bytes(dt) * pitch + 4.0), st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_fwd_kernel<T_>, dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, st,
+                                       (const T_*)x, M, pitch, C, w, b, relu, out));
     return io_check_launch("head1_fwd");
 }
 
-extern "C" int io_head1_bwd(const float* dy, const float* out, const float* x, int M, int pitch, int C, const float* w,
-                            int relu, float* dx, float* dw, float* db, float* partial, size_t partial_floats,
+extern "C" int io_head1_bwd(const float* dy, const float* out, const void* x, int M, int pitch, int C, const float* w,
+                            int relu, void* dx, float* dw, float* db, float* partial, size_t partial_floats, int dt,
                             hipStream_t st) {
+    IO_DT_REQUIRE(dt);
     IO_REQUIRE(C % 4 == 0 && C <= 64 && pitch % 4 == 0 && pitch >= C && pitch <= 64 && M > 0, IO_ERR_SHAPE,
                "head1: C=%d pitch=%d (C <= pitch <= 64, multiples of 4)", C, pitch);
     int nb;
     const int rpb = rows_per_block(M, &nb);
     IO_REQUIRE(partial_floats >= (size_t)nb * (C + 1), IO_ERR_WORKSPACE, "head1_bwd: workspace %zu < %zu floats",
                partial_floats, (size_t)nb * (C + 1));
-    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * M * C, 4.0 * M * (2.0 * pitch + 2), st);
-    hipLaunchKernelGGL(head1_bwd_kernel, dim3(nb), dim3(kThreads), 0, st, dy, out, x, M, pitch, C, w, relu, rpb, dx,
-                       partial);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * M * C, (double)M * (2.0 * io_dtype_bytes(dt) * pitch + 8.0), st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_bwd_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, dy, out, (const T_*)x, M,
+                                       pitch, C, w, relu, rpb, (T_*)dx, partial));
     // the per-block sums are [nb][C+1]: column sums give dw[0..C) and db
     hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C + 1, C, dw);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, st, partial + C, nb, C + 1, 1, db);

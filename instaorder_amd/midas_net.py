@@ -195,6 +195,7 @@ class _InstaDepthBase(nn.Module):
         for i in (4, 3, 2, 1):
             setattr(self.scratch, "refinenet%d" % i, FeatureFusionBlock(features))
         self.non_negative = non_negative
+        self.dtype = "fp32"       # 'bf16': activations / GEMM operands in bf16 (set by SingleStageModel from params['dtype'])
         self.scratch.output_conv = nn.Sequential(                              # midas_net.py:134-141
             Conv2d(features, 128, 3, 1, 1, bias=True),
             _Fn(lambda x: ops.upsample2x(x, False)),
@@ -213,6 +214,9 @@ class _InstaDepthBase(nn.Module):
             parameters = parameters["model"]
         self.load_state_dict(parameters, strict=False)
 
+    def _act_dtype(self):
+        return torch.bfloat16 if self.dtype == "bf16" else torch.float32
+
     def _order_branch(self, net, fc, x8m, l1, l2, l3):
         f1 = net.run_layer1(x8m)
         f2 = net.layer2(ops.add(f1, l1))
@@ -226,7 +230,7 @@ class _InstaDepthBase(nn.Module):
         if not img.is_cuda:
             raise RuntimeError("instaorder_amd: input must be on the GPU; there is no CPU fallback")
         p, s = self.pretrained, self.scratch
-        x8 = ops.nhwc_from_nchw(img.float(), pad_to=8)
+        x8 = ops.nhwc_from_nchw(img.float(), pad_to=8, dtype=self._act_dtype())
         l1 = p.run_layer1(x8)
         l2 = p.layer2(l1)
         l3 = p.layer3(l2)
@@ -243,11 +247,11 @@ class _InstaDepthBase(nn.Module):
         return disp, (l1, l2, l3)
 
 
-def _pair_inputs(mask1, mask2, feats):
+def _pair_inputs(mask1, mask2, feats, dtype):
     """Both mask orders as one 2B batch: rows [0,B) = (mask1, mask2), rows [B,2B) = (mask2, mask1); the injected
     encoder features are the same for both."""
     m = torch.cat([torch.cat([mask1, mask2], 1), torch.cat([mask2, mask1], 1)], 0).float()
-    return ops.nhwc_from_nchw(m, pad_to=8), tuple(torch.cat([f, f], 0) for f in feats)
+    return ops.nhwc_from_nchw(m, pad_to=8, dtype=dtype), tuple(torch.cat([f, f], 0) for f in feats)
 
 
 class InstaDepthNet_od(_InstaDepthBase):
@@ -264,7 +268,7 @@ class InstaDepthNet_od(_InstaDepthBase):
 
     def forward(self, img, mask1, mask2):
         disp, (l1, l2, l3) = self._encode_decode(img)
-        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8)
+        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
         depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
         occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
         return disp, depth_order, occ_order
@@ -277,7 +281,7 @@ class InstaDepthNet_od(_InstaDepthBase):
         two separate calls."""
         with _BnMode(repeat=2):
             disp, feats = self._encode_decode(img)
-        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats)
+        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
         with _BnMode(groups=2):
             depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
             occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
@@ -295,7 +299,7 @@ class InstaDepthNet_d(_InstaDepthBase):
 
     def forward(self, img, mask1, mask2):
         disp, (l1, l2, l3) = self._encode_decode(img)
-        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8)
+        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
         depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None
 
@@ -303,7 +307,7 @@ class InstaDepthNet_d(_InstaDepthBase):
         """See InstaDepthNet_od.forward_pair."""
         with _BnMode(repeat=2):
             disp, feats = self._encode_decode(img)
-        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats)
+        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
         with _BnMode(groups=2):
             depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None

@@ -1,8 +1,9 @@
 """Operator layer for graphs the fixed ResNet-50 executor (io_net_*) does not cover -- today the MiDaS branch
 (InstaDepthNet_od / _d, midas/midas_net.py:116-212).  Every function is a ``torch.autograd.Function`` whose forward
-and backward are launches of libinstaorder_hip.so on **NHWC fp32** tensors; torch supplies memory, streams and the
-autograd tape only.  Filters are taken in the reference's OIHW layout (what ``state_dict`` holds) and re-laid out to
-the kernels' [Cout][taps][Cin] once per call.
+and backward are launches of libinstaorder_hip.so on **NHWC** tensors, fp32 or bf16 (the element type of the input
+selects the kernels; parameters and their gradients are always fp32); torch supplies memory, streams and the autograd
+tape only.  Filters are taken in the reference's OIHW layout (what ``state_dict`` holds) and re-laid out to the
+kernels' [Cout][taps][Cin] (in the activation type) once per call.
 
 There is no CPU path: inputs must live on an MI355X.
 """
@@ -30,18 +31,24 @@ def _L():
 
 
 def _chk(t, name):
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-        raise RuntimeError("instaorder_amd.ops: %s must be a contiguous fp32 tensor on the GPU (no CPU fallback)" % name)
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous()):
+        raise RuntimeError("instaorder_amd.ops: %s must be a contiguous fp32 / bf16 tensor on the GPU (no CPU fallback)"
+                           % name)
 
 
-def nhwc_from_nchw(x, pad_to=None):
-    """[N,C,H,W] -> contiguous [N,H,W,C'] (C' = pad_to, zero filled, for the 8-channel stems)."""
+def _dt(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def nhwc_from_nchw(x, pad_to=None, dtype=None):
+    """[N,C,H,W] -> contiguous [N,H,W,C'] (C' = pad_to, zero filled, for the 8-channel stems) of ``dtype``."""
     N, Cc, H, W = x.shape
+    dtype = dtype or x.dtype
     if pad_to is not None and pad_to != Cc:
-        out = torch.zeros((N, H, W, pad_to), device=x.device, dtype=x.dtype)
+        out = torch.zeros((N, H, W, pad_to), device=x.device, dtype=dtype)
         out[..., :Cc] = x.permute(0, 2, 3, 1)
         return out
-    return x.permute(0, 2, 3, 1).contiguous()
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
 def nchw_from_nhwc(x):
@@ -60,11 +67,12 @@ class _Conv(torch.autograd.Function):
         N, H, W_, Cs = x.shape
         Co, Ci, R, S = w.shape
         Cop = ((Co + 63) // 64) * 64 if co_pad else Co
-        wk = torch.zeros((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
+        wk = torch.zeros((Cop, R * S, Cs), device=x.device, dtype=x.dtype)
         wk[:Co, :, :Ci] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Ci)
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
-        y = torch.empty((N, Ho, Wo, Cop), device=x.device, dtype=torch.float32)
-        _lib.check(_L().io_conv2d_fwd(_p(x), _p(wk), _p(y), N, H, W_, Cs, Cop, R, S, stride, pad, _st()), "io_conv2d_fwd")
+        y = torch.empty((N, Ho, Wo, Cop), device=x.device, dtype=x.dtype)
+        _lib.check(_L().io_conv2d_fwd_dt(_p(x), _p(wk), _p(y), N, H, W_, Cs, Cop, R, S, stride, pad, _dt(x), _dt(x), _st()),
+                   "io_conv2d_fwd_dt")
         ctx.save_for_backward(x, wk)
         ctx.geom = (N, H, W_, Cs, Cop, Co, Ci, R, S, stride, pad)
         return y
@@ -79,18 +87,17 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if Cs == 8:
                 raise RuntimeError("ops.conv2d: no data gradient for the packed 8-channel stem input")
-            wt = torch.empty((Cs, R * S, Cop), device=x.device, dtype=torch.float32)
-            _lib.check(L.io_filter_transpose(_p(wk), Cop, R * S, Cs, _p(wt), _st()), "io_filter_transpose")
+            wt = wk.permute(2, 1, 0).contiguous()            # [Cin][taps][Cout], a few MB at most
             dx = torch.empty_like(x)
-            _lib.check(L.io_conv2d_dgrad(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Cop, R, S, stride, pad, _st()),
-                       "io_conv2d_dgrad")
+            _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Cop, R, S, stride, pad, _dt(x),
+                                            _st()), "io_conv2d_dgrad_dt")
         dw = None
         if ctx.needs_input_grad[1]:
             nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Cop, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
             dwk = torch.empty((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
-            _lib.check(L.io_conv2d_wgrad(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Cop, R, S, stride, pad, _p(ws), nb, _st()),
-                       "io_conv2d_wgrad")
+            _lib.check(L.io_conv2d_wgrad_dt(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Cop, R, S, stride, pad, _p(ws), nb, _dt(x),
+                                            _dt(x), _st()), "io_conv2d_wgrad_dt")
             dw = dwk[:Co, :, :Ci].reshape(Co, R, S, Ci).permute(0, 3, 1, 2).contiguous()
         return dx, dw, None, None, None
 
@@ -106,12 +113,13 @@ class _GroupedConv(torch.autograd.Function):
         if Co != Cc:
             raise ValueError("grouped conv: Cin must equal Cout")
         L = _L()
-        wc = torch.empty((Cc, R * S, 64), device=x.device, dtype=torch.float32)
+        wc = torch.empty((Cc, R * S, 64), device=x.device, dtype=x.dtype)
         wtc = torch.empty_like(wc)
-        _lib.check(L.io_gconv_pack(_p(w.detach().contiguous()), Cc, cg, R * S, _p(wc), _p(wtc), _st()), "io_gconv_pack")
+        _lib.check(L.io_gconv_pack(_p(w.detach().contiguous()), Cc, cg, R * S, _p(wc), _p(wtc), _dt(x), _st()),
+                   "io_gconv_pack")
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
-        y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
-        _lib.check(L.io_gconv2d_fwd(_p(x), _p(wc), _p(y), N, H, W_, Cc, R, S, stride, pad, _st()), "io_gconv2d_fwd")
+        y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
+        _lib.check(L.io_gconv2d_fwd(_p(x), _p(wc), _p(y), N, H, W_, Cc, R, S, stride, pad, _dt(x), _st()), "io_gconv2d_fwd")
         ctx.save_for_backward(x, wtc)
         ctx.geom = (N, H, W_, Cc, cg, R, S, stride, pad)
         return y
@@ -123,11 +131,12 @@ class _GroupedConv(torch.autograd.Function):
         dy = dy.contiguous()
         L = _L()
         dx = torch.empty_like(x)
-        _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wtc), _p(dx), N, H, W_, Cc, R, S, stride, pad, _st()), "io_gconv2d_dgrad")
+        _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wtc), _p(dx), N, H, W_, Cc, R, S, stride, pad, _dt(x), _st()),
+                   "io_gconv2d_dgrad")
         nb = int(L.io_gconv2d_wgrad_workspace_bytes(N, H, W_, Cc, R, S, stride, pad))
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
         dwc = torch.empty((Cc, R * S, 64), device=x.device, dtype=torch.float32)
-        _lib.check(L.io_gconv2d_wgrad(_p(x), _p(dy), _p(dwc), N, H, W_, Cc, R, S, stride, pad, _p(ws), nb, _st()),
+        _lib.check(L.io_gconv2d_wgrad(_p(x), _p(dy), _p(dwc), N, H, W_, Cc, R, S, stride, pad, _p(ws), nb, _dt(x), _st()),
                    "io_gconv2d_wgrad")
         dw = torch.empty((Cc, cg, R, S), device=x.device, dtype=torch.float32)
         _lib.check(L.io_gconv_unpack_grad(_p(dwc), Cc, cg, R * S, _p(dw), _st()), "io_gconv_unpack_grad")
@@ -159,13 +168,13 @@ class _BatchNorm(torch.autograd.Function):
         M = x.numel() // Cc
         dev = x.device
         G = int(groups) if training else 1
-        mean, rstd, scale, shift = (torch.empty(G * Cc, device=dev) for _ in range(4))
+        mean, rstd, scale, shift = (torch.empty(G * Cc, device=dev, dtype=torch.float32) for _ in range(4))
         if training:
             npart = int(L.io_bn_partial_floats(M, Cc, G))
-            part = torch.empty(npart, device=dev)
-            _lib.check(L.io_bn_stats_finalize(_p(x), M, Cc, G, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
-                                              _p(running_var), 0.1, 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift), _p(part),
-                                              npart, _st()), "io_bn_stats_finalize")
+            part = torch.empty(npart, device=dev, dtype=torch.float32)
+            _lib.check(L.io_bn_stats_finalize_dt(_p(x), M, Cc, G, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
+                                                 _p(running_var), 0.1, 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift),
+                                                 _p(part), npart, _dt(x), _st()), "io_bn_stats_finalize_dt")
             for _ in range(int(repeat) - 1):          # same statistics again (G == 1 when repeat > 1)
                 n = M // G
                 var_unb = (1.0 / (rstd * rstd) - 1e-5) * (float(n) / float(max(n - 1, 1)))
@@ -176,8 +185,8 @@ class _BatchNorm(torch.autograd.Function):
                                             1e-5, _p(mean), _p(scale), _p(shift), _st()), "io_bn_eval_prepare")
             rstd = scale / gamma.detach()
         out = torch.empty_like(x)
-        _lib.check(L.io_bn_apply(_p(x), M, Cc, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
-                                 None, None, int(relu), _p(out), _st()), "io_bn_apply")
+        _lib.check(L.io_bn_apply_dt(_p(x), M, Cc, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
+                                    None, None, int(relu), _p(out), _dt(x), _st()), "io_bn_apply_dt")
         ctx.save_for_backward(x, out, gamma, mean, rstd)
         ctx.cfg = (M, Cc, bool(relu), identity is not None, bool(training), G)
         return out
@@ -192,14 +201,14 @@ class _BatchNorm(torch.autograd.Function):
         dout = dout.contiguous()
         dev = x.device
         npart = int(L.io_bn_partial_floats(M, Cc, G))
-        part = torch.empty(npart, device=dev)
-        coef = torch.empty(2 * G * Cc, device=dev)
+        part = torch.empty(npart, device=dev, dtype=torch.float32)
+        coef = torch.empty(2 * G * Cc, device=dev, dtype=torch.float32)
         dgamma, dbeta = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         dx = torch.empty_like(x)
         dz = torch.empty_like(x) if has_id else None          # gradient of the pre-ReLU sum = gradient of `identity`
-        _lib.check(L.io_bn_bwd(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, G, _p(gamma.detach()), _p(mean),
-                               _p(rstd), _p(dgamma), _p(dbeta), _p(dx), _p(dz), _p(part), npart, _p(coef), _st()),
-                   "io_bn_bwd")
+        _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, G, _p(gamma.detach()),
+                                  _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dx), _p(dz), _p(part), npart, _p(coef),
+                                  _dt(x), _st()), "io_bn_bwd_dt")
         return dx, dgamma, dbeta, None, None, None, None, dz, None, None
 
 
@@ -216,9 +225,9 @@ class _MaxPool(torch.autograd.Function):
         _chk(x, "x")
         N, H, W_, Cc = x.shape
         Ho, Wo = (H + 1) // 2, (W_ + 1) // 2
-        out = torch.empty((N, Ho, Wo, Cc), device=x.device)
+        out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
         idx = torch.empty((N, Ho, Wo, Cc // 4), dtype=torch.int32, device=x.device)
-        _lib.check(_L().io_maxpool_fwd(_p(x), N, H, W_, Cc, _p(out), _p(idx), _st()), "io_maxpool_fwd")
+        _lib.check(_L().io_maxpool_fwd_dt(_p(x), N, H, W_, Cc, _p(out), _p(idx), _dt(x), _st()), "io_maxpool_fwd_dt")
         ctx.save_for_backward(idx)
         ctx.geom = (N, H, W_, Cc)
         return out
@@ -227,8 +236,9 @@ class _MaxPool(torch.autograd.Function):
     def backward(ctx, dy):
         idx, = ctx.saved_tensors
         N, H, W_, Cc = ctx.geom
-        dx = torch.empty((N, H, W_, Cc), device=dy.device)
-        _lib.check(_L().io_maxpool_bwd(_p(dy.contiguous()), _p(idx), N, H, W_, Cc, _p(dx), _st()), "io_maxpool_bwd")
+        dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=dy.dtype)
+        _lib.check(_L().io_maxpool_bwd_dt(_p(dy.contiguous()), _p(idx), N, H, W_, Cc, _p(dx), _dt(dy), _st()),
+                   "io_maxpool_bwd_dt")
         return dx
 
 
@@ -245,23 +255,24 @@ class _AvgPoolFc(torch.autograd.Function):
         _chk(x, "x")
         N, H, W_, Cc = x.shape
         K = w.shape[0]
-        pooled = torch.empty((N, Cc), device=x.device)
-        logits = torch.empty((N, K), device=x.device)
+        pooled = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+        logits = torch.empty((N, K), device=x.device, dtype=torch.float32)
         wd, bd = w.detach().contiguous(), b.detach().contiguous()
-        _lib.check(_L().io_avgpool_fc_fwd(_p(x), N, H * W_, Cc, _p(wd), _p(bd), K, None, None, 0, _p(pooled), _p(logits),
-                                          _st()), "io_avgpool_fc_fwd")
+        _lib.check(_L().io_avgpool_fc_fwd_dt(_p(x), N, H * W_, Cc, _p(wd), _p(bd), K, None, None, 0, _p(pooled), _p(logits),
+                                             _dt(x), _st()), "io_avgpool_fc_fwd_dt")
         ctx.save_for_backward(pooled, wd)
-        ctx.geom = (N, H, W_, Cc, K)
+        ctx.geom = (N, H, W_, Cc, K, x.dtype)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         pooled, wd = ctx.saved_tensors
-        N, H, W_, Cc, K = ctx.geom
-        dx = torch.empty((N, H, W_, Cc), device=pooled.device)
+        N, H, W_, Cc, K, xdt = ctx.geom
+        dx = torch.empty((N, H, W_, Cc), device=pooled.device, dtype=xdt)
         dw, db = torch.empty((K, Cc), device=pooled.device), torch.empty(K, device=pooled.device)
-        _lib.check(_L().io_avgpool_fc_bwd(_p(dlogits.contiguous()), _p(pooled), N, H * W_, Cc, _p(wd), K, None, 0, None,
-                                          _p(dx), _p(dw), _p(db), None, None, _st()), "io_avgpool_fc_bwd")
+        _lib.check(_L().io_avgpool_fc_bwd_dt(_p(dlogits.float().contiguous()), _p(pooled), N, H * W_, Cc, _p(wd), K, None, 0,
+                                             None, _p(dx), _p(dw), _p(db), None, None, _dt(dx), _st()),
+                   "io_avgpool_fc_bwd_dt")
         return dx, dw, db
 
 
@@ -275,16 +286,17 @@ class _Upsample(torch.autograd.Function):
     def forward(ctx, x, align):
         _chk(x, "x")
         N, H, W_, Cc = x.shape
-        out = torch.empty((N, 2 * H, 2 * W_, Cc), device=x.device)
-        _lib.check(_L().io_upsample2x_bilinear_fwd(_p(x), N, H, W_, Cc, int(align), _p(out), _st()), "io_upsample2x_fwd")
+        out = torch.empty((N, 2 * H, 2 * W_, Cc), device=x.device, dtype=x.dtype)
+        _lib.check(_L().io_upsample2x_bilinear_fwd(_p(x), N, H, W_, Cc, int(align), _p(out), _dt(x), _st()),
+                   "io_upsample2x_fwd")
         ctx.geom = (N, H, W_, Cc, int(align))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         N, H, W_, Cc, align = ctx.geom
-        dx = torch.empty((N, H, W_, Cc), device=dy.device)
-        _lib.check(_L().io_upsample2x_bilinear_bwd(_p(dy.contiguous()), N, H, W_, Cc, align, _p(dx), _st()),
+        dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=dy.dtype)
+        _lib.check(_L().io_upsample2x_bilinear_bwd(_p(dy.contiguous()), N, H, W_, Cc, align, _p(dx), _dt(dy), _st()),
                    "io_upsample2x_bwd")
         return dx, None
 
@@ -306,7 +318,7 @@ class _BiasAct(torch.autograd.Function):
             bd = bias.detach()
             if bd.numel() != Cc:                       # padded output channels carry no bias
                 bd = torch.cat([bd, torch.zeros(Cc - bd.numel(), device=x.device)])
-        _lib.check(_L().io_bias_act(_p(x), _p(bd), M, Cc, int(relu), _p(out), _st()), "io_bias_act")
+        _lib.check(_L().io_bias_act(_p(x), _p(bd), M, Cc, int(relu), _p(out), _dt(x), _st()), "io_bias_act")
         ctx.save_for_backward(out)
         ctx.cfg = (M, Cc, bool(relu), None if bias is None else bias.numel())
         return out
@@ -320,13 +332,13 @@ class _BiasAct(torch.autograd.Function):
         dx = dy
         if relu:
             dx = torch.empty_like(dy)
-            _lib.check(L.io_relu_bwd(_p(dy), _p(out), dy.numel(), _p(dx), _st()), "io_relu_bwd")
+            _lib.check(L.io_relu_bwd(_p(dy), _p(out), dy.numel(), _p(dx), _dt(dy), _st()), "io_relu_bwd")
         db = None
         if nbias is not None:
             npart = int(L.io_colsum_partial_floats(M, Cc))
-            part = torch.empty(npart, device=dy.device)
-            dbf = torch.empty(Cc, device=dy.device)
-            _lib.check(L.io_colsum(_p(dx), M, Cc, _p(dbf), _p(part), npart, _st()), "io_colsum")
+            part = torch.empty(npart, device=dy.device, dtype=torch.float32)
+            dbf = torch.empty(Cc, device=dy.device, dtype=torch.float32)
+            _lib.check(L.io_colsum(_p(dx), M, Cc, _p(dbf), _p(part), npart, _dt(dx), _st()), "io_colsum")
             db = dbf[:nbias].clone()
         return dx, db, None
 
@@ -346,7 +358,7 @@ class _Add(torch.autograd.Function):
         _chk(a, "a")
         _chk(b, "b")
         out = torch.empty_like(a)
-        _lib.check(_L().io_add(_p(a), _p(b), a.numel(), _p(out), _st()), "io_add")
+        _lib.check(_L().io_add(_p(a), _p(b), a.numel(), _p(out), _dt(a), _st()), "io_add")
         return out
 
     @staticmethod
@@ -367,9 +379,9 @@ class _Head1(torch.autograd.Function):
         N, H, W_, pitch = x.shape
         Cc = w.numel()
         M = N * H * W_
-        out = torch.empty((N, H, W_), device=x.device)
+        out = torch.empty((N, H, W_), device=x.device, dtype=torch.float32)
         wd, bd = w.detach().reshape(-1).contiguous(), b.detach().reshape(-1).contiguous()
-        _lib.check(_L().io_head1_fwd(_p(x), M, pitch, Cc, _p(wd), _p(bd), int(relu), _p(out), _st()), "io_head1_fwd")
+        _lib.check(_L().io_head1_fwd(_p(x), M, pitch, Cc, _p(wd), _p(bd), int(relu), _p(out), _dt(x), _st()), "io_head1_fwd")
         ctx.save_for_backward(x, out, wd)
         ctx.cfg = (M, pitch, Cc, int(relu), tuple(w.shape))
         return out
@@ -380,11 +392,11 @@ class _Head1(torch.autograd.Function):
         M, pitch, Cc, relu, wshape = ctx.cfg
         L = _L()
         npart = int(L.io_colsum_partial_floats(M, Cc))
-        part = torch.empty(npart, device=x.device)
+        part = torch.empty(npart, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         dw, db = torch.empty(Cc, device=x.device), torch.empty(1, device=x.device)
-        _lib.check(L.io_head1_bwd(_p(dy.contiguous()), _p(out), _p(x), M, pitch, Cc, _p(wd), relu, _p(dx), _p(dw), _p(db),
-                                  _p(part), npart, _st()), "io_head1_bwd")
+        _lib.check(L.io_head1_bwd(_p(dy.float().contiguous()), _p(out), _p(x), M, pitch, Cc, _p(wd), relu, _p(dx), _p(dw),
+                                  _p(db), _p(part), npart, _dt(x), _st()), "io_head1_bwd")
         return dx, dw.view(wshape), db, None
 
 

@@ -22,6 +22,7 @@ class SingleStageModel(object):
             # single_stage_model.py:17-22: the MiDaS-based nets take only the (optional) pretrained MiDaS weights
             cls = midas_net.InstaDepthNet_od if params["algo"] == "InstaDepthNet_od" else midas_net.InstaDepthNet_d
             net = cls(params.get("pretrained_weight"), non_negative=True)
+            net.dtype = params.get("dtype", "fp32")
         else:
             arch = params["backbone_arch"]
             if arch not in _BACKBONES:

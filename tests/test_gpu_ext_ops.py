@@ -31,19 +31,19 @@ def test_grouped_conv3x3(C, cg, H, stride):
     wd = dev(w.detach().reshape(C, cg, 9))
     wc = torch.empty(C, 9, 64, device=DEV)
     wtc = torch.empty(C, 9, 64, device=DEV)
-    _lib.check(L().io_gconv_pack(P(wd), C, cg, 9, P(wc), P(wtc), ST()), "pack")
+    _lib.check(L().io_gconv_pack(P(wd), C, cg, 9, P(wc), P(wtc), 0, ST()), "pack")
     xd = dev(x.detach().permute(0, 2, 3, 1))
     yd = torch.empty(N, Ho, Ho, C, device=DEV)
-    _lib.check(L().io_gconv2d_fwd(P(xd), P(wc), P(yd), N, H, H, C, 3, 3, stride, 1, ST()), "fwd")
+    _lib.check(L().io_gconv2d_fwd(P(xd), P(wc), P(yd), N, H, H, C, 3, 3, stride, 1, 0, ST()), "fwd")
     assert relerr(yd.permute(0, 3, 1, 2), y.detach()) < 2e-6
     dyd = dev(dy.permute(0, 2, 3, 1))
     dxd = torch.empty(N, H, H, C, device=DEV)
-    _lib.check(L().io_gconv2d_dgrad(P(dyd), P(wtc), P(dxd), N, H, H, C, 3, 3, stride, 1, ST()), "dgrad")
+    _lib.check(L().io_gconv2d_dgrad(P(dyd), P(wtc), P(dxd), N, H, H, C, 3, 3, stride, 1, 0, ST()), "dgrad")
     assert relerr(dxd.permute(0, 3, 1, 2), gx) < 2e-6
     nb = L().io_gconv2d_wgrad_workspace_bytes(N, H, H, C, 3, 3, stride, 1)
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
     dwc = torch.empty(C, 9, 64, device=DEV)
-    _lib.check(L().io_gconv2d_wgrad(P(xd), P(dyd), P(dwc), N, H, H, C, 3, 3, stride, 1, P(ws), nb, ST()), "wgrad")
+    _lib.check(L().io_gconv2d_wgrad(P(xd), P(dyd), P(dwc), N, H, H, C, 3, 3, stride, 1, P(ws), nb, 0, ST()), "wgrad")
     dw = torch.empty(C, cg, 9, device=DEV)
     _lib.check(L().io_gconv_unpack_grad(P(dwc), C, cg, 9, P(dw), ST()), "unpack")
     assert relerr(dw.view(C, cg, 3, 3), gw) < 2e-6
@@ -59,10 +59,10 @@ def test_upsample2x_bilinear(N, H, W, C, align):
     gx, = torch.autograd.grad(y, [x], dy)
     xd = dev(x.detach().permute(0, 2, 3, 1))
     out = torch.empty(N, 2 * H, 2 * W, C, device=DEV)
-    _lib.check(L().io_upsample2x_bilinear_fwd(P(xd), N, H, W, C, align, P(out), ST()), "up fwd")
+    _lib.check(L().io_upsample2x_bilinear_fwd(P(xd), N, H, W, C, align, P(out), 0, ST()), "up fwd")
     assert relerr(out.permute(0, 3, 1, 2), y.detach()) < 1e-6
     dx = torch.empty(N, H, W, C, device=DEV)
-    _lib.check(L().io_upsample2x_bilinear_bwd(P(dev(dy.permute(0, 2, 3, 1))), N, H, W, C, align, P(dx), ST()), "up bwd")
+    _lib.check(L().io_upsample2x_bilinear_bwd(P(dev(dy.permute(0, 2, 3, 1))), N, H, W, C, align, P(dx), 0, ST()), "up bwd")
     assert relerr(dx.permute(0, 3, 1, 2), gx) < 1e-6
 
 
@@ -72,22 +72,22 @@ def test_bias_relu_add_colsum():
     x, b = torch.randn(M, C, generator=g), torch.randn(C, generator=g)
     xd, bd = dev(x), dev(b)
     out = torch.empty(M, C, device=DEV)
-    _lib.check(L().io_bias_act(P(xd), P(bd), M, C, 1, P(out), ST()), "bias_act")
+    _lib.check(L().io_bias_act(P(xd), P(bd), M, C, 1, P(out), 0, ST()), "bias_act")
     assert torch.equal(out.cpu(), torch.relu(x + b))
-    _lib.check(L().io_bias_act(P(xd), None, M, C, 1, P(out), ST()), "relu")
+    _lib.check(L().io_bias_act(P(xd), None, M, C, 1, P(out), 0, ST()), "relu")
     assert torch.equal(out.cpu(), torch.relu(x))
     dy = torch.randn(M, C, generator=g)
     dx = torch.empty(M, C, device=DEV)
-    _lib.check(L().io_relu_bwd(P(dev(dy)), P(out), M * C, P(dx), ST()), "relu_bwd")
+    _lib.check(L().io_relu_bwd(P(dev(dy)), P(out), M * C, P(dx), 0, ST()), "relu_bwd")
     assert torch.equal(dx.cpu(), dy * (x > 0))
-    _lib.check(L().io_add(P(xd), P(dev(dy)), M * C, P(dx), ST()), "add")
+    _lib.check(L().io_add(P(xd), P(dev(dy)), M * C, P(dx), 0, ST()), "add")
     assert torch.equal(dx.cpu(), x + dy)
     for Cc in (32, 128, 256):
         v = torch.randn(M, Cc, generator=g)
         npart = L().io_colsum_partial_floats(M, Cc)
         part = torch.empty(npart, device=DEV)
         s = torch.empty(Cc, device=DEV)
-        _lib.check(L().io_colsum(P(dev(v)), M, Cc, P(s), P(part), npart, ST()), "colsum")
+        _lib.check(L().io_colsum(P(dev(v)), M, Cc, P(s), P(part), npart, 0, ST()), "colsum")
         assert relerr(s, v.double().sum(0)) < 1e-6
 
 
@@ -105,13 +105,69 @@ def test_head_one_channel(relu):
     gx, gw, gb = torch.autograd.grad(y, [xr, w, b], dy)
     xd = dev(x)
     out = torch.empty(M, device=DEV)
-    _lib.check(L().io_head1_fwd(P(xd), M, pitch, C, P(dev(w.detach())), P(dev(b.detach())), relu, P(out), ST()), "head fwd")
+    _lib.check(L().io_head1_fwd(P(xd), M, pitch, C, P(dev(w.detach())), P(dev(b.detach())), relu, P(out), 0, ST()), "head fwd")
     assert relerr(out, y.detach()) < 1e-6
     npart = L().io_colsum_partial_floats(M, C)
     part = torch.empty(npart, device=DEV)
     dx = torch.full((M, pitch), 7.0, device=DEV)
     dw, db = torch.empty(C, device=DEV), torch.empty(1, device=DEV)
     _lib.check(L().io_head1_bwd(P(dev(dy)), P(out), P(xd), M, pitch, C, P(dev(w.detach())), relu, P(dx), P(dw), P(db), P(part),
-                                npart, ST()), "head bwd")
+                                npart, 0, ST()), "head bwd")
     assert relerr(dx[:, :C], gx) < 1e-6 and float(dx[:, C:].abs().max()) == 0.0
     assert relerr(dw, gw) < 1e-5 and relerr(db, gb) < 1e-5
+
+
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+def test_grouped_conv_and_decoder_ops_bf16():
+    """The same kernels on bf16 storage (dtype = 1): inputs rounded to bf16, fp64 torch reference, one output
+    rounding (2^-8) on bf16 results, fp32-accumulated filter / bias gradients."""
+    C, cg, H, N, stride = 512, 16, 10, 2, 2
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(N, C, H, H, generator=g)).requires_grad_(True)
+    w = _bf(torch.randn(C, cg, 3, 3, generator=g) / np.sqrt(9 * cg)).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=1, groups=C // cg)
+    Ho = y.shape[2]
+    dy = _bf(torch.randn(y.shape, generator=g))
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    bdev = lambda t: t.float().bfloat16().to(DEV).contiguous()
+    wc = torch.empty(C, 9, 64, device=DEV, dtype=torch.bfloat16)
+    wtc = torch.empty_like(wc)
+    _lib.check(L().io_gconv_pack(P(dev(w.detach().reshape(C, cg, 9))), C, cg, 9, P(wc), P(wtc), 1, ST()), "pack")
+    xd = bdev(x.detach().permute(0, 2, 3, 1))
+    yd = torch.empty(N, Ho, Ho, C, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().io_gconv2d_fwd(P(xd), P(wc), P(yd), N, H, H, C, 3, 3, stride, 1, 1, ST()), "fwd")
+    assert relerr(yd.float().permute(0, 3, 1, 2), y.detach()) < 6e-3
+    dyd = bdev(dy.permute(0, 2, 3, 1))
+    dxd = torch.empty(N, H, H, C, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().io_gconv2d_dgrad(P(dyd), P(wtc), P(dxd), N, H, H, C, 3, 3, stride, 1, 1, ST()), "dgrad")
+    assert relerr(dxd.float().permute(0, 3, 1, 2), gx) < 6e-3
+    nb = L().io_gconv2d_wgrad_workspace_bytes(N, H, H, C, 3, 3, stride, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dwc = torch.empty(C, 9, 64, device=DEV)
+    _lib.check(L().io_gconv2d_wgrad(P(xd), P(dyd), P(dwc), N, H, H, C, 3, 3, stride, 1, P(ws), nb, 1, ST()), "wgrad")
+    dw = torch.empty(C, cg, 9, device=DEV)
+    _lib.check(L().io_gconv_unpack_grad(P(dwc), C, cg, 9, P(dw), ST()), "unpack")
+    assert relerr(dw.view(C, cg, 3, 3), gw) < 2e-5
+    # bilinear x2, bias + ReLU, column sums on bf16 tensors
+    xs = _bf(torch.randn(2, 64, 5, 7, generator=g)).requires_grad_(True)
+    up = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=True)
+    dup = _bf(torch.randn(up.shape, generator=g))
+    gxs, = torch.autograd.grad(up, [xs], dup)
+    out = torch.empty(2, 10, 14, 64, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().io_upsample2x_bilinear_fwd(P(bdev(xs.detach().permute(0, 2, 3, 1))), 2, 5, 7, 64, 1, P(out), 1, ST()), "up")
+    assert relerr(out.float().permute(0, 3, 1, 2), up.detach()) < 6e-3
+    dxs = torch.empty(2, 5, 7, 64, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().io_upsample2x_bilinear_bwd(P(bdev(dup.permute(0, 2, 3, 1))), 2, 5, 7, 64, 1, P(dxs), 1, ST()), "up bwd")
+    assert relerr(dxs.float().permute(0, 3, 1, 2), gxs) < 6e-3
+    M, Cc = 2000, 128
+    v, b = _bf(torch.randn(M, Cc, generator=g)), torch.randn(Cc, generator=g).double()
+    o = torch.empty(M, Cc, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().io_bias_act(P(bdev(v)), P(dev(b)), M, Cc, 1, P(o), 1, ST()), "bias_act")
+    assert relerr(o.float(), torch.relu(v + b)) < 6e-3
+    npart = L().io_colsum_partial_floats(M, Cc)
+    part, sm = torch.empty(npart, device=DEV), torch.empty(Cc, device=DEV)
+    _lib.check(L().io_colsum(P(bdev(v)), M, Cc, P(sm), P(part), npart, 1, ST()), "colsum")
+    assert relerr(sm, v.sum(0)) < 1e-5

@@ -20,11 +20,11 @@ def load(tag):
     return g, spec
 
 
-def build(algo, g, spec):
+def build(algo, g, spec, dtype="fp32"):
     import instaorder_amd as ia
     S, B, seed = (int(v) for v in g["meta"])
     cfg = dict(algo=algo, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), optim="SGD", pretrained_weight=None,
-               use_rgb=True, **WEIGHTS)
+               use_rgb=True, dtype=dtype, **WEIGHTS)
     m = getattr(ia, algo)(cfg, dist_model=False)
     sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
     m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
@@ -115,3 +115,29 @@ def test_net_forward_InstaDepthNet_decisions():
                                                                     t["modal2"][i, 0].numpy())
     assert disp1.shape == (1, 64, 64) and d in (0, 1, 2) and isinstance(o12, bool)
     assert rel_err(disp1.cpu().numpy()[0], g["eval_disp"][i]) < 2e-3      # batch-1 eval == row i of the batch-2 golden
+
+
+def test_bf16_mode_close_to_reference():
+    """bf16 activations / operands through the whole MiDaS-based net (grouped convolutions, decoder, both branches):
+    outputs and losses stay close to the fp32 reference golden (the synthetic weights are well conditioned, see
+    synthetic.make_spec_state_dict); the training step runs and produces a sane update."""
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec, dtype="bf16")
+    m.switch_to("eval")
+    with torch.no_grad():
+        d, dep, occ = m.model(t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())
+    e = (rel_err(d.cpu().numpy(), g["eval_disp"]), rel_err(dep.cpu().numpy(), g["eval_dep"]),
+         rel_err(occ.cpu().numpy(), g["eval_occ"]))
+    print("bf16 eval rel err (disp, depth logits, occ logits): %.2e %.2e %.2e" % e)
+    assert max(e) < 5e-2
+    m.switch_to("train")
+    feed(m, algo, t)
+    logs, l = m.step()
+    for k in ("loss_overlap", "loss_distinct", "loss_occ", "loss_smooth"):
+        ref = float(g["step_" + k])
+        assert abs(float(logs[k]) - ref) <= 3e-2 * max(1.0, abs(ref)), (k, float(logs[k]), ref)
+    gn = float(m.optim.flat_grads.double().norm())
+    ref_gn = float(np.sqrt((g["grad_norms"] ** 2).sum()))
+    print("bf16 step: gradient norm %.4f (fp32 reference %.4f)" % (gn, ref_gn))
+    assert abs(gn - ref_gn) < 0.1 * ref_gn
