@@ -253,6 +253,13 @@ int io_head1_fwd(const void* x, int M, int pitch, int C, const float* w, const f
                  hipStream_t stream);
 int io_head1_bwd(const float* dy, const float* out, const void* x, int M, int pitch, int C, const float* w, int relu,
                  void* dx, float* dw, float* db, float* partial, size_t partial_floats, int dtype, hipStream_t stream);
+/* io_conv2d_fwd_bnstats for either storage type and for the grouped window form (gw = 64; w = wc of io_gconv_pack,
+ * Cin == Cout); gw = 0 is the dense convolution */
+int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                             int stride, int pad, int G, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* mean, float* rstd, float* scale,
+                             float* shift, float* workspace, size_t workspace_floats, int dtype, int gw,
+                             hipStream_t stream);
 /* storage-typed forms of io_maxpool_* / io_avgpool_fc_* (pooled / logits / parameter gradients stay float) */
 int io_maxpool_fwd_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int dtype, hipStream_t stream);
 int io_maxpool_bwd_dt(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, int dtype,

@@ -328,3 +328,27 @@ extern "C" int io_avgpool_fc_bwd_dt(const float* dlogits, const float* pooled, i
     IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "avgpool_fc: unknown dtype %d", dtype);
     return io_avgpool_fc_bwd_t(dlogits, pooled, N, HW, C, w0, K0, w1, K1, relu_mask, dx, dw0, db0, dw1, db1, st, dtype);
 }
+
+
+/* conv + training BatchNorm statistics in one pass, storage-typed, dense (gw = 0) or grouped-window (gw = 64) */
+extern "C" int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
+                                        int R, int S, int stride, int pad, int G, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                        float* rstd, float* scale, float* shift, float* workspace,
+                                        size_t workspace_floats, int dtype, int gw, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_bnstats: unknown dtype %d", dtype);
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    g.gw = gw;
+    const int M = N * g.Ho * g.Wo;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_fwd_bnstats: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, Cout, R, S, stride, pad, G);
+    IO_REQUIRE(workspace_floats >= need, IO_ERR_WORKSPACE, "conv2d_fwd_bnstats: workspace %zu < %zu floats",
+               workspace_floats, need);
+    float* tmean = workspace;
+    float* tm2 = workspace + need / 2;
+    int rc = io_launch_conv_nt(g, x, w, y, nullptr, nullptr, Cin == 8, st, tmean, tm2, nullptr, dtype, dtype);
+    if (rc) return rc;
+    return io_bn_finalize_tiles(tmean, tm2, M, Cout, G, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                rstd, scale, shift, st);
+}

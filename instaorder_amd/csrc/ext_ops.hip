@@ -186,13 +186,16 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const T_* __re
         partial[(size_t)blockIdx.x * C + tx] = s;
     }
 }
+// one 64-lane wave per column: lanes stride over the nb partials (fp64), then a butterfly reduction -- fixed order
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nb, int stride, int C,
                                     float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x;
     if (c >= C) return;
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)partial[(size_t)b * stride + c];
-    out[c] = (float)s;
+    for (int b = threadIdx.x; b < nb; b += 64) s += (double)partial[(size_t)b * stride + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // ---- 1x1 convolution to one channel (+ReLU), midas_net.py:139-140 ---------------------------------------------------
@@ -387,7 +390,7 @@ extern "C" int io_colsum(const void* x, int M, int C, float* out, float* partial
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C, st);
     IO_BY_DTYPE(dt, hipLaunchKernelGGL(colsum_partial_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, (const T_*)x, M, C, rpb,
                                        partial));
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C, C, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial, nb, C, C, out);
     return io_check_launch("colsum");
 }
 
@@ -416,7 +419,7 @@ extern "C" int io_head1_bwd(const float* dy, const float* out, const void* x, in
     IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_bwd_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, dy, out, (const T_*)x, M,
                                        pitch, C, w, relu, rpb, (T_*)dx, partial));
     // the per-block sums are [nb][C+1]: column sums give dw[0..C) and db
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(io_cdiv(C, 64)), dim3(64), 0, st, partial, nb, C + 1, C, dw);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial, nb, C + 1, C, dw);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, st, partial + C, nb, C + 1, 1, db);
     return io_check_launch("head1_bwd");
 }

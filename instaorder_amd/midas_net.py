@@ -60,6 +60,27 @@ class _BnMode(object):
         _BnMode.groups, _BnMode.repeat = self.prev
 
 
+class _Counters(object):
+    """num_batches_tracked of every BatchNorm layer a forward pass touches advances in ONE multi-tensor launch at the
+    end of the pass instead of one tiny launch per layer (there are 210 of them)."""
+    pending = None
+
+    def __enter__(self):
+        _Counters.pending = []
+
+    def __exit__(self, *a):
+        todo, _Counters.pending = _Counters.pending, None
+        for k in sorted(set(k for _, k in todo)):
+            torch._foreach_add_([t for t, kk in todo if kk == k], k)
+
+    @staticmethod
+    def bump(t, k):
+        if _Counters.pending is None:
+            t += k
+        else:
+            _Counters.pending.append((t, k))
+
+
 class BatchNorm2d(nn.Module):
     def __init__(self, c):
         super(BatchNorm2d, self).__init__()
@@ -71,9 +92,16 @@ class BatchNorm2d(nn.Module):
 
     def forward(self, x, relu=False, identity=None):
         if self.training:
-            self.num_batches_tracked += _BnMode.groups * _BnMode.repeat
+            _Counters.bump(self.num_batches_tracked, _BnMode.groups * _BnMode.repeat)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                               identity, _BnMode.groups, _BnMode.repeat)
+
+    def after(self, conv, x, relu=False, identity=None):
+        """bn(conv(x)) (+ identity) (+ ReLU) as one fused node (statistics in the convolution's epilogue)."""
+        if self.training:
+            _Counters.bump(self.num_batches_tracked, _BnMode.groups * _BnMode.repeat)
+        return ops.conv_bn(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, conv.stride,
+                           conv.padding, conv.groups, self.training, relu, identity, _BnMode.groups, _BnMode.repeat)
 
 
 class _Fn(nn.Module):
@@ -103,12 +131,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
+        out = self.bn1.after(self.conv1, x, relu=True)
+        out = self.bn2.after(self.conv2, out, relu=True)
         identity = x
         if self.downsample is not None:
-            identity = self.downsample[1](self.downsample[0](x))
-        return self.bn3(self.conv3(out), relu=True, identity=identity)
+            identity = self.downsample[1].after(self.downsample[0], x)
+        return self.bn3.after(self.conv3, out, relu=True, identity=identity)
 
 
 def _make_layer(inplanes, planes, blocks, stride, groups, base_width):
@@ -145,7 +173,7 @@ class _Trunk(nn.Module):
 
     def run_layer1(self, x8):
         seq = self.layer1
-        y = seq[1](seq[0](x8), relu=True)
+        y = seq[1].after(seq[0], x8, relu=True)
         return seq[4](seq[3](y))
 
 
@@ -267,10 +295,11 @@ class InstaDepthNet_od(_InstaDepthBase):
         common_utils.init_weights(self.oo_net, init_type="xavier")
 
     def forward(self, img, mask1, mask2):
-        disp, (l1, l2, l3) = self._encode_decode(img)
-        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
-        depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
-        occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
+        with _Counters():
+            disp, (l1, l2, l3) = self._encode_decode(img)
+            x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
+            depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
+            occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
         return disp, depth_order, occ_order
 
     def forward_pair(self, img, mask1, mask2):
@@ -279,12 +308,13 @@ class InstaDepthNet_od(_InstaDepthBase):
         batch with per-order BatchNorm statistics.  Returns (disp[B,H,W], depth[2B,3], occ[2B,2]), rows [0,B) =
         call (mask1, mask2), rows [B,2B) = call (mask2, mask1).  Same values, gradients and running statistics as the
         two separate calls."""
-        with _BnMode(repeat=2):
-            disp, feats = self._encode_decode(img)
-        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
-        with _BnMode(groups=2):
-            depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
-            occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
+        with _Counters():
+            with _BnMode(repeat=2):
+                disp, feats = self._encode_decode(img)
+            x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
+            with _BnMode(groups=2):
+                depth_order = self._order_branch(self.do_net, self.depth_fc, x8m, l1, l2, l3)
+                occ_order = self._order_branch(self.oo_net, self.occ_fc, x8m, l1, l2, l3)
         return disp, depth_order, occ_order
 
 
@@ -298,16 +328,18 @@ class InstaDepthNet_d(_InstaDepthBase):
         common_utils.init_weights(self.gdo_net, init_type="xavier")
 
     def forward(self, img, mask1, mask2):
-        disp, (l1, l2, l3) = self._encode_decode(img)
-        x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
-        depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+        with _Counters():
+            disp, (l1, l2, l3) = self._encode_decode(img)
+            x8m = ops.nhwc_from_nchw(torch.cat([mask1, mask2], 1).float(), pad_to=8, dtype=self._act_dtype())
+            depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None
 
     def forward_pair(self, img, mask1, mask2):
         """See InstaDepthNet_od.forward_pair."""
-        with _BnMode(repeat=2):
-            disp, feats = self._encode_decode(img)
-        x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
-        with _BnMode(groups=2):
-            depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+        with _Counters():
+            with _BnMode(repeat=2):
+                disp, feats = self._encode_decode(img)
+            x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
+            with _BnMode(groups=2):
+                depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None

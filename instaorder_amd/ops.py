@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["conv2d", "batch_norm", "max_pool_3x3s2", "avgpool_fc", "upsample2x", "bias_act", "relu", "add", "head1",
+__all__ = ["conv2d", "conv_bn", "batch_norm", "max_pool_3x3s2", "avgpool_fc", "upsample2x", "bias_act", "relu", "add", "head1",
            "nhwc_from_nchw", "nchw_from_nhwc"]
 
 
@@ -152,6 +152,12 @@ def conv2d(x, w, stride=1, pad=0, groups=1, co_pad=False):
 
 
 # ---- BatchNorm (+ residual add) (+ ReLU) ---------------------------------------------------------------------------------
+def _momentum(repeat):
+    """R identical module calls advance a running estimate R times with the same statistic:
+    r <- (1-m)^R r + (1 - (1-m)^R) s, i.e. ONE update with momentum 1 - (1-m)^R (m = 0.1)."""
+    return 1.0 - 0.9 ** int(repeat)
+
+
 class _BatchNorm(torch.autograd.Function):
     """nn.BatchNorm2d (+ `out += identity`) (+ nn.ReLU) of resnet_cls.py:96-116.  Training: batch statistics, running
     estimates advanced in place (momentum 0.1, unbiased variance); eval: running estimates.
@@ -173,13 +179,8 @@ class _BatchNorm(torch.autograd.Function):
             npart = int(L.io_bn_partial_floats(M, Cc, G))
             part = torch.empty(npart, device=dev, dtype=torch.float32)
             _lib.check(L.io_bn_stats_finalize_dt(_p(x), M, Cc, G, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
-                                                 _p(running_var), 0.1, 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift),
-                                                 _p(part), npart, _dt(x), _st()), "io_bn_stats_finalize_dt")
-            for _ in range(int(repeat) - 1):          # same statistics again (G == 1 when repeat > 1)
-                n = M // G
-                var_unb = (1.0 / (rstd * rstd) - 1e-5) * (float(n) / float(max(n - 1, 1)))
-                running_mean.mul_(0.9).add_(mean, alpha=0.1)
-                running_var.mul_(0.9).add_(var_unb, alpha=0.1)
+                                                 _p(running_var), _momentum(repeat), 1e-5, _p(mean), _p(rstd), _p(scale),
+                                                 _p(shift), _p(part), npart, _dt(x), _st()), "io_bn_stats_finalize_dt")
         else:
             _lib.check(L.io_bn_eval_prepare(Cc, _p(gamma.detach()), _p(beta.detach()), _p(running_mean), _p(running_var),
                                             1e-5, _p(mean), _p(scale), _p(shift), _st()), "io_bn_eval_prepare")
@@ -216,6 +217,122 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, relu=False, 
     if repeat > 1 and groups > 1:
         raise ValueError("batch_norm: repeat and groups are exclusive")
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, relu, identity, groups, repeat)
+
+
+class _ConvBn(torch.autograd.Function):
+    """conv (dense or grouped) -> BatchNorm (+ identity) (+ ReLU) as ONE node: in training mode the batch statistics are
+    accumulated in the convolution's epilogue (per 128-row tile, merged with Chan's update) whenever the rows per
+    statistics group are a multiple of 128 -- no separate pass over the conv output (resnet_cls.py:99-114)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
+                bn_groups, repeat):
+        _chk(x, "x")
+        L = _L()
+        dev, dt = x.device, _dt(x)
+        N, H, W_, Cs = x.shape
+        Co, Cig, R, S = w.shape
+        dense = groups == 1
+        if dense:
+            wop = torch.zeros((Co, R * S, Cs), device=dev, dtype=x.dtype)
+            wop[:, :, :Cig] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Cig)
+            wback = wop
+        else:
+            if Co != Cs or Co // groups != Cig:
+                raise ValueError("grouped conv: expected [C, C/groups, R, S] filters on C input channels")
+            wop = torch.empty((Co, R * S, 64), device=dev, dtype=x.dtype)
+            wback = torch.empty_like(wop)
+            _lib.check(L.io_gconv_pack(_p(w.detach().contiguous()), Co, Cig, R * S, _p(wop), _p(wback), dt, _st()),
+                       "io_gconv_pack")
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
+        M = N * Ho * Wo
+        G = int(bn_groups) if training else 1
+        y = torch.empty((N, Ho, Wo, Co), device=dev, dtype=x.dtype)
+        mean, rstd, scale, shift = (torch.empty(G * Co, device=dev, dtype=torch.float32) for _ in range(4))
+        gd, bd = gamma.detach(), beta.detach()
+        if training and M % G == 0 and (M // G) % 128 == 0:
+            nws = int(L.io_conv2d_bnstats_workspace_floats(N, H, W_, Co, R, S, stride, pad, G))
+            ws = torch.empty(nws, device=dev, dtype=torch.float32)
+            _lib.check(L.io_conv2d_fwd_bnstats_dt(_p(x), _p(wop), _p(y), N, H, W_, Cs, Co, R, S, stride, pad, G, _p(gd), _p(bd),
+                                                  _p(running_mean), _p(running_var), _momentum(repeat), 1e-5, _p(mean),
+                                                  _p(rstd), _p(scale), _p(shift), _p(ws), nws, dt, 0 if dense else 64, _st()),
+                       "io_conv2d_fwd_bnstats_dt")
+        else:
+            if dense:
+                _lib.check(L.io_conv2d_fwd_dt(_p(x), _p(wop), _p(y), N, H, W_, Cs, Co, R, S, stride, pad, dt, dt, _st()),
+                           "io_conv2d_fwd_dt")
+            else:
+                _lib.check(L.io_gconv2d_fwd(_p(x), _p(wop), _p(y), N, H, W_, Co, R, S, stride, pad, dt, _st()), "io_gconv2d_fwd")
+            if training:
+                npart = int(L.io_bn_partial_floats(M, Co, G))
+                part = torch.empty(npart, device=dev, dtype=torch.float32)
+                _lib.check(L.io_bn_stats_finalize_dt(_p(y), M, Co, G, _p(gd), _p(bd), _p(running_mean), _p(running_var),
+                                                     _momentum(repeat), 1e-5, _p(mean), _p(rstd), _p(scale), _p(shift),
+                                                     _p(part), npart, dt, _st()), "io_bn_stats_finalize_dt")
+            else:
+                _lib.check(L.io_bn_eval_prepare(Co, _p(gd), _p(bd), _p(running_mean), _p(running_var), 1e-5, _p(mean),
+                                                _p(scale), _p(shift), _st()), "io_bn_eval_prepare")
+                rstd = scale / gd
+        out = torch.empty_like(y)
+        _lib.check(L.io_bn_apply_dt(_p(y), M, Co, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
+                                    None, None, int(relu), _p(out), dt, _st()), "io_bn_apply_dt")
+        ctx.save_for_backward(x, wback, y, out, gamma, mean, rstd)
+        ctx.cfg = (N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, bool(relu), identity is not None, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wback, y, out, gamma, mean, rstd = ctx.saved_tensors
+        N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, relu, has_id, training = ctx.cfg
+        if not training:
+            raise RuntimeError("ops.conv_bn: backward through eval-mode BatchNorm is not implemented")
+        L = _L()
+        dev, dt = x.device, _dt(x)
+        dout = dout.contiguous()
+        npart = int(L.io_bn_partial_floats(M, Co, G))
+        part = torch.empty(npart, device=dev, dtype=torch.float32)
+        coef = torch.empty(2 * G * Co, device=dev, dtype=torch.float32)
+        dgamma, dbeta = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+        dy = torch.empty_like(y)
+        dz = torch.empty_like(y) if has_id else None
+        _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(y), M, Co, G, _p(gamma.detach()),
+                                  _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dy), _p(dz), _p(part), npart, _p(coef), dt,
+                                  _st()), "io_bn_bwd_dt")
+        dx = None
+        if dense:
+            if ctx.needs_input_grad[0]:
+                if Cs == 8:
+                    raise RuntimeError("ops.conv_bn: no data gradient for the packed 8-channel stem input")
+                wt = wback.permute(2, 1, 0).contiguous()
+                dx = torch.empty_like(x)
+                _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Co, R, S, stride, pad, dt,
+                                                _st()), "io_conv2d_dgrad_dt")
+            nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Co, R, S, stride, pad))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            dwk = torch.empty((Co, R * S, Cs), device=dev, dtype=torch.float32)
+            _lib.check(L.io_conv2d_wgrad_dt(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Co, R, S, stride, pad, _p(ws), nb, dt, dt,
+                                            _st()), "io_conv2d_wgrad_dt")
+            dw = dwk[:, :, :Cig].reshape(Co, R, S, Cig).permute(0, 3, 1, 2).contiguous()
+        else:
+            dx = torch.empty_like(x)
+            _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wback), _p(dx), N, H, W_, Co, R, S, stride, pad, dt, _st()),
+                       "io_gconv2d_dgrad")
+            nb = int(L.io_gconv2d_wgrad_workspace_bytes(N, H, W_, Co, R, S, stride, pad))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            dwc = torch.empty((Co, R * S, 64), device=dev, dtype=torch.float32)
+            _lib.check(L.io_gconv2d_wgrad(_p(x), _p(dy), _p(dwc), N, H, W_, Co, R, S, stride, pad, _p(ws), nb, dt, _st()),
+                       "io_gconv2d_wgrad")
+            dw = torch.empty((Co, Cig, R, S), device=dev, dtype=torch.float32)
+            _lib.check(L.io_gconv_unpack_grad(_p(dwc), Co, Cig, R * S, _p(dw), _st()), "io_gconv_unpack_grad")
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, dz, None, None
+
+
+def conv_bn(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu=False, identity=None,
+            bn_groups=1, repeat=1):
+    if repeat > 1 and bn_groups > 1:
+        raise ValueError("conv_bn: repeat and bn_groups are exclusive")
+    return _ConvBn.apply(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
+                         bn_groups, repeat)
 
 
 # ---- pooling / heads --------------------------------------------------------------------------------------------------
