@@ -87,7 +87,7 @@ __device__ __forceinline__ ColMap col_map(int C4) {
 // written by ty == 0 to dst0/dst1[(quad)*4 ..]
 template <int MAXQ>
 __device__ __forceinline__ void reduce_rows_store(const ColMap& cm, f32x4 (&s0)[MAXQ], f32x4 (&s1)[MAXQ],
-                                                  float* dst0, float* dst1, int C4) {
+                                                  float* dst0, float* dst1, int C4, int qs = 4) {
     __shared__ f32x4 red[2][kThreads];
     for (int i = 0; i < MAXQ; ++i) {
         if (i >= cm.nq) break;
@@ -103,8 +103,8 @@ __device__ __forceinline__ void reduce_rows_store(const ColMap& cm, f32x4 (&s0)[
         }
         const int q = cm.tx + cm.TX * i;
         if (cm.ty == 0 && q < C4) {
-            st4(dst0 + q * 4, red[0][threadIdx.x]);
-            st4(dst1 + q * 4, red[1][threadIdx.x]);
+            st4(dst0 + q * qs, red[0][threadIdx.x]);
+            st4(dst1 + q * qs, red[1][threadIdx.x]);
         }
         __syncthreads();
     }
@@ -319,57 +319,72 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
                                                                 const float* __restrict__ mscale,
                                                                 const float* __restrict__ mshift,
                                                                 float* __restrict__ p1, float* __restrict__ p2) {
-    const int C4 = C >> 2;
-    const ColMap cm = col_map(C4);
+    // a thread owns up to two 16-byte channel chunks (4 fp32 / 8 bf16) and strides over rows, 4 rows in flight
+    constexpr int VEC = Chunk<T>::VEC, NV = Chunk<T>::NV, U = 4;
+    const int CV = C / VEC;
+    const ColMap cm = col_map(CV);
     const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
     const int r0 = b * rpb, r1 = min(r0 + rpb, Mg);
     const size_t goff = (size_t)g * Mg * C;
-    f32x4 s1[2], s2[2], mu[2], rs[2], msc[2], msh[2];
+    f32x4 s1[2][NV], s2[2][NV];
+    Tab<NV> mu[2], rs[2], msc[2], msh[2];
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
-        s1[i] = 0.f; s2[i] = 0.f; mu[i] = 0.f; rs[i] = 0.f; msc[i] = 0.f; msh[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            s1[i][k] = 0.f; s2[i][k] = 0.f; mu[i].v[k] = 0.f; rs[i].v[k] = 0.f; msc[i].v[k] = 0.f; msh[i].v[k] = 0.f;
+        }
         const int q = cm.tx + cm.TX * i;
-        if (i < cm.nq && q < C4) {
-            mu[i] = ld4(mean + g * C + q * 4);
-            rs[i] = ld4(rstd + g * C + q * 4);
+        if (i < cm.nq && q < CV) {
+            mu[i] = ldt<NV>(mean + g * C + q * VEC);
+            rs[i] = ldt<NV>(rstd + g * C + q * VEC);
             if (mscale) {
-                msc[i] = ld4(mscale + g * C + q * 4);
-                msh[i] = ld4(mshift + g * C + q * 4);
+                msc[i] = ldt<NV>(mscale + g * C + q * VEC);
+                msh[i] = ldt<NV>(mshift + g * C + q * VEC);
             }
         }
     }
-    constexpr int U = 2;   // rows in flight per thread (x3 tensors)
     for (int r = r0 + cm.ty; r < r1; r += U * cm.TY) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = cm.tx + cm.TX * i;
-            if (i < cm.nq && q < C4) {
-                f32x4 d[U], a[U], yv[U];
+            if (i < cm.nq && q < CV) {
+                Chunk<T> d[U], a[U], yv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int rr = r + u * cm.TY;
-                    const size_t ro = goff + (size_t)rr * C + q * 4;
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const bool in = rr < r1;
-                    d[u] = in ? ld4(dout + ro) : z;
-                    yv[u] = in ? ld4(y + ro) : mu[i];
-                    a[u] = (in && act) ? ld4(act + ro) : d[u];
+                    if (rr < r1) {
+                        const size_t ro = goff + (size_t)rr * C + q * VEC;
+                        d[u] = ldc(dout + ro);
+                        yv[u] = ldc(y + ro);
+                        if (act) a[u] = ldc(act + ro);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (mscale) a[u] = bn_affine(yv[u], mu[i], msc[i], msh[i]);   // ReLU mask recomputed from y
-                    if (act || mscale) {
+                    if (r + u * cm.TY < r1) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) d[u][k] = a[u][k] > 0.f ? d[u][k] : 0.f;
+                        for (int k = 0; k < NV; ++k) {
+                            f32x4 dd = d[u].v[k];
+                            if (act || mscale) {
+                                const f32x4 av = act ? a[u].v[k] : bn_affine(yv[u].v[k], mu[i].v[k], msc[i].v[k], msh[i].v[k]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) dd[e] = av[e] > 0.f ? dd[e] : 0.f;
+                            }
+                            s1[i][k] += dd;
+                            s2[i][k] += dd * ((yv[u].v[k] - mu[i].v[k]) * rs[i].v[k]);
+                        }
                     }
-                    const f32x4 xh = (yv[u] - mu[i]) * rs[i];
-                    s1[i] += d[u];
-                    s2[i] += d[u] * xh;
                 }
             }
         }
     }
     const size_t o = ((size_t)g * nb + b) * C;
-    reduce_rows_store<2>(cm, s1, s2, p1 + o, p2 + o, C4);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        f32x4 t1[2] = {s1[0][k], s1[1][k]}, t2[2] = {s2[0][k], s2[1][k]};
+        reduce_rows_store<2>(cm, t1, t2, p1 + o + 4 * k, p2 + o + 4 * k, CV, VEC);
+    }
 }
 
 // block = 8 channels x 32 lanes over the partials; ALL loads of a lane are issued before the first use (the
