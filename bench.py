@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "infer"], help="train = fwd+bwd+SGD (the "
                     "BASELINE metric, default); fwd = both directional passes + loss in training mode (batch "
                     "statistics), no backward; infer = the same in eval mode (inference.py's forward)")
+    ap.add_argument("--host-inputs", default="", choices=["", "pageable", "pinned"], help="hand the step HOST tensors "
+                    "(as the reference's DataLoader does): the timed region then includes the H2D copies of "
+                    "set_input -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -127,6 +130,8 @@ def main():
     base = (synthetic.make_depth_batch if depthnet else synthetic.make_pair_batch)(1000 + rank, min(B, 32), S)
     reps = (B + min(B, 32) - 1) // min(B, 32)
     dev = {k: torch.from_numpy(np.concatenate([v] * reps, 0)[:B]).cuda() for k, v in base.items()}
+    if args.host_inputs:
+        dev = {k: (v.cpu().pin_memory() if args.host_inputs == "pinned" else v.cpu()) for k, v in dev.items()}
 
     def one_step():
         if args.algo == "InstaOrderNet_o":
@@ -188,6 +193,7 @@ def main():
                                                                 {"train": "fwd+bwd+SGD", "fwd": "forward+loss, train mode",
                                                                  "infer": "forward+loss, eval mode"}[args.mode],
                                                                 4 if depthnet else (1 if args.dtype == "fp32" else 2)),
+                   "inputs": ("host, " + args.host_inputs) if args.host_inputs else "resident in HBM",
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
                    "hip_graph": bool(getattr(model, "_use_graph", False) and getattr(model, "_graph", None) is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
