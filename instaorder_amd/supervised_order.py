@@ -299,29 +299,24 @@ class _DepthBase(SingleStageModel):
         return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
 
     def _disp_order_count(self, disp1, disp2):
-        """supervised_order.py:152-173 (no gradient flows through these counts in the reference either)."""
+        """supervised_order.py:152-173 (no gradient flows through these counts in the reference either), for the whole
+        batch at once and without a host round trip: per-sample masked max / min, comparisons, masked counts."""
         with torch.no_grad():
             e1 = _erode_cross(self.modal1[:, 0] != 0)
             e2 = _erode_cross(self.modal2[:, 0] != 0)
+            order = self.depth_order1
+            # the reference's .max()/.min() of an empty selection would raise; such pairs are skipped here
+            use = (self.is_overlap == 0) & ((order == 0) | (order == 1)) & e1.flatten(1).any(1) & e2.flatten(1).any(1)
+            inf = float("inf")
             total = torch.zeros((), device=disp1.device, dtype=torch.float32)
-            distinct = (self.is_overlap == 0)
-            d1, d2 = disp1[:, 0], disp2[:, 0]
-            # the reference's .max()/.min() of an empty selection would raise; pairs with an empty eroded mask are
-            # skipped here
-            for bb in torch.nonzero(distinct).flatten().tolist():
-                a, b = e1[bb], e2[bb]
-                if not (bool(a.any()) and bool(b.any())):
-                    continue
-                order = int(self.depth_order1[bb])
-                if order not in (0, 1):
-                    continue
-                le = order == self._LE_ORDER
-                for d, flip in ((d1[bb], False), (d2[bb], True)):
-                    use_le = le != flip
-                    if use_le:
-                        total += (d[a] <= d[b].max()).sum() + (d[a].min() <= d[b]).sum()
-                    else:
-                        total += (d[a] >= d[b].max()).sum() + (d[a].min() >= d[b]).sum()
+            for d, flip in ((disp1[:, 0], False), (disp2[:, 0], True)):
+                mx2 = d.masked_fill(~e2, -inf).amax((1, 2))[:, None, None]       # max over eroded mask 2
+                mn1 = d.masked_fill(~e1, inf).amin((1, 2))[:, None, None]        # min over eroded mask 1
+                le = (((d <= mx2) & e1).sum((1, 2)) + ((mn1 <= d) & e2).sum((1, 2))).float()
+                ge = (((d >= mx2) & e1).sum((1, 2)) + ((mn1 >= d) & e2).sum((1, 2))).float()
+                # disp1 uses `<=` when depth_order1 == 0 and `>=` when it is 1; disp2 the other way round
+                use_le = (order == self._LE_ORDER) != flip
+                total = total + (torch.where(use_le, le, ge) * use.float()).sum()
             return total / float(disp1.shape[2] * disp1.shape[3])
 
     _LE_ORDER = 0     # both reference classes use `<=` on disp1 when depth_order1 == 0 (supervised_order.py:158-162, 289-293)
