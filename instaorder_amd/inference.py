@@ -189,6 +189,117 @@ def infer_order_sup_occ_depth(model, image, inmodal, bboxes, pairs, method, patc
     return res["occ_order"], res["depth_order"]
 
 
+def _matrices(n, pairs, dec, want_occ):
+    occ = np.zeros((n, n), dtype=np.int64)
+    dep = np.zeros((n, n), dtype=np.int64)
+    host = {k: v.cpu().numpy() for k, v in dec.items()}
+    for k, (i, j) in enumerate(pairs):
+        if want_occ and "i_over_j" in host:
+            occ[i, j] = int(host["i_over_j"][k])
+            occ[j, i] = int(host["j_over_i"][k])
+        d = int(host["depth"][k])
+        if d == 0:
+            dep[i, j], dep[j, i] = 1, 0
+        elif d == 1:
+            dep[i, j], dep[j, i] = 0, 1
+        else:
+            dep[i, j] = dep[j, i] = 2
+    return occ, dep
+
+
+def infer_depthnet_batched(model, rgb, masks, pairs=None, max_pairs=64):
+    """All pairs of one image through InstaDepthNet_od / _d (the per-pair loop of inference.py:515-625 calls the whole
+    net twice per pair): the image-only encoder + decoder run ONCE per image, the order branches see every pair in
+    both mask orders as one batch (eval mode: BatchNorm uses the running estimates, so batching is exact).
+    rgb [1,3,S,S] normalised, masks [N,S,S].  Returns dict(pairs, depth_order, occ_order | None, disp [S,S])."""
+    from . import midas_net, ops
+    net = model.model.module
+    dev = next(net.parameters()).device
+    n = masks.shape[0]
+    pairs = upper_pairs(n) if pairs is None else list(pairs)
+    rgb = rgb.to(dev, torch.float32)
+    masks = masks.to(dev, torch.float32)
+    was_training = net.training
+    net.eval()
+    has_occ = hasattr(net, "oo_net")
+    dep1, dep2, occ1, occ2 = [], [], [], []
+    with torch.no_grad():
+        disp, feats = net._encode_decode(rgb)
+        for c0 in range(0, len(pairs), max_pairs):
+            chunk = pairs[c0:c0 + max_pairs]
+            p = len(chunk)
+            ii = torch.tensor([a for a, _ in chunk], device=dev)
+            jj = torch.tensor([b for _, b in chunk], device=dev)
+            mi, mj = masks[ii][:, None], masks[jj][:, None]
+            x8m = ops.nhwc_from_nchw(torch.cat([torch.cat([mi, mj], 1), torch.cat([mj, mi], 1)], 0), pad_to=8,
+                                     dtype=net._act_dtype())
+            l1, l2, l3 = (f.expand(2 * p, -1, -1, -1).contiguous() for f in feats)
+            if has_occ:
+                d = net._order_branch(net.do_net, net.depth_fc, x8m, l1, l2, l3)
+                o = net._order_branch(net.oo_net, net.occ_fc, x8m, l1, l2, l3)
+                occ1.append(o[:p]); occ2.append(o[p:])
+            else:
+                d = net._order_branch(net.gdo_net, net.fc, x8m, l1, l2, l3)
+            dep1.append(d[:p]); dep2.append(d[p:])
+    net.train(was_training)
+    d1, d2 = torch.cat(dep1, 0), torch.cat(dep2, 0)
+    if has_occ:
+        dec = decide(torch.cat([torch.cat(occ1, 0), d1], 1), torch.cat([torch.cat(occ2, 0), d2], 1), 2, 3)
+    else:
+        dec = decide(d1, d2, 0, 3)
+    occ, dep = _matrices(n, pairs, dec, has_occ)
+    return {"pairs": pairs, "depth_order": dep, "occ_order": occ if has_occ else None, "disp": disp[0]}
+
+
+def net_forward_midas_pretrained(pred_disp, inmodal1, inmodal2, disp_select_method):
+    """Reference signature (inference.py:79-104): depth order of two instances from a disparity map (0: first is
+    closer, 1: farther, 2: equal) by the mean / median of the 5-95 % clipped inverse disparity inside each mask."""
+    dev = pred_disp.device
+    depth = 1 / (pred_disp + 1e-6)
+    m1 = torch.as_tensor(np.asarray(inmodal1).astype(bool), device=dev)
+    m2 = torch.as_tensor(np.asarray(inmodal2).astype(bool), device=dev)
+    vals = []
+    for m in (m1, m2):
+        v = depth[m]
+        v = torch.clip(v, torch.quantile(v, 0.05), torch.quantile(v, 0.95))
+        vals.append(torch.median(v) if disp_select_method == "median" else torch.mean(v))
+    if vals[0] < vals[1]:
+        return 0
+    return 1 if vals[0] > vals[1] else 2
+
+
+def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size, disp_select_method,
+                          use_rgb=True):
+    """Reference signature (inference.py:515-625); returns (depth order matrix, clipped disparity | None).
+    Methods: InstaOrderNet_d (the batched ResNet path) and InstaDepthNet_d / InstaDepthNet_od (batched MiDaS path;
+    with ``disp_select_method`` 'mean' / 'median' the order comes from the predicted disparity instead of the head)."""
+    if pairs != "all":
+        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
+    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
+    if method == "InstaOrderNet_d":
+        res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+        return res["depth_order"], None
+    if method not in ("InstaDepthNet_d", "InstaDepthNet_od"):
+        raise ValueError("method name should be one of {InstaOrderNet_d, InstaDepthNet_d, InstaDepthNet_od}")
+    res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks))
+    if disp_select_method == "":
+        return res["depth_order"], None
+    # the reference takes the disparity of a call with empty masks; the disparity does not depend on the masks
+    disp = res["disp"]
+    clipped = torch.clip(disp, torch.quantile(disp, 0.05), torch.quantile(disp, 0.95))
+    n = masks.shape[0]
+    order = np.zeros((n, n), dtype=np.int64)
+    for i, j in res["pairs"]:
+        a = net_forward_midas_pretrained(disp, masks[i], masks[j], disp_select_method)
+        if a == 0:
+            order[i, j], order[j, i] = 1, 0
+        elif a == 1:
+            order[i, j], order[j, i] = 0, 1
+        else:
+            order[i, j] = order[j, i] = 2
+    return order, clipped
+
+
 # ---- metrics (host) -------------------------------------------------------------------------------
 def eval_order_recall_precision_f1(order_matrix, gt_order_matrix, zd=0):
     """Binary recall / precision / F1 (x100) over entries whose ground truth is not -1

@@ -141,3 +141,28 @@ def test_bf16_mode_close_to_reference():
     ref_gn = float(np.sqrt((g["grad_norms"] ** 2).sum()))
     print("bf16 step: gradient norm %.4f (fp32 reference %.4f)" % (gn, ref_gn))
     assert abs(gn - ref_gn) < 0.1 * ref_gn
+
+
+def test_batched_depthnet_inference_equals_per_pair_calls():
+    """inference.py:515-625 for InstaDepthNet_od: one encoder pass per image + all pairs batched through the order
+    branches must give the decisions of the per-pair two-call loop (net_forward_InstaDepthNet)."""
+    from instaorder_amd import inference
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("eval")
+    items = synthetic.make_images(7, 1, 4, 64)
+    rgb, masks = synthetic.image_mode_inputs(items[0]["image"], items[0]["modal"], 64)
+    res = inference.infer_depthnet_batched(m, torch.from_numpy(rgb), torch.from_numpy(masks))
+    assert res["disp"].shape == (64, 64) and len(res["pairs"]) == 6
+    for (i, j) in res["pairs"]:
+        d, o12, o21, _, _ = inference.net_forward_InstaDepthNet(m, torch.from_numpy(rgb), masks[i], masks[j])
+        want = {0: (1, 0), 1: (0, 1), 2: (2, 2)}[d]
+        assert (res["depth_order"][i, j], res["depth_order"][j, i]) == want
+        assert res["occ_order"][i, j] == int(o12) and res["occ_order"][j, i] == int(o21)
+    order, clipped = inference.infer_order_sup_depth(m, items[0]["image"], items[0]["modal"], None, "all", algo, "image",
+                                                     64, "")
+    assert (order == res["depth_order"]).all() and clipped is None
+    order2, clipped2 = inference.infer_order_sup_depth(m, items[0]["image"], items[0]["modal"], None, "all", algo,
+                                                       "image", 64, "median")
+    assert order2.shape == (4, 4) and clipped2.shape == (64, 64)
