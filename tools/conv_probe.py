@@ -27,6 +27,6 @@ nb = L.io_conv2d_wgrad_workspace_bytes(N, Hh, Hh, Cin, Cout, k, k, st, pad)
 ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
 for _ in range(reps):
     L.io_conv2d_fwd(P(x), P(w), P(y), N, Hh, Hh, Cin, Cout, k, k, st, pad, ST())
-    L.io_conv2d_dgrad(P(dy), P(wt), P(dx), None, N, Hh, Hh, Cin, Cout, k, k, st, pad, ST())
+    L.io_conv2d_dgrad(P(dy), P(wt), P(dx), None, None, N, Hh, Hh, Cin, Cout, k, k, st, pad, ST())
     L.io_conv2d_wgrad(P(x), P(dy), P(dw), N, Hh, Hh, Cin, Cout, k, k, st, pad, P(ws), nb, ST())
 torch.cuda.synchronize()

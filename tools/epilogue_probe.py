@@ -1,3 +1,5 @@
+"""Cost of the fused data-gradient epilogues (ReLU mask, residual add, BN-backward reductions) per layer shape:
+time of the NT kernel alone, from the library's HIP-event profiler.  usage: python tools/epilogue_probe.py"""
 import ctypes as C, sys, torch
 sys.path.insert(0, ".")
 from instaorder_amd import _lib, engine
