@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--host-inputs", default="", choices=["", "pageable", "pinned"], help="hand the step HOST tensors "
                     "(as the reference's DataLoader does): the timed region then includes the H2D copies of "
                     "set_input -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "images20"], help="pairs = a synthetic pair "
+                    "batch (default); images20 = BASELINE configs[3]: synthetic 20-instance images, all 190 pairs of "
+                    "every image enumerated (upper triangle, image-major), the pair list sharded contiguously across "
+                    "ranks, each step gathers its pair batch from the instance masks on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -133,7 +137,34 @@ def main():
     if args.host_inputs:
         dev = {k: (v.cpu().pin_memory() if args.host_inputs == "pinned" else v.cpu()) for k, v in dev.items()}
 
+    pair_src = None
+    if args.workload == "images20":
+        assert not depthnet and not args.host_inputs
+        from instaorder_amd import distributed_utils, inference
+        n_inst = 20
+        per_img = n_inst * (n_inst - 1) // 2
+        n_img = max(1, (world * B * (args.steps + args.warmup) + per_img - 1) // per_img)
+        n_img = min(n_img, 24)                                   # the list wraps around beyond that
+        imgs = synthetic.make_images(4242, n_img, n_inst, S)
+        rgbs = torch.cat([torch.from_numpy(synthetic.image_mode_inputs(it["image"], it["modal"], S)[0]) for it in imgs]).cuda()
+        masks = torch.stack([torch.from_numpy(it["modal"].astype(np.float32)) for it in imgs]).cuda()    # [I,20,S,S]
+        plist = [(k, i, j) for k in range(n_img) for (i, j) in inference.upper_pairs(n_inst)]
+        beg, end, sub = distributed_utils.shard_range(len(plist), world, rank)
+        mine = torch.tensor([plist[q % len(plist)] for q in range(beg, end)], device="cuda")            # [sub, 3]
+        pair_src = {"rgbs": rgbs, "masks": masks, "mine": mine, "cursor": 0}
+
+    def gather_pairs():
+        p = pair_src
+        idx = (torch.arange(B, device="cuda") + p["cursor"]) % p["mine"].shape[0]
+        p["cursor"] = (p["cursor"] + B) % p["mine"].shape[0]
+        sel = p["mine"][idx]
+        dev["rgb"] = p["rgbs"][sel[:, 0]]
+        dev["modal1"] = p["masks"][sel[:, 0], sel[:, 1]][:, None]
+        dev["modal2"] = p["masks"][sel[:, 0], sel[:, 2]][:, None]
+
     def one_step():
+        if pair_src is not None:
+            gather_pairs()
         if args.algo == "InstaOrderNet_o":
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["occ_order"])
         elif args.algo == "InstaDepthNet_d":
@@ -192,8 +223,10 @@ def main():
                                "(BASELINE.json configs[%d])" % (args.algo, B, S, S, args.dtype,
                                                                 {"train": "fwd+bwd+SGD", "fwd": "forward+loss, train mode",
                                                                  "infer": "forward+loss, eval mode"}[args.mode],
-                                                                4 if depthnet else (1 if args.dtype == "fp32" else 2)),
+                                                                4 if depthnet else (3 if args.workload == "images20"
+                                                                                    else (1 if args.dtype == "fp32" else 2))),
                    "inputs": ("host, " + args.host_inputs) if args.host_inputs else "resident in HBM",
+                   "pair_source": "20-instance images, 190 pairs each, sharded by rank" if pair_src else "pair batch",
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
                    "hip_graph": bool(getattr(model, "_use_graph", False) and getattr(model, "_graph", None) is not None),
                    "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
