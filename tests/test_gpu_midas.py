@@ -166,3 +166,31 @@ def test_batched_depthnet_inference_equals_per_pair_calls():
     order2, clipped2 = inference.infer_order_sup_depth(m, items[0]["image"], items[0]["modal"], None, "all", algo,
                                                        "image", 64, "median")
     assert order2.shape == (4, 4) and clipped2.shape == (64, 64)
+
+
+def test_checkpoint_roundtrip_with_momentum(tmp_path):
+    """single_stage_model.py:54-72 for the MiDaS-based net: {'step','state_dict','optimizer'} written after a step
+    restores parameters, BN buffers and the SGD momentum buffers (torch.optim.SGD state layout) in a fresh model."""
+    algo, tag = CASES[1]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("train")
+    feed(m, algo, t)
+    m.step()
+    m.save_state(str(tmp_path), 7)
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt_iter_7.pth.tar"), map_location="cpu", weights_only=False)
+    assert ck["step"] == 7 and len(ck["optimizer"]["state"]) == len(g["names"])
+    assert set(ck["optimizer"]["state"][0].keys()) == {"momentum_buffer"}
+    m2, _ = build(algo, g, spec)
+    m2.load_state(str(tmp_path), 7, resume=True)
+    a, b = m.model.state_dict(), m2.model.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(m.optim._buf, m2.optim._buf)
+    # and the next step is identical
+    feed(m, algo, t)
+    feed(m2, algo, t)
+    l1, l2 = m.step()[1]["loss"], m2.step()[1]["loss"]
+    assert float(l1) == float(l2)
+    assert torch.equal(m.optim.flat_params, m2.optim.flat_params)
