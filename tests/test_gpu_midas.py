@@ -194,3 +194,47 @@ def test_checkpoint_roundtrip_with_momentum(tmp_path):
     l1, l2 = m.step()[1]["loss"], m2.step()[1]["loss"]
     assert float(l1) == float(l2)
     assert torch.equal(m.optim.flat_params, m2.optim.flat_params)
+
+
+def test_larger_input_against_oracle():
+    """A shape the goldens do not cover (128 x 128, 4 pairs: the fused conv + statistics path is taken down to layer3,
+    the pair mode batches 8 mask orders with two statistics groups): HIP path against the CPU oracle on the same
+    seeded weights / inputs -- eval outputs, all loss terms of a training-mode pass, and the gradient norm."""
+    from oracle import midas_oracle as mo
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    import instaorder_amd as ia
+    S, B, seed = 128, 4, 77
+    cfg = dict(algo=algo, lr=1e-3, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True, **WEIGHTS)
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    st = mo.state_from_numpy(sd, prefix="module.")
+    t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(seed + 1, B, S).items()}
+    m.switch_to("eval")
+    with torch.no_grad():
+        d, dep, occ = m.model(t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())
+        od, odep, oocc = mo.forward(st, t["rgb"], t["modal1"], t["modal2"], False, "od")
+    assert rel_err(d.cpu().numpy(), od.numpy()) < 1e-3
+    assert rel_err(dep.cpu().numpy(), odep.numpy()) < 1e-3 and rel_err(occ.cpu().numpy(), oocc.numpy()) < 1e-3
+    o1 = mo.forward(st, t["rgb"], t["modal1"], t["modal2"], True, "od")
+    o2 = mo.forward(st, t["rgb"], t["modal2"], t["modal1"], True, "od")
+    ologs, ototal = mo.losses(o1, o2, t, WEIGHTS, 1, "od")
+    names = [str(n) for n in g["names"]]
+    ograds = torch.autograd.grad(ototal, [st[n] for n in names], allow_unused=True)
+    ogn = float(torch.sqrt(sum((x.double() ** 2).sum() for x in ograds if x is not None)))
+    m.switch_to("train")
+    feed(m, algo, t)
+    logs, l = m.step()
+    for k, v in ologs.items():
+        tol = 5e-3 if k == "loss_disp_order" else 2e-3
+        assert abs(float(logs[k]) - float(v)) <= tol * max(1.0, abs(float(v))), (k, float(logs[k]), float(v))
+    gn = float(m.optim.flat_grads.double().norm())
+    assert abs(gn - ogn) < 0.03 * ogn, (gn, ogn)
+    rm_h = torch.cat([b.reshape(-1) for k, b in m.model.named_buffers() if k.endswith("running_mean")]).cpu().numpy()
+    seen, rm_o = set(), []
+    for k, _, a in spec:
+        if k.endswith("running_mean") and not a:
+            rm_o.append(st[k].reshape(-1))
+    # named_buffers() lists shared buffers once, like the alias-free spec entries
+    assert rel_err(rm_h, torch.cat(rm_o).numpy()) < 1e-3
