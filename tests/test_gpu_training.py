@@ -1,0 +1,39 @@
+"""End-to-end sanity of the training loop on the MI355X: a fixed synthetic pair batch must be over-fitted (forward,
+loss, backward, momentum SGD, step-LR schedule and BatchNorm state all have to cooperate), in fp32 and in bf16."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ALGO_CLASSES, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("algo", ["InstaOrderNet_o", "InstaOrderNet_od"])
+def test_overfits_a_fixed_batch(algo, dtype):
+    import instaorder_amd as ia
+    from instaorder_amd.scheduler import StepLRScheduler
+    S, B = 64, 16
+    cfg = dict(algo=algo, lr=0.02, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype=dtype,
+               backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    sd = synthetic.make_state_dict(5, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    sched = StepLRScheduler(m.optim, [30], [0.1], 0.02, [], [], last_iter=-1)
+    b = {k: torch.from_numpy(v) for k, v in synthetic.make_pair_batch(3, B, S).items()}
+    m.switch_to("train")
+    losses = []
+    for it in range(40):
+        sched.step(it)
+        if algo == "InstaOrderNet_od":
+            m.set_input(b["rgb"], b["modal1"], b["modal2"], b["depth_order"], b["count"], b["is_overlap"], b["occ_order"])
+        else:
+            m.set_input(b["rgb"], b["modal1"], b["modal2"], b["occ_order"])
+        out = m.step()
+        losses.append(float(out[1]["loss"] if isinstance(out, tuple) else out["loss"]))
+    assert all(np.isfinite(losses)), losses
+    print(algo, dtype, "loss %.4f -> %.4f" % (losses[0], losses[-1]))
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert m.optim.param_groups[0]["lr"] == pytest.approx(0.002)
