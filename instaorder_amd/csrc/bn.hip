@@ -53,10 +53,10 @@ __device__ __forceinline__ Chunk<bf16_t> ldc(const bf16_t* p) {
 __device__ __forceinline__ void stc(float* p, const Chunk<float>& c) { *reinterpret_cast<f32x4*>(p) = c.v[0]; }
 __device__ __forceinline__ void stc(bf16_t* p, const Chunk<bf16_t>& c) {
     uint4 r;
-    r.x = (unsigned)io_f2bf(c.v[0][0]) | ((unsigned)io_f2bf(c.v[0][1]) << 16);
-    r.y = (unsigned)io_f2bf(c.v[0][2]) | ((unsigned)io_f2bf(c.v[0][3]) << 16);
-    r.z = (unsigned)io_f2bf(c.v[1][0]) | ((unsigned)io_f2bf(c.v[1][1]) << 16);
-    r.w = (unsigned)io_f2bf(c.v[1][2]) | ((unsigned)io_f2bf(c.v[1][3]) << 16);
+    r.x = io_f2bf2(c.v[0][0], c.v[0][1]);
+    r.y = io_f2bf2(c.v[0][2], c.v[0][3]);
+    r.z = io_f2bf2(c.v[1][0], c.v[1][1]);
+    r.w = io_f2bf2(c.v[1][2], c.v[1][3]);
     *reinterpret_cast<uint4*>(p) = r;
 }
 // per-channel table entries for the channels of one chunk

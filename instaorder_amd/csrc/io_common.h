@@ -32,10 +32,13 @@ static inline int io_dtype_bytes(int dt) { return dt == IO_BF16 ? 2 : 4; }
 
 #ifdef __HIPCC__
 __device__ __forceinline__ float io_bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
-__device__ __forceinline__ bf16_t io_f2bf(float f) {      // round to nearest even (NaN stays NaN)
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round to nearest even in hardware (v_cvt_pk_bf16_f32 on gfx950: one instruction per PAIR of values, NaN stays NaN)
+typedef __bf16 io_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float io_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t io_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned io_f2bf2(float lo, float hi) {     // lo in bits [15:0], hi in bits [31:16]
+    const io_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, io_bf16x2));
 }
 // 4 consecutive elements <-> float4
 __device__ __forceinline__ f32x4 io_ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -51,8 +54,8 @@ __device__ __forceinline__ f32x4 io_ldv(const bf16_t* p) {
 __device__ __forceinline__ void io_stv(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void io_stv(bf16_t* p, f32x4 v) {
     uint2 r;
-    r.x = (unsigned)io_f2bf(v[0]) | ((unsigned)io_f2bf(v[1]) << 16);
-    r.y = (unsigned)io_f2bf(v[2]) | ((unsigned)io_f2bf(v[3]) << 16);
+    r.x = io_f2bf2(v[0], v[1]);
+    r.y = io_f2bf2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = r;
 }
 #endif
