@@ -6,8 +6,9 @@
  * it replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
  *
  * Conventions (all entry points):
- *   - plain pointers are DEVICE pointers unless stated otherwise; fp32, NHWC activations,
- *     filters as [Cout][R*S][Cin] ("KRSC"); the 5-channel network input is padded to 8 channels;
+ *   - plain pointers are DEVICE pointers unless stated otherwise; NHWC activations, fp32 (`float*`) or, in the
+ *     `_dt` / `dtype` entry points, of the stated storage type (`void*`: float or bfloat16); filters as
+ *     [Cout][R*S][Cin] ("KRSC"); the 5-channel network input is padded to 8 channels; tensors may exceed 4 GiB;
  *   - return 0 on success, a negative IO_ERR_* code on failure; never throw; the message of the
  *     last failure on the calling thread is returned by io_last_error_string();
  *   - never allocate device memory, never synchronise: work is enqueued on `stream`
