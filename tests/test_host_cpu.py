@@ -217,3 +217,24 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("# oracle", ""), fn
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The drop-in boundary is a C ABI: a C translation unit (gcc -std=c99, no HIP / torch headers) includes
+    include/instaorder_hip.h, links libinstaorder_hip.so and runs the planning entry points without a GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = os.path.join(ROOT, "instaorder_amd", "libinstaorder_hip.so")
+    assert os.path.exists(lib), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    exe = str(tmp_path / "abi_smoke")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, lib, "-Wl,-rpath," + os.path.dirname(lib),
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    out = r.stdout
+    assert "tensors 163 convs 53 bns 53 logits 5 param_floats" in out, out
