@@ -32,7 +32,8 @@ extern "C" {
 #define IO_ERR_STATE (-4)      /* call sequence violated (e.g. backward before forward) */
 #define IO_ERR_NODEVICE (-5)   /* no gfx950 device visible                             */
 
-#ifndef __HIP__
+/* hipStream_t comes from the HIP runtime header when the caller has included it; otherwise it is an opaque pointer */
+#if !defined(__HIP__) && !defined(HIP_INCLUDE_HIP_HIP_RUNTIME_API_H)
 typedef void* hipStream_t;
 #endif
 

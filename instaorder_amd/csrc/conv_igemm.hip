@@ -917,6 +917,7 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
         p.ntile_c = g.Ci / p.bnc;
         p.tiles = (g.Co / p.bmo) * g.Th * g.Tw * p.ntile_c;
     }
+    if (p.tiles < 1) p.tiles = 1;               // unsupported channel counts are rejected by the launcher, not here
     const int nkt = io_cdiv(M, 32);
     // 2 blocks fit a CU (LDS), so 512 run at once: fill at most two full rounds -- one block more than that would
     // cost a third, almost empty round (a 3x3 conv with 36 tiles: 29 splits = 1044 blocks ran 25 % slower than 28)

@@ -454,3 +454,37 @@ def test_sgd_momentum():
         opt.step()
         engine.sgd_momentum(dp, gr.to(DEV), buf, 1e-2, 0.9, 1e-3)
     assert relerr(dp, par.detach()) < 1e-6
+
+
+def test_c_abi_from_plain_c_program(tmp_path):
+    """The library used the way a non-Python host would: a C program with the HIP runtime only (hipMalloc'd buffers,
+    NULL stream) runs a convolution forward, data gradient and filter gradient and checks them against host loops."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers on this box")
+    lib = os.path.join(root, "instaorder_amd", "libinstaorder_hip.so")
+    exe = str(tmp_path / "abi_gpu")
+    cmd = ["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "abi_gpu.c"), "-o", exe, lib, "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1000:])
+
+
+def test_unsupported_channel_counts_are_errors_not_crashes():
+    """Filter gradient with Cin = 32 (the kernel needs multiples of 64): the planning call and the launch must return
+    an error code with a message (this used to divide by zero on the host)."""
+    N, H, Cin, Cout = 2, 8, 32, 64
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, H, H, Cin, Cout, 3, 3, 1, 1)
+    x = torch.zeros(N, H, H, Cin, device=DEV)
+    dy = torch.zeros(N, H, H, Cout, device=DEV)
+    dw = torch.zeros(Cout, 9, Cin, device=DEV)
+    ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=DEV)
+    rc = L().io_conv2d_wgrad(P(x), P(dy), P(dw), N, H, H, Cin, Cout, 3, 3, 1, 1, P(ws), int(nb), ST())
+    assert rc == -1 and b"multiple of 64" in L().io_last_error_string()
