@@ -957,6 +957,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): needs the packed input with Ci=8 (5 padded)");
     else
         IO_REQUIRE(g.Ci % (128 / es) == 0, IO_ERR_SHAPE, "conv_nt: Ci=%d must be a multiple of %d", g.Ci, 128 / es);
+    IO_REQUIRE(g.N > 0 && g.Ho > 0 && g.Wo > 0 && g.Hi > 0 && g.Wi > 0, IO_ERR_SHAPE,
+               "conv_nt: empty tensor (N=%d, in %dx%d, out %dx%d)", g.N, g.Hi, g.Wi, g.Ho, g.Wo);
     const long M = (long)g.N * g.Ho * g.Wo;
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
     // whole tensors may exceed 4 GiB (descriptors are rebased per tile); what a tile spans -- the samples of 128
@@ -1029,6 +1031,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     else
         IO_REQUIRE(g.Ci % 64 == 0 && dt_in == dt_dy, IO_ERR_SHAPE,
                    "conv_wgrad: Ci=%d must be a multiple of 64 (and one storage type)", g.Ci);
+    IO_REQUIRE(g.N > 0 && g.Ho > 0 && g.Wo > 0 && g.Hi > 0 && g.Wi > 0, IO_ERR_SHAPE,
+               "conv_wgrad: empty tensor (N=%d, in %dx%d, out %dx%d)", g.N, g.Hi, g.Wi, g.Ho, g.Wo);
     IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW, IO_ERR_SHAPE, "conv_wgrad: dY must be dense");
     IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co), IO_ERR_SHAPE,
                "conv_wgrad: grouped mode needs a 64-channel window and Ci == Co");

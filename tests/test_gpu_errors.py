@@ -1,0 +1,88 @@
+"""Error behaviour of the C ABI: unsupported shapes / too-small workspaces return a negative code and leave a message
+in io_last_error_string(); nothing aborts, divides by zero or launches."""
+import ctypes as C
+
+import pytest
+import torch
+
+from instaorder_amd import _lib
+from test_gpu_ops import L, P, ST
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bad(rc):
+    assert rc < 0, rc
+    assert len(L().io_last_error_string()) > 0
+
+
+def buf(n=1 << 16):
+    return torch.zeros(n, device=DEV)
+
+
+def test_conv_entry_points_reject_bad_shapes():
+    a, b, c = buf(), buf(), buf()
+    bad(L().io_conv2d_fwd(P(a), P(b), P(c), 1, 8, 8, 3, 64, 3, 3, 1, 1, ST()))           # Cin not a multiple of 32
+    bad(L().io_conv2d_fwd(P(a), P(b), P(c), 1, 8, 8, 32, 10, 3, 3, 1, 1, ST()))          # Cout not a multiple of 64
+    bad(L().io_conv2d_fwd(P(a), P(b), P(c), 0, 8, 8, 32, 64, 3, 3, 1, 1, ST()))          # empty batch
+    bad(L().io_conv2d_fwd(P(a), P(b), P(c), 1, 2, 2, 32, 64, 7, 7, 1, 0, ST()))          # window larger than the image
+    bad(L().io_conv2d_dgrad(P(a), P(b), P(c), None, None, 1, 8, 8, 48, 64, 3, 3, 1, 1, ST()))
+    bad(L().io_conv2d_wgrad(P(a), P(b), P(c), 1, 8, 8, 32, 64, 3, 3, 1, 1, P(a), 0, ST()))
+    bad(L().io_conv2d_wgrad(P(a), P(b), P(c), 1, 8, 8, 64, 96, 3, 3, 1, 1, P(a), 1 << 16, ST()))
+    # workspace too small for a split reduction
+    need = L().io_conv2d_wgrad_workspace_bytes(8, 32, 32, 64, 64, 3, 3, 1, 1)
+    assert need > 0
+    big = torch.zeros(8 * 32 * 32 * 64, device=DEV)
+    bad(L().io_conv2d_wgrad(P(big), P(big), P(c), 8, 32, 32, 64, 64, 3, 3, 1, 1, P(a), need - 1, ST()))
+    bad(L().io_conv2d_fwd_dt(P(a), P(b), P(c), 1, 8, 8, 64, 64, 3, 3, 1, 1, 7, 7, ST()))  # unknown dtype
+
+
+def test_bn_pool_loss_sgd_reject_bad_arguments():
+    a, b = buf(), buf()
+    t = [buf(64) for _ in range(8)]
+    npart = L().io_bn_partial_floats(64, 64, 1)
+    bad(L().io_bn_stats_finalize(P(a), 64, 6, 1, P(t[0]), P(t[1]), None, None, 0.1, 1e-5, P(t[2]), P(t[3]), P(t[4]),
+                                 P(t[5]), P(b), npart, ST()))                              # C not 4 * 2^k
+    bad(L().io_bn_stats_finalize(P(a), 65, 64, 2, P(t[0]), P(t[1]), None, None, 0.1, 1e-5, P(t[2]), P(t[3]), P(t[4]),
+                                 P(t[5]), P(b), npart, ST()))                              # M not divisible by G
+    bad(L().io_bn_stats_finalize(P(a), 64, 64, 1, P(t[0]), P(t[1]), None, None, 0.1, 1e-5, P(t[2]), P(t[3]), P(t[4]),
+                                 P(t[5]), P(b), 1, ST()))                                  # partial buffer too small
+    bad(L().io_bn_apply(P(a), 64, 48, 1, 0, P(t[0]), P(t[1]), P(t[2]), None, None, None, None, 1, P(b), ST()))
+    idx = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    bad(L().io_maxpool_fwd(P(a), 1, 8, 8, 6, P(b), P(idx), ST()))                          # C not a multiple of 4
+    bad(L().io_upsample2x_bilinear_fwd(P(a), 1, 4, 4, 6, 1, P(b), 0, ST()))
+    bad(L().io_upsample2x_bilinear_fwd(P(a), 1, 4, 4, 8, 1, P(b), 9, ST()))                # unknown dtype
+    bad(L().io_gconv_pack(P(a), 96, 8, 9, P(b), P(b), 0, ST()))                            # C not a multiple of 64
+    bad(L().io_gconv_pack(P(a), 128, 24, 9, P(b), P(b), 0, ST()))                          # group width does not divide 64
+    bad(L().io_head1_fwd(P(a), 16, 64, 5, P(t[0]), P(t[1]), 1, P(b), 0, ST()))
+    bad(L().io_colsum(P(a), 16, 48, P(t[0]), P(b), 1 << 16, 0, ST()))                      # C does not divide 256
+    bad(L().io_add(P(a), P(b), 6, P(b), 0, ST()))
+    planes = (C.c_void_p * 1)(a.data_ptr())
+    strides = (C.c_long * 1)(64)
+    bad(L().io_pack_planes_nhwc8(planes, strides, 0, 1, 8, 8, P(b), ST()))
+    bad(L().io_pack_planes_nhwc8(planes, strides, 6, 1, 8, 8, P(b), ST()))
+
+
+def test_network_executor_rejects_bad_calls():
+    heads = (C.c_int * 1)(2)
+    assert not L().io_net_create(9, 1, heads)                                               # in_channels > 5
+    assert not L().io_net_create(5, 3, heads)                                               # too many heads
+    net = C.c_void_p(L().io_net_create(5, 1, heads))
+    assert net
+    try:
+        assert L().io_net_workspace_bytes(net, 4, 100, 1) == 0                              # S not a multiple of 32
+        assert L().io_net_workspace_bytes(net, 0, 64, 1) == 0
+        assert L().io_net_activation_offset(net, 4, 64, 99) == -1
+        bad(L().io_net_set_dtype(net, 5))
+        n = L().io_net_param_floats(net)
+        params, running = buf(n), buf(L().io_net_running_floats(net))
+        x8 = torch.zeros(4, 64, 64, 8, device=DEV)
+        logits = torch.zeros(4, 2, device=DEV)
+        need = L().io_net_workspace_bytes(net, 4, 64, 1)
+        ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+        bad(L().io_net_forward(net, P(params), P(running), P(x8), 4, 64, 2, 1, P(ws), need - 1, P(logits), ST()))
+        bad(L().io_net_forward(net, P(params), P(running), P(x8), 4, 64, 3, 1, P(ws), need, P(logits), ST()))   # G !| N
+        bad(L().io_net_forward(net, P(params), P(running), P(x8), 4, 64, 2, 0, P(ws), need, P(logits), ST()))   # eval G != 1
+    finally:
+        L().io_net_destroy(net)
