@@ -86,3 +86,45 @@ def test_network_executor_rejects_bad_calls():
         bad(L().io_net_forward(net, P(params), P(running), P(x8), 4, 64, 2, 0, P(ws), need, P(logits), ST()))   # eval G != 1
     finally:
         L().io_net_destroy(net)
+
+
+def test_two_host_threads_on_two_streams():
+    """The library keeps no global mutable state on the data path: two host threads, each on its own HIP stream with its
+    own buffers, interleave launches of all three convolution kernels and get the results of the serial run."""
+    import threading
+    N, H, Ci, Co = 4, 16, 64, 128
+    g = torch.Generator(device=DEV).manual_seed(1)
+    data = []
+    for _ in range(2):
+        x = torch.randn(N, H, H, Ci, device=DEV, generator=g)
+        w = torch.randn(Co, 9, Ci, device=DEV, generator=g) * 0.05
+        dy = torch.randn(N, H, H, Co, device=DEV, generator=g)
+        data.append((x, w, dy))
+    nb = L().io_conv2d_wgrad_workspace_bytes(N, H, H, Ci, Co, 3, 3, 1, 1)
+
+    def run(x, w, dy, stream, reps):
+        y = torch.empty(N, H, H, Co, device=DEV)
+        dw = torch.empty(Co, 9, Ci, device=DEV)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+        s = C.c_void_p(stream.cuda_stream)
+        for _ in range(reps):
+            assert L().io_conv2d_fwd(P(x), P(w), P(y), N, H, H, Ci, Co, 3, 3, 1, 1, s) == 0
+            assert L().io_conv2d_wgrad(P(x), P(dy), P(dw), N, H, H, Ci, Co, 3, 3, 1, 1, P(ws), nb, s) == 0
+        stream.synchronize()
+        return y, dw
+
+    torch.cuda.synchronize()
+    serial = [run(*d, torch.cuda.current_stream(), 1) for d in data]
+    out = [None, None]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def worker(i):
+        out[i] = run(*data[i], streams[i], 50)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert torch.equal(out[i][0], serial[i][0]) and torch.equal(out[i][1], serial[i][1])
