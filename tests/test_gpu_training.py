@@ -37,3 +37,29 @@ def test_overfits_a_fixed_batch(algo, dtype):
     print(algo, dtype, "loss %.4f -> %.4f" % (losses[0], losses[-1]))
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert m.optim.param_groups[0]["lr"] == pytest.approx(0.002)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_is_bitwise_deterministic(dtype):
+    """No atomics, fixed-order split-K / BatchNorm reductions: the same step from the same state gives the same bits
+    (parameters, gradients, running statistics, loss)."""
+    import instaorder_amd as ia
+    algo, S, B = "InstaOrderNet_od", 128, 8
+    cfg = dict(algo=algo, lr=0.01, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype=dtype,
+               backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    sd = synthetic.make_state_dict(9, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+    b = {k: torch.from_numpy(v) for k, v in synthetic.make_pair_batch(4, B, S).items()}
+    results = []
+    for rep in range(2):
+        m = getattr(ia, algo)(cfg, dist_model=False)
+        m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m.switch_to("train")
+        for _ in range(3):          # the third step replays the captured hipGraph
+            m.set_input(b["rgb"], b["modal1"], b["modal2"], b["depth_order"], b["count"], b["is_overlap"], b["occ_order"])
+            out = m.step()
+        results.append((m.net.flat_params.clone(), m.net.flat_grads.clone(), m.net.flat_running.clone(),
+                        float(out[1]["loss"])))
+    for a, c in zip(results[0][:3], results[1][:3]):
+        assert torch.equal(a, c)
+    assert results[0][3] == results[1][3]
