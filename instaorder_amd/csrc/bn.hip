@@ -1,11 +1,12 @@
-// BatchNorm2d (train + eval) over NHWC fp32 activations, with "groups": the N samples are split
+// BatchNorm2d (train + eval) over NHWC activations (fp32 or bf16 storage; statistics, tables and parameter gradients
+// are always fp32), with "groups": the N samples are split
 // into G equal consecutive groups that are normalised with SEPARATE batch statistics.  G = 2 is how
 // one launch serves the reference's two directional passes (supervised_order.py:537-538), which are
 // separate module calls and therefore separate BN batches; running statistics are advanced group by
 // group so they end up exactly as after two sequential calls.
 //
-// All kernels are HBM-bound streaming passes: each thread owns one float4 of channels and strides
-// over rows, so a wave reads whole contiguous NHWC rows (1 KiB per wave-instruction for C >= 256).
+// All kernels are HBM-bound streaming passes: each thread owns one 16-byte chunk of channels (4 fp32 / 8 bf16) and
+// strides over rows, so a wave reads whole contiguous NHWC rows (1 KiB per wave-instruction for C >= 256).
 // Reductions are two-level (per-block fp32 partials, fp64 finalize) and deterministic.
 // Reference semantics: nn.BatchNorm2d, resnet_cls.py:142, 87-92, 189 (eps 1e-5, momentum 0.1,
 // biased variance for normalisation, unbiased for the running estimate).

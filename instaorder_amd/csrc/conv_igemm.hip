@@ -1,21 +1,25 @@
-// Implicit-GEMM convolutions on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolutions on the matrix cores of gfx950: v_mfma_f32_32x32x2_f32 on fp32 data (the reference's
+// precision) and v_mfma_f32_32x32x16_bf16 on bf16 data (dtype switch), fp32 accumulation in both.
 //
-// Everything the ResNet-50 path needs from "conv" is one of two GEMM shapes over NHWC data:
+// Everything the ResNet / ResNeXt paths need from "conv" is one of two GEMM shapes over NHWC data:
 //
 //   NT  out[m][o] = sum_{tap,c} In[pix(m,tap)][c] * W[o][tap][c]      (+ add[m][o])
-//       forward conv (resnet_cls.py:23-31, :140) and both data-gradient forms.  Both operands
-//       are K-contiguous, so the k index is permuted freely: each lane fetches 4 consecutive k
-//       with one ds_read_b128 and feeds them to 4 MFMAs.
+//       forward conv (resnet_cls.py:23-31, :140) and both data-gradient forms; with IoConvGeom::gw also the grouped
+//       3x3 convolution as a block-diagonal one.  Both operands are K-contiguous, so the k index is permuted
+//       freely: each lane fetches 16 bytes of consecutive k with one ds_read_b128 and feeds them to 4 fp32 MFMAs or
+//       1 bf16 MFMA.  Optional epilogues: BatchNorm statistics of the output, residual add, ReLU mask, BatchNorm
+//       backward reductions.
 //   TN  dW[o][tap][c] = sum_m dY[m][o] * In[pix(m,tap)][c]
-//       weight gradient; the reduction index m is the slow (row) dimension of both operands, so
-//       tiles are stored as loaded ([m][channel]) and fragments are column slices (ds_read_b32,
-//       consecutive lanes -> consecutive banks).  Split over m with a deterministic second pass.
+//       weight gradient; the reduction index m is the slow (row) dimension of both operands.  fp32: tiles are
+//       stored as loaded ([m][channel]) and fragments are column slices (ds_read_b32, consecutive lanes ->
+//       consecutive banks).  bf16: the staging pass transposes 8x8 blocks in registers so that the LDS image is the
+//       NT kernel's.  Split over m with a deterministic second pass.
 //
-// fp32 MFMA runs at the vector rate (64 FLOP/clk/SIMD), so the kernels are compute bound by a
-// wide margin (LDS needs ~16 B/clk/CU of 256); the design goal is simply to keep one MFMA chain
-// per SIMD busy: 128x128x32 block tile, 4 waves in 2x2, 2x2 MFMA tiles per wave (4 independent
-// accumulators), register-staged double buffering (global loads of tile k+1 fly under the 64
-// MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.
+// fp32 MFMA runs at the vector rate (64 FLOP/clk/SIMD), so the fp32 kernels are compute bound by a wide margin
+// (LDS needs ~16 B/clk/CU of 256); the design goal is simply to keep one MFMA chain per SIMD busy: 128x128x32 block
+// tile, 4 waves in 2x2, 2x2 MFMA tiles per wave (4 independent accumulators), register-staged double buffering
+// (global loads of tile k+1 fly under the 64 MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.  Operands are addressed
+// with 32-bit offsets through buffer descriptors rebased per tile, so tensors may exceed 4 GiB.
 #include <string.h>
 
 #include "io_common.h"
