@@ -27,6 +27,29 @@ def upper_pairs(n):
     return [(i, j) for i in range(n) for j in range(i + 1, n)]
 
 
+def bordering(a, b):
+    """Reference inference.py:691-696: does mask ``a``, dilated once with the 3x3 cross, touch mask ``b``?
+    (cv2.dilate with a cross kernel on a binary image = OR of the four one-pixel shifts.)"""
+    a = np.asarray(a) == 1
+    d = a.copy()
+    d[1:] |= a[:-1]
+    d[:-1] |= a[1:]
+    d[:, 1:] |= a[:, :-1]
+    d[:, :-1] |= a[:, 1:]
+    return bool(np.any(d & (np.asarray(b) != 0)))
+
+
+def select_pairs(inmodal, pairs):
+    """The pair list of the reference's double loop: every i < j ("all") or only neighbouring instances ("nbor",
+    inference.py:446-447: ``bordering(inmodal[i], inmodal[j])`` -- only the first mask is dilated)."""
+    n = inmodal.shape[0]
+    if pairs == "all":
+        return upper_pairs(n)
+    if pairs == "nbor":
+        return [(i, j) for (i, j) in upper_pairs(n) if bordering(inmodal[i], inmodal[j])]
+    raise ValueError("pairs must be 'all' or 'nbor', got %r" % (pairs,))
+
+
 def _heads(method):
     if method in ("InstaOrderNet_od",):
         return 2, 3
@@ -172,20 +195,18 @@ def _image_mode_only(patch_or_image, image, inmodal, input_size):
 def infer_order_sup_occ(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size=256, use_rgb=True):
     """Reference signature (inference.py:439-512); returns the occlusion order matrix
     (1 at [i, j] = i occludes j)."""
-    if pairs != "all":
-        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
     rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
-    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method,
+                              pairs=select_pairs(inmodal, pairs))
     return res["occ_order"]
 
 
 def infer_order_sup_occ_depth(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size,
                               disp_select_method=""):
     """Reference signature (inference.py:349-436); returns (occ_order, depth_order)."""
-    if pairs != "all":
-        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
     rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
-    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method,
+                              pairs=select_pairs(inmodal, pairs))
     return res["occ_order"], res["depth_order"]
 
 
@@ -273,15 +294,14 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
     """Reference signature (inference.py:515-625); returns (depth order matrix, clipped disparity | None).
     Methods: InstaOrderNet_d (the batched ResNet path) and InstaDepthNet_d / InstaDepthNet_od (batched MiDaS path;
     with ``disp_select_method`` 'mean' / 'median' the order comes from the predicted disparity instead of the head)."""
-    if pairs != "all":
-        raise NotImplementedError("pairs='nbor' needs the bordering() dilation heuristic (out of scope)")
     rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
+    plist = select_pairs(inmodal, pairs)
     if method == "InstaOrderNet_d":
-        res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method)
+        res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method, pairs=plist)
         return res["depth_order"], None
     if method not in ("InstaDepthNet_d", "InstaDepthNet_od"):
         raise ValueError("method name should be one of {InstaOrderNet_d, InstaDepthNet_d, InstaDepthNet_od}")
-    res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks))
+    res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), pairs=plist)
     if disp_select_method == "":
         return res["depth_order"], None
     # the reference takes the disparity of a call with empty masks; the disparity does not depend on the masks

@@ -238,3 +238,25 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     out = r.stdout
     assert "tensors 163 convs 53 bns 53 logits 5 param_floats" in out, out
+
+
+def test_bordering_and_pair_selection():
+    """inference.py:691-696 / :446-447: neighbour test = one cross dilation of the FIRST mask; checked against
+    scipy's binary_dilation with the same structuring element."""
+    from scipy import ndimage
+    from instaorder_amd import inference
+    rng = np.random.RandomState(3)
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    for _ in range(50):
+        a = (rng.rand(12, 15) < 0.15).astype(np.uint8)
+        b = (rng.rand(12, 15) < 0.15).astype(np.uint8)
+        want = bool(np.any(ndimage.binary_dilation(a.astype(bool), structure=cross) & (b != 0)))
+        assert inference.bordering(a, b) == want
+    m = np.zeros((3, 8, 8), np.uint8)
+    m[0, 1:3, 1:3] = 1
+    m[1, 3:5, 1:3] = 1          # touches mask 0 from below
+    m[2, 6:8, 6:8] = 1          # far away
+    assert inference.select_pairs(m, "all") == [(0, 1), (0, 2), (1, 2)]
+    assert inference.select_pairs(m, "nbor") == [(0, 1)]
+    with pytest.raises(ValueError):
+        inference.select_pairs(m, "some")
