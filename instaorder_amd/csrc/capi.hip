@@ -155,7 +155,7 @@ extern "C" int io_conv2d_dgrad_bnbwd(const float* dy, const float* wt, float* dz
     const size_t per = (tiles + tiles / 64 + G + 2) * (size_t)Cin;
     IO_REQUIRE(workspace_floats >= 2 * per + 2 * (size_t)G * Cin, IO_ERR_WORKSPACE,
                "conv2d_dgrad_bnbwd: workspace %zu < %zu floats", workspace_floats, 2 * per + 2 * (size_t)G * Cin);
-    IoBwStats bw;
+    IoBwStats bw{};
     bw.y = y; bw.mean = mean; bw.rstd = rstd; bw.mscale = scale; bw.mshift = shift;
     bw.p1 = workspace; bw.p2 = workspace + per; bw.Mg = M / G;
     int rc = io_run_dgrad(dy, wt, dz, nullptr, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, st, &bw);

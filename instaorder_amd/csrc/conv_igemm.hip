@@ -366,6 +366,9 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
             bw_s2[j] = 0.f;
         }
     }
+    float ep_bias[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) ep_bias[j] = bw.bias ? bw.bias[n0 + wn * (BN / WN) + j * 32 + (lane & 31)] : 0.f;
     const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
     constexpr unsigned JS = 32u * OS;     // byte step between a lane's column blocks
 #pragma unroll
@@ -393,6 +396,15 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
             }
+        }
+        if (bw.bias) {   // folded BatchNorm of an inference forward: + bias[o], optional ReLU
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + ep_bias[j];
+                    acc[i][j][r] = (bw.relu && v < 0.f) ? 0.f : v;
+                }
         }
         if (mask) {      // ReLU backward of the tensor this gradient belongs to: zero where it was clipped
 #pragma unroll
@@ -949,7 +961,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     memset(&bws, 0, sizeof(bws));
     if (bw) {
         bws = *bw;
-        IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg % 128 == 0, IO_ERR_SHAPE,
+        IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg % 128 == 0), IO_ERR_SHAPE,
                    "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group");
     }
     IO_REQUIRE((st_mean == nullptr) == (st_m2 == nullptr), IO_ERR_SHAPE, "conv_nt: statistics outputs come in pairs");
@@ -988,7 +1000,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
-                     (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + (bw ? 1.0 : 0.0)) +
+                     (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
                          (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
                      st);
 #define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_)                                                                   \

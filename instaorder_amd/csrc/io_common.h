@@ -106,6 +106,10 @@ struct IoBwStats {
     const float *mean, *rstd, *mscale, *mshift;
     float *p1, *p2;     // [M/128][C] tile partials
     int Mg;
+    // Independent of the above (y may be null): inference epilogue out = [relu](acc + bias[o] (+ add)) -- the
+    // BatchNorm of an eval-mode forward folded into the convolution (filters pre-scaled by gamma * rstd).
+    const float* bias;
+    int relu;
 };
 
 // internal launchers shared between the C ABI and the network executor

@@ -111,6 +111,7 @@ struct Plan {
     size_t gbuf[5];      // gradient scratch (training only)
     size_t wt, wg_partial, wg_partial_bytes;
     size_t wop;          // bf16 mode: operand copy of the whole flat parameter buffer (same element offsets)
+    size_t wfold, fbias; // eval: filters with the BatchNorm scale folded in (storage type, parameter offsets) + biases
     size_t total;
 };
 
@@ -131,6 +132,8 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     const size_t e = (size_t)io_dtype_bytes(net->dtype);   // activation element size
     const size_t maxact = (size_t)N * H0 * H0 * 64 * e;   // == N*H1*H1*256*e, the largest activations
     p.wop = net->dtype == IO_BF16 ? a.take((size_t)net->param_floats * sizeof(bf16_t)) : 0;
+    p.wfold = training ? 0 : a.take((size_t)net->param_floats * e);
+    p.fbias = training ? 0 : a.take((size_t)net->bn_channels * f);
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
     p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
@@ -207,6 +210,35 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     return p;
 }
 
+// ---- eval mode: BatchNorm folded into the convolutions -----------------------------------------------
+// y = gamma * (conv(x, w) - mean) / sqrt(var + eps) + beta = conv(x, w * s) + (beta - mean * s), s = gamma / sqrt(var+eps):
+// one launch rewrites every filter (scaled per output channel, in the activation storage type) and every bias, then
+// each convolution applies bias (+ residual) (+ ReLU) in its epilogue -- an inference forward has no BatchNorm pass.
+struct FoldDesc {
+    long w_off, g_off, b_off, run_off, bias_off;
+    int rows, rowlen;
+};
+struct FoldTable {
+    int n;
+    FoldDesc d[56];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bn_kernel(FoldTable t, const float* __restrict__ params,
+                                                     const float* __restrict__ running, float eps,
+                                                     T* __restrict__ wout, float* __restrict__ bias) {
+    const FoldDesc d = t.d[blockIdx.y];
+    for (int row = blockIdx.x; row < d.rows; row += gridDim.x) {
+        const float s = params[d.g_off + row] / sqrtf(running[d.run_off + d.rows + row] + eps);
+        if (threadIdx.x == 0) bias[d.bias_off + row] = params[d.b_off + row] - running[d.run_off + row] * s;
+        const float* src = params + d.w_off + (size_t)row * d.rowlen;
+        T* dst = wout + d.w_off + (size_t)row * d.rowlen;
+        for (int k = threadIdx.x; k < d.rowlen; k += 256) {
+            if constexpr (sizeof(T) == 2) dst[k] = io_f2bf(src[k] * s);
+            else dst[k] = src[k] * s;
+        }
+    }
+}
+
 #define IO_TRY(expr)            \
     do {                        \
         int rc_ = (expr);       \
@@ -237,6 +269,11 @@ struct Ctx {
         return net->dtype == IO_BF16 ? (const void*)(reinterpret_cast<const bf16_t*>(ws + plan.wop) + w_off)
                                      : (const void*)(params + w_off);
     }
+    const void* wfold(long w_off) const {      // eval: folded filter in the activation storage type
+        return net->dtype == IO_BF16 ? (const void*)(reinterpret_cast<const bf16_t*>(ws + plan.wfold) + w_off)
+                                     : (const void*)(reinterpret_cast<const float*>(ws + plan.wfold) + w_off);
+    }
+    float* fbias(const BnL& b) const { return buf(plan.fbias) + chan_prefix[b.index]; }
     Tables tables(const BnL& b) const {
         float* base = buf(plan.tables) + (size_t)4 * kMaxGroups * chan_prefix[b.index];
         const size_t gs = (size_t)kMaxGroups * b.C;
@@ -291,7 +328,72 @@ int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, co
                          h2, relu, out, c.st, c.dt());
 }
 
+// conv + folded BatchNorm (+ residual) (+ ReLU) of an inference forward
+int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int H, const void* add, int relu) {
+    IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
+    IoBwStats ep{};
+    ep.bias = c.fbias(b);
+    ep.relu = relu;
+    return io_launch_conv_nt(g, x, c.wfold(L.w_off), y, add, nullptr, L.cin_store == 8, c.st, nullptr, nullptr, &ep,
+                             c.dt(), c.dt());
+}
+
+int run_forward_eval(Ctx& c, const void* x8, float* logits) {
+    const io_net* net = c.net;
+    const Plan& p = c.plan;
+    const int H0 = c.S / 2, H1 = c.S / 4;
+    {
+        FoldTable t;
+        t.n = 0;
+        auto add = [&](const ConvL& L, const BnL& b) {
+            FoldDesc& d = t.d[t.n++];
+            d.w_off = L.w_off; d.g_off = b.g_off; d.b_off = b.b_off; d.run_off = b.run_off;
+            d.bias_off = c.chan_prefix[b.index];
+            d.rows = L.cout; d.rowlen = L.k * L.k * L.cin_store;
+        };
+        add(net->stem, net->bn1);
+        for (const Block& b : net->blocks) {
+            add(b.c1, b.b1); add(b.c2, b.b2); add(b.c3, b.b3);
+            if (b.down) add(b.cd, b.bd);
+        }
+        IO_REQUIRE(t.n <= 56, IO_ERR_STATE, "fold table overflow");
+        IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, (4.0 + io_dtype_bytes(c.dt())) * (double)net->param_floats, c.st);
+        if (c.dt() == IO_BF16)
+            hipLaunchKernelGGL(fold_bn_kernel<bf16_t>, dim3(64, t.n), dim3(256), 0, c.st, t, c.params, c.running, kBnEps,
+                               reinterpret_cast<bf16_t*>(c.ws + p.wfold), c.buf(p.fbias));
+        else
+            hipLaunchKernelGGL(fold_bn_kernel<float>, dim3(64, t.n), dim3(256), 0, c.st, t, c.params, c.running, kBnEps,
+                               reinterpret_cast<float*>(c.ws + p.wfold), c.buf(p.fbias));
+        IO_TRY(io_check_launch("fold_bn"));
+    }
+    IO_TRY(conv_folded(c, net->stem, net->bn1, x8, c.act(p.a0), c.S, nullptr, 1));
+    IO_TRY(io_maxpool_fwd_t(c.act(p.a0), c.N, H0, H0, 64, c.act(p.p0), nullptr, c.st, c.dt()));
+    const void* x = c.act(p.p0);
+    int H = H1;
+    for (size_t i = 0; i < net->blocks.size(); ++i) {
+        const Block& b = net->blocks[i];
+        const BlockBufs& bb = p.blk[i];
+        const int Ho = H / b.stride;
+        IO_TRY(conv_folded(c, b.c1, b.b1, x, c.act(bb.a1), H, nullptr, 1));
+        IO_TRY(conv_folded(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.a2), H, nullptr, 1));
+        const void* identity = x;
+        if (b.down) {
+            IO_TRY(conv_folded(c, b.cd, b.bd, x, c.act(bb.yd), H, nullptr, 0));
+            identity = c.act(bb.yd);
+        }
+        IO_TRY(conv_folded(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.out), Ho, identity, 1));
+        x = c.act(bb.out);
+        H = Ho;
+    }
+    const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
+    const float* b1 = net->n_heads > 1 ? c.params + net->fcb_off[1] : nullptr;
+    return io_avgpool_fc_fwd_t(x, c.N, H * H, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
+                               net->head_dims[0], w1, b1, net->n_heads > 1 ? net->head_dims[1] : 0, c.buf(p.pooled),
+                               logits, c.st, c.dt());
+}
+
 int run_forward(Ctx& c, const void* x8, float* logits) {
+    if (!c.training) return run_forward_eval(c, x8, logits);
     const io_net* net = c.net;
     const Plan& p = c.plan;
     const int H0 = c.S / 2, H1 = c.S / 4;
@@ -358,7 +460,7 @@ bool tiles_ok(const Ctx& c, int M) { return (M / c.G) % kIoStatTileRows == 0; }
 
 IoBwStats bw_for(const Ctx& c, const BnL& b, const void* y, int M, bool mask_from_y) {
     Tables t = c.tables(b);
-    IoBwStats bw;
+    IoBwStats bw{};
     bw.y = y;
     bw.mean = t.mean;
     bw.rstd = t.rstd;
