@@ -262,6 +262,12 @@ int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H
                              float* running_var, float momentum, float eps, float* mean, float* rstd, float* scale,
                              float* shift, float* workspace, size_t workspace_floats, int dtype, int gw,
                              hipStream_t stream);
+/* y = [relu](conv(x, w) + bias[o] (+ add)): a biased nn.Conv2d, or conv + eval-mode BatchNorm (+ residual) (+ ReLU) with
+ * the BatchNorm folded into pre-scaled filters (w[o] * gamma[o]/sqrt(var[o]+eps), bias = beta - mean * that) --
+ * resnet_cls.py:99-114 in model.eval().  add (optional) has the shape and type of y.  gw as above. */
+int io_conv2d_fwd_bias_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                          int stride, int pad, const float* bias, const void* add, int relu, int dtype, int gw,
+                          hipStream_t stream);
 /* storage-typed forms of io_maxpool_* / io_avgpool_fc_* (pooled / logits / parameter gradients stay float) */
 int io_maxpool_fwd_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int dtype, hipStream_t stream);
 int io_maxpool_bwd_dt(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, int dtype,

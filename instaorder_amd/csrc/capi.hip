@@ -352,3 +352,19 @@ extern "C" int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, i
     return io_bn_finalize_tiles(tmean, tm2, M, Cout, G, gamma, beta, running_mean, running_var, momentum, eps, mean,
                                 rstd, scale, shift, st);
 }
+
+
+/* convolution with an inference epilogue: y = [relu](conv(x, w) + bias[o] (+ add)) -- a BatchNorm in eval mode folded
+ * into pre-scaled filters, or a biased nn.Conv2d; dense (gw = 0) or grouped-window (gw = 64) */
+extern "C" int io_conv2d_fwd_bias_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
+                                     int S, int stride, int pad, const float* bias, const void* add, int relu, int dtype,
+                                     int gw, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_bias: unknown dtype %d", dtype);
+    IO_REQUIRE(bias != nullptr, IO_ERR_SHAPE, "conv2d_fwd_bias: bias is required");
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    g.gw = gw;
+    IoBwStats ep{};
+    ep.bias = bias;
+    ep.relu = relu;
+    return io_launch_conv_nt(g, x, w, y, add, nullptr, Cin == 8, st, nullptr, nullptr, &ep, dtype, dtype);
+}

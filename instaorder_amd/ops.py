@@ -233,21 +233,34 @@ class _ConvBn(torch.autograd.Function):
         N, H, W_, Cs = x.shape
         Co, Cig, R, S = w.shape
         dense = groups == 1
+        wsrc = w.detach()
+        if not training:
+            # inference: the BatchNorm is folded into the filters (scaled per output channel) and a bias; the
+            # convolution's epilogue adds bias (+ identity) (+ ReLU) -- no pass over the conv output
+            fscale = gamma.detach() / torch.sqrt(running_var + 1e-5)
+            fbias = (beta.detach() - running_mean * fscale).contiguous()
+            wsrc = wsrc * fscale.view(-1, 1, 1, 1)
         if dense:
             wop = torch.zeros((Co, R * S, Cs), device=dev, dtype=x.dtype)
-            wop[:, :, :Cig] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Cig)
+            wop[:, :, :Cig] = wsrc.permute(0, 2, 3, 1).reshape(Co, R * S, Cig)
             wback = wop
         else:
             if Co != Cs or Co // groups != Cig:
                 raise ValueError("grouped conv: expected [C, C/groups, R, S] filters on C input channels")
             wop = torch.empty((Co, R * S, 64), device=dev, dtype=x.dtype)
             wback = torch.empty_like(wop)
-            _lib.check(L.io_gconv_pack(_p(w.detach().contiguous()), Co, Cig, R * S, _p(wop), _p(wback), dt, _st()),
+            _lib.check(L.io_gconv_pack(_p(wsrc.contiguous()), Co, Cig, R * S, _p(wop), _p(wback), dt, _st()),
                        "io_gconv_pack")
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
         M = N * Ho * Wo
         G = int(bn_groups) if training else 1
         y = torch.empty((N, Ho, Wo, Co), device=dev, dtype=x.dtype)
+        if not training:
+            _lib.check(L.io_conv2d_fwd_bias_dt(_p(x), _p(wop), _p(y), N, H, W_, Cs, Co, R, S, stride, pad, _p(fbias),
+                                               _p(identity), int(relu), dt, 0 if dense else 64, _st()),
+                       "io_conv2d_fwd_bias_dt")
+            ctx.cfg = (N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, bool(relu), identity is not None, False)
+            return y
         mean, rstd, scale, shift = (torch.empty(G * Co, device=dev, dtype=torch.float32) for _ in range(4))
         gd, bd = gamma.detach(), beta.detach()
         if training and M % G == 0 and (M // G) % 128 == 0:
@@ -282,10 +295,10 @@ class _ConvBn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, wback, y, out, gamma, mean, rstd = ctx.saved_tensors
         N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, relu, has_id, training = ctx.cfg
         if not training:
             raise RuntimeError("ops.conv_bn: backward through eval-mode BatchNorm is not implemented")
+        x, wback, y, out, gamma, mean, rstd = ctx.saved_tensors
         L = _L()
         dev, dt = x.device, _dt(x)
         dout = dout.contiguous()
