@@ -17,6 +17,11 @@ __all__ = ["conv2d", "conv_bn", "batch_norm", "max_pool_3x3s2", "avgpool_fc", "u
            "nhwc_from_nchw", "nchw_from_nhwc"]
 
 
+# bumped by whoever changes parameters behind torch's back (the HIP optimiser kernels update them in place without
+# touching torch's version counters): invalidates the folded inference operands cached on the parameters
+WEIGHTS_EPOCH = [0]
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -234,9 +239,25 @@ class _ConvBn(torch.autograd.Function):
         Co, Cig, R, S = w.shape
         dense = groups == 1
         wsrc = w.detach()
+        cache_key = None
         if not training:
             # inference: the BatchNorm is folded into the filters (scaled per output channel) and a bias; the
-            # convolution's epilogue adds bias (+ identity) (+ ReLU) -- no pass over the conv output
+            # convolution's epilogue adds bias (+ identity) (+ ReLU) -- no pass over the conv output.  The folded
+            # operands are kept on the parameter until the weights change (torch version counters + WEIGHTS_EPOCH,
+            # which the HIP-side optimiser bumps): an inference loop re-packs nothing.
+            cache_key = (x.dtype, Cs, WEIGHTS_EPOCH[0], w._version, gamma._version, beta._version, running_mean._version,
+                         running_var._version)
+            hit = getattr(w, "_io_folded", None)
+            if hit is not None and hit[0] == cache_key:
+                wop, fbias = hit[1], hit[2]
+                Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
+                y = torch.empty((N, Ho, Wo, Co), device=dev, dtype=x.dtype)
+                _lib.check(L.io_conv2d_fwd_bias_dt(_p(x), _p(wop), _p(y), N, H, W_, Cs, Co, R, S, stride, pad, _p(fbias),
+                                                   _p(identity), int(relu), dt, 0 if dense else 64, _st()),
+                           "io_conv2d_fwd_bias_dt")
+                ctx.cfg = (N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, N * Ho * Wo, 1, bool(relu),
+                           identity is not None, False)
+                return y
             fscale = gamma.detach() / torch.sqrt(running_var + 1e-5)
             fbias = (beta.detach() - running_mean * fscale).contiguous()
             wsrc = wsrc * fscale.view(-1, 1, 1, 1)
@@ -256,6 +277,7 @@ class _ConvBn(torch.autograd.Function):
         G = int(bn_groups) if training else 1
         y = torch.empty((N, Ho, Wo, Co), device=dev, dtype=x.dtype)
         if not training:
+            w._io_folded = (cache_key, wop, fbias)
             _lib.check(L.io_conv2d_fwd_bias_dt(_p(x), _p(wop), _p(y), N, H, W_, Cs, Co, R, S, stride, pad, _p(fbias),
                                                _p(identity), int(relu), dt, 0 if dense else 64, _st()),
                        "io_conv2d_fwd_bias_dt")

@@ -125,6 +125,8 @@ class FlatSGD(torch.optim.Optimizer):
         if not gathered:
             self.gather_grads()
         engine.sgd_momentum(self.flat_params, self.flat_grads, self._buf, g["lr"], g["momentum"], g["weight_decay"])
+        from . import ops
+        ops.WEIGHTS_EPOCH[0] += 1          # parameters changed in place, invisibly to torch's version counters
         return None
 
     def state_dict(self):

@@ -238,3 +238,36 @@ def test_larger_input_against_oracle():
             rm_o.append(st[k].reshape(-1))
     # named_buffers() lists shared buffers once, like the alias-free spec entries
     assert rel_err(rm_h, torch.cat(rm_o).numpy()) < 1e-3
+
+
+def test_folded_inference_cache_follows_the_weights():
+    """Eval-mode operands (BatchNorm folded into the filters) are cached on the parameters; a training step -- whose
+    HIP optimiser updates the weights without touching torch's version counters -- and load_state_dict must
+    invalidate them."""
+    algo, tag = CASES[1]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    args = (t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())
+    m.switch_to("eval")
+    with torch.no_grad():
+        a1 = m.model(*args)[0].clone()
+        a2 = m.model(*args)[0].clone()          # served from the cache
+    assert torch.equal(a1, a2)
+    m.switch_to("train")
+    feed(m, algo, t)
+    m.step()
+    m.switch_to("eval")
+    with torch.no_grad():
+        b1 = m.model(*args)[0].clone()
+    assert not torch.equal(a1, b1)               # weights moved: stale operands would reproduce a1
+    m2, _ = build(algo, g, spec)                 # reference for the post-step weights: a fresh model with them loaded
+    m2.model.load_state_dict(m.model.state_dict())
+    m2.switch_to("eval")
+    with torch.no_grad():
+        b2 = m2.model(*args)[0]
+    assert torch.equal(b1, b2)
+    sd = synthetic.make_spec_state_dict(int(g["meta"][2]), spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    with torch.no_grad():
+        c1 = m.model(*args)[0]
+    assert torch.equal(c1, a1)                   # original weights again -> original output
