@@ -39,6 +39,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// n / d for small non-negative n (< 2^16) with rd = 1.0f / d: (n + 0.5) * rd is at least 0.5 / d away from an integer
+__device__ __forceinline__ int sdiv(int n, float rd) { return (int)(((float)n + 0.5f) * rd); }
+__device__ __forceinline__ int stem_kp(int wT, int cr) { return (wT * cr + 31) / 32 * 32; }   // = io_stem_kp
 __device__ __forceinline__ int fdiv(int n, IoFastDiv f) {
     return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift);
 }
@@ -98,7 +101,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // A k-tile row is always 128 bytes (32 floats or 64 bf16) and a lane always moves 16-byte chunks, so the LDS
 // image, the addressing and the fragment reads are byte-for-byte the same in both modes.  TO: storage type of
 // out / add / mask / bw.y (the fp32 stem writes bf16 activations in bf16 mode).
-template <typename TA, typename TO, int BN, bool STEM, int NW>
+// STEM: 0 regular conv, 1 stem on the packed x8 input (k = tap x 8 channels, 3 of them padding), 2 stem in exact-K
+// mode (fp32 only): k = tap * g.cr + channel over the real channels, gathered one dword at a time, filters pre-packed
+// as [Co][kp] -- 8 k-tiles instead of 13 for the 7x7 / 5-channel stem.
+template <typename TA, typename TO, int BN, int STEM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -111,6 +117,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     constexpr int BM = 128, BK = 128 / ES, LDT = 32 + 4, NT = NW * 64;   // LDT in 4-byte words
     constexpr int CPT = ES / 2;             // stem: 16-byte chunks per 8-channel tap (fp32 2, bf16 1)
     constexpr int TPT = 8 / CPT;            // stem: taps per k-tile
+    constexpr bool XK = STEM == 2;          // exact-K stem
+    static_assert(!XK || ES == 4, "the exact-K stem is an fp32 path");
     constexpr int WN = NW / 2;              // waves along N (2 along M)
     constexpr int TI = 2, TJ = BN / (32 * WN);
     constexpr int AR = (BM * 8) / NT;       // A rows loaded per thread (8 float4 per row)
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     const int kw = g.gw ? g.gw : g.Ci;           // filter row length per tap
     const int cbase = g.gw ? n0 : 0;             // first input channel of the k range
     const int nkc = STEM ? 1 : kw / BK;
-    const int nk = STEM ? (g.wT + TPT - 1) / TPT : g.Th * g.Tw * nkc;
+    const int kp = XK ? stem_kp(g.wT, g.cr) : 0;
+    const int nk = XK ? kp / 32 : STEM ? (g.wT + TPT - 1) / TPT : g.Th * g.Tw * nkc;
 
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
     // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
@@ -159,7 +168,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     unsigned wv[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-        wv[j] = (unsigned)((n0 + lr + RS * j) * g.wT * kw + (STEM ? 0 : kq * VE)) * (unsigned)ES;
+        wv[j] = XK ? (unsigned)((n0 + lr + RS * j) * kp + kq * VE) * (unsigned)ES
+                   : (unsigned)((n0 + lr + RS * j) * g.wT * kw + (STEM ? 0 : kq * VE)) * (unsigned)ES;
     const bool nopad = g.Th == 1 && g.Tw == 1 && g.dh0 == 0 && g.dw0 == 0 && g.is == 1 && g.Hi >= g.Ho &&
                        g.Wi >= g.Wo;   // 1x1 stride-1: a row is valid for every k-tile or for none
 
@@ -168,7 +178,35 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     // Loads are branch-free and the loop body below is ONE basic block (the last iteration simply
     // re-fetches the final k-tile and discards it), so the scheduler is free to sink the address
     // arithmetic and the global loads of tile k+1 into the shadow of the 64 MFMAs of tile k.
+    const float rcr = 1.0f / (float)(XK ? g.cr : 1), rS = 1.0f / (float)g.S;
     auto load_tile = [&](int kt) {
+        if constexpr (XK) {
+            // a lane's 4 consecutive k indices belong to (up to) two taps: one dword load per element
+            unsigned eoff[4];
+            int edh[4], edw[4];
+            bool eok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = kt * 32 + kq * 4 + i;
+                const int tp = sdiv(e, rcr), ch = e - tp * g.cr;
+                eok[i] = tp < g.wT;
+                const int r = sdiv(tp, rS), s = tp - r * g.S;
+                edh[i] = g.dh0 + g.dhs * r;
+                edw[i] = g.dw0 + g.dws * s;
+                eoff[i] = (unsigned)((edh[i] * g.Wi + edw[i]) * g.Ci + ch) * 4u;
+            }
+#pragma unroll
+            for (int j = 0; j < AR; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hi = hi0[j] + edh[i], wi = wi0[j] + edw[i];
+                    const bool ok = eok[i] && rvalid[j] && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                    ra[j][i] = ld_el<float>(rs_in, ok ? rowv[j] + eoff[i] : kInvalidOff);
+                }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) rb[j] = bld4(rs_w, wv[j] + (unsigned)kt * 128u);
+            return;
+        }
         int dh, dw;
         unsigned aoff, woff;     // wave-uniform for the regular path
         bool tapok = true;
@@ -476,7 +514,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // ------------------------------------------------------------------------------------------
 // fp32 MFMA.  TX / TDY: storage of the conv input and of dY; bf16 operands are widened when they are staged (used
 // for the stem in bf16 mode: fp32 packed input x bf16 dY; all other bf16 convs run conv_wgrad_bf16_kernel below).
-template <typename TX, typename TDY, int BMO, int BNC, bool STEM>
+// STEM as in the NT kernel; 2 (exact-K, fp32 input): columns are k = tap * g.cr + channel, dW is the packed [Co][kp].
+template <typename TX, typename TDY, int BMO, int BNC, int STEM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int tiles,
@@ -515,9 +554,24 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const int qa = tid % QA, ra0 = tid / QA;
     const int qb = tid % QB, rb0 = tid / QB;
 
-    int dh, dw, widx, coff;
+    constexpr bool XK = STEM == 2;
+    static_assert(!XK || sizeof(TX) == 4, "the exact-K stem gathers fp32 dwords");
+    int dh = 0, dw = 0, widx = 0, coff = 0;
     bool tapok = true;
-    if (STEM) {
+    int xdh[4], xdw[4], xch[4];       // exact-K: tap offsets / channel of this thread's 4 columns
+    bool xok[4];
+    if (XK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = c0 + qb * 4 + i;
+            const int tp = col / g.cr;
+            xch[i] = col - tp * g.cr;
+            xok[i] = tp < g.wT;
+            const int r = tp / g.S, s = tp - r * g.S;
+            xdh[i] = g.dh0 + g.dhs * r;
+            xdw[i] = g.dw0 + g.dws * s;
+        }
+    } else if (STEM) {
         const int col = c0 + qb * 4;
         const int tp = col >> 3;
         tapok = tp < g.wT;
@@ -550,13 +604,25 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     f32x4 ra[RA], rb[RB];
     // The gather offsets of a k-tile are computed one iteration ahead of its loads (`prep`), so that the loads
     // themselves are the first thing a loop iteration issues and have the whole MFMA stream to land under.
-    unsigned offb[RB];
+    unsigned offb[XK ? 4 * RB : RB];
     auto prep = [&](int kt) {
         const int mb = kt * BKM;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int m = mb + rb0 + SB * j;
-            if (lin) {
+            if constexpr (XK) {
+                const bool rok = m < M;
+                const int mm = rok ? m : 0;
+                const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hi = ho * g.is + xdh[i], wi = wo * g.is + xdw[i];
+                    const bool ok = rok && xok[i] && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                    offb[4 * j + i] = ok ? (unsigned)((((n - n_lo) * g.Hi + hi) * g.Wi + wi) * g.Ci + xch[i]) * 4u
+                                         : kInvalidOff;
+                }
+            } else if (lin) {
                 offb[j] = (unsigned)((m - ipix_lo) * g.Ci + coff) * (unsigned)sizeof(TX);
             } else {
                 bool ok = tapok && m < M;
@@ -578,7 +644,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
             ra[j] = bldv<TDY>(rs_dy, (unsigned)((m - mfirst) * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) rb[j] = bldv<TX>(rs_in, offb[j]);
+        for (int j = 0; j < RB; ++j) {
+            if constexpr (XK) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[j][i] = ld_el<float>(rs_in, offb[4 * j + i]);
+            } else {
+                rb[j] = bldv<TX>(rs_in, offb[j]);
+            }
+        }
     };
     auto store_tile = [&](int buf) {
         float* a = sA + buf * BKM * BMO + ra0 * BMO + qa * 4;
@@ -666,7 +739,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 
     // epilogue: rows = output channel o, cols = input channel (or flattened stem column)
     const int kwid = g.gw ? g.gw : g.Ci;          // filter row length per tap (grouped: the window)
-    const size_t wrow = (size_t)g.wT * kwid;
+    const size_t wrow = XK ? (size_t)stem_kp(g.wT, g.cr) : (size_t)g.wT * kwid;
     float* base = dst + (size_t)split * g.Co * wrow;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -912,6 +985,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// floats per output channel of the filter (gradient) a launch addresses
+inline size_t io_filter_row(const IoConvGeom& g) {
+    return g.cr ? (size_t)io_stem_kp(g.wT, g.cr) : (size_t)g.wT * (g.gw ? g.gw : g.Ci);
+}
+
 struct WgradPlan {
     int bmo, bnc, ntile_c, tiles, splits, kps;
 };
@@ -922,7 +1000,8 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
     p.bmo = (g.Co % 128 == 0) ? 128 : 64;
     if (stem) {
         p.bnc = 64;
-        p.ntile_c = io_cdiv((long)g.wT * g.Ci, 64);
+        p.ntile_c = g.cr ? io_stem_kp(g.wT, g.cr) / 64 + (io_stem_kp(g.wT, g.cr) % 64 != 0)
+                         : io_cdiv((long)g.wT * g.Ci, 64);
         p.tiles = (g.Co / p.bmo) * p.ntile_c;
     } else if (g.gw) {
         p.bmo = p.bnc = g.gw;
@@ -951,7 +1030,7 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     WgradPlan p = plan_wgrad(g, stem);
     if (p.splits == 1) return 0;
-    return (size_t)p.splits * g.Co * g.wT * (g.gw ? g.gw : g.Ci) * sizeof(float);
+    return (size_t)p.splits * g.Co * io_filter_row(g) * sizeof(float);
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
@@ -969,6 +1048,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                "conv_nt: fused statistics need a plain dense forward convolution");
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_nt: Co=%d must be a multiple of 64", g.Co);
     const int es = io_dtype_bytes(dt_in), os = io_dtype_bytes(dt_out);
+    IO_REQUIRE(!g.cr || (stem && dt_in == IO_F32 && dt_out == IO_F32 && g.cr > 0 && g.cr <= 8), IO_ERR_SHAPE,
+               "conv_nt: the exact-K mode is for the fp32 stem (1..8 real channels)");
     if (stem)
         IO_REQUIRE(g.Ci == 8, IO_ERR_SHAPE, "conv_nt(stem): needs the packed input with Ci=8 (5 padded)");
     else
@@ -979,7 +1060,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     IO_REQUIRE(M > 0 && M < (1L << 31), IO_ERR_SHAPE, "conv_nt: bad M=%ld", M);
     // whole tensors may exceed 4 GiB (descriptors are rebased per tile); what a tile spans -- the samples of 128
     // consecutive rows, relative to the first -- must fit 32-bit byte offsets, and pixel counts must fit an int
-    const double w_b = (double)es * g.Co * g.wT * (g.gw ? g.gw : g.Ci);
+    const double w_b = (double)es * g.Co * (double)io_filter_row(g);
     const double span = 128.0 / ((double)g.Ho * g.Wo) + 2.0;
     IO_REQUIRE(w_b < 4.0e9 && span * es * g.Hi * g.Wi * g.Ci < 4.0e9 && span * os * g.outH * g.outW * g.Co < 4.0e9,
                IO_ERR_SHAPE, "conv_nt: filter or per-tile sample span larger than 4 GB (32-bit offsets)");
@@ -1019,20 +1100,22 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
         if (dt_in == IO_BF16) {
             IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
-            IO_LAUNCH_NT(bf16_t, bf16_t, 64, true);
+            IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1);
         } else if (dt_out == IO_BF16) {
-            IO_LAUNCH_NT(float, bf16_t, 64, true);
+            IO_LAUNCH_NT(float, bf16_t, 64, 1);
+        } else if (g.cr) {
+            IO_LAUNCH_NT(float, float, 64, 2);
         } else {
-            IO_LAUNCH_NT(float, float, 64, true);
+            IO_LAUNCH_NT(float, float, 64, 1);
         }
     } else if (dt_in == IO_BF16) {
         IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
-        if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, false);
-        else IO_LAUNCH_NT(bf16_t, bf16_t, 64, false);
+        if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, 0);
+        else IO_LAUNCH_NT(bf16_t, bf16_t, 64, 0);
     } else {
         IO_REQUIRE(dt_out == IO_F32, IO_ERR_SHAPE, "conv_nt: fp32 operands write fp32 outputs (except the stem)");
-        if (bn == 128) IO_LAUNCH_NT(float, float, 128, false);
-        else IO_LAUNCH_NT(float, float, 64, false);
+        if (bn == 128) IO_LAUNCH_NT(float, float, 128, 0);
+        else IO_LAUNCH_NT(float, float, 64, 0);
     }
 #undef IO_LAUNCH_NT
     return io_check_launch("conv_nt");
@@ -1041,6 +1124,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, float* dw, float* partial,
                          size_t partial_bytes, int stem, hipStream_t st, int dt_in, int dt_dy) {
     IO_REQUIRE(g.Co % 64 == 0, IO_ERR_SHAPE, "conv_wgrad: Co=%d must be a multiple of 64", g.Co);
+    IO_REQUIRE(!g.cr || (stem && dt_in == IO_F32 && g.cr > 0 && g.cr <= 8), IO_ERR_SHAPE,
+               "conv_wgrad: the exact-K mode is for the fp32 stem (1..8 real channels)");
     if (stem)
         IO_REQUIRE(g.Ci == 8 && g.Co == 64 && (dt_in == IO_F32 || dt_dy == IO_BF16), IO_ERR_SHAPE,
                    "conv_wgrad(stem): need Ci=8, Co=64 (and bf16 dY with a bf16 input)");
@@ -1082,14 +1167,17 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     } while (0)
 #define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
     do {                                                                               \
-        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 128, false);    \
-        else if (p.bmo == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 64, false);                \
-        else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, false);                \
-        else IO_LAUNCH_WG(TX_, TDY_, 64, 64, false);                                   \
+        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 128, 0);    \
+        else if (p.bmo == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 64, 0);                \
+        else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, 0);                \
+        else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                   \
     } while (0)
     if (stem && dt_in == IO_F32) {
-        if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, true);
-        else IO_LAUNCH_WG(float, float, 64, 64, true);
+        if (g.cr) {
+            if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 2);
+            else IO_LAUNCH_WG(float, float, 64, 64, 2);
+        } else if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 1);
+        else IO_LAUNCH_WG(float, float, 64, 64, 1);
     } else if (dt_in == IO_BF16) {
         // 64-row k-tiles; the split count can only shrink, so the fp32 plan's partial buffer is large enough
         const int nkt64 = io_cdiv((long)Md, 64), kps64 = io_cdiv(p.kps, 2);
@@ -1123,7 +1211,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
     if (splits > 1) {
-        const size_t n4 = (size_t)g.Co * g.wT * (g.gw ? g.gw : g.Ci) / 4;
+        const size_t n4 = (size_t)g.Co * io_filter_row(g) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
                            splits);
         rc = io_check_launch("splitk_reduce");

@@ -90,8 +90,11 @@ struct IoConvGeom {
     int S, wT;           // filter width S and total taps wT=R*S: weights [Co][wT][Ci]
     int gw;              // 0: dense.  > 0: grouped convolution run as a block-diagonal one: output channels
                          // [t*gw, (t+1)*gw) read only input channels [t*gw, (t+1)*gw); weights [Co][wT][gw]
+    int cr;              // stem only.  > 0: exact-K mode: the reduction runs over the wT x cr REAL channels of the packed
+                         // x8 input (k = tap * cr + channel), filters / filter gradients are [Co][io_stem_kp(wT, cr)]
     IoFastDiv fd_howo, fd_wo;   // division by Ho*Wo and by Wo (filled by io_geom_finish)
 };
+static inline int io_stem_kp(int wT, int cr) { return (wT * cr + 31) / 32 * 32; }   // packed row length (k-tiles of 32)
 static inline void io_geom_finish(IoConvGeom& g) {
     g.fd_howo = io_fastdiv(g.Ho * g.Wo);
     g.fd_wo = io_fastdiv(g.Wo);
@@ -145,6 +148,9 @@ int io_pack_planes_t(const float* const* planes, const long* sample_strides, int
                      void* out, hipStream_t st, int dt);
 // fp32 master filter -> filter of storage type dt, either as is (transpose = 0) or as W^T [C][T][O]
 int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int transpose, hipStream_t st, int dt);
+// exact-K stem: fp32 filter [O][T][8] -> [O][io_stem_kp(T, cr)] and the packed filter gradient back (pad channels 0)
+int io_stem_pack_filter(const float* w, float* wp, int O, int T, int cr, hipStream_t st);
+int io_stem_unpack_grad(const float* dwp, float* dw, int O, int T, int cr, hipStream_t st);
 constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics
 int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,

@@ -481,6 +481,40 @@ int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int tran
     return io_check_launch("filter_prepare");
 }
 
+// Exact-K stem (conv_igemm.hip): filter [O][T][8] <-> packed rows [O][kp], k = tap * cr + channel over the cr real
+// channels (the columns past T * cr are zero).
+namespace {
+__global__ __launch_bounds__(256) void stem_pack_filter_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                              int O, int T, int cr, int kp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= O * kp) return;
+    const int o = idx / kp, k = idx - o * kp;
+    const int tp = k / cr, ch = k - tp * cr;
+    wp[idx] = tp < T ? w[((size_t)o * T + tp) * 8 + ch] : 0.f;
+}
+__global__ __launch_bounds__(256) void stem_unpack_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
+                                                              int O, int T, int cr, int kp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= O * T * 8) return;
+    const int ch = idx & 7, ot = idx >> 3;
+    const int o = ot / T, tp = ot - o * T;
+    dw[idx] = ch < cr ? dwp[(size_t)o * kp + tp * cr + ch] : 0.f;
+}
+}  // namespace
+
+int io_stem_pack_filter(const float* w, float* wp, int O, int T, int cr, hipStream_t st) {
+    const int kp = io_stem_kp(T, cr);
+    hipLaunchKernelGGL(stem_pack_filter_kernel, dim3(io_cdiv((long)O * kp, 256)), dim3(256), 0, st, w, wp, O, T, cr, kp);
+    return io_check_launch("stem_pack_filter");
+}
+
+int io_stem_unpack_grad(const float* dwp, float* dw, int O, int T, int cr, hipStream_t st) {
+    const int kp = io_stem_kp(T, cr);
+    hipLaunchKernelGGL(stem_unpack_grad_kernel, dim3(io_cdiv((long)O * T * 8, 256)), dim3(256), 0, st, dwp, dw, O, T,
+                       cr, kp);
+    return io_check_launch("stem_unpack_grad");
+}
+
 extern "C" int io_filter_transpose(const float* w, int O, int T, int C, float* wt, hipStream_t st) {
     return io_filter_prepare_t(w, O, T, C, wt, 1, st, IO_F32);
 }

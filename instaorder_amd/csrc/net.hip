@@ -111,6 +111,7 @@ struct Plan {
     size_t gbuf[5];      // gradient scratch (training only)
     size_t wt, wg_partial, wg_partial_bytes;
     size_t wop;          // bf16 mode: operand copy of the whole flat parameter buffer (same element offsets)
+    size_t stem_wp, stem_dwp;   // fp32: exact-K stem filter / filter gradient, [64][io_stem_kp]
     size_t wfold, fbias; // eval: filters with the BatchNorm scale folded in (storage type, parameter offsets) + biases
     size_t total;
 };
@@ -132,6 +133,11 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     const size_t e = (size_t)io_dtype_bytes(net->dtype);   // activation element size
     const size_t maxact = (size_t)N * H0 * H0 * 64 * e;   // == N*H1*H1*256*e, the largest activations
     p.wop = net->dtype == IO_BF16 ? a.take((size_t)net->param_floats * sizeof(bf16_t)) : 0;
+    {
+        const size_t sb = (size_t)64 * io_stem_kp(49, net->in_ch) * f;
+        p.stem_wp = a.take(sb);
+        p.stem_dwp = a.take(sb);
+    }
     p.wfold = training ? 0 : a.take((size_t)net->param_floats * e);
     p.fbias = training ? 0 : a.take((size_t)net->bn_channels * f);
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
@@ -171,6 +177,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
         size_t wg = 0, wtmax = 0;
         {
             IoConvGeom g = io_geom_fwd(N, S, S, 8, 64, 7, 7, 2, 3);
+            if (net->dtype == IO_F32) g.cr = net->in_ch;
             wg = io_conv_wgrad_partial_bytes(g, 1);
         }
         H = H1;
@@ -281,10 +288,20 @@ struct Ctx {
     }
 };
 
+// fp32 stem: the reduction runs over the real input channels only (exact-K mode of the conv kernels); the filter is
+// re-packed per pass (64 x 256 floats)
+bool stem_exact(const Ctx& c, const ConvL& L) { return L.cin_store == 8 && c.net->dtype == IO_F32; }
+
 int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
-    return io_launch_conv_nt(g, x, c.wop(L.w_off), y, nullptr, nullptr, stem, c.st,
+    const void* w = c.wop(L.w_off);
+    if (stem_exact(c, L)) {
+        g.cr = L.cin;
+        IO_TRY(io_stem_pack_filter(c.params + L.w_off, c.buf(c.plan.stem_wp), L.cout, L.k * L.k, L.cin, c.st));
+        w = c.buf(c.plan.stem_wp);
+    }
+    return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, stem, c.st,
                              stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr, nullptr,
                              c.dt(), c.dt());
 }
@@ -334,7 +351,13 @@ int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void*
     IoBwStats ep{};
     ep.bias = c.fbias(b);
     ep.relu = relu;
-    return io_launch_conv_nt(g, x, c.wfold(L.w_off), y, add, nullptr, L.cin_store == 8, c.st, nullptr, nullptr, &ep,
+    const void* w = c.wfold(L.w_off);
+    if (stem_exact(c, L)) {
+        g.cr = L.cin;
+        IO_TRY(io_stem_pack_filter((const float*)w, c.buf(c.plan.stem_wp), L.cout, L.k * L.k, L.cin, c.st));
+        w = c.buf(c.plan.stem_wp);
+    }
+    return io_launch_conv_nt(g, x, w, y, add, nullptr, L.cin_store == 8, c.st, nullptr, nullptr, &ep,
                              c.dt(), c.dt());
 }
 
@@ -445,6 +468,12 @@ int bn_back(const Ctx& c, const BnL& b, const void* dout, int mask, const void* 
 int conv_wgrad(const Ctx& c, const ConvL& L, const void* x, const void* dy, int H) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;
+    if (stem_exact(c, L)) {
+        g.cr = L.cin;
+        IO_TRY(io_launch_conv_wgrad(g, x, dy, c.buf(c.plan.stem_dwp), c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes,
+                                    1, c.st, c.dt(), c.dt()));
+        return io_stem_unpack_grad(c.buf(c.plan.stem_dwp), c.grads + L.w_off, L.cout, L.k * L.k, L.cin, c.st);
+    }
     return io_launch_conv_wgrad(g, x, dy, c.grads + L.w_off, c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes, stem,
                                 c.st, c.dt(), c.dt());
 }
