@@ -114,7 +114,12 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
                                                          IoBwStats bw) {
     constexpr int ES = sizeof(TA), OS = sizeof(TO);
     constexpr int VE = 16 / ES;             // elements per 16-byte chunk
-    constexpr int BM = 128, BK = 128 / ES, LDT = 32 + 4, NT = NW * 64;   // LDT in 4-byte words
+    // LDS rows: BN = 128 pads them to 36 words (conflict-free 16-byte fragment reads, 73.7 KB, 2 blocks per CU either
+    // way); BN = 64 keeps them at 32 words and XORs the 16-byte chunk index with bits 1..3 of the row instead -- equally
+    // conflict-free (16 consecutive rows of one logical chunk hit 16 distinct bank quads) and 48 KB, so THREE blocks
+    // share a CU: the short-K / HBM-bound 64-channel layers and the stem want tiles in flight, not a bigger tile.
+    constexpr bool SWZ = BN == 64;
+    constexpr int BM = 128, BK = 128 / ES, LDT = SWZ ? 32 : 32 + 4, NT = NW * 64;   // LDT in 4-byte words
     constexpr int CPT = ES / 2;             // stem: 16-byte chunks per 8-channel tap (fp32 2, bf16 1)
     constexpr int TPT = 8 / CPT;            // stem: taps per k-tile
     constexpr bool XK = STEM == 2;          // exact-K stem
@@ -248,9 +253,10 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
             th = really ? th + (wrapt ? 1 : 0) : th;
         }
     };
+    const int wchunk = SWZ ? (kq ^ ((lr >> 1) & 7)) : kq;      // (the row step RS = 32 leaves bits 1..3 alone)
     auto store_tile = [&](int buf) {
-        float* a = sA + buf * BM * LDT + lr * LDT + kq * 4;
-        float* b = sB + buf * BN * LDT + lr * LDT + kq * 4;
+        float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
+        float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
 #pragma unroll
         for (int j = 0; j < AR; ++j) st4(a + RS * j * LDT, ra[j]);
 #pragma unroll
@@ -272,11 +278,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     // issued under the first 48 MFMAs of tile k, and the LDS refill + barrier sit between MFMA groups
     // 3 and 4 of tile k -- whose operands are already in registers -- with the first fragments of
     // tile k+1 fetched right behind the barrier, under that last group.
-    const int a_off = (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    const int b_off = (wn * (BN / WN) + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int rsw = SWZ ? (lane >> 1) & 7 : 0;                 // all fragment rows of a lane are = lane mod 32
+    const int a_off = (wm * 64 + (lane & 31)) * LDT + (SWZ ? 0 : (lane >> 5) * 4);
+    const int b_off = (wn * (BN / WN) + (lane & 31)) * LDT + (SWZ ? 0 : (lane >> 5) * 4);
     auto read_frags = [&](int buf, int kk, f32x4 (&a)[TI], f32x4 (&b)[TJ]) {
-        const float* al = sA + buf * BM * LDT + a_off + kk * 8;
-        const float* bl = sB + buf * BN * LDT + b_off + kk * 8;
+        const int koff = SWZ ? ((((lane >> 5) + kk * 2) ^ rsw) * 4) : kk * 8;
+        const float* al = sA + buf * BM * LDT + a_off + koff;
+        const float* bl = sB + buf * BN * LDT + b_off + koff;
 #pragma unroll
         for (int i = 0; i < TI; ++i) a[i] = ld4(al + i * 32 * LDT);
 #pragma unroll
@@ -1075,7 +1083,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
-    const size_t lds = (size_t)2 * (128 + bn) * 36 * sizeof(float);
+    const size_t lds = (size_t)2 * (128 + bn) * (bn == 64 ? 32 : 36) * sizeof(float);
     dim3 grid((unsigned)tiles), block(kThreads);
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
@@ -1089,7 +1097,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
             (void)hipFuncSetAttribute((const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + BN_) * 36 * 4); \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
             attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>), grid, block, lds, st, g,               \
