@@ -278,6 +278,26 @@ int io_avgpool_fc_bwd_dt(const float* dlogits, const float* pooled, int N, int H
                          const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
                          float* db1, int dtype, hipStream_t stream);
 
+/* ---- input pipeline on the device: crop with zero padding + resize + flip + normalise of one uint8
+ * image and two uint8 instance masks per pair, into the fp32 tensors set_input() takes -- the per-item work of
+ * SupOcclusionOrderDataset._get_pair / _get_pair_image / _get_pair_resize (datasets/occ_order_dataset.py:81-180,
+ * utils/data_utils.py:105-124: crop_padding) and of the per-pair pre-processing of inference.py:449-482.
+ * Masks: INTER_NEAREST; image: OpenCV's 8-bit fixed-point INTER_LINEAR (interp 1) or INTER_CUBIC (interp 2), then
+ * x / 255, (x - mean) / std.  `arena` is one device buffer holding the decoded images (HxWx3) and masks (HxW), all
+ * uint8, addressed by byte offsets; desc_dev / desc_host are the same P descriptors in device and host memory (the
+ * host copy is validated against arena_bytes).  rgb[P][3][S][S] (NULL: masks only), modal1 / modal2 [P][S][S]. */
+typedef struct io_pair_desc {
+    int64_t image_off;            /* byte offset of the image in the arena                               */
+    int64_t mask1_off, mask2_off; /* byte offsets of the two instance masks                              */
+    int32_t H, W;                 /* image (and mask) size                                               */
+    int32_t x, y, w, h;           /* crop rectangle in image coordinates; parts outside the image read 0 */
+    int32_t flip;                 /* != 0: mirror the outputs horizontally                               */
+    int32_t interp;               /* image interpolation: 1 linear, 2 cubic                              */
+} io_pair_desc;
+int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
+                      const io_pair_desc* desc_host, int P, int S, const float* mean3, const float* std3, float* rgb,
+                      float* modal1, float* modal2, hipStream_t stream);
+
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of
  * classes written.  flops / bytes are the ALGORITHMIC figures of the timed launches. */

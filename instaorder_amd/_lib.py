@@ -20,6 +20,12 @@ class TensorInfo(C.Structure):
                 ("bn_index", C.c_int), ("running_offset", C.c_long)]
 
 
+class PairDesc(C.Structure):
+    _fields_ = [("image_off", C.c_int64), ("mask1_off", C.c_int64), ("mask2_off", C.c_int64), ("H", C.c_int32),
+                ("W", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("flip", C.c_int32), ("interp", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -52,6 +58,7 @@ SIGNATURES = {
     "io_avgpool_fc_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "io_avgpool_fc_bwd": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "io_pack_planes_nhwc8": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), _I, _I, _I, _I, _P, _P]),
+    "io_pair_planes_u8": (_I, [_P, _Z, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "io_order_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P]),
     "io_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),
     "io_net_create": (_P, [_I, _I, C.POINTER(C.c_int)]),

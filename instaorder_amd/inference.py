@@ -114,8 +114,12 @@ def decision_margins(pair_logits, method):
 
 
 def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, return_logits=False,
-                        world_size=1, rank=0):
+                        world_size=1, rank=0, pair_planes=None):
     """Order matrices of one image.  rgb[1,3,S,S] normalised fp32, masks[N,S,S] in {0,1}.
+
+    ``pair_planes = (rgb[P,3,S,S], modal_i[P,1,S,S], modal_j[P,1,S,S])`` (one entry per pair of ``pairs``, e.g. from
+    ``datasets.PairRenderer``) replaces the shared image and masks: the 'patch' pre-processing of the reference crops
+    every pair differently (inference.py:449-465).
 
     With ``world_size > 1`` the pair list is sharded contiguously across ranks
     (``distributed_utils.shard_range``) and the tiny per-pair decisions are all-gathered."""
@@ -124,10 +128,14 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
     n = masks.shape[0]
     pairs = upper_pairs(n) if pairs is None else list(pairs)
     P = len(pairs)
-    S = masks.shape[-1]
+    S = masks.shape[-1] if pair_planes is None else pair_planes[0].shape[-1]
     dev = net.flat_params.device
-    rgb = rgb.to(dev, torch.float32).contiguous()
-    masks = masks.to(dev, torch.float32).contiguous()
+    if pair_planes is None:
+        rgb = rgb.to(dev, torch.float32).contiguous()
+        masks = masks.to(dev, torch.float32).contiguous()
+    else:
+        pair_planes = [t.to(dev, torch.float32).contiguous() for t in pair_planes]
+        assert all(t.shape[0] == P for t in pair_planes), "pair_planes: one entry per pair"
     beg, end = 0, P
     if world_size > 1:
         beg, end, _ = distributed_utils.shard_range(P, world_size, rank)
@@ -142,13 +150,23 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
         for c0 in range(0, len(my), max_pairs):
             chunk = my[c0:c0 + max_pairs]
             p = len(chunk)
-            ii = torch.tensor([a for a, _ in chunk], device=dev)
-            jj = torch.tensor([b for _, b in chunk], device=dev)
-            mi, mj = masks[ii].contiguous(), masks[jj].contiguous()
             x8 = torch.empty((2 * p, S, S, 8), device=dev, dtype=engine.TORCH_DTYPE[net.dtype])
-            rgbp = [(rgb, c * HW) for c in range(3)]
-            engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[:p])
-            engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, 0, 0, 0], p, S, S, x8[p:])
+            if pair_planes is None:
+                ii = torch.tensor([a for a, _ in chunk], device=dev)
+                jj = torch.tensor([b for _, b in chunk], device=dev)
+                mi, mj = masks[ii].contiguous(), masks[jj].contiguous()
+                rgbp, rs = [(rgb, c * HW) for c in range(3)], 0
+            else:
+                k0 = beg + c0                  # (a sharded list wraps around only when P < world_size)
+                sel = [(k0 + t) % P for t in range(p)]
+                if sel == list(range(sel[0], sel[0] + p)):
+                    rp, mi, mj = [t[sel[0]:sel[0] + p] for t in pair_planes]
+                else:
+                    idx = torch.tensor(sel, device=dev)
+                    rp, mi, mj = [t[idx].contiguous() for t in pair_planes]
+                rgbp, rs = [(rp, c * HW) for c in range(3)], 3 * HW
+            engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, rs, rs, rs], p, S, S, x8[:p])
+            engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, rs, rs, rs], p, S, S, x8[p:])
             z = net.forward_packed(x8, 1)
             l1[c0:c0 + p], l2[c0:c0 + p] = z[:p], z[p:]
     net.train(was_training)
@@ -183,30 +201,60 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
     return res
 
 
-def _image_mode_only(patch_or_image, image, inmodal, input_size):
-    if patch_or_image != "image" or image.shape[0] != image.shape[1] or image.shape[0] != input_size:
-        raise NotImplementedError(
-            "only patch_or_image='image' on square images of the network size is built here; crop/resize "
-            "pre-processing (cv2) is outside the hot path (SURVEY.md section 8)")
-    from .synthetic import image_mode_inputs
-    return image_mode_inputs(image, inmodal, input_size)
+_RENDERERS = {}
+
+
+def _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, input_size):
+    """The per-pair pre-processing of inference.py:449-482 on the device (datasets.PairRenderer): 'patch' = square
+    crop around the pair (zero padded), INTER_CUBIC; 'image' = zero padding to a square, INTER_LINEAR; masks
+    INTER_NEAREST; then x / 255 and the ImageNet mean / std (utils/data_utils.py:9-10, 28-34).  Returns
+    (rgb[P,3,S,S], modal_i[P,1,S,S], modal_j[P,1,S,S]).  The 'resize' / 'orig' modes go through MiDaS' float
+    ``Resize`` transform (utils/data_utils.py:37-53) and are not built."""
+    from . import datasets
+    if patch_or_image not in ("patch", "image"):
+        raise NotImplementedError("patch_or_image=%r: only 'patch' and 'image' are built (the 'resize' / 'orig' modes "
+                                  "use the float cv2 path of midas/transforms.py)" % (patch_or_image,))
+    dev = model.net.flat_params.device
+    key = (int(input_size), str(dev))
+    if key not in _RENDERERS:
+        _RENDERERS[key] = datasets.PairRenderer(input_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], dev)
+    modal = np.ascontiguousarray(inmodal.astype(np.uint8))
+    image = np.ascontiguousarray(image.astype(np.uint8))
+    _, hh, ww = modal.shape
+    items = []
+    for i, j in pair_list:
+        if patch_or_image == "patch":
+            cx, cy, size = datasets.patch_box(bboxes, i, j)
+            box = (int(cx - size / 2.), int(cy - size / 2.), int(size), int(size))
+            items.append((0, i, j, box, datasets.INTER_CUBIC, False))
+        else:
+            hw = int(max(hh, ww))
+            box = (-((hw - ww) // 2), -((hw - hh) // 2), hw, hw)
+            items.append((0, i, j, box, datasets.INTER_LINEAR, False))
+    return _RENDERERS[key].render([image], [modal], items)
+
+
+def _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size):
+    pair_list = select_pairs(inmodal, pairs)
+    n = inmodal.shape[0]
+    if not pair_list:
+        z = np.zeros((n, n), dtype=np.int64)
+        return {"occ_order": z, "depth_order": z.copy()}
+    planes = _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, input_size)
+    return infer_order_batched(model, None, torch.from_numpy(np.asarray(inmodal)), method, pairs=pair_list,
+                               pair_planes=planes)
 
 
 def infer_order_sup_occ(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size=256, use_rgb=True):
-    """Reference signature (inference.py:439-512); returns the occlusion order matrix
-    (1 at [i, j] = i occludes j)."""
-    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
-    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method,
-                              pairs=select_pairs(inmodal, pairs))
-    return res["occ_order"]
+    """Reference signature (inference.py:439-512): image uint8 [H,W,3], inmodal [N,H,W], bboxes [N,4] xywh; returns
+    the occlusion order matrix (1 at [i, j] = i occludes j)."""
+    return _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size)["occ_order"]
 
 
 def infer_order_sup_occ_depth(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size,
                               disp_select_method=""):
     """Reference signature (inference.py:349-436); returns (occ_order, depth_order)."""
-    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
-    res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method,
-                              pairs=select_pairs(inmodal, pairs))
+    res = _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size)
     return res["occ_order"], res["depth_order"]
 
 
@@ -294,13 +342,18 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
     """Reference signature (inference.py:515-625); returns (depth order matrix, clipped disparity | None).
     Methods: InstaOrderNet_d (the batched ResNet path) and InstaDepthNet_d / InstaDepthNet_od (batched MiDaS path;
     with ``disp_select_method`` 'mean' / 'median' the order comes from the predicted disparity instead of the head)."""
-    rgb, masks = _image_mode_only(patch_or_image, image, inmodal, input_size)
-    plist = select_pairs(inmodal, pairs)
     if method == "InstaOrderNet_d":
-        res = infer_order_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), method, pairs=plist)
-        return res["depth_order"], None
+        return _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size)["depth_order"], None
     if method not in ("InstaDepthNet_d", "InstaDepthNet_od"):
         raise ValueError("method name should be one of {InstaOrderNet_d, InstaDepthNet_d, InstaDepthNet_od}")
+    # the batched MiDaS path runs the encoder once per IMAGE, which needs one image shared by all pairs: only the
+    # pre-processing that is the identity (square image of the network size, 'image' mode) is built for it
+    if patch_or_image != "image" or image.shape[0] != image.shape[1] or image.shape[0] != input_size:
+        raise NotImplementedError("InstaDepthNet inference: only patch_or_image='image' on square images of the network "
+                                  "size (per-pair crops would run the MiDaS encoder once per pair)")
+    from .synthetic import image_mode_inputs
+    rgb, masks = image_mode_inputs(image, inmodal, input_size)
+    plist = select_pairs(inmodal, pairs)
     res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), pairs=plist)
     if disp_select_method == "":
         return res["depth_order"], None

@@ -168,6 +168,83 @@ def make_images(seed, n_images, n_inst, S=256):
     return items
 
 
+class SyntheticReader(object):
+    """Stand-in for ``datasets/reader.py:InstaOrderDataset`` (the COCO / InstaOrder json is not available): seeded
+    scenes with non-square images of different sizes, rectangle / ellipse instances, and InstaOrder-style annotations
+    -- an occlusion matrix ({0,1}, bidirectional pairs allowed, some images without any occluding pair) and depth
+    relations "i<j" / "i=j" with overlap flag and count.  Implements the reader methods the dataset classes call
+    (occ_order_dataset.py:182-200, depth_occ_order_dataset.py:150-160, 197-205) plus ``load_image``."""
+
+    def __init__(self, seed, n_images=6, n_inst=5, max_side=160, min_side=72, empty_every=4):
+        rng = np.random.RandomState(seed)
+        self.scenes = []
+        for k in range(n_images):
+            H, W = int(rng.randint(min_side, max_side + 1)), int(rng.randint(min_side, max_side + 1))
+            image = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+            modal = np.zeros((n_inst, H, W), np.uint8)
+            for i in range(n_inst):
+                h, w = int(rng.randint(8, H // 2 + 1)), int(rng.randint(8, W // 2 + 1))
+                top, left = int(rng.randint(0, H - h + 1)), int(rng.randint(0, W - w + 1))
+                if rng.rand() < 0.5:
+                    modal[i, top:top + h, left:left + w] = 1
+                else:
+                    yy, xx = np.mgrid[0:H, 0:W]
+                    cy, cx = top + (h - 1) / 2.0, left + (w - 1) / 2.0
+                    modal[i][((yy - cy) / (h / 2.0)) ** 2 + ((xx - cx) / (w / 2.0)) ** 2 <= 1.0] = 1
+            bboxes = []
+            for m in modal:
+                ys, xs = np.where(m > 0)
+                bboxes.append([xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1])
+            occ = (rng.rand(n_inst, n_inst) < 0.3).astype(np.int64)
+            np.fill_diagonal(occ, 0)
+            if empty_every and k % empty_every == empty_every - 1:
+                occ[:] = 0                                   # an image without occluding pairs: the dataset re-draws
+            depth = -np.ones((n_inst, n_inst), np.int64)
+            overlap = -np.ones((n_inst, n_inst), np.int64)
+            count = -np.ones((n_inst, n_inst), np.int64)
+            relations = []
+            for i in range(n_inst):
+                for j in range(i + 1, n_inst):
+                    if rng.rand() < 0.25:
+                        continue                             # not every pair is annotated
+                    a, b = (i, j) if rng.rand() < 0.5 else (j, i)
+                    equal = rng.rand() < 0.2
+                    ov, ct = int(rng.rand() < 0.5), int(rng.randint(1, 4))
+                    if equal:
+                        depth[a, b] = depth[b, a] = 2
+                    else:
+                        depth[a, b], depth[b, a] = 1, 0      # a closer than b
+                    overlap[a, b] = overlap[b, a] = ov
+                    count[a, b] = count[b, a] = ct
+                    relations.append("%d%s%d" % (a, "=" if equal else "<", b))
+            self.scenes.append(dict(image=image, modal=modal, bboxes=np.asarray(bboxes, np.int64),
+                                    category=rng.randint(1, 80, size=n_inst).astype(np.int64), occ=occ, depth=depth,
+                                    overlap=overlap, count=count, relations=relations))
+        self.depth_all = [(k, r) for k, sc in enumerate(self.scenes) for r in sc["relations"]]
+
+    def get_image_length(self):
+        return len(self.scenes)
+
+    def get_geometric_length(self):
+        return len(self.depth_all)
+
+    def get_imgId_and_depth(self, i):
+        return self.depth_all[i]
+
+    def get_image_instances(self, idx, with_gt=False, **kw):
+        sc = self.scenes[idx]
+        return sc["modal"], sc["category"], sc["bboxes"], None, "scene%d" % idx
+
+    def get_gt_ordering(self, idx, type="occlusion", rm_bidirec=0, rm_overlap=0):
+        sc = self.scenes[idx]
+        if type == "occlusion":
+            return sc["occ"].copy()
+        return [sc["depth"].copy(), sc["overlap"].copy(), sc["count"].copy()]
+
+    def load_image(self, image_fn):
+        return self.scenes[int(str(image_fn).rsplit("scene", 1)[1])]["image"]
+
+
 def image_mode_inputs(image, modal, input_size):
     """The reference's ``patch_or_image == 'image'`` preprocessing
     (inference.py:467-482) for an image that is already square and already

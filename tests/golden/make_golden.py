@@ -456,7 +456,61 @@ def case_depthnet(algo, S, B, seed, tag):
           "params", len(names), "state entries", len(spec))
 
 
+DATASET_VARIANTS = [   # (name, dataset class, algo, patch_or_image, phase, seed)
+    ("o_patch_train", "occ", "InstaOrderNet_o", "patch", "train", 101),
+    ("o_image_train", "occ", "InstaOrderNet_o", "image", "train", 102),
+    ("ordernet_patch_val", "occ", "OrderNet", "patch", "val", 103),
+    ("od_patch_train", "depth_occ", "InstaOrderNet_od", "patch", "train", 104),
+    ("od_resize_train", "depth_occ", "InstaOrderNet_od", "resize", "train", 105),
+]
+DATASET_S = 40
+DATASET_READER_SEED = 77
+
+
+def dataset_config(mode):
+    """the `data` sections of experiments/InstaOrder/InstaOrderNet_{o,od}/config.yaml with a small input size"""
+    cfg = dict(load_cfg("InstaOrderNet_o")["data"])
+    cfg.update(load_cfg("InstaOrderNet_od")["data"])
+    cfg.update(input_size=DATASET_S, patch_or_image=mode, extend_bidirec=True)
+    return cfg
+
+
+def case_dataset_items(tag):
+    """Items of the reference's own SupOcclusionOrderDataset / SupDepthOccOrderDataset over synthetic annotations
+    (synthetic.SyntheticReader in place of the COCO json reader) with ``cv2.resize`` bound to the oracle's restatement
+    of it (cv2 is not installed here): pins crop arithmetic, padding, flip, normalisation, label layout and the order
+    of the np.random draws."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import preprocess_oracle as po
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC = po.INTER_NEAREST, po.INTER_LINEAR, po.INTER_CUBIC
+    cv2.resize = lambda img, size, interpolation=po.INTER_LINEAR: po.resize(img, size, interpolation)
+    from datasets import reader as ref_reader
+    from datasets import occ_order_dataset, depth_occ_order_dataset
+    rd = synthetic.SyntheticReader(DATASET_READER_SEED)
+    ref_reader.InstaOrderDataset = lambda annot_fn: rd
+    out = {}
+    for name, kind, algo, mode, phase, seed in DATASET_VARIANTS:
+        cls = occ_order_dataset.SupOcclusionOrderDataset if kind == "occ" else \
+            depth_occ_order_dataset.SupDepthOccOrderDataset
+        ds = cls(dataset_config(mode), phase, algo)
+        ds._load_image = lambda fn: rd.load_image(fn)
+        np.random.seed(seed)
+        n = min(len(ds), 8)
+        items = [ds[i] for i in range(n)]
+        for f in range(len(items[0])):
+            col = [np.asarray(it[f].numpy() if torch.is_tensor(it[f]) else it[f]) for it in items]
+            out["%s_f%d" % (name, f)] = np.stack(col)
+        print(name, "items", n, "fields", len(items[0]))
+    import json
+    out["config_json"] = np.array(json.dumps(dataset_config("patch")))
+    out["variants"] = np.array(["|".join(str(v) for v in row) for row in DATASET_VARIANTS])
+    out["reader_seed"] = np.array(DATASET_READER_SEED)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+
+
 CASES = {
+    "dataset_items": lambda: case_dataset_items("dataset_items"),
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),
     "od_S64_B6": lambda: case_train("InstaOrderNet_od", 64, 6, 12, 3, "od_S64_B6"),
     "d_S64_B6": lambda: case_train("InstaOrderNet_d", 64, 6, 13, 1, "d_S64_B6"),

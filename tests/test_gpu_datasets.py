@@ -1,0 +1,146 @@
+"""Device input pipeline (io_pair_planes_u8 / instaorder_amd.datasets) against the oracle and the golden items made by
+the reference's own dataset classes; then through the drivers that consume it."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from instaorder_amd import _lib, datasets, synthetic
+from oracle import preprocess_oracle as po
+
+pytestmark = pytest.mark.gpu
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _oracle_items(images, masks, items, S):
+    out = [po.render_pair(images[ii], masks[ii][i1], masks[ii][i2], box, interp, flip, S, MEAN, STD)
+           for (ii, i1, i2, box, interp, flip) in items]
+    return (np.stack([o[0] for o in out]), np.stack([o[1] for o in out]).astype(np.float32)[:, None],
+            np.stack([o[2] for o in out]).astype(np.float32)[:, None])
+
+
+@pytest.mark.parametrize("S", [32, 96])
+def test_renderer_bit_exact_against_oracle(S):
+    """crops inside / straddling / outside the image, up- and down-scaling, non-square crops, both interpolations,
+    flips: every output bit equals the oracle's (integer resize + correctly rounded fp32 normalisation)."""
+    rng = np.random.RandomState(5 + S)
+    images = [rng.randint(0, 256, (H, W, 3)).astype(np.uint8) for H, W in [(61, 83), (120, 47), (33, 33)]]
+    masks = [(rng.rand(3, im.shape[0], im.shape[1]) < 0.4).astype(np.uint8) for im in images]
+    masks[1][2] *= 7                                    # use_category: mask values are category ids
+    items = []
+    for ii, im in enumerate(images):
+        H, W = im.shape[:2]
+        boxes = [(0, 0, W, H), (-9, -13, W + 20, H + 30), (W // 3, H // 4, 11, 11), (W - 5, H - 6, 40, 40),
+                 (-30, 5, 25, 25), (2, 3, 3 * S, 3 * S), (5, 5, 7, 19), (-500, -500, 10, 10), (1, 1, 1, 1)]
+        for k, box in enumerate(boxes):
+            items.append((ii, k % 3, (k + 1) % 3, box, 1 + (k + ii) % 2, bool(k % 2)))
+            items.append((ii, (k + 2) % 3, k % 3, box, 2 - (k + ii) % 2, not bool(k % 2)))
+    r = datasets.PairRenderer(S, MEAN, STD)
+    rgb, m1, m2 = r.render(images, masks, items)
+    want = _oracle_items(images, masks, items, S)
+    for got, w, name in zip((rgb, m1, m2), want, ("rgb", "modal1", "modal2")):
+        got = got.cpu().numpy()
+        bad = np.argwhere(got != w)
+        assert bad.size == 0, "%s differs at %s: %r vs %r" % (name, bad[0], got[tuple(bad[0])], w[tuple(bad[0])])
+    # masks only (load_rgb: False -> zeros image, occ_order_dataset.py:231-232), and buffer reuse across calls
+    rgb0, m1b, m2b = r.render(images, masks, items[:5], load_rgb=False)
+    assert float(rgb0.abs().max()) == 0.0 and np.array_equal(m1b.cpu().numpy(), want[1][:5])
+    rgb2, _, _ = r.render(images, masks, items[7:19])
+    assert np.array_equal(rgb2.cpu().numpy(), want[0][7:19])
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_batches_equal_reference_dataset_items(k):
+    """batch() == what a DataLoader over the reference's dataset class collates (tests/golden/dataset_items.npz)."""
+    z = load_golden("dataset_items")
+    cfg = json.loads(str(z["config_json"]))
+    name, kind, algo, mode, phase, seed = str(z["variants"][k]).split("|")
+    cfg = dict(cfg, patch_or_image=mode)
+    rd = synthetic.SyntheticReader(int(z["reader_seed"]))
+    cls = datasets.SupOcclusionOrderBatches if kind == "occ" else datasets.SupDepthOccOrderBatches
+    ds = cls(cfg, phase, algo, rd, rd.load_image)
+    np.random.seed(int(seed))
+    n = z[name + "_f0"].shape[0]
+    out = ds.batch(range(n))
+    assert len(out) == (4 if kind == "occ" else 7)
+    for f, t in enumerate(out):
+        assert t.is_cuda
+        g = z["%s_f%d" % (name, f)]
+        assert np.array_equal(t.cpu().numpy().astype(g.dtype), g), (name, f)
+
+
+def test_batches_feed_a_training_step_and_patch_inference():
+    """the tuple plugs into set_input()/step(); the 'patch' and 'image' inference drivers (inference.py:439-512) run on
+    non-square uint8 images and agree with the oracle pre-processing + the batched driver on explicit planes."""
+    import instaorder_amd as ia
+    from instaorder_amd import inference
+    rd = synthetic.SyntheticReader(9, n_images=4, n_inst=4, empty_every=0)
+    S = 64
+    cfg = dict(input_size=S, patch_or_image="patch", data_mean=MEAN, data_std=STD, load_rgb=True, use_category=False,
+               dataset="InstaOrder", remove_occ_bidirec=0, base_aug=dict(flip=True, shift=[-0.2, 0.2], scale=[0.8, 1.2]))
+    ds = datasets.SupOcclusionOrderBatches(cfg, "train", "InstaOrderNet_o", rd, rd.load_image,
+                                           rng=np.random.RandomState(3))
+    params = dict(algo="InstaOrderNet_o", lr=1e-3, weight_decay=1e-4, optim="SGD", use_rgb=True,
+                  backbone_arch="resnet50_cls", backbone_param=dict(in_channels=5, num_classes=2))
+    m = ia.InstaOrderNet_o(params, dist_model=False)
+    losses = []
+    for it in range(3):
+        m.set_input(*ds.batch([0, 1, 2, 3, 0, 1]))
+        losses.append(float(m.step()["loss"]))
+    assert all(np.isfinite(losses))
+    m.switch_to("eval")
+    sc = rd.scenes[1]
+    for mode, interp in (("patch", po.INTER_CUBIC), ("image", po.INTER_LINEAR)):
+        got = inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", mode, S)
+        pairs = inference.upper_pairs(sc["modal"].shape[0])
+        planes = []
+        H, W = sc["image"].shape[:2]
+        for i, j in pairs:
+            if mode == "patch":
+                cx, cy, size = datasets.patch_box(sc["bboxes"], i, j)
+                box = (int(cx - size / 2.), int(cy - size / 2.), int(size), int(size))
+            else:
+                hw = max(H, W)
+                box = (-((hw - W) // 2), -((hw - H) // 2), hw, hw)
+            planes.append(po.render_pair(sc["image"], sc["modal"][i], sc["modal"][j], box, interp, False, S, MEAN, STD))
+        pp = (torch.from_numpy(np.stack([p[0] for p in planes])),
+              torch.from_numpy(np.stack([p[1] for p in planes]).astype(np.float32)[:, None]),
+              torch.from_numpy(np.stack([p[2] for p in planes]).astype(np.float32)[:, None]))
+        want = inference.infer_order_batched(m, None, torch.from_numpy(sc["modal"]), "InstaOrderNet_o", pairs=pairs,
+                                             pair_planes=pp)["occ_order"]
+        assert np.array_equal(got, want), mode
+    with pytest.raises(NotImplementedError):
+        inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "orig", S)
+
+
+def test_descriptor_validation():
+    """descriptors that would read outside the arena are refused before anything is launched"""
+    L = _lib.lib()
+    arena = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    out = torch.empty((1, 3, 8, 8), device="cuda")
+    m = torch.empty((1, 1, 8, 8), device="cuda")
+    mean, std = (C.c_float * 3)(*MEAN), (C.c_float * 3)(*STD)
+
+    def call(**kw):
+        d = (_lib.PairDesc * 1)()
+        base = dict(image_off=0, mask1_off=1024, mask2_off=2048, H=16, W=16, x=0, y=0, w=16, h=16, flip=0, interp=1)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d[0], k, v)
+        dev = torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda()
+        return L.io_pair_planes_u8(C.c_void_p(arena.data_ptr()), C.c_size_t(4096), C.c_void_p(dev.data_ptr()),
+                                   C.cast(d, C.c_void_p), 1, 8, C.cast(mean, C.c_void_p), C.cast(std, C.c_void_p),
+                                   C.c_void_p(out.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(m.data_ptr()),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    assert call() == 0
+    assert call(image_off=4096 - 100) != 0 and b"image outside" in _lib.last_error().encode()
+    assert call(mask2_off=4000) != 0
+    assert call(interp=3) != 0
+    assert call(w=0) != 0
+    assert call(H=0) != 0
+    torch.cuda.synchronize()
