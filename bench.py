@@ -80,9 +80,12 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "infer"], help="train = fwd+bwd+SGD (the "
                     "BASELINE metric, default); fwd = both directional passes + loss in training mode (batch "
                     "statistics), no backward; infer = the same in eval mode (inference.py's forward)")
-    ap.add_argument("--host-inputs", default="", choices=["", "pageable", "pinned"], help="hand the step HOST tensors "
-                    "(as the reference's DataLoader does): the timed region then includes the H2D copies of "
-                    "set_input -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
+    ap.add_argument("--host-inputs", default="", choices=["", "pageable", "pinned", "u8"], help="hand the step HOST "
+                    "tensors (as the reference's DataLoader does): the timed region then includes the H2D copies of "
+                    "set_input -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value.  u8 = the "
+                    "whole input pipeline inside the timed region: per-item planning on the host (reference dataset "
+                    "logic), upload of the uint8 images + masks, crop / resize / normalise on the device "
+                    "(instaorder_amd.datasets), over synthetic 480x640 scenes")
     ap.add_argument("--workload", default="pairs", choices=["pairs", "images20"], help="pairs = a synthetic pair "
                     "batch (default); images20 = BASELINE configs[3]: synthetic 20-instance images, all 190 pairs of "
                     "every image enumerated (upper triangle, image-major), the pair list sharded contiguously across "
@@ -134,7 +137,20 @@ def main():
     base = (synthetic.make_depth_batch if depthnet else synthetic.make_pair_batch)(1000 + rank, min(B, 32), S)
     reps = (B + min(B, 32) - 1) // min(B, 32)
     dev = {k: torch.from_numpy(np.concatenate([v] * reps, 0)[:B]).cuda() for k, v in base.items()}
-    if args.host_inputs:
+    u8 = None
+    if args.host_inputs == "u8":
+        assert args.algo == "InstaOrderNet_o" and args.workload == "pairs"
+        from instaorder_amd import datasets
+        rd = synthetic.SyntheticReader(500 + rank, n_images=32, n_inst=8, max_side=640, min_side=480, empty_every=0)
+        dcfg = dict(input_size=S, patch_or_image="patch", data_mean=[0.485, 0.456, 0.406],
+                    data_std=[0.229, 0.224, 0.225], load_rgb=True, use_category=False, dataset="InstaOrder",
+                    remove_occ_bidirec=0, base_aug=dict(flip=True, shift=[-0.2, 0.2], scale=[0.8, 1.2]))
+        u8 = {"ds": datasets.SupOcclusionOrderBatches(dcfg, "train", "InstaOrderNet_o", rd, rd.load_image,
+                                                      rng=np.random.RandomState(7 + rank))}
+        n_img = len(u8["ds"])
+        u8["it"] = datasets.BatchPrefetcher(u8["ds"], ([(s_ * B + k) % n_img for k in range(B)]
+                                                      for s_ in range(args.steps + args.warmup)))
+    elif args.host_inputs:
         dev = {k: (v.cpu().pin_memory() if args.host_inputs == "pinned" else v.cpu()) for k, v in dev.items()}
 
     pair_src = None
@@ -165,7 +181,9 @@ def main():
     def one_step():
         if pair_src is not None:
             gather_pairs()
-        if args.algo == "InstaOrderNet_o":
+        if u8 is not None:
+            model.set_input(*next(u8["it"]))
+        elif args.algo == "InstaOrderNet_o":
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["occ_order"])
         elif args.algo == "InstaDepthNet_d":
             model.set_input(dev["rgb"], dev["modal1"], dev["modal2"], dev["depth_order"], dev["count"],

@@ -312,3 +312,59 @@ class SupDepthOccOrderBatches(_Batches):
         ovl = torch.tensor(np.asarray([p["is_overlap"] for p in plans])).to(dev)
         occ = torch.tensor(np.asarray([p["occ"] for p in plans], dtype=np.float32)).to(dev)
         return rgb, m1, m2, depth, count, ovl, occ
+
+
+class BatchPrefetcher(object):
+    """Builds the next batches on a worker thread and a side HIP stream while the GPU runs the current step -- the role
+    of the reference's DataLoader workers (trainer.py:95-101: ``workers`` processes + default collate), with the
+    uint8 upload and the render kernel off the compute stream.  ``index_batches``: iterable of index lists."""
+
+    def __init__(self, batches, index_batches, depth=2):
+        import queue
+        import threading
+        self.batches = batches
+        self._q = queue.Queue(maxsize=depth)
+        self._stream = torch.cuda.Stream(device=batches.device)
+        self._err = None
+        self._stop = False
+
+        def work():
+            try:
+                with torch.cuda.stream(self._stream):
+                    for idx in index_batches:
+                        if self._stop:
+                            break
+                        out = self.batches.batch(idx)
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                        self._q.put((out, ev))
+            except BaseException as e:          # surfaced on the consumer side
+                self._err = e
+            self._q.put(None)
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is None:
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        out, ev = item
+        cur = torch.cuda.current_stream(self.batches.device)
+        cur.wait_event(ev)
+        for t in out:
+            t.record_stream(cur)
+        return out
+
+    def close(self):
+        self._stop = True
+        while self._thread.is_alive():
+            try:
+                self._q.get(timeout=0.1)
+            except Exception:
+                pass

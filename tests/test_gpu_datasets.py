@@ -144,3 +144,24 @@ def test_descriptor_validation():
     assert call(w=0) != 0
     assert call(H=0) != 0
     torch.cuda.synchronize()
+
+
+def test_prefetcher_yields_the_same_batches_in_order():
+    """worker thread + side stream: same tensors as direct batch() calls with the same generator state, in order;
+    errors of the worker surface at the consumer"""
+    cfg = dict(input_size=48, patch_or_image="patch", data_mean=MEAN, data_std=STD, load_rgb=True, use_category=False,
+               dataset="InstaOrder", remove_occ_bidirec=0, base_aug=dict(flip=True, shift=[-0.2, 0.2], scale=[0.8, 1.2]))
+    rd = synthetic.SyntheticReader(21, n_images=5, n_inst=4, empty_every=0)
+    idx = [[0, 1, 2], [3, 4, 0, 1], [2], [4, 3]]
+    a = datasets.SupOcclusionOrderBatches(cfg, "train", "InstaOrderNet_o", rd, rd.load_image, rng=np.random.RandomState(4))
+    want = [[t.cpu().numpy() for t in a.batch(i)] for i in idx]
+    b = datasets.SupOcclusionOrderBatches(cfg, "train", "InstaOrderNet_o", rd, rd.load_image, rng=np.random.RandomState(4))
+    got = [[t.cpu().numpy() for t in out] for out in datasets.BatchPrefetcher(b, idx, depth=2)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for x, y in zip(g, w):
+            assert np.array_equal(x, y)
+    bad = datasets.BatchPrefetcher(b, [[0], [99]])
+    next(bad)
+    with pytest.raises(IndexError):
+        next(bad)
