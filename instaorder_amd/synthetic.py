@@ -175,7 +175,10 @@ class SyntheticReader(object):
     relations "i<j" / "i=j" with overlap flag and count.  Implements the reader methods the dataset classes call
     (occ_order_dataset.py:182-200, depth_occ_order_dataset.py:150-160, 197-205) plus ``load_image``."""
 
-    def __init__(self, seed, n_images=6, n_inst=5, max_side=160, min_side=72, empty_every=4):
+    def __init__(self, seed, n_images=6, n_inst=5, max_side=160, min_side=72, empty_every=4, rule="random"):
+        """rule 'random': occlusion entries are coin flips (fixtures); 'lower': i occludes j iff their boxes
+        intersect and the centre of i lies lower in the image -- a relation a network can learn from the two masks
+        (tools/train_synthetic.py)."""
         rng = np.random.RandomState(seed)
         self.scenes = []
         for k in range(n_images):
@@ -197,6 +200,14 @@ class SyntheticReader(object):
                 bboxes.append([xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1])
             occ = (rng.rand(n_inst, n_inst) < 0.3).astype(np.int64)
             np.fill_diagonal(occ, 0)
+            if rule == "lower":
+                bb = np.asarray(bboxes, np.float64)
+                cy = bb[:, 1] + bb[:, 3] / 2.0
+                for i in range(n_inst):
+                    for j in range(n_inst):
+                        touch = (bb[i, 0] < bb[j, 0] + bb[j, 2] and bb[j, 0] < bb[i, 0] + bb[i, 2] and
+                                 bb[i, 1] < bb[j, 1] + bb[j, 3] and bb[j, 1] < bb[i, 1] + bb[i, 3])
+                        occ[i, j] = int(i != j and touch and cy[i] > cy[j])
             if empty_every and k % empty_every == empty_every - 1:
                 occ[:] = 0                                   # an image without occluding pairs: the dataset re-draws
             depth = -np.ones((n_inst, n_inst), np.int64)
