@@ -266,18 +266,23 @@ class SupOcclusionOrderBatches(_Batches):
 class SupDepthOccOrderBatches(_Batches):
     """``SupDepthOccOrderDataset`` (depth_occ_order_dataset.py:20-240) for algo 'InstaOrderNet_od' /
     'InstaDepthNet_od': one item per annotated depth relation "i<j" / "i=j"."""
+    WITH_OCC = True
 
     def __len__(self):
         return self.data_reader.get_geometric_length()
 
+    def _get_pair_ind(self, img_id):
+        """depth_occ_order_dataset.py:150-160 (no category scaling, no re-draw in this class)."""
+        modal, category, bboxes, amodal, image_fn = self.data_reader.get_image_instances(img_id, with_gt=True)
+        modal = np.ascontiguousarray(modal.astype(np.uint8))
+        gt_depth = self.data_reader.get_gt_ordering(img_id, type="depth", rm_overlap=self.config["remove_depth_overlap"])
+        gt_occ = self.data_reader.get_gt_ordering(img_id, type="occlusion", rm_bidirec=self.config["remove_occ_bidirec"])
+        return modal, bboxes, image_fn, gt_depth, gt_occ
+
     def plan(self, idx):
         rng = self.rng
         img_id, depth_order = self.data_reader.get_imgId_and_depth(idx)
-        modal, bboxes, image_fn = self._instances(img_id)
-        gt_depth, gt_overlap, gt_count = self.data_reader.get_gt_ordering(
-            img_id, type="depth", rm_overlap=self.config["remove_depth_overlap"])
-        gt_occ = self.data_reader.get_gt_ordering(img_id, type="occlusion",
-                                                  rm_bidirec=self.config["remove_occ_bidirec"])
+        modal, bboxes, image_fn, (gt_depth, gt_overlap, gt_count), gt_occ = self._get_pair_ind(img_id)
         split_char = "<" if "<" in depth_order else "="
         idx1, idx2 = list(map(int, depth_order.split(split_char)))
         box, interp, flip = self._crop(modal, bboxes, idx1, idx2)
@@ -291,27 +296,47 @@ class SupDepthOccOrderBatches(_Batches):
             raise Exception("inconsistent depth annotation for {} in image {}".format(depth_order, img_id))
         depth_count = gt_count[idx1, idx2]                      # indexed before the direction swap (:222-223)
         is_overlap = gt_overlap[idx1, idx2]
-        a_over_b, b_over_a = gt_occ[idx1, idx2], gt_occ[idx2, idx1]
+        occ = None
+        if self.WITH_OCC:
+            a_over_b, b_over_a = gt_occ[idx1, idx2], gt_occ[idx2, idx1]
         if rng.rand() < 0.5:
-            occ = [b_over_a, a_over_b]
+            if self.WITH_OCC:
+                occ = [b_over_a, a_over_b]
         else:
             depth_label = 1 if depth_label == 0 else depth_label
-            occ = [a_over_b, b_over_a]
+            if self.WITH_OCC:
+                occ = [a_over_b, b_over_a]
             idx1, idx2 = idx2, idx1
         return dict(modal=modal, image_fn=image_fn, idx1=int(idx1), idx2=int(idx2), box=box, interp=interp,
                     flip=flip, depth=int(depth_label), count=depth_count, is_overlap=is_overlap, occ=occ)
 
     def batch(self, indices):
-        """(rgb, modal1, modal2, depth_order, count, is_overlap, occ_order) on the GPU (depth_occ_order_dataset.py:
-        234-240 + default collate)."""
+        """(rgb, modal1, modal2, depth_order, count, is_overlap[, occ_order]) on the GPU (depth_occ_order_dataset.py:
+        234-240, depth_order_dataset.py:238-244 + default collate)."""
         plans = [self.plan(i) for i in indices]
         rgb, m1, m2 = self._render(plans)
         dev = rgb.device
         depth = torch.tensor([p["depth"] for p in plans], dtype=torch.long).to(dev)
         count = torch.tensor(np.asarray([p["count"] for p in plans])).to(dev)
         ovl = torch.tensor(np.asarray([p["is_overlap"] for p in plans])).to(dev)
+        if not self.WITH_OCC:
+            return rgb, m1, m2, depth, count, ovl
         occ = torch.tensor(np.asarray([p["occ"] for p in plans], dtype=np.float32)).to(dev)
         return rgb, m1, m2, depth, count, ovl, occ
+
+
+class SupDepthOrderBatches(SupDepthOccOrderBatches):
+    """``SupDepthOrderDataset`` (depth_order_dataset.py:22-244) for algo 'InstaOrderNet_d' / 'InstaDepthNet_d': the
+    depth relation items without the occlusion label; category scaling and the re-draw of images that carry no depth
+    annotation as in :180-197 (the reference passes the re-drawn RELATION index on as an image id -- kept)."""
+    WITH_OCC = False
+
+    def _get_pair_ind(self, img_id):
+        modal, bboxes, image_fn = self._instances(img_id)
+        gt = self.data_reader.get_gt_ordering(img_id, type="depth", rm_overlap=self.config["remove_depth_overlap"])
+        if gt[0].sum() == gt[0].shape[0] * gt[0].shape[1] * (-1):
+            return self._get_pair_ind(self.rng.choice(len(self)))
+        return modal, bboxes, image_fn, gt, None
 
 
 class BatchPrefetcher(object):

@@ -462,6 +462,7 @@ DATASET_VARIANTS = [   # (name, dataset class, algo, patch_or_image, phase, seed
     ("ordernet_patch_val", "occ", "OrderNet", "patch", "val", 103),
     ("od_patch_train", "depth_occ", "InstaOrderNet_od", "patch", "train", 104),
     ("od_resize_train", "depth_occ", "InstaOrderNet_od", "resize", "train", 105),
+    ("d_patch_train", "depth", "InstaOrderNet_d", "patch", "train", 106),
 ]
 DATASET_S = 40
 DATASET_READER_SEED = 77
@@ -486,13 +487,14 @@ def case_dataset_items(tag):
     cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC = po.INTER_NEAREST, po.INTER_LINEAR, po.INTER_CUBIC
     cv2.resize = lambda img, size, interpolation=po.INTER_LINEAR: po.resize(img, size, interpolation)
     from datasets import reader as ref_reader
-    from datasets import occ_order_dataset, depth_occ_order_dataset
+    from datasets import occ_order_dataset, depth_occ_order_dataset, depth_order_dataset
     rd = synthetic.SyntheticReader(DATASET_READER_SEED)
     ref_reader.InstaOrderDataset = lambda annot_fn: rd
     out = {}
     for name, kind, algo, mode, phase, seed in DATASET_VARIANTS:
-        cls = occ_order_dataset.SupOcclusionOrderDataset if kind == "occ" else \
-            depth_occ_order_dataset.SupDepthOccOrderDataset
+        cls = {"occ": occ_order_dataset.SupOcclusionOrderDataset,
+               "depth_occ": depth_occ_order_dataset.SupDepthOccOrderDataset,
+               "depth": depth_order_dataset.SupDepthOrderDataset}[kind]
         ds = cls(dataset_config(mode), phase, algo)
         ds._load_image = lambda fn: rd.load_image(fn)
         np.random.seed(seed)

@@ -51,13 +51,14 @@ def _variants():
     return z, cfg, rows
 
 
-@pytest.mark.parametrize("k", range(5))
+@pytest.mark.parametrize("k", range(6))
 def test_item_logic_matches_reference_datasets(k):
     z, cfg, rows = _variants()
     name, kind, algo, mode, phase, seed = rows[k]
     cfg = dict(cfg, patch_or_image=mode)
     rd = synthetic.SyntheticReader(int(z["reader_seed"]))
-    cls = datasets.SupOcclusionOrderBatches if kind == "occ" else datasets.SupDepthOccOrderBatches
+    cls = {"occ": datasets.SupOcclusionOrderBatches, "depth_occ": datasets.SupDepthOccOrderBatches,
+           "depth": datasets.SupDepthOrderBatches}[kind]
     ds = cls(cfg, phase, algo, rd, rd.load_image)
     np.random.seed(int(seed))
     n = z[name + "_f0"].shape[0]
@@ -74,4 +75,5 @@ def test_item_logic_matches_reference_datasets(k):
         else:
             assert p["depth"] == int(z[name + "_f3"][i])
             assert int(p["count"]) == int(z[name + "_f4"][i]) and int(p["is_overlap"]) == int(z[name + "_f5"][i])
-            assert np.array_equal(np.asarray(p["occ"], np.float64), z[name + "_f6"][i].astype(np.float64))
+            if kind == "depth_occ":
+                assert np.array_equal(np.asarray(p["occ"], np.float64), z[name + "_f6"][i].astype(np.float64))

@@ -53,7 +53,7 @@ def test_renderer_bit_exact_against_oracle(S):
     assert np.array_equal(rgb2.cpu().numpy(), want[0][7:19])
 
 
-@pytest.mark.parametrize("k", range(5))
+@pytest.mark.parametrize("k", range(6))
 def test_batches_equal_reference_dataset_items(k):
     """batch() == what a DataLoader over the reference's dataset class collates (tests/golden/dataset_items.npz)."""
     z = load_golden("dataset_items")
@@ -61,12 +61,13 @@ def test_batches_equal_reference_dataset_items(k):
     name, kind, algo, mode, phase, seed = str(z["variants"][k]).split("|")
     cfg = dict(cfg, patch_or_image=mode)
     rd = synthetic.SyntheticReader(int(z["reader_seed"]))
-    cls = datasets.SupOcclusionOrderBatches if kind == "occ" else datasets.SupDepthOccOrderBatches
+    cls = {"occ": datasets.SupOcclusionOrderBatches, "depth_occ": datasets.SupDepthOccOrderBatches,
+           "depth": datasets.SupDepthOrderBatches}[kind]
     ds = cls(cfg, phase, algo, rd, rd.load_image)
     np.random.seed(int(seed))
     n = z[name + "_f0"].shape[0]
     out = ds.batch(range(n))
-    assert len(out) == (4 if kind == "occ" else 7)
+    assert len(out) == {"occ": 4, "depth_occ": 7, "depth": 6}[kind]
     for f, t in enumerate(out):
         assert t.is_cuda
         g = z["%s_f%d" % (name, f)]
