@@ -283,7 +283,9 @@ int io_avgpool_fc_bwd_dt(const float* dlogits, const float* pooled, int N, int H
  * SupOcclusionOrderDataset._get_pair / _get_pair_image / _get_pair_resize (datasets/occ_order_dataset.py:81-180,
  * utils/data_utils.py:105-124: crop_padding) and of the per-pair pre-processing of inference.py:449-482.
  * Masks: INTER_NEAREST; image: OpenCV's 8-bit fixed-point INTER_LINEAR (interp 1) or INTER_CUBIC (interp 2), then
- * x / 255, (x - mean) / std.  `arena` is one device buffer holding the decoded images (HxWx3) and masks (HxW), all
+ * x / 255, (x - mean) / std in fp32 (mean / std rounded to fp32 first, as transforms.Normalize does); interp 3:
+ * INTER_CUBIC on the float64 image x / 255., normalised in float64 and rounded once -- MiDaS' Resize / NormalizeImage /
+ * PrepareForNet chain of the 'resize' inference mode (utils/data_utils.py:37-53, midas/transforms.py:163-173, 206-222).  `arena` is one device buffer holding the decoded images (HxWx3) and masks (HxW), all
  * uint8, addressed by byte offsets; desc_dev / desc_host are the same P descriptors in device and host memory (the
  * host copy is validated against arena_bytes).  rgb[P][3][S][S] (NULL: masks only), modal1 / modal2 [P][S][S]. */
 typedef struct io_pair_desc {
@@ -292,10 +294,10 @@ typedef struct io_pair_desc {
     int32_t H, W;                 /* image (and mask) size                                               */
     int32_t x, y, w, h;           /* crop rectangle in image coordinates; parts outside the image read 0 */
     int32_t flip;                 /* != 0: mirror the outputs horizontally                               */
-    int32_t interp;               /* image interpolation: 1 linear, 2 cubic                              */
+    int32_t interp;               /* image interpolation: 1 linear, 2 cubic, 3 cubic in float64           */
 } io_pair_desc;
 int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
-                      const io_pair_desc* desc_host, int P, int S, const float* mean3, const float* std3, float* rgb,
+                      const io_pair_desc* desc_host, int P, int S, const double* mean3, const double* std3, float* rgb,
                       float* modal1, float* modal2, hipStream_t stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch

@@ -66,9 +66,29 @@ __device__ __forceinline__ int nearest_index(int d, int src, int dst) {
     return min((int)floor((double)d * scale), src - 1);
 }
 
+// interp 3: INTER_CUBIC on the float64 image x / 255. (MiDaS' Resize transform, midas/transforms.py:163-173 via
+// utils/data_utils.py:37-53): OpenCV's non-fixed-point path -- float coefficients, double accumulation left to right
+// (HResizeCubic<double,double,float>, VResizeCubic<double,double,float>), then (x - mean) / std in double and one
+// rounding to fp32 (PrepareForNet).
+__device__ __forceinline__ void cubic_coefs_f(int d, int src, int dst, int (&idx)[4], float (&c)[4]) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    f -= (float)s;
+    const float A = -0.75f;
+    const float x1 = f + 1.f;
+    c[0] = ((A * x1 - 5.f * A) * x1 + 8.f * A) * x1 - 4.f * A;
+    c[1] = ((A + 2.f) * f - (A + 3.f)) * f * f + 1.f;
+    const float xr = 1.f - f;
+    c[2] = ((A + 2.f) * xr - (A + 3.f)) * xr * xr + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(s - 1 + k, 0), src - 1);
+}
+
 __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restrict__ arena,
                                                          const io_pair_desc* __restrict__ desc, int S,
-                                                         float m0, float m1, float m2, float s0, float s1, float s2,
+                                                         double m0, double m1, double m2, double s0, double s1, double s2,
                                                          float* __restrict__ rgb, float* __restrict__ modal1,
                                                          float* __restrict__ modal2) {
     const int p = blockIdx.y;
@@ -90,8 +110,37 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
     }
     if (!rgb) return;
 
-    const Taps tx = make_taps(dx, d.w, S, d.interp), ty = make_taps(oy, d.h, S, d.interp);
     const uint8_t* img = arena + d.image_off;
+    const double mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    if (d.interp == 3) {
+        int xi[4], yi[4];
+        float xa[4], ya[4];
+        cubic_coefs_f(dx, d.w, S, xi, xa);
+        cubic_coefs_f(oy, d.h, S, yi, ya);
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = d.y + yi[r];
+            double hrow[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ix = d.x + xi[k];
+                const bool in = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                const uint8_t* px = img + (in ? ((size_t)iy * d.W + ix) * 3 : 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double v = in ? (double)px[c] / 255.0 : 0.0;
+                    hrow[c] = k == 0 ? v * (double)xa[0] : hrow[c] + v * (double)xa[k];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = r == 0 ? hrow[c] * (double)ya[0] : acc[c] + hrow[c] * (double)ya[r];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[(p * 3 + c) * plane + pix] = (float)((acc[c] - mean[c]) / sd[c]);
+        return;
+    }
+    const Taps tx = make_taps(dx, d.w, S, d.interp), ty = make_taps(oy, d.h, S, d.interp);
     int h[4][3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -112,7 +161,6 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
             }
         }
     }
-    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int v;
@@ -124,14 +172,14 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
         }
         v = min(max(v, 0), 255);
         const float x = __fdiv_rn((float)v, 255.f);
-        rgb[(p * 3 + c) * plane + pix] = __fdiv_rn(__fsub_rn(x, mean[c]), sd[c]);
+        rgb[(p * 3 + c) * plane + pix] = __fdiv_rn(__fsub_rn(x, (float)mean[c]), (float)sd[c]);
     }
 }
 
 }  // namespace
 
 extern "C" int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
-                                 const io_pair_desc* desc_host, int P, int S, const float* mean3, const float* std3,
+                                 const io_pair_desc* desc_host, int P, int S, const double* mean3, const double* std3,
                                  float* rgb, float* modal1, float* modal2, hipStream_t st) {
     IO_REQUIRE(P > 0 && S > 0 && arena && desc_dev && desc_host && modal1 && modal2, IO_ERR_SHAPE,
                "pair_planes: empty batch or null pointer (P=%d, S=%d)", P, S);
@@ -143,15 +191,15 @@ extern "C" int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const
         const size_t hw = (size_t)(d.H > 0 ? d.H : 0) * (size_t)(d.W > 0 ? d.W : 0);
         IO_REQUIRE(d.H > 0 && d.W > 0 && d.w > 0 && d.h > 0, IO_ERR_SHAPE,
                    "pair_planes: pair %d has an empty image or crop (%dx%d, crop %dx%d)", p, d.H, d.W, d.w, d.h);
-        IO_REQUIRE(d.interp == 1 || d.interp == 2, IO_ERR_SHAPE, "pair_planes: pair %d interp=%d (1 linear, 2 cubic)",
-                   p, d.interp);
+        IO_REQUIRE(d.interp >= 1 && d.interp <= 3, IO_ERR_SHAPE,
+                   "pair_planes: pair %d interp=%d (1 linear, 2 cubic, 3 cubic in float64)", p, d.interp);
         IO_REQUIRE(d.mask1_off >= 0 && d.mask2_off >= 0 && (size_t)d.mask1_off + hw <= arena_bytes &&
                        (size_t)d.mask2_off + hw <= arena_bytes,
                    IO_ERR_SHAPE, "pair_planes: pair %d masks outside the arena", p);
         IO_REQUIRE(!rgb || (d.image_off >= 0 && (size_t)d.image_off + 3 * hw <= arena_bytes), IO_ERR_SHAPE,
                    "pair_planes: pair %d image outside the arena", p);
     }
-    float m[3] = {0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+    double m[3] = {0.0, 0.0, 0.0}, s[3] = {1.0, 1.0, 1.0};
     if (rgb)
         for (int c = 0; c < 3; ++c) {
             m[c] = mean3[c];

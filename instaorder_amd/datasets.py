@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-INTER_LINEAR, INTER_CUBIC = 1, 2
+INTER_LINEAR, INTER_CUBIC, INTER_CUBIC_F64 = 1, 2, 3     # io_pair_desc.interp
 
 
 # ---- utils/data_utils.py:61-73 --------------------------------------------------------------------------------------
@@ -76,8 +76,8 @@ class PairRenderer(object):
             raise RuntimeError("instaorder_amd.datasets.PairRenderer needs a GPU (there is no CPU path)")
         self.S = int(input_size)
         self.device = torch.device(device)
-        self.mean = (C.c_float * 3)(*[float(v) for v in mean])
-        self.std = (C.c_float * 3)(*[float(v) for v in std])
+        self.mean = (C.c_double * 3)(*[float(v) for v in mean])
+        self.std = (C.c_double * 3)(*[float(v) for v in std])
         self._pinned = [None, None]
         self._events = [None, None]
         self._turn = 0

@@ -212,12 +212,9 @@ def _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, 
     ``Resize`` transform (utils/data_utils.py:37-53) and are not built."""
     from . import datasets
     if patch_or_image not in ("patch", "image"):
-        raise NotImplementedError("patch_or_image=%r: only 'patch' and 'image' are built (the 'resize' / 'orig' modes "
-                                  "use the float cv2 path of midas/transforms.py)" % (patch_or_image,))
+        raise NotImplementedError("patch_or_image=%r: 'patch', 'image' and 'resize' are built ('orig' feeds the "
+                                  "network non-square inputs)" % (patch_or_image,))
     dev = model.net.flat_params.device
-    key = (int(input_size), str(dev))
-    if key not in _RENDERERS:
-        _RENDERERS[key] = datasets.PairRenderer(input_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], dev)
     modal = np.ascontiguousarray(inmodal.astype(np.uint8))
     image = np.ascontiguousarray(image.astype(np.uint8))
     _, hh, ww = modal.shape
@@ -231,7 +228,34 @@ def _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, 
             hw = int(max(hh, ww))
             box = (-((hw - ww) // 2), -((hw - hh) // 2), hw, hw)
             items.append((0, i, j, box, datasets.INTER_LINEAR, False))
-    return _RENDERERS[key].render([image], [modal], items)
+    return _renderer(dev, input_size).render([image], [modal], items)
+
+
+def _renderer(dev, input_size):
+    from . import datasets
+    key = (int(input_size), str(dev))
+    if key not in _RENDERERS:
+        _RENDERERS[key] = datasets.PairRenderer(input_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], dev)
+    return _RENDERERS[key]
+
+
+def resize_mode_inputs(dev, image, inmodal, input_size):
+    """The 'resize' pre-processing (inference.py:484-488, 562-566): ``transform_resize`` = INTER_CUBIC on the float64
+    image / 255. + ImageNet normalisation (utils/data_utils.py:37-53) and INTER_NEAREST masks, the whole image squeezed
+    to input_size x input_size (a multiple of 32, so MiDaS' Resize keeps it).  One image shared by all pairs:
+    returns (rgb[1,3,S,S], masks[N,S,S]) on the device."""
+    from . import datasets
+    if input_size % 32:
+        raise ValueError("'resize' mode: input_size must be a multiple of 32 (midas/transforms.py:96-105)")
+    modal = np.ascontiguousarray(inmodal.astype(np.uint8))
+    image = np.ascontiguousarray(image.astype(np.uint8))
+    n, hh, ww = modal.shape
+    box = (0, 0, ww, hh)
+    r = _renderer(dev, input_size)
+    rgb, _, _ = r.render([image], [modal], [(0, 0, 0, box, datasets.INTER_CUBIC_F64, False)])
+    _, m, _ = r.render([image], [modal], [(0, i, i, box, datasets.INTER_CUBIC_F64, False) for i in range(n)],
+                       load_rgb=False)
+    return rgb, m[:, 0]
 
 
 def _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size):
@@ -240,6 +264,9 @@ def _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, inp
     if not pair_list:
         z = np.zeros((n, n), dtype=np.int64)
         return {"occ_order": z, "depth_order": z.copy()}
+    if patch_or_image == "resize":
+        rgb, masks = resize_mode_inputs(model.net.flat_params.device, image, inmodal, input_size)
+        return infer_order_batched(model, rgb, masks, method, pairs=pair_list)
     planes = _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, input_size)
     return infer_order_batched(model, None, torch.from_numpy(np.asarray(inmodal)), method, pairs=pair_list,
                                pair_planes=planes)
@@ -346,14 +373,18 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
         return _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size)["depth_order"], None
     if method not in ("InstaDepthNet_d", "InstaDepthNet_od"):
         raise ValueError("method name should be one of {InstaOrderNet_d, InstaDepthNet_d, InstaDepthNet_od}")
-    # the batched MiDaS path runs the encoder once per IMAGE, which needs one image shared by all pairs: only the
-    # pre-processing that is the identity (square image of the network size, 'image' mode) is built for it
-    if patch_or_image != "image" or image.shape[0] != image.shape[1] or image.shape[0] != input_size:
-        raise NotImplementedError("InstaDepthNet inference: only patch_or_image='image' on square images of the network "
-                                  "size (per-pair crops would run the MiDaS encoder once per pair)")
-    from .synthetic import image_mode_inputs
-    rgb, masks = image_mode_inputs(image, inmodal, input_size)
+    # the batched MiDaS path runs the encoder once per IMAGE, which needs one image shared by all pairs
     plist = select_pairs(inmodal, pairs)
+    if patch_or_image == "resize":              # what the reference's InstaDepthNet configs use (config.yaml:51)
+        dev = next(model.model.parameters()).device
+        rgb, masks = resize_mode_inputs(dev, image, inmodal, input_size)
+        rgb, masks = rgb.cpu().numpy(), masks.cpu().numpy()
+    elif patch_or_image == "image" and image.shape[0] == image.shape[1] == input_size:
+        from .synthetic import image_mode_inputs
+        rgb, masks = image_mode_inputs(image, inmodal, input_size)
+    else:
+        raise NotImplementedError("InstaDepthNet inference: patch_or_image='resize', or 'image' on square images of the "
+                                  "network size (per-pair crops would run the MiDaS encoder once per pair)")
     res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), pairs=plist)
     if disp_select_method == "":
         return res["depth_order"], None

@@ -30,6 +30,7 @@ Two layers:
 import numpy as np
 
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
+INTER_CUBIC_F64 = 3      # not a cv2 constant: INTER_CUBIC applied to the float64 image x / 255. (render_pair)
 COEF_BITS = 11
 COEF_SCALE = 1 << COEF_BITS
 
@@ -101,6 +102,57 @@ def resize(img, dsize, interpolation=INTER_LINEAR):
     return out[:, :, 0] if squeeze else out
 
 
+def resize_cubic_f64(img, dsize):
+    """cv2.resize(float64 HxWxC image, (width, height), interpolation=cv2.INTER_CUBIC): the non-fixed-point path of
+    resizeGeneric_ (HResizeCubic<double,double,float> / VResizeCubic<double,double,float>): float coefficients, double
+    products accumulated left to right, no rounding step.  Same pinning status as ``resize`` (unpinned)."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = img.shape[:2]
+    assert img.dtype == np.float64 and img.ndim == 3
+
+    def taps(src, dst):
+        fx, sx = _coords(src, dst)
+        A, one = np.float32(-0.75), np.float32(1)
+        x1 = fx + one
+        c0 = ((A * x1 - np.float32(5) * A) * x1 + np.float32(8) * A) * x1 - np.float32(4) * A
+        c1 = ((A + np.float32(2)) * fx - (A + np.float32(3))) * fx * fx + one
+        xr = one - fx
+        c2 = ((A + np.float32(2)) * xr - (A + np.float32(3))) * xr * xr + one
+        c3 = one - c0 - c1 - c2
+        coef = np.stack([c0, c1, c2, c3], 1).astype(np.float64)
+        return np.clip(sx[:, None] + np.arange(-1, 3)[None, :], 0, src - 1), coef
+
+    xi, xa = taps(sw, dw)
+    yi, ya = taps(sh, dh)
+    H = img[:, xi[:, 0], :] * xa[None, :, 0, None]
+    for k in range(1, 4):
+        H = H + img[:, xi[:, k], :] * xa[None, :, k, None]
+    out = H[yi[:, 0]] * ya[:, 0, None, None]
+    for k in range(1, 4):
+        out = out + H[yi[:, k]] * ya[:, k, None, None]
+    return out
+
+
+def constrain_to_multiple_of(x, multiple, max_val=None):
+    """midas/transforms.py:96-105 for resize_method 'upper_bound' (min_val = 0)."""
+    y = int(np.round(x / multiple) * multiple)
+    if max_val is not None and y > max_val:
+        y = int(np.floor(x / multiple) * multiple)
+    return y
+
+
+def transform_resize(image, width, height):
+    """utils/data_utils.py:37-53: Resize(width, height, keep_aspect_ratio=False, ensure_multiple_of=32,
+    resize_method='upper_bound', INTER_CUBIC) on image / 255., NormalizeImage(ImageNet mean / std), PrepareForNet ->
+    float32 [3, H', W']."""
+    h, w = image.shape[:2]
+    new_h = constrain_to_multiple_of((height / h) * h, 32, max_val=height)
+    new_w = constrain_to_multiple_of((width / w) * w, 32, max_val=width)
+    x = resize_cubic_f64(image / 255., (new_w, new_h))
+    x = (x - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    return np.ascontiguousarray(np.transpose(x, (2, 0, 1))).astype(np.float32)
+
+
 # ---- utils/data_utils.py -------------------------------------------------------------------------------------------
 def combine_bbox(bboxes):
     """utils/data_utils.py:61-73 (xywh rows -> enclosing xywh)."""
@@ -157,6 +209,13 @@ def render_pair(image, mask1, mask2, box, interp, flip, sz, mean, std):
     """(rgb[3,sz,sz] fp32 normalised, modal1[sz,sz], modal2[sz,sz] in the mask dtype) of one planned item."""
     m1 = resize(crop_padding(mask1, box), (sz, sz), INTER_NEAREST)
     m2 = resize(crop_padding(mask2, box), (sz, sz), INTER_NEAREST)
+    if interp == INTER_CUBIC_F64:
+        x = resize_cubic_f64(crop_padding(image, box) / 255., (sz, sz))
+        x = (x - list(mean)) / list(std)
+        if flip:
+            m1, m2, x = m1[:, ::-1], m2[:, ::-1], x[:, ::-1, :]
+        return (np.ascontiguousarray(np.transpose(x, (2, 0, 1))).astype(np.float32), np.ascontiguousarray(m1),
+                np.ascontiguousarray(m2))
     rgb = resize(crop_padding(image, box), (sz, sz), interp)
     if flip:
         m1, m2, rgb = m1[:, ::-1], m2[:, ::-1], rgb[:, ::-1, :]

@@ -485,7 +485,14 @@ def case_dataset_items(tag):
     from oracle import preprocess_oracle as po
     cv2 = sys.modules["cv2"]
     cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC = po.INTER_NEAREST, po.INTER_LINEAR, po.INTER_CUBIC
-    cv2.resize = lambda img, size, interpolation=po.INTER_LINEAR: po.resize(img, size, interpolation)
+
+    def cv2_resize(img, size, interpolation=po.INTER_LINEAR):
+        if img.dtype == np.float64:
+            assert interpolation == po.INTER_CUBIC
+            return po.resize_cubic_f64(img, size)
+        return po.resize(img, size, interpolation)
+
+    cv2.resize = cv2_resize
     from datasets import reader as ref_reader
     from datasets import occ_order_dataset, depth_occ_order_dataset, depth_order_dataset
     rd = synthetic.SyntheticReader(DATASET_READER_SEED)
@@ -504,6 +511,11 @@ def case_dataset_items(tag):
             col = [np.asarray(it[f].numpy() if torch.is_tensor(it[f]) else it[f]) for it in items]
             out["%s_f%d" % (name, f)] = np.stack(col)
         print(name, "items", n, "fields", len(items[0]))
+    # the 'resize' inference transform (utils/data_utils.py:37-53 through midas/transforms.py) on two scenes
+    from utils.data_utils import transform_resize
+    for k, (w, h) in enumerate([(64, 64), (96, 64)]):
+        out["transform_resize_%d" % k] = transform_resize(rd.scenes[k]["image"], w, h)
+        print("transform_resize", k, out["transform_resize_%d" % k].shape)
     import json
     out["config_json"] = np.array(json.dumps(dataset_config("patch")))
     out["variants"] = np.array(["|".join(str(v) for v in row) for row in DATASET_VARIANTS])

@@ -77,3 +77,16 @@ def test_item_logic_matches_reference_datasets(k):
             assert int(p["count"]) == int(z[name + "_f4"][i]) and int(p["is_overlap"]) == int(z[name + "_f5"][i])
             if kind == "depth_occ":
                 assert np.array_equal(np.asarray(p["occ"], np.float64), z[name + "_f6"][i].astype(np.float64))
+
+
+def test_transform_resize_matches_reference_chain():
+    """the 'resize' inference transform: the reference's own utils.data_utils.transform_resize (MiDaS Resize ->
+    NormalizeImage -> PrepareForNet; cv2.resize bound to the oracle's float64 cubic) == oracle.transform_resize"""
+    z = np.load(GOLD)
+    rd = synthetic.SyntheticReader(int(z["reader_seed"]))
+    for k, (w, h) in enumerate([(64, 64), (96, 64)]):
+        got = po.transform_resize(rd.scenes[k]["image"], w, h)
+        assert got.dtype == np.float32 and np.array_equal(got, z["transform_resize_%d" % k])
+    flat = np.full((30, 50, 3), 77, np.uint8)              # constant image: cubic weights sum to one (within 1 ulp of fp32)
+    out = po.resize_cubic_f64(flat / 255., (64, 32))
+    assert np.abs(out - 77 / 255.).max() < 1e-6

@@ -39,6 +39,7 @@ def test_renderer_bit_exact_against_oracle(S):
         for k, box in enumerate(boxes):
             items.append((ii, k % 3, (k + 1) % 3, box, 1 + (k + ii) % 2, bool(k % 2)))
             items.append((ii, (k + 2) % 3, k % 3, box, 2 - (k + ii) % 2, not bool(k % 2)))
+            items.append((ii, k % 3, (k + 2) % 3, box, 3, bool((k + ii) % 2)))       # cubic on the float64 image
     r = datasets.PairRenderer(S, MEAN, STD)
     rgb, m1, m2 = r.render(images, masks, items)
     want = _oracle_items(images, masks, items, S)
@@ -114,6 +115,19 @@ def test_batches_feed_a_training_step_and_patch_inference():
         want = inference.infer_order_batched(m, None, torch.from_numpy(sc["modal"]), "InstaOrderNet_o", pairs=pairs,
                                              pair_planes=pp)["occ_order"]
         assert np.array_equal(got, want), mode
+    # 'resize': the golden transform of the reference chain, then the shared-image batched driver
+    z = load_golden("dataset_items")
+    rd77 = synthetic.SyntheticReader(int(z["reader_seed"]))
+    rgb, masks = inference.resize_mode_inputs("cuda:0", rd77.scenes[0]["image"], rd77.scenes[0]["modal"], 64)
+    assert np.array_equal(rgb[0].cpu().numpy(), z["transform_resize_0"])
+    assert np.array_equal(masks.cpu().numpy(),
+                          np.stack([po.resize(mm, (64, 64), po.INTER_NEAREST) for mm in rd77.scenes[0]["modal"]]))
+    got = inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "resize", S)
+    want = inference.infer_order_batched(
+        m, torch.from_numpy(po.transform_resize(sc["image"], S, S))[None],
+        torch.from_numpy(np.stack([po.resize(mm, (S, S), po.INTER_NEAREST) for mm in sc["modal"]]).astype(np.float32)),
+        "InstaOrderNet_o")["occ_order"]
+    assert np.array_equal(got, want)
     with pytest.raises(NotImplementedError):
         inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "orig", S)
 
@@ -124,7 +138,7 @@ def test_descriptor_validation():
     arena = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     out = torch.empty((1, 3, 8, 8), device="cuda")
     m = torch.empty((1, 1, 8, 8), device="cuda")
-    mean, std = (C.c_float * 3)(*MEAN), (C.c_float * 3)(*STD)
+    mean, std = (C.c_double * 3)(*MEAN), (C.c_double * 3)(*STD)
 
     def call(**kw):
         d = (_lib.PairDesc * 1)()
@@ -141,7 +155,7 @@ def test_descriptor_validation():
     assert call() == 0
     assert call(image_off=4096 - 100) != 0 and b"image outside" in _lib.last_error().encode()
     assert call(mask2_off=4000) != 0
-    assert call(interp=3) != 0
+    assert call(interp=4) != 0
     assert call(w=0) != 0
     assert call(H=0) != 0
     torch.cuda.synchronize()

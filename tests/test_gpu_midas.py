@@ -166,6 +166,15 @@ def test_batched_depthnet_inference_equals_per_pair_calls():
     order2, clipped2 = inference.infer_order_sup_depth(m, items[0]["image"], items[0]["modal"], None, "all", algo,
                                                        "image", 64, "median")
     assert order2.shape == (4, 4) and clipped2.shape == (64, 64)
+    # 'resize' (the mode of the reference's InstaDepthNet configs) on a non-square uint8 scene: the device transform
+    # feeds the same batched path as explicit oracle-transformed inputs
+    from oracle import preprocess_oracle as po
+    sc = synthetic.SyntheticReader(31, n_images=1, n_inst=4, empty_every=0).scenes[0]
+    order3, _ = inference.infer_order_sup_depth(m, sc["image"], sc["modal"], sc["bboxes"], "all", algo, "resize", 64, "")
+    rgb3 = po.transform_resize(sc["image"], 64, 64)[None]
+    masks3 = np.stack([po.resize(mm, (64, 64), po.INTER_NEAREST) for mm in sc["modal"]]).astype(np.float32)
+    want3 = inference.infer_depthnet_batched(m, torch.from_numpy(rgb3), torch.from_numpy(masks3))["depth_order"]
+    assert (order3 == want3).all()
 
 
 def test_checkpoint_roundtrip_with_momentum(tmp_path):
