@@ -128,7 +128,9 @@ class _OrderBase(SingleStageModel):
                 ws_keep = None
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: a data-pipeline thread (datasets.BatchPrefetcher) may allocate / launch on its own
+                # stream while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     logits, losses, ws_keep = self._fwd_loss_bwd(N, S)
                 self._graph, self._graph_key, self._graph_out, self._graph_ws = g, key, (logits, losses), ws_keep
                 g.replay()
