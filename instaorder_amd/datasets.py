@@ -208,7 +208,11 @@ class SupOcclusionOrderBatches(_Batches):
     def _get_pair_ind(self, idx):
         """occ_order_dataset.py:182-200 (dataset 'InstaOrder' / COCOA branches)."""
         modal, bboxes, image_fn = self._instances(idx)
-        if self.config["dataset"] == "InstaOrder":
+        if self.config["dataset"] == "KINS":
+            from . import inference as infer
+            amodal = self.data_reader.get_image_instances(idx, with_gt=True)[3]
+            gt = infer.infer_gt_order(modal, amodal)
+        elif self.config["dataset"] == "InstaOrder":
             gt = self.data_reader.get_gt_ordering(idx, type="occlusion", rm_bidirec=self.config["remove_occ_bidirec"])
         else:
             gt = self.data_reader.get_gt_ordering(idx)

@@ -523,7 +523,41 @@ def case_dataset_items(tag):
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
 
 
+def case_heuristics(tag):
+    """inference.py's annotation-free baselines, infer_gt_order and eval_order on synthetic scenes; cv2.dilate (absent)
+    is scipy's binary_dilation with the same cross."""
+    from scipy import ndimage
+    cv2 = sys.modules["cv2"]
+    cv2.dilate = lambda a, k, iterations=1: ndimage.binary_dilation(a.astype(bool), structure=k.astype(bool),
+                                                                     iterations=iterations).astype(np.uint8)
+    import inference as ref_inf
+    rd = synthetic.SyntheticReader(88, n_images=4, n_inst=6, empty_every=0)
+    out = {}
+    for k, sc in enumerate(rd.scenes):
+        m = sc["modal"]
+        rng = np.random.RandomState(k)
+        amodal = np.stack([ndimage.binary_dilation(x.astype(bool), iterations=int(rng.randint(1, 6))).astype(np.uint8)
+                           for x in m])
+        out["amodal_%d" % k] = amodal
+        out["occ_area_s_%d" % k] = ref_inf.infer_occ_order_area(m, "smaller")
+        out["occ_area_l_%d" % k] = ref_inf.infer_occ_order_area(m, "larger")
+        out["occ_y_lo_%d" % k] = ref_inf.infer_occ_order_yaxis(m, "lower")
+        out["occ_y_hi_%d" % k] = ref_inf.infer_occ_order_yaxis(m, "higher")
+        out["dep_area_s_%d" % k] = ref_inf.infer_depth_order_area(m, "smaller")
+        out["dep_area_l_%d" % k] = ref_inf.infer_depth_order_area(m, "larger")
+        out["dep_y_lo_%d" % k] = ref_inf.infer_depth_order_yaxis(m, "lower")
+        out["dep_y_hi_%d" % k] = ref_inf.infer_depth_order_yaxis(m, "higher")
+        gt = ref_inf.infer_gt_order(m, amodal)
+        out["gt_%d" % k] = gt
+        ev = ref_inf.eval_order(out["occ_area_s_%d" % k], gt)
+        out["eval_%d" % k] = np.asarray(ev[:4], np.float64)
+        out["eval_err_%d" % k] = ev[4]
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, "scenes", len(rd.scenes), "gt ones", [int(out["gt_%d" % k].sum()) for k in range(len(rd.scenes))])
+
+
 CASES = {
+    "heuristics": lambda: case_heuristics("heuristics"),
     "dataset_items": lambda: case_dataset_items("dataset_items"),
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),
     "od_S64_B6": lambda: case_train("InstaOrderNet_od", 64, 6, 12, 3, "od_S64_B6"),

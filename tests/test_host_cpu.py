@@ -260,3 +260,27 @@ def test_bordering_and_pair_selection():
     assert inference.select_pairs(m, "nbor") == [(0, 1)]
     with pytest.raises(ValueError):
         inference.select_pairs(m, "some")
+
+
+def test_heuristic_baselines_and_gt_order_match_reference():
+    """inference.py:272-347, 719-754 (area / y-axis baselines, infer_gt_order, eval_order) against matrices produced by
+    the reference's own functions (tests/golden/heuristics.npz)."""
+    from instaorder_amd import inference
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heuristics.npz"))
+    rd = synthetic.SyntheticReader(88, n_images=4, n_inst=6, empty_every=0)
+    for k, sc in enumerate(rd.scenes):
+        m = sc["modal"]
+        got = {"occ_area_s": inference.infer_occ_order_area(m, "smaller"),
+               "occ_area_l": inference.infer_occ_order_area(m, "larger"),
+               "occ_y_lo": inference.infer_occ_order_yaxis(m, "lower"),
+               "occ_y_hi": inference.infer_occ_order_yaxis(m, "higher"),
+               "dep_area_s": inference.infer_depth_order_area(m, "smaller"),
+               "dep_area_l": inference.infer_depth_order_area(m, "larger"),
+               "dep_y_lo": inference.infer_depth_order_yaxis(m, "lower"),
+               "dep_y_hi": inference.infer_depth_order_yaxis(m, "higher"),
+               "gt": inference.infer_gt_order(m, z["amodal_%d" % k])}
+        for name, v in got.items():
+            assert np.array_equal(v, z["%s_%d" % (name, k)]), (name, k)
+        ev = inference.eval_order(got["occ_area_s"], got["gt"])
+        assert np.allclose(np.asarray(ev[:4], np.float64), z["eval_%d" % k])
+        assert np.array_equal(ev[4], z["eval_err_%d" % k])
