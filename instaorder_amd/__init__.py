@@ -6,6 +6,7 @@ Public surface mirrors the reference's ``models`` / ``utils`` packages for this 
     from instaorder_amd import InstaDepthNet_od, InstaDepthNet_d       # MiDaS-based nets (midas_net.py)
     from instaorder_amd import backbone            # backbone.resnet50_cls
     from instaorder_amd import utils               # DistModule, average_gradients, StepLRScheduler, ...
+    from instaorder_amd import evaluate            # tools/test.py Tester loops (P / R / F1, WHDR) over the batched drivers
     from instaorder_amd import datasets            # SupOcclusionOrderBatches, SupDepthOccOrderBatches, SupDepthOrderBatches, PairRenderer
 
 Importing the package does not load the HIP library; the first op does, and fails loudly when

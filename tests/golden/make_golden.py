@@ -556,7 +556,145 @@ def case_heuristics(tag):
     print(tag, "scenes", len(rd.scenes), "gt ones", [int(out["gt_%d" % k].sum()) for k in range(len(rd.scenes))])
 
 
+TESTER_SCENARIOS = [   # (name, trainval_dataset, order_method, patch_or_image, algo or None)
+    ("occ_area", "SupOcclusionOrderDataset", "area", "patch", None),
+    ("occ_yaxis", "SupOcclusionOrderDataset", "yaxis", "patch", None),
+    ("dep_area", "SupDepthOrderDataset", "area", "resize", None),
+    ("dep_yaxis", "SupDepthOrderDataset", "yaxis", "resize", None),
+    ("occ_net_patch", "SupOcclusionOrderDataset", "InstaOrderNet_o", "patch", "InstaOrderNet_o"),
+    ("occ_net_image", "SupOcclusionOrderDataset", "InstaOrderNet_o", "image", "InstaOrderNet_o"),
+    ("od_net_resize", "SupDepthOccOrderDataset", "InstaOrderNet_od", "resize", "InstaOrderNet_od"),
+]
+TESTER_S, TESTER_SEED, TESTER_READER_SEED, TESTER_WARM = 64, 31, 91, 6
+
+
+def case_tester(tag):
+    """The reference's own tools/test.py Tester loops (eval_occ_order / eval_depth_order / eval_occ_depth_order) over
+    synthetic scenes: heuristics and the supervised nets in 'patch' / 'image' / 'resize' mode (cv2.resize = the oracle's
+    restatement, cv2.dilate = scipy's binary_dilation).  Recorded: every predicted order matrix, the pair logits
+    behind it, and the aggregated metrics the Tester logs."""
+    import importlib.util
+    import logging
+    from argparse import Namespace
+    from scipy import ndimage
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import preprocess_oracle as po
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC = po.INTER_NEAREST, po.INTER_LINEAR, po.INTER_CUBIC
+
+    def cv2_resize(img, size, interpolation=po.INTER_LINEAR):
+        if img.dtype == np.float64:
+            return po.resize_cubic_f64(img, size)
+        return po.resize(img, size, interpolation)
+
+    cv2.resize = cv2_resize
+    cv2.dilate = lambda a, k, iterations=1: ndimage.binary_dilation(a.astype(bool), structure=k.astype(bool),
+                                                                     iterations=iterations).astype(np.uint8)
+    sys.modules.setdefault("wandb", mock.MagicMock(name="wandb"))
+    spec = importlib.util.spec_from_file_location("ref_tools_test", os.path.join(REF, "tools", "test.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    import inference as infer
+    rd = synthetic.SyntheticReader(TESTER_READER_SEED, n_images=4, n_inst=5, empty_every=0)
+
+    class _Img:
+        def __init__(self, a):
+            self.a = a
+
+        def convert(self, mode):
+            return self.a
+
+    T.Image = types.SimpleNamespace(open=lambda path: _Img(rd.load_image(os.path.basename(path))))
+    data_cfg = dict(load_cfg("InstaOrderNet_o")["data"])
+    data_cfg.update(load_cfg("InstaOrderNet_od")["data"])
+    data_cfg.update(input_size=TESTER_S, val_image_root="/nowhere")
+    out = {"data_cfg_json": np.array(__import__("json").dumps(data_cfg)),
+           "scenarios": np.array(["|".join(str(v) for v in r) for r in TESTER_SCENARIOS]),
+           "meta": np.array([TESTER_S, TESTER_SEED, TESTER_READER_SEED, TESTER_WARM])}
+    models_cache = {}
+
+    def get_model(algo):
+        if algo not in models_cache:
+            m, _ = build(algo, TESTER_SEED, dist_model=False, style="kaiming")
+            m.switch_to("train")
+            for it in range(TESTER_WARM):
+                b = synthetic.make_pair_batch(TESTER_SEED + 300 + it, 8, TESTER_S)
+                with torch.no_grad():
+                    m.model(torch.cat([torch.from_numpy(b["modal1"]), torch.from_numpy(b["modal2"]),
+                                       torch.from_numpy(b["rgb"])], 1))
+            m.switch_to("eval")
+            models_cache[algo] = m
+        return models_cache[algo]
+
+    for name, kind, method, mode, algo in TESTER_SCENARIOS:
+        cfg = dict(data_cfg, trainval_dataset=kind, patch_or_image=mode)
+        t = object.__new__(T.Tester)
+        t.args = Namespace(data=cfg, model=dict(use_rgb=True), order_method=method, pairs="all", zd=0, save_pngs=0,
+                           disp_select_method="", order_th=0.1, load_model="x")
+        T.args = t.args                                   # the loops also read the module-level `args` (test.py:423)
+        t.data_reader, t.data_length, t.dataset = rd, rd.get_image_length(), "InstaOrder"
+        t.data_root, t.gt_ordering, t.curr_step = "/nowhere", "ann", 5
+        t.logger = logging.getLogger("tester_golden")
+        logged = {}
+        t.wb_logger = types.SimpleNamespace(log=lambda d, step=None: logged.update(d))
+        logits = []
+        hook = None
+        if algo is not None:
+            t.model = get_model(algo)
+            net = t.model.model.module
+            for b in ([net.fc] if algo == "InstaOrderNet_o" else [net.fc_occ, net.fc_depth]):
+                b.bias.data.zero_()
+            hook = t.model.model.register_forward_hook(
+                lambda mod, inp, o: logits.append((torch.cat(o, 1) if isinstance(o, tuple) else o)[0].detach().numpy().copy()))
+        run = {"SupOcclusionOrderDataset": t.eval_occ_order, "SupDepthOrderDataset": t.eval_depth_order,
+               "SupDepthOccOrderDataset": t.eval_occ_depth_order}[kind]
+        if algo is not None:
+            run()                                         # pass 1: logits with a zero head bias -> centre the head
+            med = -np.median(np.stack(logits), 0).astype(np.float32)
+            if algo == "InstaOrderNet_o":
+                net.fc.bias.data.copy_(torch.from_numpy(med))
+            else:
+                net.fc_occ.bias.data.copy_(torch.from_numpy(med[:2]))
+                net.fc_depth.bias.data.copy_(torch.from_numpy(med[2:]))
+            out[name + "_head_bias"] = med
+            logits.clear()
+            logged.clear()
+        preds = []
+        wrapped = {}
+        for fn in ("infer_occ_order_area", "infer_occ_order_yaxis", "infer_depth_order_area", "infer_depth_order_yaxis",
+                   "infer_order_sup_occ", "infer_order_sup_occ_depth", "infer_order_sup_depth"):
+            orig = getattr(infer, fn)
+            wrapped[fn] = orig
+
+            def rec(*a, _o=orig, **k):
+                r = _o(*a, **k)
+                preds.append(r)
+                return r
+
+            setattr(infer, fn, rec)
+        try:
+            run()
+        finally:
+            for fn, orig in wrapped.items():
+                setattr(infer, fn, orig)
+            if hook is not None:
+                hook.remove()
+        for i, r in enumerate(preds):
+            if isinstance(r, tuple):
+                out["%s_pred_occ_%d" % (name, i)], out["%s_pred_dep_%d" % (name, i)] = np.asarray(r[0]), np.asarray(r[1])
+            else:
+                out["%s_pred_%d" % (name, i)] = np.asarray(r)
+        if logits:
+            out[name + "_logits"] = np.stack(logits)      # call order: image-major, pair-major, (a,b) then (b,a)
+        for k, v in logged.items():
+            if isinstance(v, (int, float, np.floating, np.integer)):
+                out["%s_log_%s" % (name, k.replace("/", "."))] = np.float64(v)
+        print(name, {k: round(float(v), 3) for k, v in logged.items() if isinstance(v, (float, np.floating))})
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+
+
 CASES = {
+    "tester": lambda: case_tester("tester"),
     "heuristics": lambda: case_heuristics("heuristics"),
     "dataset_items": lambda: case_dataset_items("dataset_items"),
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),

@@ -284,3 +284,35 @@ def test_heuristic_baselines_and_gt_order_match_reference():
         ev = inference.eval_order(got["occ_area_s"], got["gt"])
         assert np.allclose(np.asarray(ev[:4], np.float64), z["eval_%d" % k])
         assert np.array_equal(ev[4], z["eval_err_%d" % k])
+
+
+def _tester_golden():
+    import json
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tester.npz"))
+    cfg = json.loads(str(z["data_cfg_json"]))
+    rows = [str(v).split("|") for v in z["scenarios"]]
+    return z, cfg, rows
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_evaluate_heuristics_equal_reference_tester(k):
+    """instaorder_amd.evaluate against the reference's own tools/test.py Tester loops (tests/golden/tester.npz) for the
+    model-free methods: per-image matrices and the aggregated P / R / F1 / WHDR means."""
+    from instaorder_amd import evaluate
+    z, cfg, rows = _tester_golden()
+    name, kind, method, mode, algo = rows[k]
+    assert algo == "None"
+    S, seed, rseed, warm = [int(v) for v in z["meta"]]
+    rd = synthetic.SyntheticReader(rseed, n_images=4, n_inst=5, empty_every=0)
+    res = evaluate.evaluate(None, rd, rd.load_image, dict(cfg, trainval_dataset=kind, patch_or_image=mode), method,
+                            return_orders=True)
+    for i in range(4):
+        occ, dep = res["orders"][i]
+        assert np.array_equal(occ if dep is None else dep, z["%s_pred_%d" % (name, i)])
+    if kind == "SupOcclusionOrderDataset":
+        for key in ("recall", "precision", "f1"):
+            assert abs(res[key] - float(z["%s_log_val.%s" % (name, key)])) < 1e-9
+    else:
+        for key in evaluate.WHDR_KEYS:
+            ovl, eq = key.split("_")
+            assert abs(res["WHDR_" + key] - float(z["%s_log_val_%s.WHDR_%s" % (name, ovl, eq)])) < 1e-9
