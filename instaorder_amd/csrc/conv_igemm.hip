@@ -523,7 +523,13 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // fp32 MFMA.  TX / TDY: storage of the conv input and of dY; bf16 operands are widened when they are staged (used
 // for the stem in bf16 mode: fp32 packed input x bf16 dY; all other bf16 convs run conv_wgrad_bf16_kernel below).
 // STEM as in the NT kernel; 2 (exact-K, fp32 input): columns are k = tap * g.cr + channel, dW is the packed [Co][kp].
-template <typename TX, typename TDY, int BMO, int BNC, int STEM>
+// TR (fp32 operands, not the stem): transposed staging.  A thread fetches 4 CONSECUTIVE rows m of its 4-channel chunk
+// and writes the 4x4 block transposed -- pure register renaming -- so the LDS image is [channel][32 m] (36-word
+// pitch), k-contiguous like the NT kernel's: fragments are one ds_read_b128 per 4 MFMAs instead of four
+// ds_read_b32 (24 instead of 136 LDS instructions per thread and k-tile).  The 16-byte chunk index is XORed with
+// bits 4..5 of the channel so that both the transposed writes (16 lanes = 16 channel chunks, 4 channels apart) and
+// the fragment reads (16 consecutive channels) touch 16 distinct bank quads.
+template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int tiles,
@@ -534,9 +540,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     constexpr int RA = (BKM * QA) / kThreads;          // rows per thread (A)
     constexpr int RB = (BKM * QB) / kThreads;
     constexpr int SA = kThreads / QA, SB = kThreads / QB;   // row step between a thread's rows
+    static_assert(!TR || (STEM == 0 && sizeof(TX) == 4 && sizeof(TDY) == 4), "transposed staging: fp32, not the stem");
+    constexpr int LDT = 36;                            // TR: words per LDS row (32 m + 4 pad)
+    constexpr int NA = TR ? 4 : RA, NB = TR ? 4 : RB;  // 16-byte loads per thread and operand
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                    // [2][BKM][BMO]
-    float* sB = smem + 2 * BKM * BMO;    // [2][BKM][BNC]
+    float* sA = smem;                                        // [2][BKM][BMO]   (TR: [2][BMO][LDT])
+    float* sB = smem + (TR ? 2 * BMO * LDT : 2 * BKM * BMO); // [2][BKM][BNC]   (TR: [2][BNC][LDT])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -561,6 +570,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     }
     const int qa = tid % QA, ra0 = tid / QA;
     const int qb = tid % QB, rb0 = tid / QB;
+    // TR: ra0 / rb0 number the 4-row groups of a k-tile (8 of them); with 64-wide tiles only half the threads stage
+    const bool actA = !TR || ra0 < BKM / 4, actB = !TR || rb0 < BKM / 4;
 
     constexpr bool XK = STEM == 2;
     static_assert(!XK || sizeof(TX) == 4, "the exact-K stem gathers fp32 dwords");
@@ -609,15 +620,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)ipix_lo * (size_t)(g.Ci * (int)sizeof(TX)), in_bytes);
     const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc_at(dy, (size_t)mfirst * (size_t)(g.Co * (int)sizeof(TDY)), dy_bytes);
     const bool lin = !STEM && T == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
-    f32x4 ra[RA], rb[RB];
+    f32x4 ra[NA], rb[NB];
     // The gather offsets of a k-tile are computed one iteration ahead of its loads (`prep`), so that the loads
     // themselves are the first thing a loop iteration issues and have the whole MFMA stream to land under.
-    unsigned offb[XK ? 4 * RB : RB];
+    unsigned offb[XK ? 4 * RB : NB];
     auto prep = [&](int kt) {
         const int mb = kt * BKM;
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int m = mb + rb0 + SB * j;
+        for (int j = 0; j < NB; ++j) {
+            const int m = TR ? mb + 4 * rb0 + j : mb + rb0 + SB * j;
             if constexpr (XK) {
                 const bool rok = m < M;
                 const int mm = rok ? m : 0;
@@ -631,9 +642,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
                                          : kInvalidOff;
                 }
             } else if (lin) {
-                offb[j] = (unsigned)((m - ipix_lo) * g.Ci + coff) * (unsigned)sizeof(TX);
+                offb[j] = actB ? (unsigned)((m - ipix_lo) * g.Ci + coff) * (unsigned)sizeof(TX) : kInvalidOff;
             } else {
-                bool ok = tapok && m < M;
+                bool ok = tapok && m < M && actB;
                 const int mm = ok ? m : 0;
                 const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
@@ -647,12 +658,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     auto load_tile = [&](int kt) {
         const int mb = kt * BKM;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int m = mb + ra0 + SA * j;
-            ra[j] = bldv<TDY>(rs_dy, (unsigned)((m - mfirst) * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY));   // m >= M -> 0
+        for (int j = 0; j < NA; ++j) {
+            const int m = TR ? mb + 4 * ra0 + j : mb + ra0 + SA * j;
+            ra[j] = bldv<TDY>(rs_dy, actA ? (unsigned)((m - mfirst) * g.Co + o0 + qa * 4) * (unsigned)sizeof(TDY)
+                                          : kInvalidOff);                                        // m >= M -> 0
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
+        for (int j = 0; j < NB; ++j) {
             if constexpr (XK) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rb[j][i] = ld_el<float>(rs_in, offb[4 * j + i]);
@@ -662,6 +674,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
         }
     };
     auto store_tile = [&](int buf) {
+        if constexpr (TR) {
+            // rows = channels qa*4 + i, 16-byte chunk = the row group, XORed with bits 4..5 of the channel
+            float* a = sA + buf * BMO * LDT + (qa * 4) * LDT + ((ra0 ^ ((qa >> 2) & 3)) * 4);
+            float* b = sB + buf * BNC * LDT + (qb * 4) * LDT + ((rb0 ^ ((qb >> 2) & 3)) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 ta = {ra[0][i], ra[1][i], ra[2][i], ra[3][i]};
+                const f32x4 tb = {rb[0][i], rb[1][i], rb[2][i], rb[3][i]};
+                if (actA) st4(a + i * LDT, ta);
+                if (actB) st4(b + i * LDT, tb);
+            }
+            return;
+        }
         float* a = sA + buf * BKM * BMO + ra0 * BMO + qa * 4;
         float* b = sB + buf * BKM * BNC + rb0 * BNC + qb * 4;
 #pragma unroll
@@ -683,6 +708,26 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     const int a_off = (lane >> 5) * BMO + wm * (BMO / 2) + (lane & 31);
     const int b_off = (lane >> 5) * BNC + wn * (BNC / 2) + (lane & 31);
     auto read_frags = [&](int buf, int grp, float (&a)[4][TI], float (&b)[4][TJ]) {
+        if constexpr (TR) {
+            // one 16-byte read per operand tile: 4 consecutive m of the lane's channel (lanes >= 32: the next 4),
+            // element s4 feeds MFMA s4 of the group -- the k index is permuted alike in both operands
+            const int chunk = grp * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int row = wm * (BMO / 2) + i * 32 + (lane & 31);
+                const f32x4 v = ld4(sA + buf * BMO * LDT + row * LDT + ((chunk ^ ((row >> 4) & 3)) * 4));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) a[s4][i] = v[s4];
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int row = wn * (BNC / 2) + j * 32 + (lane & 31);
+                const f32x4 v = ld4(sB + buf * BNC * LDT + row * LDT + ((chunk ^ ((row >> 4) & 3)) * 4));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) b[s4][j] = v[s4];
+            }
+            return;
+        }
         const float* al = sA + buf * BKM * BMO + a_off + grp * 8 * BMO;
         const float* bl = sB + buf * BKM * BNC + b_off + grp * 8 * BNC;
 #pragma unroll
@@ -1173,12 +1218,27 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, STEM_>), grid, block, lds, st, g,          \
                            (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes, dy_bytes); \
     } while (0)
+#define IO_LAUNCH_WGT(BMO_, BNC_)                                                                               \
+    do {                                                                                                        \
+        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                      \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true>,        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true>), grid, block, lds, st, g,     \
+                           (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes,        \
+                           dy_bytes);                                                                           \
+    } while (0)
 #define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
     do {                                                                               \
-        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 128, 0);    \
-        else if (p.bmo == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 64, 0);                \
-        else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, 0);                \
-        else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                   \
+        /* transposed staging pays on 128 x 128 tiles (3x3 layers 112 -> 117 TF/s); with a 64-wide operand half   \
+         * the threads have nothing to stage and it loses (l1 3x3: 103 -> 85 TF/s), so those keep the row layout */ \
+        if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGT(128, 128);                     \
+        else if (p.bmo == 128) IO_LAUNCH_WG(TX_, TDY_, 128, 64, 0);                    \
+        else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, 0);                    \
+        else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                       \
     } while (0)
     if (stem && dt_in == IO_F32) {
         if (g.cr) {
@@ -1215,6 +1275,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         IO_LAUNCH_WG_SHAPES(float, float);
     }
 #undef IO_LAUNCH_WG_SHAPES
+#undef IO_LAUNCH_WGT
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
