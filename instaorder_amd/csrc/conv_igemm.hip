@@ -529,7 +529,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // ds_read_b32 (24 instead of 136 LDS instructions per thread and k-tile).  The 16-byte chunk index is XORed with
 // bits 4..5 of the channel so that both the transposed writes (16 lanes = 16 channel chunks, 4 channels apart) and
 // the fragment reads (16 consecutive channels) touch 16 distinct bank quads.
-template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false>
+// W4 (with TR): 4 | Wo, see prep().
+template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false, bool W4 = false>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int tiles,
@@ -624,8 +625,27 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     // The gather offsets of a k-tile are computed one iteration ahead of its loads (`prep`), so that the loads
     // themselves are the first thing a loop iteration issues and have the whole MFMA stream to land under.
     unsigned offb[XK ? 4 * RB : NB];
+    // TR with 4 | Wo (every ResNet shape): a thread's 4 consecutive rows are 4 consecutive wo of ONE output row, so a
+    // k-tile costs one row decode and four adds instead of four decodes
+    static_assert(!W4 || TR, "W4 is a variant of the transposed staging");
     auto prep = [&](int kt) {
         const int mb = kt * BKM;
+        if constexpr (W4) {
+            const int m0 = mb + 4 * rb0;
+            const bool ok0 = tapok && actB && m0 < M;
+            const int mm = ok0 ? m0 : 0;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+            const int hi = ho * g.is + dh, wi0 = wo * g.is + dw;
+            const bool okh = ok0 && (unsigned)hi < (unsigned)g.Hi;
+            const int base = (((n - n_lo) * g.Hi + hi) * g.Wi + wi0) * g.Ci + coff;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const bool ok = okh && (unsigned)(wi0 + j * g.is) < (unsigned)g.Wi;
+                offb[j] = ok ? (unsigned)(base + j * g.is * g.Ci) * (unsigned)sizeof(TX) : kInvalidOff;
+            }
+            return;        // (1x1 stride-1 layers are this form too: dh = dw = 0, is = 1)
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int m = TR ? mb + 4 * rb0 + j : mb + rb0 + SB * j;
@@ -1223,13 +1243,20 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                      \
         static bool attr_done = false;                                                                          \
         if (!attr_done) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true>,        \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, false>, \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, true>,  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
             attr_done = true;                                                                                   \
         }                                                                                                       \
-        hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true>), grid, block, lds, st, g,     \
-                           (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes,        \
-                           dy_bytes);                                                                           \
+        if (g.Wo % 4 == 0)                                                                                      \
+            hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, true>), grid, block, lds,  \
+                               st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps,       \
+                               in_bytes, dy_bytes);                                                             \
+        else                                                                                                    \
+            hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, false>), grid, block, lds, \
+                               st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps,       \
+                               in_bytes, dy_bytes);                                                             \
     } while (0)
 #define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
     do {                                                                               \
