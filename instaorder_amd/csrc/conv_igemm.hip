@@ -529,7 +529,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // ds_read_b32 (24 instead of 136 LDS instructions per thread and k-tile).  The 16-byte chunk index is XORed with
 // bits 4..5 of the channel so that both the transposed writes (16 lanes = 16 channel chunks, 4 channels apart) and
 // the fragment reads (16 consecutive channels) touch 16 distinct bank quads.
-// W4 (with TR): 4 | Wo, see prep().
+// W4: the row decode of prep() shared by a thread's rows -- with TR: 4 | Wo (4 consecutive wo); without TR: 32 | Wo (the
+// 32 rows of a k-tile lie in one output row, whose (n, ho) is wave-uniform).
 template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false, bool W4 = false>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
@@ -627,10 +628,26 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     unsigned offb[XK ? 4 * RB : NB];
     // TR with 4 | Wo (every ResNet shape): a thread's 4 consecutive rows are 4 consecutive wo of ONE output row, so a
     // k-tile costs one row decode and four adds instead of four decodes
-    static_assert(!W4 || TR, "W4 is a variant of the transposed staging");
+    static_assert(!W4 || STEM == 0, "W4: regular convolutions");
     auto prep = [&](int kt) {
         const int mb = kt * BKM;
-        if constexpr (W4) {
+        if constexpr (W4 && !TR) {
+            const bool ok0 = tapok && mb < M;                  // uniform: scalar decode of the k-tile's first row
+            const int mm = ok0 ? mb : 0;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo_b = rem - ho * g.Wo;
+            const int hi = ho * g.is + dh;
+            const bool okh = ok0 && (unsigned)hi < (unsigned)g.Hi;
+            const int base = (((n - n_lo) * g.Hi + hi) * g.Wi + dw) * g.Ci + coff;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int wis = (wo_b + rb0 + SB * j) * g.is;
+                const bool ok = okh && (unsigned)(wis + dw) < (unsigned)g.Wi;
+                offb[j] = ok ? (unsigned)(base + wis * g.Ci) * (unsigned)sizeof(TX) : kInvalidOff;
+            }
+            return;
+        }
+        if constexpr (W4 && TR) {
             const int m0 = mb + 4 * rb0;
             const bool ok0 = tapok && actB && m0 < M;
             const int mm = ok0 ? m0 : 0;
@@ -1246,14 +1263,24 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     }
     const double Md = (double)g.N * g.Ho * g.Wo;
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
+    // 64-wide tiles (row layout): scalar row decode per k-tile when 32 | Wo.  Measured on the 64-channel 3x3 layer:
+    // 104 -> 113 TF/s; the 1x1 stride-1 layers (HBM-bound, already without per-row divisions) gain nothing from it
+    const bool lin1x1 = g.Th * g.Tw == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+    const bool w32 = !stem && !lin1x1 && g.Wo % 32 == 0;
     IoProfScope prof(stem ? IO_PROF_WGRAD_STEM : IO_PROF_WGRAD, 2.0 * Md * g.Co * kred,
                      io_dtype_bytes(dt_dy) * Md * g.Co + io_dtype_bytes(dt_in) * (double)g.N * g.Hi * g.Wi * g.Ci +
                          4.0 * g.Co * kred, st);
 #define IO_LAUNCH_WG(TX_, TDY_, BMO_, BNC_, STEM_)                                                              \
     do {                                                                                                        \
         const size_t lds = (size_t)2 * 32 * (BMO_ + BNC_) * sizeof(float);                                      \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, STEM_>), grid, block, lds, st, g,          \
-                           (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes, dy_bytes); \
+        if (STEM_ == 0 && w32)                                                                                  \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, 0, false, true>), grid, block, lds, st, \
+                               g, (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes,    \
+                               dy_bytes);                                                                       \
+        else                                                                                                    \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TX_, TDY_, BMO_, BNC_, STEM_>), grid, block, lds, st, g,      \
+                               (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes,       \
+                               dy_bytes);                                                                       \
     } while (0)
 #define IO_LAUNCH_WGT(BMO_, BNC_)                                                                               \
     do {                                                                                                        \
