@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     // TR: ra0 / rb0 number the 4-row groups of a k-tile (8 of them); with 64-wide tiles only half the threads stage
     const bool actA = !TR || ra0 < BKM / 4, actB = !TR || rb0 < BKM / 4;
 
-    constexpr bool XK = STEM == 2;
+    constexpr bool XK = STEM >= 2;            // exact-K stem; STEM == 3: 32 | Wo (uniform row decode per k-tile)
     static_assert(!XK || sizeof(TX) == 4, "the exact-K stem gathers fp32 dwords");
     int dh = 0, dw = 0, widx = 0, coff = 0;
     bool tapok = true;
@@ -666,7 +666,28 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int m = TR ? mb + 4 * rb0 + j : mb + rb0 + SB * j;
-            if constexpr (XK) {
+            if constexpr (STEM == 3) {
+                if (j == 0) {
+                    // 32 | Wo: the k-tile's 32 rows lie in one output row -- (n, ho) decoded once on the scalar unit,
+                    // the 4 taps of this thread's columns checked once for both of its rows
+                    const bool ok0 = mb < M;
+                    const int mm = ok0 ? mb : 0;
+                    const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+                    const int ho = fdiv(rem, g.fd_wo), wo_b = rem - ho * g.Wo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int hi = ho * g.is + xdh[i];
+                        const bool okh = ok0 && xok[i] && (unsigned)hi < (unsigned)g.Hi;
+                        const int base = (((n - n_lo) * g.Hi + hi) * g.Wi + xdw[i]) * g.Ci + xch[i];
+#pragma unroll
+                        for (int jj = 0; jj < RB; ++jj) {
+                            const int wis = (wo_b + rb0 + SB * jj) * g.is;
+                            const bool ok = okh && (unsigned)(wis + xdw[i]) < (unsigned)g.Wi;
+                            offb[4 * jj + i] = ok ? (unsigned)(base + wis * g.Ci) * 4u : kInvalidOff;
+                        }
+                    }
+                }
+            } else if constexpr (XK) {
                 const bool rok = m < M;
                 const int mm = rok ? m : 0;
                 const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
@@ -1312,7 +1333,10 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                       \
     } while (0)
     if (stem && dt_in == IO_F32) {
-        if (g.cr) {
+        if (g.cr && g.Wo % 32 == 0) {
+            if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 3);
+            else IO_LAUNCH_WG(float, float, 64, 64, 3);
+        } else if (g.cr) {
             if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 2);
             else IO_LAUNCH_WG(float, float, 64, 64, 2);
         } else if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 1);
