@@ -67,6 +67,9 @@ CONV_CASES = [
     (2, 16, 16, 256, 512, 1, 2, 0),     # strided 1x1 downsample
     (2, 8, 8, 512, 2048, 1, 1, 0),
     (1, 8, 8, 512, 512, 3, 1, 1),
+    (1, 32, 32, 64, 64, 3, 1, 1),       # 32 | Wo: scalar row decode of the 64-wide filter-gradient tiles
+    (1, 64, 64, 64, 128, 3, 2, 1),      # the same through a strided 3x3 with a 128 x 64 tile
+    (1, 12, 12, 256, 128, 3, 1, 1),     # 4 | Wo on 128 x 128 tiles with rows that wrap inside a k-tile (Wo = 12)
 ]
 
 
