@@ -104,8 +104,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // STEM: 0 regular conv, 1 stem on the packed x8 input (k = tap x 8 channels, 3 of them padding), 2 stem in exact-K
 // mode (fp32 only): k = tap * g.cr + channel over the real channels, gathered one dword at a time, filters pre-packed
 // as [Co][kp] -- 8 k-tiles instead of 13 for the 7x7 / 5-channel stem.
-template <typename TA, typename TO, int BN, int STEM, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
+// NBUF = 1: single LDS buffer (a second barrier per k-tile) + MINB blocks per CU requested from the register allocator --
+// more tiles in flight per CU for the latency-bound bf16 shapes.
+template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1>
+__global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
                                                          const TO* __restrict__ mask, int ntn, size_t in_bytes,
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     static_assert(TJ >= 1 && BR >= 1, "tile too small for this wave count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                       // [2][BM][LDT]
-    float* sB = smem + 2 * BM * LDT;        // [2][BN][LDT]
+    float* sB = smem + NBUF * BM * LDT;     // [NBUF][BN][LDT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -319,7 +321,8 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
     __syncthreads();
     if (nk > 0) read_frags(0, 0, fa, fb);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = NBUF == 2 ? kt & 1 : 0;
+        const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         const bool more = kt + 1 < nk;
         advance(more);
         load_tile(more ? kt + 1 : kt);
@@ -334,10 +337,11 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
             for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(buf ^ 1);
+        if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
+        store_tile(nbuf);
         __syncthreads();
         f32x4 na[TI], nb[TJ];
-        read_frags(buf ^ 1, 0, na, nb);       // first fragments of tile kt+1 (unused after the last tile)
+        read_frags(nbuf, 0, na, nb);       // first fragments of tile kt+1 (unused after the last tile)
         __builtin_amdgcn_sched_barrier(0);
         mma16(fa, fb);                         // group 4 of tile kt, operands already in registers
 #pragma unroll
@@ -531,8 +535,9 @@ __global__ __launch_bounds__(NW * 64) void conv_nt_kernel(IoConvGeom g, const TA
 // the fragment reads (16 consecutive channels) touch 16 distinct bank quads.
 // W4: the row decode of prep() shared by a thread's rows -- with TR: 4 | Wo (4 consecutive wo); without TR: 32 | Wo (the
 // 32 rows of a k-tile lie in one output row, whose (n, ho) is wave-uniform).
-template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false, bool W4 = false>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
+template <typename TX, typename TDY, int BMO, int BNC, int STEM, bool TR = false, bool W4 = false, int NBUF = 2,
+          int MINB = 1>
+__global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_kernel(IoConvGeom g, const TX* __restrict__ in,
                                                              const TDY* __restrict__ dy,
                                                              float* __restrict__ dst, int ntile_c, int tiles,
                                                              int kps, size_t in_bytes, size_t dy_bytes) {
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     constexpr int NA = TR ? 4 : RA, NB = TR ? 4 : RB;  // 16-byte loads per thread and operand
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                                        // [2][BKM][BMO]   (TR: [2][BMO][LDT])
-    float* sB = smem + (TR ? 2 * BMO * LDT : 2 * BKM * BMO); // [2][BKM][BNC]   (TR: [2][BNC][LDT])
+    float* sB = smem + (TR ? NBUF * BMO * LDT : NBUF * BKM * BMO);   // [2][BKM][BNC]   (TR: [2][BNC][LDT])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -815,7 +820,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
     __syncthreads();
     if (kt0 < kt1) read_frags(0, 0, fa, fb);
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
+        const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
         __builtin_amdgcn_sched_barrier(0);
         prep(kt + 2 < kt1 ? kt + 2 : kt);           // rows past M read zeros anyway; clamp keeps it branch-free
@@ -833,10 +839,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(buf ^ 1);
+        if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
+        store_tile(nbuf);
         __syncthreads();
         float na[4][TI], nb[4][TJ];
-        read_frags(buf ^ 1, 0, na, nb);
+        read_frags(nbuf, 0, na, nb);
         __builtin_amdgcn_sched_barrier(0);
         mma16(fa, fb);
 #pragma unroll
@@ -883,8 +890,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(IoConvGeom g, cons
 // b128 minimum) and each global row still gets 128 contiguous bytes from 8 lanes.
 // Grid: 1-D, XCD-remapped so that the blocks of one m-range (all taps / channel tiles of a split) share an L2.
 // W8: 8 | Wo -- a thread's 8 rows are 8 consecutive wo of one output row: one row decode per k-tile instead of eight.
-template <int BMO, int BNC, bool STEM, bool W8 = false>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
+template <int BMO, int BNC, bool STEM, bool W8 = false, int NBUF = 2, int MINB = 1>
+__global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
                                                                   const bf16_t* __restrict__ dy,
                                                                   float* __restrict__ dst, int ntile_c, int tiles,
                                                                   int kps, size_t in_bytes, size_t dy_bytes) {
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                      // [2][BMO][LDT]
-    float* sB = smem + 2 * BMO * LDT;      // [2][BNC][LDT]
+    float* sB = smem + NBUF * BMO * LDT;   // [NBUF][BNC][LDT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1039,7 +1046,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
     __syncthreads();
     if (kt0 < kt1) read_frags(0, 0, fa, fb);
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
+        const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
@@ -1051,10 +1059,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_bf16_kernel(IoConvGeom g,
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
         }
-        store_tile(buf ^ 1);
+        if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
+        store_tile(nbuf);
         __syncthreads();
         f32x4 na[TI], nb[TJ];
-        read_frags(buf ^ 1, 0, na, nb);
+        read_frags(nbuf, 0, na, nb);
         mma(fa, fb);
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = na[i];
@@ -1203,7 +1212,6 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const int ntn = g.Co / bn;
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
-    const size_t lds = (size_t)2 * (128 + bn) * (bn == 64 ? 32 : 36) * sizeof(float);
     dim3 grid((unsigned)tiles), block(kThreads);
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
@@ -1212,38 +1220,44 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
                          (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
                      st);
-#define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_)                                                                   \
+#define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
     do {                                                                                                     \
+        const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_>,    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4>), grid, block, lds, st, g,               \
-                           (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add, (const TO_*)mask,    \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_>), grid, block, ldsz, st,   \
+                           g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add, (const TO_*)mask, \
                            ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);                          \
     } while (0)
+    // 128-wide tiles run single-buffered (36.9 KB of LDS, a second barrier per k-tile) with the register allocator held
+    // to three blocks per CU: three waves per SIMD keep the matrix pipe fuller than two even on the MFMA-bound layers
+    // (fp32 3x3 256->256: 132 -> 139 TF/s) and put more loads in flight on the short-K ones (same-box A/B over all
+    // ResNet-50 shapes: forward 46.2 -> 43.5 ms, data gradient 46.3 -> 44.0 ms in fp32; 11.5 -> 10.3 and 11.9 -> 10.7 ms
+    // in bf16).
     if (stem) {
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
         if (dt_in == IO_BF16) {
             IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
-            IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1);
+            IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1, 2, 1);
         } else if (dt_out == IO_BF16) {
-            IO_LAUNCH_NT(float, bf16_t, 64, 1);
+            IO_LAUNCH_NT(float, bf16_t, 64, 1, 2, 1);
         } else if (g.cr) {
-            IO_LAUNCH_NT(float, float, 64, 2);
+            IO_LAUNCH_NT(float, float, 64, 2, 2, 1);
         } else {
-            IO_LAUNCH_NT(float, float, 64, 1);
+            IO_LAUNCH_NT(float, float, 64, 1, 2, 1);
         }
     } else if (dt_in == IO_BF16) {
         IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
-        if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, 0);
-        else IO_LAUNCH_NT(bf16_t, bf16_t, 64, 0);
+        if (bn == 128) IO_LAUNCH_NT(bf16_t, bf16_t, 128, 0, 1, 3);
+        else IO_LAUNCH_NT(bf16_t, bf16_t, 64, 0, 1, 4);      // 64-wide: 24.6 KB, four blocks per CU
     } else {
         IO_REQUIRE(dt_out == IO_F32, IO_ERR_SHAPE, "conv_nt: fp32 operands write fp32 outputs (except the stem)");
-        if (bn == 128) IO_LAUNCH_NT(float, float, 128, 0);
-        else IO_LAUNCH_NT(float, float, 64, 0);
+        if (bn == 128) IO_LAUNCH_NT(float, float, 128, 0, 1, 3);
+        else IO_LAUNCH_NT(float, float, 64, 0, 1, 4);
     }
 #undef IO_LAUNCH_NT
     return io_check_launch("conv_nt");
@@ -1303,25 +1317,25 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                                (const TX_*)in, (const TDY_*)dy, dst, p.ntile_c, p.tiles, p.kps, in_bytes,       \
                                dy_bytes);                                                                       \
     } while (0)
-#define IO_LAUNCH_WGT(BMO_, BNC_)                                                                               \
+#define IO_LAUNCH_WGT_(BMO_, BNC_, W4_, NBUF_, MINB_)                                                           \
     do {                                                                                                        \
-        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                      \
+        const size_t lds = (size_t)NBUF_ * (BMO_ + BNC_) * 36 * sizeof(float);                                  \
         static bool attr_done = false;                                                                          \
         if (!attr_done) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, false>, \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, true>,  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            (void)hipFuncSetAttribute(                                                                          \
+                (const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, W4_, NBUF_, MINB_>,           \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                          \
             attr_done = true;                                                                                   \
         }                                                                                                       \
-        if (g.Wo % 4 == 0)                                                                                      \
-            hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, true>), grid, block, lds,  \
-                               st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps,       \
-                               in_bytes, dy_bytes);                                                             \
-        else                                                                                                    \
-            hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, false>), grid, block, lds, \
-                               st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles, p.kps,       \
-                               in_bytes, dy_bytes);                                                             \
+        hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, W4_, NBUF_, MINB_>), grid,     \
+                           block, lds, st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles,      \
+                           p.kps, in_bytes, dy_bytes);                                                          \
+    } while (0)
+#define IO_LAUNCH_WGT(BMO_, BNC_)                                                                               \
+    do {                                                                                                        \
+        /* single LDS buffer + three blocks per CU, as in the NT kernel: 3x3 layers 124 -> 128 TF/s */          \
+        if (g.Wo % 4 == 0) IO_LAUNCH_WGT_(BMO_, BNC_, true, 1, 3);                                              \
+        else IO_LAUNCH_WGT_(BMO_, BNC_, false, 1, 3);                                                           \
     } while (0)
 #define IO_LAUNCH_WG_SHAPES(TX_, TDY_)                                                 \
     do {                                                                               \
@@ -1348,25 +1362,24 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         dst = splits == 1 ? dw : partial;
         dim3 grid1((unsigned)(p.tiles * splits));
         const bool w8 = g.Wo % 8 == 0;       // measured: 3x3 / strided layers 400-470 -> 490-540 TF/s
-#define IO_LAUNCH_WGB(BMO_, BNC_, STEM_)                                                                         \
+#define IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, W8_, NBUF_, MINB_)                                                     \
     do {                                                                                                         \
-        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 36 * sizeof(float);                                       \
+        const size_t lds = (size_t)NBUF_ * (BMO_ + BNC_) * 36 * sizeof(float);                                   \
         static bool attr_done = false;                                                                           \
         if (!attr_done) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, false>,             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, !STEM_>,            \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, W8_, NBUF_, MINB_>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
             attr_done = true;                                                                                    \
         }                                                                                                        \
-        if (!STEM_ && w8)                                                                                        \
-            hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, !STEM_>), grid1, block, lds, st, g,    \
-                               (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes,   \
-                               dy_bytes);                                                                        \
-        else                                                                                                     \
-            hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, false>), grid1, block, lds, st, g,     \
-                               (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes,   \
-                               dy_bytes);                                                                        \
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, W8_, NBUF_, MINB_>), grid1, block, lds,    \
+                           st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64,          \
+                           in_bytes, dy_bytes);                                                                  \
+    } while (0)
+#define IO_LAUNCH_WGB(BMO_, BNC_, STEM_)                                                                         \
+    do {                                                                                                         \
+        /* (single-buffered with three blocks per CU, what the other GEMMs run, measured 15 % slower here) */    \
+        if (!STEM_ && w8) IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, !STEM_, 2, 1);                                       \
+        else IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, false, 2, 1);                                                     \
     } while (0)
         if (stem) IO_LAUNCH_WGB(64, 64, true);
         else if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGB(128, 128, false);
@@ -1374,11 +1387,13 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         else if (p.bnc == 128) IO_LAUNCH_WGB(64, 128, false);
         else IO_LAUNCH_WGB(64, 64, false);
 #undef IO_LAUNCH_WGB
+#undef IO_LAUNCH_WGB_
     } else {
         IO_LAUNCH_WG_SHAPES(float, float);
     }
 #undef IO_LAUNCH_WG_SHAPES
 #undef IO_LAUNCH_WGT
+#undef IO_LAUNCH_WGT_
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
