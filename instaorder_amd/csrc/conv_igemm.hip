@@ -1242,11 +1242,11 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(bn == 64, IO_ERR_SHAPE, "conv_nt(stem): Co must be 64");
         if (dt_in == IO_BF16) {
             IO_REQUIRE(dt_out == IO_BF16, IO_ERR_SHAPE, "conv_nt: bf16 operands write bf16 outputs");
-            IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1, 2, 1);
+            IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1, 1, 4);
         } else if (dt_out == IO_BF16) {
             IO_LAUNCH_NT(float, bf16_t, 64, 1, 2, 1);
         } else if (g.cr) {
-            IO_LAUNCH_NT(float, float, 64, 2, 2, 1);
+            IO_LAUNCH_NT(float, float, 64, 2, 1, 4);      // (3.3 -> 3.1 ms against the double-buffered form)
         } else {
             IO_LAUNCH_NT(float, float, 64, 1, 2, 1);
         }
