@@ -10,6 +10,6 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c -d /tmp/pmc_$c -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /tmp/pmc_$c.log 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pmc_$c 'conv_nt_kernel<float, float, 128, false' > $R/gpurun_out/traffic_$c.txt
+  python3 $R/tools/pmc_summary.py /tmp/pmc_$c 'conv_nt_kernel<float, float, 128, 0,' > $R/gpurun_out/traffic_$c.txt
 done
 cat $R/gpurun_out/traffic_FETCH_SIZE.txt $R/gpurun_out/traffic_WRITE_SIZE.txt
