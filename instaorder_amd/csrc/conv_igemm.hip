@@ -1131,7 +1131,7 @@ struct WgradPlan {
     int bmo, bnc, ntile_c, tiles, splits, kps;
 };
 
-WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
+WgradPlan plan_wgrad(const IoConvGeom& g, int stem, bool fp32 = true) {
     WgradPlan p;
     const long M = (long)g.N * g.Ho * g.Wo;
     p.bmo = (g.Co % 128 == 0) ? 128 : 64;
@@ -1150,10 +1150,13 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
         p.tiles = (g.Co / p.bmo) * g.Th * g.Tw * p.ntile_c;
     }
     if (p.tiles < 1) p.tiles = 1;               // unsupported channel counts are rejected by the launcher, not here
+    const bool fp32_tr = fp32 && !stem && !g.gw && p.bmo == 128 && p.bnc == 128;
     const int nkt = io_cdiv(M, 32);
     // 2 blocks fit a CU (LDS), so 512 run at once: fill at most two full rounds -- one block more than that would
     // cost a third, almost empty round (a 3x3 conv with 36 tiles: 29 splits = 1044 blocks ran 25 % slower than 28)
-    int want = 1024 / p.tiles;
+    // the fp32 128 x 128 kernel runs three blocks per CU (768 at once): one full round -- three for the layers with many
+    // tiles, whose blocks would otherwise be few and long (same-box A/B: +1..4 % per layer against 1024)
+    int want = (fp32_tr ? (p.tiles >= 128 ? 2304 : 768) : 1024) / p.tiles;
     int maxs = nkt / 8 > 0 ? nkt / 8 : 1;       // at least 8 k-tiles (256 rows) per split
     p.splits = want < maxs ? want : maxs;
     if (p.splits < 1) p.splits = 1;
@@ -1165,9 +1168,11 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem) {
 }  // namespace
 
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
-    WgradPlan p = plan_wgrad(g, stem);
-    if (p.splits == 1) return 0;
-    return (size_t)p.splits * g.Co * io_filter_row(g) * sizeof(float);
+    // sized for either storage type: the fp32 and the bf16 kernels split differently
+    const int s0 = plan_wgrad(g, stem, true).splits, s1 = plan_wgrad(g, stem, false).splits;
+    const int splits = s0 > s1 ? s0 : s1;
+    if (splits == 1) return 0;
+    return (size_t)splits * g.Co * io_filter_row(g) * sizeof(float);
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
@@ -1282,7 +1287,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     IO_REQUIRE(g.os == 1 && g.Ho == g.outH && g.Wo == g.outW, IO_ERR_SHAPE, "conv_wgrad: dY must be dense");
     IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co), IO_ERR_SHAPE,
                "conv_wgrad: grouped mode needs a 64-channel window and Ci == Co");
-    WgradPlan p = plan_wgrad(g, stem);
+    WgradPlan p = plan_wgrad(g, stem, dt_in == IO_F32 && dt_dy == IO_F32);
     const size_t need = io_conv_wgrad_partial_bytes(g, stem);
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
