@@ -575,18 +575,23 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
         // the previous block's bn3.  With one, the mask is idempotent and is applied by both kernels (the
         // strided one only touches its own output lattice).
-        if (!b.down && ii > 0 && tiles_ok(c, Min)) {
-            const Block& pb = net->blocks[ii - 1];
-            IoBwStats bw = bw_for(c, pb.b3, c.act(p.blk[ii - 1].y3), Min, false);
-            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, Gd, xmask, H, &bw));
-            have_tiles = true;
-        } else {
-            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, b.down ? nullptr : Gd, xmask, H));
-        }
+        // With a downsample branch its (strided) data gradient goes FIRST into d(x_in) -- the lattice classes it
+        // does not reach are written as zeros -- so that conv1's dense stride-1 data gradient is again the launch
+        // that completes d(x_in) and can carry the previous block's bn3 reductions there too.
+        const void* partial = Gd;          // what conv1's data gradient accumulates onto: the identity path ...
         if (b.down) {
             IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.act(bb.yd), Mout, Ga, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
-            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, Ge, xmask, H));
+            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, nullptr, nullptr, H));
+            partial = Ge;                  // ... or the downsample path
+        }
+        if (ii > 0 && tiles_ok(c, Min)) {
+            const Block& pb = net->blocks[ii - 1];
+            IoBwStats bw = bw_for(c, pb.b3, c.act(p.blk[ii - 1].y3), Min, false);
+            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, partial, xmask, H, &bw));
+            have_tiles = true;
+        } else {
+            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, partial, xmask, H));
         }
         void* t = Gd; Gd = Ge; Ge = t;
     }
