@@ -70,6 +70,7 @@ CONV_CASES = [
     (1, 32, 32, 64, 64, 3, 1, 1),       # 32 | Wo: scalar row decode of the 64-wide filter-gradient tiles
     (1, 64, 64, 64, 128, 3, 2, 1),      # the same through a strided 3x3 with a 128 x 64 tile
     (1, 12, 12, 256, 128, 3, 1, 1),     # 4 | Wo on 128 x 128 tiles with rows that wrap inside a k-tile (Wo = 12)
+    (8, 64, 64, 128, 512, 1, 1, 0),     # 1024 tiles of a 1x1 GEMM: the grid that keeps the two-block NT build
 ]
 
 
