@@ -112,11 +112,16 @@ class FlatSGD(torch.optim.Optimizer):
     def gather_grads(self):
         """Per-tensor autograd gradients -> the flat gradient buffer (missing gradients count as zero)."""
         with torch.no_grad():
+            dst, src = [], []
             for p, (off, k) in zip(self._params, self._spans):
                 if p.grad is None:
                     self.flat_grads[off:off + k].zero_()
                 else:
-                    self.flat_grads[off:off + k].copy_(p.grad.reshape(-1))
+                    dst.append(self.flat_grads[off:off + k].view(p.shape))
+                    src.append(p.grad)
+            if dst:
+                # one multi-tensor copy instead of a launch per parameter (680 tensors in InstaDepthNet_od)
+                torch._foreach_copy_(dst, src)
         return self.flat_grads
 
     @torch.no_grad()
