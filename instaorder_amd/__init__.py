@@ -3,7 +3,7 @@
 Public surface mirrors the reference's ``models`` / ``utils`` packages for this path:
 
     from instaorder_amd import InstaOrderNet_o, InstaOrderNet_od, InstaOrderNet_d, OrderNet
-    from instaorder_amd import InstaDepthNet_od, InstaDepthNet_d       # MiDaS-based nets (midas_net.py)
+    from instaorder_amd import InstaDepthNet_od, InstaDepthNet_d       # MiDaS-based nets (midas_net.py; MidasNet there too)
     from instaorder_amd import backbone            # backbone.resnet50_cls
     from instaorder_amd import utils               # DistModule, average_gradients, StepLRScheduler, ...
     from instaorder_amd import evaluate            # tools/test.py Tester loops (P / R / F1, WHDR) over the batched drivers

@@ -105,7 +105,7 @@ def evaluate(model, data_reader, load_image, data_cfg, order_method, pairs="all"
             elif order_method == "yaxis":   # :314-318
                 pred_dep = infer.infer_depth_order_yaxis(modal, closer="lower" if dataset in ("COCOA", "InstaOrder")
                                                          else "higher")
-            elif order_method in ("InstaOrderNet_d", "InstaDepthNet_d"):
+            elif order_method in ("InstaOrderNet_d", "InstaDepthNet_d", "midas_pretrained"):
                 pred_dep, _ = infer.infer_order_sup_depth(model, image, modal, boxes, pairs, order_method, mode, size,
                                                           disp_select_method)
             else:

@@ -447,8 +447,35 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
     with ``disp_select_method`` 'mean' / 'median' the order comes from the predicted disparity instead of the head)."""
     if method == "InstaOrderNet_d":
         return _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size)["depth_order"], None
+    if method == "midas_pretrained":
+        # inference.py:583-590: `model` is the bare MidasNet; the order comes from its disparity under the two masks
+        dev = next(model.parameters()).device
+        if patch_or_image == "resize":
+            rgb, masks = resize_mode_inputs(dev, image, inmodal, input_size)
+        elif patch_or_image == "image" and image.shape[0] == image.shape[1] == input_size:
+            from .synthetic import image_mode_inputs
+            rgb, masks = image_mode_inputs(image, inmodal, input_size)
+            rgb, masks = torch.from_numpy(rgb).to(dev), torch.from_numpy(masks)
+        else:
+            raise NotImplementedError("midas_pretrained: patch_or_image='resize', or 'image' on square images of the "
+                                      "network size")
+        with torch.no_grad():
+            disp = model(rgb.to(dev)).squeeze().float()
+        clipped = torch.clip(disp, torch.quantile(disp, 0.05), torch.quantile(disp, 0.95))
+        masks_np = masks.cpu().numpy() if torch.is_tensor(masks) else masks
+        n = inmodal.shape[0]
+        order = np.zeros((n, n), dtype=np.int64)
+        for i, j in select_pairs(inmodal, pairs):
+            a = net_forward_midas_pretrained(disp, masks_np[i], masks_np[j], disp_select_method)
+            if a == 0:
+                order[i, j], order[j, i] = 1, 0
+            elif a == 1:
+                order[i, j], order[j, i] = 0, 1
+            else:
+                order[i, j] = order[j, i] = 2
+        return order, clipped
     if method not in ("InstaDepthNet_d", "InstaDepthNet_od"):
-        raise ValueError("method name should be one of {InstaOrderNet_d, InstaDepthNet_d, InstaDepthNet_od}")
+        raise ValueError("method name should be one of {InstaOrderNet_d, midas_pretrained, InstaDepthNet_d, InstaDepthNet_od}")
     # the batched MiDaS path runs the encoder once per IMAGE, which needs one image shared by all pairs
     plist = select_pairs(inmodal, pairs)
     if patch_or_image == "resize":              # what the reference's InstaDepthNet configs use (config.yaml:51)

@@ -343,3 +343,18 @@ class InstaDepthNet_d(_InstaDepthBase):
             with _BnMode(groups=2):
                 depth_order = self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
         return disp, depth_order, None
+
+
+class MidasNet(_InstaDepthBase):
+    """midas_net.py:215-277: MiDaS v2.1 alone -- ResNeXt-101 32x8d encoder + RefineNet decoder + output head;
+    ``forward(x[B,3,H,W])`` -> disparity [B,H,W].  Same ``pretrained.*`` / ``scratch.*`` state_dict keys as the reference
+    (``model-f6b98070.pt`` loads through ``load``); the method 'midas_pretrained' of tools/test.py:139-146 and
+    inference.py:583-590."""
+
+    def __init__(self, path=None, features=256, num_classes=3, non_negative=True):
+        super(MidasNet, self).__init__(path, features, non_negative)
+
+    def forward(self, x):
+        with _Counters():
+            disp, _ = self._encode_decode(x)
+        return disp

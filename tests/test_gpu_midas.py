@@ -280,3 +280,41 @@ def test_folded_inference_cache_follows_the_weights():
     with torch.no_grad():
         c1 = m.model(*args)[0]
     assert torch.equal(c1, a1)                   # original weights again -> original output
+
+
+def test_midasnet_alone_and_midas_pretrained_method():
+    """midas/midas_net.py:215-277: MidasNet (encoder + decoder + head) shares its state_dict keys with the MiDaS part of
+    InstaDepthNet_d, whose disparity is pinned by the reference golden -- with the shared tensors copied over, its output
+    is that disparity bit for bit; the 'midas_pretrained' method (inference.py:583-590, tools/test.py:139-146) orders
+    instances from it."""
+    from instaorder_amd import inference, midas_net
+    algo, tag = CASES[1]
+    g, spec = load(tag)
+    m, t = build(algo, g, spec)
+    m.switch_to("eval")
+    net = midas_net.MidasNet(None, non_negative=True).cuda()
+    sd = m.model.state_dict()
+    own = net.state_dict()
+    shared = {k: sd["module." + k] if ("module." + k) in sd else sd[k] for k in own}
+    assert len(shared) == len(own) and all(k.startswith(("pretrained.", "scratch.")) for k in own)
+    net.load_state_dict(shared, strict=True)
+    net.eval()
+    with torch.no_grad():
+        disp = net(t["rgb"].cuda())
+        want = m.model(t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())[0]
+    assert disp.shape == want.shape and torch.equal(disp, want)
+    assert rel_err(disp.cpu().numpy(), g["eval_disp"]) < 1e-3
+    # the method: depth order of every pair from the mean / median disparity under the masks
+    sc = synthetic.SyntheticReader(33, n_images=1, n_inst=4, empty_every=0).scenes[0]
+    order, clipped = inference.infer_order_sup_depth(net, sc["image"], sc["modal"], sc["bboxes"], "all",
+                                                     "midas_pretrained", "resize", 64, "median")
+    assert order.shape == (4, 4) and clipped.shape == (64, 64)
+    from oracle import preprocess_oracle as po
+    rgb = torch.from_numpy(po.transform_resize(sc["image"], 64, 64))[None].cuda()
+    masks = np.stack([po.resize(mm, (64, 64), po.INTER_NEAREST) for mm in sc["modal"]])
+    with torch.no_grad():
+        d2 = net(rgb).squeeze().float()
+    for i in range(4):
+        for j in range(i + 1, 4):
+            a = inference.net_forward_midas_pretrained(d2, masks[i], masks[j], "median")
+            assert (order[i, j], order[j, i]) == {0: (1, 0), 1: (0, 1), 2: (2, 2)}[a]
