@@ -316,3 +316,25 @@ def test_evaluate_heuristics_equal_reference_tester(k):
         for key in evaluate.WHDR_KEYS:
             ovl, eq = key.split("_")
             assert abs(res["WHDR_" + key] - float(z["%s_log_val_%s.WHDR_%s" % (name, ovl, eq)])) < 1e-9
+
+
+def test_harness_helpers(tmp_path):
+    """AverageMeter (running / windowed), accuracy@k and create_logger of utils/common_utils.py:66-126."""
+    from instaorder_amd import common_utils as cu
+    m = cu.AverageMeter()
+    for v in (1.0, 2.0, 6.0):
+        m.update(v)
+    assert m.val == 6.0 and m.avg == 3.0 and m.count == 3
+    w = cu.AverageMeter(2)
+    for v in (1.0, 2.0, 6.0):
+        w.update(v)
+    assert w.val == 6.0 and w.avg == 4.0 and w.history == [2.0, 6.0]
+    out = torch.tensor([[0.1, 0.7, 0.2], [0.6, 0.3, 0.1], [0.2, 0.3, 0.5], [0.5, 0.4, 0.1]])
+    tgt = torch.tensor([1, 1, 2, 2])
+    a1, a2 = cu.accuracy(out, tgt, topk=(1, 2))
+    assert float(a1) == 50.0 and float(a2) == 75.0
+    lg = cu.create_logger("io_test_logger", str(tmp_path / "log.txt"))
+    lg.info("hello")
+    for h in lg.handlers:
+        h.flush()
+    assert "hello" in open(str(tmp_path / "log.txt")).read()
