@@ -392,7 +392,11 @@ def test_nccl_single_rank_dp_path():
     from instaorder_amd import distributed_utils as du
     import instaorder_amd as ia
     algo = "InstaOrderNet_o"
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     du.dist_init_("pytorch", backend="nccl")
     try:
         batch = synthetic.make_pair_batch(970, 4, 64)
