@@ -94,7 +94,24 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path when several ranks must share one GPU)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak (default, the reference's "
+                    "semantics: batch_size is per process, InstaOrderNet_o/config.yaml:49) = --batch pairs per GPU; "
+                    "strong = --batch is the GLOBAL pair batch, each of the N ranks takes batch / N of it")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the reference starts its
+    # own workers from one command (main.py:28-35).  The parent has not touched the GPU (no HIP call, no torch
+    # import yet), runs torch.distributed.run as a CHILD process and exits with its code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+            "HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     import numpy as np
     import torch
@@ -113,6 +130,9 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     B, S = args.batch, args.size
+    if args.scaling == "strong":
+        assert B % world == 0, "--scaling strong: the global batch %d must divide by %d ranks" % (B, world)
+        B //= world
     depthnet = args.algo.startswith("InstaDepthNet")
     if depthnet:
         # BASELINE configs[4] (secondary workload): the MiDaS-based net, loss weights of the reference's own
@@ -236,7 +256,7 @@ def main():
         "metric": "instance-pairs/sec (fwd+bwd)" if args.mode == "train" else "instance-pairs/sec (%s)" % args.mode,
         "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": "%s, pair-batch %d per GPU at %dx%dx5, %s, %s "
                                "(BASELINE.json configs[%d])" % (args.algo, B, S, S, args.dtype,
                                                                 {"train": "fwd+bwd+SGD", "fwd": "forward+loss, train mode",

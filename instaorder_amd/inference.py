@@ -126,14 +126,26 @@ def select_pairs(inmodal, pairs):
     raise ValueError("pairs must be 'all' or 'nbor', got %r" % (pairs,))
 
 
-def _heads(method):
+def _heads(method, net=None):
     if method in ("InstaOrderNet_od",):
         return 2, 3
     if method in ("InstaOrderNet_o",):
         return 2, 0
     if method in ("InstaOrderNet_d",):
         return 0, 3
-    raise ValueError("method name should be one of InstaOrderNet_o / InstaOrderNet_od / InstaOrderNet_d")
+    if method == "OrderNet":        # one softmax head of 3 (1>2, 2>1, none) or 4 (+ both: OrderNet_ext) classes
+        return 0, (int(net.head_dims[0]) if net is not None else 3)
+    raise ValueError("method name should be one of OrderNet / InstaOrderNet_o / InstaOrderNet_od / InstaOrderNet_d")
+
+
+def decide_ordernet(logits1, logits2):
+    """net_forward_OrderNet (inference.py:44-76) for P pairs: softmax of both mask orders, direction-averaged class
+    probabilities (1 over 2, 2 over 1, none[, both]), argmax -> the two occlusion booleans."""
+    o1, o2 = torch.softmax(logits1, 1), torch.softmax(logits2, 1)
+    cols = [(o1[:, 1] + o2[:, 0]) / 2, (o1[:, 0] + o2[:, 1]) / 2, (o1[:, 2] + o2[:, 2]) / 2]
+    cols.append((o1[:, 3] + o2[:, 3]) / 2 if o1.shape[1] == 4 else torch.zeros_like(cols[0]))
+    idx = torch.stack(cols, 1).argmax(1)          # first maximum wins, as np.argmax does
+    return {"i_over_j": (idx == 0) | (idx == 3), "j_over_i": (idx == 1) | (idx == 3)}
 
 
 def decide(logits1, logits2, kocc, kdep):
@@ -200,7 +212,7 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
     With ``world_size > 1`` the pair list is sharded contiguously across ranks
     (``distributed_utils.shard_range``) and the tiny per-pair decisions are all-gathered."""
     net = model.net
-    kocc, kdep = _heads(method)
+    kocc, kdep = _heads(method, net)
     n = masks.shape[0]
     pairs = upper_pairs(n) if pairs is None else list(pairs)
     P = len(pairs)
@@ -253,7 +265,10 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
         dist.all_gather(gathered, both)
         both = torch.cat(gathered, 0)[:P]
         l1, l2 = both[:, :K], both[:, K:]
-    dec = decide(l1, l2, kocc, kdep)
+    ordernet = method == "OrderNet"
+    dec = decide_ordernet(l1, l2) if ordernet else decide(l1, l2, kocc, kdep)
+    if ordernet:
+        kocc, kdep = 2, 0                # an occlusion matrix only
     occ = np.zeros((n, n), dtype=np.int64)
     dep = np.zeros((n, n), dtype=np.int64)
     host = {k: v.cpu().numpy() for k, v in dec.items()}      # one D2H for the whole image
@@ -518,7 +533,8 @@ def eval_order_recall_precision_f1(order_matrix, gt_order_matrix, zd=0):
     fn = float(np.sum((y == 1) & (p != 1)))
     recall = tp / (tp + fn) if tp + fn > 0 else float(zd)
     precision = tp / (tp + fp) if tp + fp > 0 else float(zd)
-    f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else float(zd)
+    # sklearn: zero_division only when there is nothing to count at all; tp = 0 with errors present is F1 = 0
+    f1 = 2 * tp / (2 * tp + fp + fn) if 2 * tp + fp + fn > 0 else float(zd)
     return recall * 100, precision * 100, f1 * 100
 
 

@@ -321,7 +321,8 @@ def recall_precision_f1(order, gt, zero_division=0):
     fn = float(((y == 1) & (p != 1)).sum())
     rec = tp / (tp + fn) if tp + fn > 0 else float(zero_division)
     pre = tp / (tp + fp) if tp + fp > 0 else float(zero_division)
-    f1 = 2 * pre * rec / (pre + rec) if pre + rec > 0 else float(zero_division)
+    # sklearn applies zero_division to F1 only when tp + fp + fn == 0; tp = 0 beside errors is F1 = 0
+    f1 = 2 * tp / (2 * tp + fp + fn) if 2 * tp + fp + fn > 0 else float(zero_division)
     return rec * 100, pre * 100, f1 * 100
 
 

@@ -380,6 +380,61 @@ def case_decisions(tag):
     print(tag, np.array(res_o)[:4].tolist(), np.array(res_od)[:4].tolist())
 
 
+def case_decisions_ordernet(tag):
+    """net_forward_OrderNet (inference.py:44-76) on crafted 3- and 4-class logits incl. ties, and the reference's
+    sklearn-based eval_order_recall_precision_f1 (inference.py:794-802) on matrices that hit every zero-division
+    corner (no positives at all; tp = 0 beside false positives / negatives) with zd = 0 and 1."""
+    import inference as infer
+    rng = np.random.RandomState(9)
+    n = 48
+    out = {}
+    for K in (3, 4):
+        a = rng.uniform(-1, 1, (n, K)).astype(np.float32)
+        b = rng.uniform(-1, 1, (n, K)).astype(np.float32)
+        a[0], b[0] = 0.25, 0.25                                   # all classes tie -> index 0 (1 over 2)
+        a[1], b[1] = [0, 0, 1] + [0] * (K - 3), [0, 0, 1] + [0] * (K - 3)
+        if K == 4:
+            a[2], b[2] = [0, 0, 0, 2], [0, 0, 0, 2]               # both
+            a[3], b[3] = [0, 0, 1, 1], [0, 0, 1, 1]               # none ties both -> none
+
+        class Fake:
+            calls, k = 0, 0
+
+            def model(self, x):
+                first = self.calls % 2 == 0
+                self.calls += 1
+                return torch.from_numpy((a if first else b)[self.k:self.k + 1])
+
+        fk, res = Fake(), []
+        img, mk = torch.zeros(1, 3, 8, 8), np.zeros((8, 8), np.float32)
+        for k in range(n):
+            fk.k, fk.calls = k, 0
+            res.append(infer.net_forward_OrderNet(fk, img, mk, mk))
+        out["l1_%d" % K], out["l2_%d" % K], out["res_%d" % K] = a, b, np.array(res).astype(np.int64)
+    gts, prs, scores = [], [], []
+    cases = [([[-1, 0], [0, -1]], [[0, 0], [0, 0]]),      # nothing to count at all
+             ([[-1, 1], [0, -1]], [[0, 0], [1, 0]]),      # tp = 0, fp = 1, fn = 1 (pair predicted the wrong way round)
+             ([[-1, 1], [1, -1]], [[0, 0], [0, 0]]),      # tp = 0, fn = 2, no predicted positive
+             ([[-1, 0], [0, -1]], [[0, 1], [1, 0]]),      # tp = 0, fp = 2, no true positive
+             ([[-1, 1], [0, -1]], [[0, 1], [0, 0]])]      # perfect
+    for gt, pr in cases:
+        gt, pr = np.array(gt), np.array(pr)
+        gts.append(gt)
+        prs.append(pr)
+        scores.append([infer.eval_order_recall_precision_f1(pr, gt, zd) for zd in (0, 1)])
+    for nn in (4, 7):
+        for _ in range(6):
+            gt, pr = rng.randint(-1, 2, (nn, nn)), rng.randint(0, 2, (nn, nn))
+            gts.append(np.pad(gt, ((0, 7 - nn), (0, 7 - nn)), constant_values=-1))
+            prs.append(np.pad(pr, ((0, 7 - nn), (0, 7 - nn))))
+            scores.append([infer.eval_order_recall_precision_f1(pr, gt, zd) for zd in (0, 1)])
+    gts = [np.pad(g, ((0, 7 - g.shape[0]), (0, 7 - g.shape[0])), constant_values=-1) for g in gts]
+    prs = [np.pad(p, ((0, 7 - p.shape[0]), (0, 7 - p.shape[0]))) for p in prs]
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), gt=np.stack(gts), pred=np.stack(prs),
+                        scores=np.array(scores, np.float64), **out)
+    print(tag, out["res_3"][:3].tolist(), out["res_4"][:4].tolist(), np.array(scores)[:5].tolist())
+
+
 # ---- MiDaS-based nets (SURVEY 8(a) row a25) -----------------------------------------------------------------------------
 DEPTH_LOSS_WEIGHTS = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1,
                           occ_order_weight=1.0)
@@ -710,6 +765,7 @@ CASES = {
     "plumbing_od": lambda: case_plumbing("InstaOrderNet_od", 19, 2, 4, 256, 6, "plumbing_od"),
     "scheduler": lambda: case_scheduler("scheduler"),
     "decisions": lambda: case_decisions("decisions"),
+    "decisions_ordernet": lambda: case_decisions_ordernet("decisions_ordernet"),
     "depthnet_od_S64_B2": lambda: case_depthnet("InstaDepthNet_od", 64, 2, 31, "depthnet_od_S64_B2"),
     "depthnet_d_S64_B2": lambda: case_depthnet("InstaDepthNet_d", 64, 2, 32, "depthnet_d_S64_B2"),
 }

@@ -1,0 +1,228 @@
+"""BASELINE.json configs[3] and configs[4] at their own shapes, and the N > 1 data-parallel path on the HIP engine.
+
+* configs[3]: InstaOrderNet_od, 20-instance images (190 pairs each), the pair list sharded by rank for 8 ranks.  One
+  GPU plays the 8 ranks in turn: (a) inference -- every rank's shard through ``infer_order_batched``, the union must be
+  the unsharded result bit for bit; (b) training -- every rank's shard through forward + loss/8 + backward, the SUM of
+  the 8 rank gradients (what the RCCL all-reduce delivers, utils/distributed_utils.py:27-31) against the CPU oracle
+  doing the same, in fp32 (tight) and in bf16 (the dtype configs[3] names; the bf16 bar of tests/test_gpu_bf16.py).
+* two ranks for real: tests/dp_worker.py under torch.distributed.run -- RCCL when the box has two GPUs, otherwise gloo
+  with both ranks on GPU 0 -- against the golden the REAL reference produced on two ranks.
+* configs[4]: InstaDepthNet_od at 384 x 384, fp32 and bf16, against oracle/midas_oracle.py (pinned at 64 x 64 by the
+  reference goldens of tests/test_gpu_midas.py; the oracle is size-agnostic)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ALGO_CLASSES, GOLDEN, ROOT, orc, rel_err, synthetic
+
+pytestmark = pytest.mark.gpu
+WORLD8 = 8
+
+
+def _cfg(algo, dtype="fp32"):
+    return dict(algo=algo, lr=1e-4, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype=dtype,
+                backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
+                distinct_weight=0.9)
+
+
+def _build(algo, seed, dtype="fp32", damp=False):
+    import instaorder_amd as ia
+    m = getattr(ia, algo)(_cfg(algo, dtype), dist_model=False)
+    sd = synthetic.make_state_dict(seed, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+    if damp:      # well-conditioned net for the bf16 comparison (tests/test_gpu_bf16.py explains why)
+        for k in sd:
+            if k.endswith("bn3.weight"):
+                sd[k] = (sd[k] * 0.1).astype(np.float32)
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return m, sd
+
+
+def _image20(seed, S):
+    item = synthetic.make_images(seed, 1, 20, S)[0]
+    rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
+    return torch.from_numpy(rgb), torch.from_numpy(masks)
+
+
+def test_config3_pair_list_sharded_over_8_ranks_inference():
+    from instaorder_amd import distributed_utils as du, inference
+    algo, S = "InstaOrderNet_od", 256
+    m, _ = _build(algo, 301)
+    m.switch_to("eval")
+    rgb, masks = _image20(4242, S)
+    pairs = inference.upper_pairs(20)
+    assert len(pairs) == 190
+    whole = inference.infer_order_batched(m, rgb, masks, algo, return_logits=True)
+    got = []
+    for r in range(WORLD8):
+        beg, end, sub = du.shard_range(len(pairs), WORLD8, r)
+        assert sub == 24 and end - beg == 24
+        mine = [pairs[k % len(pairs)] for k in range(beg, end)]          # rank 7 wraps around: 2 padding pairs
+        res = inference.infer_order_batched(m, rgb, masks, algo, pairs=mine, return_logits=True)
+        got.append(res["pair_logits"])
+    union = np.concatenate(got, 0)
+    assert union.shape[0] == 192
+    # eval mode has no cross-sample coupling: a pair's logits do not depend on which batch it rides in
+    assert np.array_equal(union[:190], whole["pair_logits"])
+    assert np.array_equal(union[190:], whole["pair_logits"][:2])         # the wrap-around duplicates
+    # matrices rebuilt from the gathered logits = the unsharded matrices
+    l = torch.from_numpy(union[:190])
+    dec = inference.decide(l[:, :5], l[:, 5:], 2, 3)
+    occ, dep = np.zeros((20, 20), np.int64), np.zeros((20, 20), np.int64)
+    for k, (i, j) in enumerate(pairs):
+        occ[i, j], occ[j, i] = int(dec["i_over_j"][k]), int(dec["j_over_i"][k])
+        d = int(dec["depth"][k])
+        dep[i, j], dep[j, i] = {0: (1, 0), 1: (0, 1), 2: (2, 2)}[d]
+    assert (occ == whole["occ_order"]).all() and (dep == whole["depth_order"]).all()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config3_sharded_training_step_equals_oracle_sum(dtype):
+    """8 ranks x 24 pairs of one 20-instance image: per-rank loss / 8, gradients SUMMED over ranks (the all-reduce),
+    rank-local BatchNorm statistics -- HIP path vs the CPU oracle on the same shards."""
+    from instaorder_amd import distributed_utils as du, engine, inference
+    algo, S = "InstaOrderNet_od", 64
+    m, sd = _build(algo, 302, dtype, damp=(dtype == "bf16"))
+    m.world_size = WORLD8                         # loss / world_size, as on a real 8-rank job
+    m.switch_to("train")
+    m.optim.param_groups[0]["lr"] = 0.0
+    rgb, masks = _image20(4243, S)
+    pairs = inference.upper_pairs(20)
+    rng = np.random.RandomState(5)
+    st0 = {k: v.clone() for k, v in m.model.state_dict().items()}
+    gsum = torch.zeros_like(m.net.flat_grads)
+    osum, losses = None, []
+    for r in range(WORLD8):
+        beg, end, _ = du.shard_range(len(pairs), WORLD8, r)
+        mine = [pairs[k % len(pairs)] for k in range(beg, end)]
+        ii, jj = [a for a, _ in mine], [b for _, b in mine]
+        B = len(mine)
+        batch = dict(rgb=rgb.expand(B, 3, S, S).contiguous().numpy(), modal1=masks[ii][:, None].numpy(),
+                     modal2=masks[jj][:, None].numpy(), occ_order=(rng.rand(B, 2) < 0.3).astype(np.float32),
+                     depth_order=rng.randint(0, 3, B).astype(np.int64), count=np.full(B, 2, np.float32),
+                     is_overlap=(rng.rand(B) < 0.5).astype(np.int64))
+        t = {k: torch.from_numpy(v.copy()) for k, v in batch.items()}
+        m.model.load_state_dict(st0)              # every rank starts the step from the same (broadcast) state
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+        _, hl, ws = m._fwd_loss_bwd(2 * B, S)       # forward (two BN groups) + loss / 8 + backward, no collective
+        m.net._pool.give(ws)
+        out = {"loss": hl[0]}
+        gsum += m.net.flat_grads
+        state = orc.state_from_numpy(sd, prefix="module.")
+        ologs, grads = orc.train_step(state, {}, batch, algo, 0.0, 0.0, world_size=WORLD8)
+        losses.append((float(out["loss"]), float(ologs["loss"])))
+        osum = grads if osum is None else {k: osum[k] + grads[k] for k in grads}
+    tol = 1e-3 if dtype == "fp32" else 1e-2
+    for got, ref in losses:
+        assert abs(got - ref) < tol * abs(ref), (got, ref)
+    # summed gradient: per-tensor views of the flat buffer against the oracle's sum
+    m.net.flat_grads.copy_(gsum)
+    m.net.attach_grads()
+    names = orc.param_names(orc.state_from_numpy(sd, prefix="module."))
+    num = da = db = 0.0
+    errs = []
+    for n, p in zip(names, m.net.parameters()):
+        a, b = p.grad.detach().cpu().double().reshape(-1), osum[n].double().reshape(-1)
+        num += float(a @ b)
+        da += float(a @ a)
+        db += float(b @ b)
+        errs.append(abs(float(a.norm()) - float(b.norm())) / max(float(b.norm()), 1e-30))
+    cos, ratio = num / (da * db) ** 0.5, (da / db) ** 0.5
+    print("config3 %s: summed-gradient cosine %.5f, norm ratio %.4f, median per-tensor norm err %.2e"
+          % (dtype, cos, ratio, float(np.median(errs))))
+    if dtype == "fp32":
+        assert cos > 0.999 and abs(ratio - 1) < 0.01 and np.median(errs) < 0.02
+    else:
+        assert cos > 0.97 and abs(ratio - 1) < 0.05
+
+
+def test_two_ranks_step_matches_reference_golden(tmp_path):
+    """Two real ranks through ``step()``: RCCL over two GPUs when the box has them, gloo with both ranks on GPU 0
+    otherwise.  Each rank checks itself against the reference's two-rank golden (tests/dp_worker.py); here: both
+    ranks end with bit-identical weights, and those weights moved."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    res = []
+    for r in range(2):
+        f = tmp_path / ("rank%d.json" % r)
+        assert f.exists(), "rank %d wrote no result\n%s\n%s" % (r, p.stdout[-2000:], p.stderr[-4000:])
+        res.append(json.load(open(f)))
+    for r in res:
+        assert r["ok"], r.get("error")
+    assert p.returncode == 0, p.stderr[-4000:]
+    print("two-rank step over", res[0]["backend"], "on", res[0]["ngpu"], "GPU(s)")
+    p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
+    g0, g1 = np.load(tmp_path / "grads_rank0.npy"), np.load(tmp_path / "grads_rank1.npy")
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
+    assert np.abs(g0).sum() > 0
+
+
+# ---- configs[4]: InstaDepthNet_od at 384 x 384 -----------------------------------------------------------------
+W4 = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1, occ_order_weight=1.0)
+
+
+def _depthnet(dtype, S, B, seed=11):
+    import instaorder_amd as ia
+    g = np.load(os.path.join(GOLDEN, "depthnet_od_S64_B2.npz"), allow_pickle=False)
+    spec = [(str(k), tuple(int(d) for d in str(s).split(",") if d), (str(a) or None))
+            for k, s, a in zip(g["keys"], g["shapes"], g["aliases"])]
+    cfg = dict(algo="InstaDepthNet_od", lr=1e-5, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True,
+               dtype=dtype, **W4)
+    m = ia.InstaDepthNet_od(cfg, dist_model=False)
+    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    batch = synthetic.make_depth_batch(seed + 100, B, S)
+    return m, sd, batch
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config4_depthnet_384(dtype):
+    from oracle import midas_oracle as mo
+    S, B = 384, 2
+    m, sd, batch = _depthnet(dtype, S, B)
+    t = {k: torch.from_numpy(v.copy()) for k, v in batch.items()}
+    st = mo.state_from_numpy(sd, prefix="module.")
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    # eval forward, both mask orders
+    m.switch_to("eval")
+    with torch.no_grad():
+        d, dep, occ = m.model(t["rgb"].cuda(), t["modal1"].cuda(), t["modal2"].cuda())
+        od, odep, oocc = mo.forward(st, t["rgb"], t["modal1"], t["modal2"], False)
+    assert d.shape == (B, S, S)
+    e = (rel_err(d.float().cpu().numpy(), od.numpy()), rel_err(dep.float().cpu().numpy(), odep.numpy()),
+         rel_err(occ.float().cpu().numpy(), oocc.numpy()))
+    print("config4 %s eval 384^2 rel err (disp, depth logits, occ logits): %.2e %.2e %.2e" % ((dtype,) + e))
+    assert max(e) < (1e-3 if dtype == "fp32" else 5e-2)
+    # one training step: all five loss terms and the gradient norm against the oracle's two-pass step
+    m.switch_to("train")
+    m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+    logs, l = m.step()
+    st = mo.state_from_numpy(sd, prefix="module.")
+    o1 = mo.forward(st, t["rgb"], t["modal1"], t["modal2"], True)
+    o2 = mo.forward(st, t["rgb"], t["modal2"], t["modal1"], True)
+    ologs, total = mo.losses(o1, o2, t, W4)
+    total.backward()
+    tol = 2e-3 if dtype == "fp32" else 3e-2
+    for k, v in logs.items():
+        ref = float(ologs[k])
+        ktol = 5e-3 if (k == "loss_disp_order" and dtype == "fp32") else tol
+        if k == "loss_disp_order" and dtype == "bf16":
+            continue                  # a count of pixel comparisons between near-equal disparities: not a bf16 target
+        assert abs(float(v) - ref) <= ktol * max(1.0, abs(ref)), (k, float(v), ref)
+    uniq = {id(p): p for p in st.values() if p.requires_grad and p.grad is not None}      # aliased keys share a tensor
+    ref_gn = float(sum(float(p.grad.double().pow(2).sum()) for p in uniq.values()) ** 0.5)
+    gn = float(m.optim.flat_grads.double().norm())
+    print("config4 %s step 384^2: gradient norm %.5f (oracle %.5f)" % (dtype, gn, ref_gn))
+    assert abs(gn - ref_gn) < (0.03 if dtype == "fp32" else 0.1) * ref_gn

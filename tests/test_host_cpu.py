@@ -338,3 +338,38 @@ def test_harness_helpers(tmp_path):
     for h in lg.handlers:
         h.flush()
     assert "hello" in open(str(tmp_path / "log.txt")).read()
+
+
+def test_ordernet_decisions_and_f1_corners_match_reference_golden():
+    """net_forward_OrderNet (inference.py:44-76) for 3- and 4-class heads, and sklearn's zero-division corners of
+    eval_order_recall_precision_f1 (inference.py:794-802) -- tests/golden/decisions_ordernet.npz holds what the
+    reference's own functions returned (make_golden.py::case_decisions_ordernet)."""
+    g = load_golden("decisions_ordernet")
+    for K in (3, 4):
+        d = inference.decide_ordernet(torch.from_numpy(g["l1_%d" % K]), torch.from_numpy(g["l2_%d" % K]))
+        assert (d["i_over_j"].numpy().astype(np.int64) == g["res_%d" % K][:, 0]).all()
+        assert (d["j_over_i"].numpy().astype(np.int64) == g["res_%d" % K][:, 1]).all()
+    assert inference._heads("OrderNet") == (0, 3)
+    for gt, pr, sc in zip(g["gt"], g["pred"], g["scores"]):
+        for zi, zd in enumerate((0, 1)):
+            assert np.allclose(inference.eval_order_recall_precision_f1(pr, gt, zd), sc[zi]), (gt, pr, zd)
+            assert np.allclose(orc.recall_precision_f1(pr, gt, zd), sc[zi])
+    # the advisor's case: one pair predicted the wrong way round, zd = 1 -> F1 is 0, not 100
+    gt, pr = np.array([[-1, 1], [0, -1]]), np.array([[0, 0], [1, 0]])
+    assert inference.eval_order_recall_precision_f1(pr, gt, 1) == (0.0, 0.0, 0.0)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself (a torch.distributed.run
+    child, before any GPU call in the parent) and hand back the child's exit code.  There is no GPU here, so both ranks
+    stop at the loud no-GPU error of the product path -- which is the evidence that two ranks were started."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""           # also where a GPU exists: this test is about the launcher
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    assert err.count("no gfx950") >= 2, err[-3000:]          # one loud refusal per rank
