@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinstaorder_hip.so")
+# IO_LIB_PATH: a tuning build of the same library (csrc/Makefile VARIANT=...), for same-box A/B runs of kernel variants
+LIB_PATH = os.environ.get("IO_LIB_PATH") or os.path.join(_HERE, "libinstaorder_hip.so")
 _lib = None
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())

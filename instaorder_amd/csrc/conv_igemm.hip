@@ -24,6 +24,10 @@
 
 #include "io_common.h"
 
+#ifndef IO_BWE_MODE
+#define IO_BWE_MODE 2      // fused BN-backward epilogue of the NT kernel: 1 = generic addressing, 2.. = dense form
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -91,6 +95,22 @@ template <> __device__ __forceinline__ void st_el<float>(float v, __amdgpu_buffe
 template <> __device__ __forceinline__ void st_el<bf16_t>(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
     __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, 0, 0);
 }
+// the same with a wave-uniform (SGPR) offset added on top of the per-lane one.  NOTE: the scalar offset takes no part in
+// the bounds check of the descriptor -- only for accesses known to be in range.
+template <typename T> __device__ __forceinline__ float ld_el_s(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff);
+template <> __device__ __forceinline__ float ld_el_s<float>(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+}
+template <> __device__ __forceinline__ float ld_el_s<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    return io_bf2f(__builtin_amdgcn_raw_buffer_load_b16(r, off, soff, 0));
+}
+template <typename T> __device__ __forceinline__ void st_el_s(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff);
+template <> __device__ __forceinline__ void st_el_s<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, soff, 0);
+}
+template <> __device__ __forceinline__ void st_el_s<bf16_t>(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, soff, 0);
+}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------
@@ -106,7 +126,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // as [Co][kp] -- 8 k-tiles instead of 13 for the 7x7 / 5-channel stem.
 // NBUF = 1: single LDS buffer (a second barrier per k-tile) + MINB blocks per CU requested from the register allocator --
 // more tiles in flight per CU for the latency-bound bf16 shapes.
-template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1>
+// BWE: the instantiation that carries the fused BatchNorm-backward epilogue (bw.y); every other launch -- forward
+// convolutions, plain data gradients -- runs the BWE = false build, whose register allocation does not pay for it.
+template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc_at(mask ? (const void*)mask : (const void*)out, out_base, out_bytes);
     const __amdgpu_buffer_rsrc_t rs_bwy = make_rsrc_at(bw.y ? bw.y : (const void*)out, out_base, out_bytes);
     float bw_mu[TJ], bw_rs[TJ], bw_sc[TJ], bw_sh[TJ], bw_s1[TJ], bw_s2[TJ];
-    if (bw.y) {
+    if constexpr (BWE) {
         const int gcol = (m0 / bw.Mg) * g.Co + n0 + wn * (BN / WN) + (lane & 31);   // group is uniform per tile
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -415,7 +437,55 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             bw_s1[j] = 0.f;
             bw_s2[j] = 0.f;
         }
+#if IO_BWE_MODE >= 2
+        // The launcher guarantees a dense output and 128 | rows per group here: row m IS pixel m and no tile is
+        // partial, so there is nothing to validate.  One VGPR offset per lane; the 16 row steps of the accumulator
+        // layout ride in the scalar offset of the buffer instructions (no per-row offset registers, no selects).
+        const unsigned colb2 = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
+        const unsigned rowstep = (unsigned)g.Co * (unsigned)OS;
+        const unsigned lane_base = (unsigned)(m0 - opix_lo + wm * 64 + 4 * (lane >> 5)) * rowstep + colb2;
+        const __amdgpu_buffer_rsrc_t rs_add0 = add ? rs_add : make_rsrc(out, 0);
+        const __amdgpu_buffer_rsrc_t rs_mask0 = mask ? rs_mask : make_rsrc(out, 0);
+        const bool nomask = mask == nullptr;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned voff = lane_base + (unsigned)(i * 32) * rowstep + (unsigned)j * 32u * OS;
+                // All three tensors are fetched unconditionally -- a per-element "load or constant" on a runtime pointer
+                // makes hipcc branch around every load and drain the queue each time; an absent `add` / `mask` has a
+                // zero-length descriptor instead, whose loads return 0 without touching memory.
+                float av[16], mv[16], yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = ld_el_s<TO>(rs_bwy, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = ld_el_s<TO>(rs_add0, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = ld_el_s<TO>(rs_mask0, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + av[r];
+                    v = (mv[r] > 0.f || nomask) ? v : 0.f;
+                    if (bw.mscale) v = __builtin_fmaf(yv[r] - bw_mu[j], bw_sc[j], bw_sh[j]) > 0.f ? v : 0.f;
+                    bw_s1[j] += v;
+                    bw_s2[j] += v * ((yv[r] - bw_mu[j]) * bw_rs[j]);
+                    st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                }
+#if IO_BWE_MODE == 3
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+#if IO_BWE_MODE == 4
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#endif
     }
+#if IO_BWE_MODE >= 2
+    if constexpr (!BWE) {
+#else
+    {
+#endif
     float ep_bias[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) ep_bias[j] = bw.bias ? bw.bias[n0 + wn * (BN / WN) + j * 32 + (lane & 31)] : 0.f;
@@ -467,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
             }
         }
-        if (bw.y) {
+        if constexpr (BWE) {
             // BN-backward reductions of the producer BN of this gradient tensor (see IoBwStats)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
@@ -495,7 +565,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             }
         }
     }
-    if (bw.y) {
+    }   // generic epilogue
+    if constexpr (BWE) {
         __syncthreads();
         float* red = smem;                   // [2 sums][2 row-waves][BN]
 #pragma unroll
@@ -1185,6 +1256,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg % 128 == 0), IO_ERR_SHAPE,
                    "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group");
     }
+    IO_REQUIRE(!(stem && bws.y), IO_ERR_SHAPE, "conv_nt: the stem has no BatchNorm-backward epilogue");
     IO_REQUIRE((st_mean == nullptr) == (st_m2 == nullptr), IO_ERR_SHAPE, "conv_nt: statistics outputs come in pairs");
     IO_REQUIRE(!st_mean || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && !add && !mask), IO_ERR_SHAPE,
                "conv_nt: fused statistics need a plain dense forward convolution");
@@ -1225,18 +1297,24 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
                          (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
                      st);
-#define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
+#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_)                                               \
     do {                                                                                                     \
         const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_>,    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                \
+            (void)hipFuncSetAttribute(                                                                       \
+                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_>,                    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                      \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_>), grid, block, ldsz, st,   \
-                           g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add, (const TO_*)mask, \
-                           ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);                          \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_>), grid, block, ldsz, \
+                           st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,               \
+                           (const TO_*)mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);        \
+    } while (0)
+#define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
+    do {                                                                                                     \
+        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0));            \
+        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false);                                       \
     } while (0)
     // 128-wide tiles run single-buffered (36.9 KB of LDS, a second barrier per k-tile) with the register allocator held
     // to three blocks per CU: three waves per SIMD keep the matrix pipe fuller than two even on the MFMA-bound layers
@@ -1268,6 +1346,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         else IO_LAUNCH_NT(float, float, 64, 0, 1, 4);
     }
 #undef IO_LAUNCH_NT
+#undef IO_LAUNCH_NT_
     return io_check_launch("conv_nt");
 }
 

@@ -105,6 +105,28 @@ def make_state_dict(seed, in_channels=5, num_classes=2, gain=0.02, prefix="", st
     return out
 
 
+def make_checkpoint_state(seed, in_channels=5, num_classes=2, prefix="module."):
+    """Seeded content of a mid-training checkpoint: trained-like weights, NON-trivial BatchNorm buffers (running mean /
+    variance, per-layer step counters) and one momentum buffer per parameter, in ``named_parameters`` order -- what
+    ``{'step','state_dict','optimizer'}`` of single_stage_model.py:66-72 carries.  Returns (state_dict, momentum list,
+    lr, step): tests/golden/make_golden.py::case_checkpoint pours it into the REFERENCE model + its torch.optim.SGD and
+    lets the reference write the file; the tests pour it into this package's model."""
+    sd = make_state_dict(seed, in_channels, num_classes, prefix=prefix, style="kaiming")
+    rng = np.random.RandomState(seed + 7919)
+    mom = []
+    for (name, shape, kind) in state_specs(in_channels, num_classes):
+        k = prefix + name
+        if kind == "bn_mean":
+            sd[k] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif kind == "bn_var":
+            sd[k] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif kind == "bn_count":
+            sd[k] = np.array(rng.randint(1, 1000), dtype=np.int64).reshape(shape)
+        else:
+            mom.append((1e-3 * rng.standard_normal(shape)).astype(np.float32))
+    return sd, mom, 3.3e-4, 4321
+
+
 def _mask(rng, S):
     """One filled rectangle or ellipse covering 5-40 % of an SxS image."""
     area = rng.uniform(0.05, 0.40) * S * S

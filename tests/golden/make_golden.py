@@ -435,6 +435,67 @@ def case_decisions_ordernet(tag):
     print(tag, out["res_3"][:3].tolist(), out["res_4"][:4].tolist(), np.array(scores)[:5].tolist())
 
 
+def case_checkpoint(tag):
+    """single_stage_model.py:54-72 / common_utils.py:128-149: a checkpoint WRITTEN BY THE REFERENCE (its own
+    ``save_state`` on its own model + torch.optim.SGD, filled with instaorder_amd.synthetic.make_checkpoint_state) is
+    loaded into the instaorder_amd model here, on the CPU, through ``load_state(..., resume=True)``; the digest of what
+    arrived in the flat buffers is the fixture (the 190 MB file itself is not).  The reverse direction is asserted
+    on the spot: a file written by the package's ``save_state`` loads into the reference model + optimiser, bit-exact."""
+    import shutil
+    import tempfile
+    import instaorder_amd as ia
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import checkpoint_digest              # the definition the tests use
+    algo, seed = "InstaOrderNet_od", 51
+    m, cfg = build(algo, seed, style="kaiming")
+    sd, mom, lr, step = synthetic.make_checkpoint_state(seed, 5, [2, 3])
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    params = m.optim.param_groups[0]["params"]
+    assert len(params) == len(mom) == 163
+    for p, b in zip(params, mom):
+        assert tuple(p.shape) == b.shape
+        m.optim.state[p]["momentum_buffer"] = torch.from_numpy(b.copy())
+    m.optim.param_groups[0]["lr"] = lr
+    d = tempfile.mkdtemp()
+    try:
+        m.save_state(d, step)                                            # the reference writes the file
+        ck = torch.load(os.path.join(d, "ckpt_iter_%d.pth.tar" % step), map_location="cpu", weights_only=False)
+        layout = dict(keys=np.array(list(ck["state_dict"].keys())),
+                      shapes=np.array([",".join(str(x) for x in v.shape) for v in ck["state_dict"].values()]),
+                      dtypes=np.array([str(v.dtype) for v in ck["state_dict"].values()]),
+                      group_keys=np.array(sorted(k for k in ck["optimizer"]["param_groups"][0] if k != "params")),
+                      n_state=np.int64(len(ck["optimizer"]["state"])),
+                      state_keys=np.array(sorted(ck["optimizer"]["state"][0].keys())))
+        mine = ia.InstaOrderNet_od(dict(cfg, dtype="fp32"), dist_model=False)
+        assert mine.load_state(d, step, resume=True) is None             # (the wrapper returns nothing, as the reference)
+        dg = checkpoint_digest(mine)
+        # ... and the values really are the seeded ones, tensor by tensor
+        for (k, v), (k2, v2) in zip(mine.model.state_dict().items(), sd.items()):
+            assert k == k2 and np.array_equal(v.cpu().numpy(), v2), k
+        for v, b in zip(mine.optim._views, mom):
+            assert np.array_equal(v.cpu().numpy(), b)
+        # reverse: package -> reference
+        d2 = tempfile.mkdtemp()
+        mine.save_state(d2, step + 1)
+        m2, _ = build(algo, seed + 1, style="xavier")
+        # the reference maps every storage with .cuda() (common_utils.py:129-130); no GPU here: identity, as the shims
+        # above already do for tensors and modules
+        torch.UntypedStorage.cuda = lambda self, *a, **k: self
+        torch.storage.TypedStorage.cuda = lambda self, *a, **k: self
+        m2.load_state(d2, step + 1, resume=True)
+        for (k, v), v2 in zip(m2.model.state_dict().items(), sd.values()):
+            assert np.array_equal(v.numpy(), v2), k
+        for p, b in zip(m2.optim.param_groups[0]["params"], mom):
+            assert np.array_equal(m2.optim.state[p]["momentum_buffer"].numpy(), b)
+        assert m2.optim.param_groups[0]["lr"] == lr
+        shutil.rmtree(d2)
+    finally:
+        shutil.rmtree(d)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), meta=np.array([seed, step]), **layout,
+                        **{k: (np.array(v) if isinstance(v, str) else v) for k, v in dg.items()})
+    print(tag, dg["sha_params"][:16], dg["sha_momentum"][:16], "lr", float(dg["lr"]))
+
+
 # ---- MiDaS-based nets (SURVEY 8(a) row a25) -----------------------------------------------------------------------------
 DEPTH_LOSS_WEIGHTS = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1,
                           occ_order_weight=1.0)
@@ -766,6 +827,7 @@ CASES = {
     "scheduler": lambda: case_scheduler("scheduler"),
     "decisions": lambda: case_decisions("decisions"),
     "decisions_ordernet": lambda: case_decisions_ordernet("decisions_ordernet"),
+    "checkpoint_od": lambda: case_checkpoint("checkpoint_od"),
     "depthnet_od_S64_B2": lambda: case_depthnet("InstaDepthNet_od", 64, 2, 31, "depthnet_od_S64_B2"),
     "depthnet_d_S64_B2": lambda: case_depthnet("InstaDepthNet_d", 64, 2, 32, "depthnet_d_S64_B2"),
 }

@@ -61,3 +61,35 @@ def eval_logits_oracle(state, batch):
     if isinstance(o, tuple):
         return torch.cat(o, 1).numpy()
     return o.numpy()
+
+
+def checkpoint_digest(model):
+    """sha256 of the package model's flat buffers (parameters in its KRSC storage layout, BN running statistics, step
+    counters, momentum) + per-tensor norms of parameters and momentum in logical OIHW order."""
+    import hashlib
+    net, opt = model.net, model.optim
+    h = lambda t: hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()   # noqa: E731
+    norm = lambda ts: np.array([float(t.detach().double().norm()) for t in ts])                        # noqa: E731
+    opt._ensure_buf()
+    return dict(sha_params=h(net.flat_params), sha_running=h(net.flat_running), sha_nbt=h(net._nbt),
+                sha_momentum=h(opt._buf), param_norms=norm([p for _, p in net._param_list]),
+                momentum_norms=norm(opt._views), lr=np.float64(opt.param_groups[0]["lr"]))
+
+
+def write_reference_layout_checkpoint(path, golden, sd, mom, lr, step):
+    """A checkpoint file with EXACTLY the structure the reference's save_state produced when
+    tests/golden/checkpoint_od.npz was made (state_dict key order / shapes / dtypes, torch.optim.SGD param-group keys,
+    one momentum_buffer per parameter), filled with the seeded values."""
+    from collections import OrderedDict
+    state = OrderedDict()
+    for k, shp, dt in zip(golden["keys"], golden["shapes"], golden["dtypes"]):
+        v = torch.from_numpy(np.array(sd[str(k)]))
+        assert ",".join(str(x) for x in v.shape) == str(shp) and str(v.dtype) == str(dt), k
+        state[str(k)] = v
+    defaults = dict(lr=lr, momentum=0.9, dampening=0, weight_decay=1e-4, nesterov=False, maximize=False, foreach=None,
+                    differentiable=False, fused=None, initial_lr=1e-4)
+    group = {str(k): defaults[str(k)] for k in golden["group_keys"] if str(k) in defaults}
+    group["params"] = list(range(len(mom)))
+    opt = {"state": {i: {"momentum_buffer": torch.from_numpy(b.copy())} for i, b in enumerate(mom)},
+           "param_groups": [group]}
+    torch.save({"step": step, "state_dict": state, "optimizer": opt}, path)

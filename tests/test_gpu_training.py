@@ -63,3 +63,40 @@ def test_step_is_bitwise_deterministic(dtype):
     for a, c in zip(results[0][:3], results[1][:3]):
         assert torch.equal(a, c)
     assert results[0][3] == results[1][3]
+
+
+def test_reference_written_checkpoint_on_device(tmp_path):
+    """The seeded content of the reference-written checkpoint (tests/golden/checkpoint_od.npz, see
+    tests/test_host_cpu.py::test_reference_written_checkpoint_digest) loaded on the GPU gives the committed digest;
+    saved and re-loaded by this package it still does, and two models resumed from it take bit-identical steps."""
+    import numpy as np
+    import instaorder_amd as ia
+    from helpers import checkpoint_digest, load_golden, synthetic, write_reference_layout_checkpoint
+    g = load_golden("checkpoint_od")
+    seed, step = (int(v) for v in g["meta"])
+    sd, mom, lr, _ = synthetic.make_checkpoint_state(seed, 5, [2, 3])
+    write_reference_layout_checkpoint(str(tmp_path / ("ckpt_iter_%d.pth.tar" % step)), g, sd, mom, lr, step)
+    cfg = dict(algo="InstaOrderNet_od", lr=1e-4, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=[2, 3]), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    models = []
+    for rnd in range(2):
+        m = ia.InstaOrderNet_od(cfg, dist_model=False)
+        assert m.net.flat_params.is_cuda
+        m.load_state(str(tmp_path), step, resume=True)
+        dg = checkpoint_digest(m)
+        for k in ("sha_params", "sha_running", "sha_nbt", "sha_momentum"):
+            assert dg[k] == str(g[k]), (rnd, k)
+        assert dg["lr"] == float(g["lr"])
+        if rnd == 0:                      # second round loads what THIS package wrote from the loaded state
+            m.save_state(str(tmp_path), step)
+        models.append(m)
+    batch = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_pair_batch(77, 4, 64).items()}
+    for m in models:
+        m.switch_to("train")
+        m.set_input(batch["rgb"], batch["modal1"], batch["modal2"], batch["depth_order"], batch["count"],
+                    batch["is_overlap"], batch["occ_order"])
+        m.step()
+    assert torch.equal(models[0].net.flat_params, models[1].net.flat_params)
+    assert torch.equal(models[0].optim._buf, models[1].optim._buf)
+    assert not np.array_equal(models[0].net.flat_params.cpu().numpy()[:1000], np.zeros(1000, np.float32))

@@ -373,3 +373,44 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert p.returncode != 0
     err = p.stderr + p.stdout
     assert err.count("no gfx950") >= 2, err[-3000:]          # one loud refusal per rank
+
+
+def _od_cfg():
+    return dict(algo="InstaOrderNet_od", lr=1e-4, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+                backbone_param=dict(in_channels=5, num_classes=[2, 3]), use_rgb=True, overlap_weight=0.1,
+                distinct_weight=0.9)
+
+
+def test_reference_written_checkpoint_digest(tmp_path):
+    """tests/golden/checkpoint_od.npz is the digest of what ``load_state(..., resume=True)`` put into this package's
+    flat buffers from a file the REFERENCE's own save_state wrote (single_stage_model.py:66-72; made in the build
+    container by make_golden.py::case_checkpoint, which also loads a package-written file back into the reference).
+    Here the same seeded content, in a file with exactly the structure the reference produced, must give that digest."""
+    import instaorder_amd as ia
+    from helpers import checkpoint_digest, write_reference_layout_checkpoint
+    g = load_golden("checkpoint_od")
+    seed, step = (int(v) for v in g["meta"])
+    sd, mom, lr, step2 = synthetic.make_checkpoint_state(seed, 5, [2, 3])
+    assert step2 == step and len(mom) == int(g["n_state"]) == 163
+    path = str(tmp_path / ("ckpt_iter_%d.pth.tar" % step))
+    write_reference_layout_checkpoint(path, g, sd, mom, lr, step)
+    m = ia.InstaOrderNet_od(_od_cfg(), dist_model=False)
+    m.load_state(str(tmp_path), step, resume=True)
+    dg = checkpoint_digest(m)
+    for k in ("sha_params", "sha_running", "sha_nbt", "sha_momentum"):
+        assert dg[k] == str(g[k]), k
+    assert np.array_equal(dg["param_norms"], g["param_norms"]) and np.array_equal(dg["momentum_norms"], g["momentum_norms"])
+    assert dg["lr"] == float(g["lr"]) == lr
+    # and what this package writes has the reference's structure, entry for entry
+    out = tmp_path / "out"
+    out.mkdir()
+    m.save_state(str(out), 9)
+    ck = torch.load(str(out / "ckpt_iter_9.pth.tar"), map_location="cpu", weights_only=False)
+    assert list(ck["state_dict"].keys()) == [str(k) for k in g["keys"]]
+    assert [",".join(str(x) for x in v.shape) for v in ck["state_dict"].values()] == [str(s) for s in g["shapes"]]
+    assert [str(v.dtype) for v in ck["state_dict"].values()] == [str(d) for d in g["dtypes"]]
+    grp = ck["optimizer"]["param_groups"][0]
+    for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov"):
+        assert k in grp
+    assert grp["params"] == list(range(163)) and len(ck["optimizer"]["state"]) == 163
+    assert sorted(ck["optimizer"]["state"][0].keys()) == [str(k) for k in g["state_keys"]]
