@@ -435,6 +435,81 @@ def case_decisions_ordernet(tag):
     print(tag, out["res_3"][:3].tolist(), out["res_4"][:4].tolist(), np.array(scores)[:5].tolist())
 
 
+BWD_TENSORS = ["conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer1.0.bn2.weight",
+               "layer1.0.downsample.0.weight", "layer1.2.conv3.weight", "layer2.0.conv2.weight", "layer2.0.bn3.bias",
+               "layer2.0.downsample.0.weight", "layer2.3.conv1.weight", "layer3.0.conv1.weight", "layer3.2.bn1.weight",
+               "layer3.5.conv2.weight", "layer3.5.conv3.weight", "layer4.0.conv2.weight", "layer4.0.downsample.1.weight",
+               "layer4.2.conv1.weight", "layer4.2.conv3.weight", "fc.weight", "fc.bias"]
+BWD_MAX = 1 << 16         # elements stored per tensor (an evenly strided subset of larger ones)
+
+
+def bwd_subset(n):
+    return np.arange(n) if n <= BWD_MAX else (np.arange(BWD_MAX, dtype=np.int64) * n) // BWD_MAX
+
+
+def case_backward(tag, algo="InstaOrderNet_o", S=64, B=16, seed=61, pre=10, lr=None):
+    """Backward parity on the REAL network (ReLUs switching) in a WELL-CONDITIONED state.  At a random initialisation
+    the reference's own fp32 gradients sit 1-2 % from an fp64 evaluation of the same graph, whatever the batch
+    (DESIGN.md section 4); ten SGD steps of the reference's recipe away from its initialisation (xavier gain 0.02,
+    lr 1e-3, momentum 0.9, wd 1e-4) they agree to ~1e-6.  So: `pre` reference steps in fp32, then the gradient of one
+    more batch twice -- in fp32 (what the reference ships) and in fp64 from the same weights (the anchor).  Stored per
+    parameter tensor: the fp64 gradient norm, the reference's fp32-vs-fp64 distance, norms of the pre-stepped weights
+    (so that a test can rebuild that state with the CPU oracle and check it), and the fp64 gradient itself (rounded to
+    fp32) on BWD_TENSORS."""
+    m, cfg = build(algo, seed, style="xavier")
+    if lr is not None:          # (InstaOrderNet_od's config starts at 1e-4, where ten steps do not get far enough)
+        cfg = dict(cfg, lr=lr)
+        for g in m.optim.param_groups:
+            g["lr"] = lr
+    m.switch_to("train")
+    for it in range(pre):
+        set_input(m, algo, synthetic.make_pair_batch(seed + 300 + it, B, S))
+        m.step()
+    state = {k: v.detach().clone() for k, v in m.model.state_dict().items()}
+
+    def run(double):
+        mm, _ = build(algo, seed, style="xavier")
+        if double:
+            mm.model.double()
+        mm.model.load_state_dict({k: (v.double() if (double and v.is_floating_point()) else v.clone())
+                                  for k, v in state.items()}, strict=True)
+        batch = synthetic.make_pair_batch(seed + 100, B, S)
+        if double:
+            batch = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in batch.items()}
+        mm.switch_to("train")
+        for g in mm.optim.param_groups:
+            g["lr"] = 0.0
+        set_input(mm, algo, batch)
+        logs = unpack_step(mm.step())
+        return logs, [(k[len("module."):], p.grad.detach().double().numpy().copy()) for k, p in mm.model.named_parameters()]
+    l32, g32 = run(False)
+    l64, g64 = run(True)
+    names = [k for k, _ in g64]
+    n64 = np.array([np.sqrt((g * g).sum()) for _, g in g64])
+    dist = np.array([np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-300)
+                     for (_, a), (_, b) in zip(g32, g64)])
+    _, pn, ps = snapshot(m, "p")
+    rm, rv, nb = snapshot(m, "bn")
+    out = dict(names=np.array(names), norms64=n64, ref_dist=dist, loss32=np.float64(l32["loss"]),
+               loss64=np.float64(l64["loss"]), meta=np.array([S, B, seed, pre]), tensors=np.array(BWD_TENSORS),
+               lr=np.float64(cfg["lr"]), weight_decay=np.float64(cfg["weight_decay"]),
+               pre_param_norms=pn, pre_param_samples=ps, pre_running_mean=rm, pre_running_var=rv)
+    d32 = dict(g32)
+    tensors = [k for k in BWD_TENSORS + ["fc_occ.weight", "fc_occ.bias", "fc_depth.weight", "fc_depth.bias"] if k in names]
+    out["tensors"] = np.array(tensors)
+    for k, g in g64:
+        if k in tensors:
+            idx = bwd_subset(g.size)
+            sub64, sub32 = g.reshape(-1)[idx], d32[k].reshape(-1)[idx]
+            out["g64/" + k] = sub64.astype(np.float32)
+            out["refsub/" + k] = np.float64(np.sqrt(((sub32 - sub64) ** 2).sum()) / np.sqrt((sub64 ** 2).sum()))
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, "loss32 %.7f loss64 %.7f" % (l32["loss"], l64["loss"]),
+          "reference fp32-vs-fp64 gradient distance per tensor: median %.2e max %.2e" % (np.median(dist), dist.max()))
+    for k in tensors:
+        print("   %-32s ref dist %.2e (subset %.2e)" % (k, dist[names.index(k)], float(out["refsub/" + k])))
+
+
 def case_checkpoint(tag):
     """single_stage_model.py:54-72 / common_utils.py:128-149: a checkpoint WRITTEN BY THE REFERENCE (its own
     ``save_state`` on its own model + torch.optim.SGD, filled with instaorder_amd.synthetic.make_checkpoint_state) is
@@ -828,6 +903,8 @@ CASES = {
     "decisions": lambda: case_decisions("decisions"),
     "decisions_ordernet": lambda: case_decisions_ordernet("decisions_ordernet"),
     "checkpoint_od": lambda: case_checkpoint("checkpoint_od"),
+    "backward_o_S64_B16": lambda: case_backward("backward_o_S64_B16"),
+    "backward_od_S128_B16": lambda: case_backward("backward_od_S128_B16", "InstaOrderNet_od", 128, 16, 62, 10, 1e-3),
     "depthnet_od_S64_B2": lambda: case_depthnet("InstaDepthNet_od", 64, 2, 31, "depthnet_od_S64_B2"),
     "depthnet_d_S64_B2": lambda: case_depthnet("InstaDepthNet_d", 64, 2, 32, "depthnet_d_S64_B2"),
 }

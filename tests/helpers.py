@@ -93,3 +93,46 @@ def write_reference_layout_checkpoint(path, golden, sd, mom, lr, step):
     opt = {"state": {i: {"momentum_buffer": torch.from_numpy(b.copy())} for i, b in enumerate(mom)},
            "param_groups": [group]}
     torch.save({"step": step, "state_dict": state, "optimizer": opt}, path)
+
+
+def prestepped_oracle_state(g, algo):
+    """The well-conditioned state of tests/golden/backward_*.npz rebuilt with the CPU oracle: reference initialisation
+    statistics + `pre` SGD steps of the reference recipe on the seeded batches (make_golden.py::case_backward ran the
+    same steps with the real reference; the stored weight norms / samples and BN statistics check the rebuild)."""
+    S, B, seed, pre = (int(v) for v in g["meta"])
+    state = orc.state_from_numpy(synthetic.make_state_dict(seed, 5, ALGO_CLASSES[algo], style="xavier"))
+    mom = {}
+    for it in range(pre):
+        orc.train_step(state, mom, synthetic.make_pair_batch(seed + 300 + it, B, S), algo, float(g["lr"]),
+                       float(g["weight_decay"]))
+    names = orc.param_names(state)
+    pn, ps = norms_and_samples([state[n] for n in names])
+    assert rel_err(pn, g["pre_param_norms"]) < 1e-5 and rel_err(ps, g["pre_param_samples"]) < 1e-4
+    rm, rv, _ = bn_vectors(state)
+    assert rel_err(rm, g["pre_running_mean"]) < 1e-4 and rel_err(rv, g["pre_running_var"]) < 1e-4
+    return state, synthetic.make_pair_batch(seed + 100, B, S)
+
+
+def bwd_subset(n, cap=1 << 16):
+    return np.arange(n) if n <= cap else (np.arange(cap, dtype=np.int64) * n) // cap
+
+
+def check_backward_golden(g, grads, label, factor=3.0, floor=2e-5):
+    """grads: name -> gradient (any float dtype, OIHW).  Every tensor's norm against the fp64 anchor, the stored
+    tensors element-wise (L2 over the stored subset), each held to `factor` x the REFERENCE's own fp32-vs-fp64 distance
+    for that tensor (+ a floor of a few fp32 ulps of accumulated rounding).  Returns the worst ratios for printing."""
+    names = [str(n) for n in g["names"]]
+    worst = (0.0, 0.0, "")
+    for n, n64, rd in zip(names, g["norms64"], g["ref_dist"]):
+        e = abs(float(grads[n].double().norm()) - n64) / max(n64, 1e-300)
+        assert e <= factor * rd + floor, (label, "norm", n, e, rd)
+    for n in (str(t) for t in g["tensors"]):
+        a = grads[n].detach().double().reshape(-1).cpu().numpy()
+        ref = g["g64/" + n].astype(np.float64)
+        sub = a[bwd_subset(a.size)]
+        e = float(np.sqrt(((sub - ref) ** 2).sum()) / np.sqrt((ref ** 2).sum()))
+        rd = float(g["refsub/" + n])
+        assert e <= factor * rd + floor, (label, "elements", n, e, rd)
+        if e / (rd + floor) > worst[0]:
+            worst = (e / (rd + floor), e, n)
+    return worst
