@@ -98,7 +98,10 @@ def write_reference_layout_checkpoint(path, golden, sd, mom, lr, step):
 def prestepped_oracle_state(g, algo):
     """The well-conditioned state of tests/golden/backward_*.npz rebuilt with the CPU oracle: reference initialisation
     statistics + `pre` SGD steps of the reference recipe on the seeded batches (make_golden.py::case_backward ran the
-    same steps with the real reference; the stored weight norms / samples and BN statistics check the rebuild)."""
+    same steps with the real reference).  Returns (state, batch, exact): `exact` says whether the rebuild landed on the
+    stored weights -- it does on the machine the golden was made on (the oracle is bit-identical to the reference
+    there); another CPU takes a slightly different path through the ill-conditioned first steps and ends a few 1e-3
+    away, in the same well-conditioned regime."""
     S, B, seed, pre = (int(v) for v in g["meta"])
     state = orc.state_from_numpy(synthetic.make_state_dict(seed, 5, ALGO_CLASSES[algo], style="xavier"))
     mom = {}
@@ -107,10 +110,33 @@ def prestepped_oracle_state(g, algo):
                        float(g["weight_decay"]))
     names = orc.param_names(state)
     pn, ps = norms_and_samples([state[n] for n in names])
-    assert rel_err(pn, g["pre_param_norms"]) < 1e-5 and rel_err(ps, g["pre_param_samples"]) < 1e-4
-    rm, rv, _ = bn_vectors(state)
-    assert rel_err(rm, g["pre_running_mean"]) < 1e-4 and rel_err(rv, g["pre_running_var"]) < 1e-4
-    return state, synthetic.make_pair_batch(seed + 100, B, S)
+    exact = rel_err(pn, g["pre_param_norms"]) < 1e-5 and rel_err(ps, g["pre_param_samples"]) < 1e-4
+    assert rel_err(pn, g["pre_param_norms"]) < 5e-2, "the rebuilt state is nowhere near the reference's"
+    return state, synthetic.make_pair_batch(seed + 100, B, S), exact
+
+
+def oracle_gradients_fp32_fp64(state, batch, algo):
+    """Gradients of one step from `state`: PyTorch-CPU fp32 (the reference's arithmetic) and fp64 (the anchor)."""
+    st32 = {k: v.clone() for k, v in state.items()}
+    st64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in state.items()}
+    b64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in batch.items()}
+    l32, g32 = orc.train_step(st32, {}, batch, algo, 0.0, 0.0)
+    l64, g64 = orc.train_step(st64, {}, b64, algo, 0.0, 0.0)
+    return l32, g32, l64, g64
+
+
+def check_against_anchor(grads, g32, g64, label, factor=3.0, floor=2e-5):
+    """Every parameter tensor, element-wise: ||g - g64|| / ||g64|| <= factor x (the same for PyTorch-CPU fp32) + floor."""
+    worst = (0.0, 0.0, 0.0, "")
+    for n in g64:
+        ref = g64[n].double()
+        den = float(ref.norm().clamp_min(1e-300))
+        e = float((grads[n].double().cpu() - ref).norm()) / den
+        ec = float((g32[n].double() - ref).norm()) / den
+        assert e <= factor * ec + floor, (label, n, e, ec)
+        if e / (ec + floor) > worst[0]:
+            worst = (e / (ec + floor), e, ec, n)
+    return worst
 
 
 def bwd_subset(n, cap=1 << 16):
