@@ -168,7 +168,8 @@ int io_net_num_logits(const io_net* net);
 /* bytes of workspace needed for a forward(/backward) of N samples of size S x S */
 size_t io_net_workspace_bytes(const io_net* net, int N, int S, int training);
 /* Byte offset, inside a TRAINING workspace of that shape, of an activation the forward pass keeps (for layer-wise
- * parity checks against resnet_cls.py:203-222): which = 0 conv1 output [N,S/2,S/2,64], 1 relu(bn1(.)), 2 max-pool
+ * parity checks against resnet_cls.py:203-222): which = 0 conv1 output [N,S/2,S/2,64], (1 = relu(bn1(.)) is not
+ * stored any more: -1), 2 max-pool
  * output [N,S/4,S/4,64], 3+i output of bottleneck i (0..15), NHWC, element type = the net's dtype.  -1 on error. */
 long io_net_activation_offset(const io_net* net, int N, int S, int which);
 /* x8[N,S,S,8] (element type = the net's dtype: float, or bf16 after io_net_set_dtype(net, 1)) -> logits[N][K].
@@ -262,6 +263,23 @@ int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H
                              float* running_var, float momentum, float eps, float* mean, float* rstd, float* scale,
                              float* shift, float* workspace, size_t workspace_floats, int dtype, int gw,
                              hipStream_t stream);
+/* conv(relu((x - in_mean[g][c]) * in_scale[g][c] + in_shift[g][c]), w): the BatchNorm + ReLU between two convolutions of a Bottleneck
+ * (models/backbone/resnet_cls.py:99-111: out = relu(bn1(conv1(x))); out = conv2(out)) applied to the operand of the
+ * SECOND convolution while it is staged, so relu(bn1(.)) is never written to memory.  Padding is zero AFTER the
+ * transform.  in_mean / in_scale / in_shift [G][Cin] are the mean / scale / shift tables io_bn_stats_finalize /
+ * io_conv2d_fwd_bnstats produce for the first BatchNorm (the expression is io_bn_apply's; in_mean may be NULL = 0).  workspace != NULL: also the training statistics of y, exactly as
+ * io_conv2d_fwd_bnstats_dt (gamma .. shift then describe the BatchNorm AFTER this convolution); workspace == NULL: they
+ * are ignored.  Output rows per group must be a multiple of 128; Cin a multiple of 32 (fp32) / 64 (bf16). */
+int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                        int stride, int pad, int G, const float* in_mean, const float* in_scale, const float* in_shift,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                        float* mean, float* rstd, float* scale, float* shift, float* workspace, size_t workspace_floats,
+                        int dtype, hipStream_t stream);
+/* The stem's pooling over a transformed input (see io_conv2d_fwd_xf_dt; tables [G][C], group = sample / (N / G)):
+ * nn.MaxPool2d(3, 2, 1) over relu(bn1(x)) (resnet_cls.py:205-208) with the arg-max indices io_maxpool_bwd consumes. */
+int io_maxpool_fwd_xf_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int G,
+                         const float* in_mean, const float* in_scale, const float* in_shift, int dtype,
+                         hipStream_t stream);
 /* y = [relu](conv(x, w) + bias[o] (+ add)): a biased nn.Conv2d, or conv + eval-mode BatchNorm (+ residual) (+ ReLU) with
  * the BatchNorm folded into pre-scaled filters (w[o] * gamma[o]/sqrt(var[o]+eps), bias = beta - mean * that) --
  * resnet_cls.py:99-114 in model.eval().  add (optional) has the shape and type of y.  gw as above. */

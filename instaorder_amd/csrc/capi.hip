@@ -354,6 +354,40 @@ extern "C" int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, i
 }
 
 
+/* Forward convolution whose INPUT goes through the BatchNorm + ReLU of the layer that produced it, applied while the
+ * operand is staged (the normalised activation never exists in memory): y = conv(relu((x - in_mean[g]) * in_scale[g] +
+ * in_shift[g]), w) -- bn_apply's expression, in_mean optional (NULL = 0) --
+ * zero padding applied AFTER the transform, as nn.Conv2d pads relu(bn(x)) (resnet_cls.py:99-111: bn -> relu -> next
+ * conv).  in_scale / in_shift: [G][Cin]; group g = the samples [g N/G, (g+1) N/G).  With workspace != NULL the training
+ * statistics of y are produced as by io_conv2d_fwd_bnstats_dt (same G). */
+extern "C" int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
+                                   int S, int stride, int pad, int G, const float* in_mean, const float* in_scale,
+                                   const float* in_shift, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
+                                   float* workspace, size_t workspace_floats, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_xf: unknown dtype %d", dtype);
+    IO_REQUIRE(in_scale && in_shift, IO_ERR_SHAPE, "conv2d_fwd_xf: in_scale / in_shift are required");
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
+    const int M = N * g.Ho * g.Wo;
+    IO_REQUIRE(G >= 1 && N % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_fwd_xf: output rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    IoBwStats ep{};
+    ep.in_mean = in_mean;
+    ep.in_scale = in_scale;
+    ep.in_shift = in_shift;
+    ep.in_Mg = M / G;
+    if (!workspace) return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, 0, st, nullptr, nullptr, &ep, dtype, dtype);
+    const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, Cout, R, S, stride, pad, G);
+    IO_REQUIRE(workspace_floats >= need, IO_ERR_WORKSPACE, "conv2d_fwd_xf: workspace %zu < %zu floats", workspace_floats,
+               need);
+    float* tmean = workspace;
+    float* tm2 = workspace + need / 2;
+    int rc = io_launch_conv_nt(g, x, w, y, nullptr, nullptr, 0, st, tmean, tm2, &ep, dtype, dtype);
+    if (rc) return rc;
+    return io_bn_finalize_tiles(tmean, tm2, M, Cout, G, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                rstd, scale, shift, st);
+}
+
 /* convolution with an inference epilogue: y = [relu](conv(x, w) + bias[o] (+ add)) -- a BatchNorm in eval mode folded
  * into pre-scaled filters, or a biased nn.Conv2d; dense (gw = 0) or grouped-window (gw = 64) */
 extern "C" int io_conv2d_fwd_bias_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,

@@ -24,10 +24,6 @@
 
 #include "io_common.h"
 
-#ifndef IO_BWE_MODE
-#define IO_BWE_MODE 2      // fused BN-backward epilogue of the NT kernel: 1 = generic addressing, 2.. = dense form
-#endif
-
 namespace {
 
 constexpr int kThreads = 256;
@@ -128,7 +124,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // more tiles in flight per CU for the latency-bound bf16 shapes.
 // BWE: the instantiation that carries the fused BatchNorm-backward epilogue (bw.y); every other launch -- forward
 // convolutions, plain data gradients -- runs the BWE = false build, whose register allocation does not pay for it.
-template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false>
+// XF: the instantiation whose A operand goes through an input transform (IoBwStats::in_scale): BatchNorm scale / shift +
+// ReLU applied to the staged chunk between its global load and its LDS store.
+template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false,
+          bool XF = false>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -203,6 +202,20 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                        g.Wi >= g.Wo;   // 1x1 stride-1: a row is valid for every k-tile or for none
 
     f32x4 ra[AR], rb[BR];
+    // XF: per-channel coefficients of the chunk being loaded (they change with the k-tile) and the validity of its rows
+    static_assert(!XF || STEM == 0, "input transform: regular convolutions");
+    constexpr int XC = ES == 4 ? 1 : 2;     // 16-byte coefficient loads per 16-byte operand chunk (4 floats or 8 bf16)
+    f32x4 xm[XC], xs[XC], xh[XC];
+    unsigned xok = 0;
+    const int xgrp = XF ? m0 / bw.in_Mg : 0;
+    const __amdgpu_buffer_rsrc_t rs_xs = make_rsrc(XF ? (const void*)(bw.in_scale + (size_t)xgrp * g.Ci) : (const void*)wgt,
+                                                   XF ? (unsigned)g.Ci * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_xh = make_rsrc(XF ? (const void*)(bw.in_shift + (size_t)xgrp * g.Ci) : (const void*)wgt,
+                                                   XF ? (unsigned)g.Ci * 4u : 0u);
+    // (no mean table: a zero-length descriptor, whose loads return 0)
+    const __amdgpu_buffer_rsrc_t rs_xm = make_rsrc((XF && bw.in_mean) ? (const void*)(bw.in_mean + (size_t)xgrp * g.Ci)
+                                                                      : (const void*)wgt,
+                                                   (XF && bw.in_mean) ? (unsigned)g.Ci * 4u : 0u);
     int th = 0, tw = 0, cc = 0;   // tap / channel-chunk counters of the k-tile being LOADED (non-stem)
     // Loads are branch-free and the loop body below is ONE basic block (the last iteration simply
     // re-fetches the final k-tile and discards it), so the scheduler is free to sink the address
@@ -254,6 +267,16 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cbase + cc * BK) * (unsigned)ES;
             woff = (unsigned)(widx * kw + cc * BK) * (unsigned)ES;
         }
+        if constexpr (XF) {
+            const unsigned coff = (unsigned)(cbase + cc * BK + kq * VE) * 4u;
+#pragma unroll
+            for (int q = 0; q < XC; ++q) {
+                xm[q] = bld4(rs_xm, coff + 16u * q);
+                xs[q] = bld4(rs_xs, coff + 16u * q);
+                xh[q] = bld4(rs_xh, coff + 16u * q);
+            }
+            xok = 0;
+        }
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             bool ok = tapok && rvalid[j];
@@ -261,6 +284,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 const int hi = hi0[j] + dh, wi = wi0[j] + dw;
                 ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
             }
+            if constexpr (XF) xok |= ok ? (1u << j) : 0u;
             ra[j] = bld4(rs_in, ok ? rowv[j] + aoff : kInvalidOff);
         }
 #pragma unroll
@@ -281,6 +305,34 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     auto store_tile = [&](int buf) {
         float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
         float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
+        if constexpr (XF) {
+            // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
+            // the zeros the buffer unit returned would be relu(shift)
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = (xok >> j) & 1u;
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(__builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
+                        ra[j][e] = ok ? v : 0.f;
+                    }
+                } else {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]);
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
+                        const int q = d >> 1, e0 = (d & 1) * 2;
+                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
+                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
+                        const float vl = fmaxf(__builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]), 0.f);
+                        const float vh = fmaxf(__builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]), 0.f);
+                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
+                    }
+                    ra[j] = __builtin_bit_cast(f32x4, o);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AR; ++j) st4(a + RS * j * LDT, ra[j]);
 #pragma unroll
@@ -437,7 +489,6 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             bw_s1[j] = 0.f;
             bw_s2[j] = 0.f;
         }
-#if IO_BWE_MODE >= 2
         // The launcher guarantees a dense output and 128 | rows per group here: row m IS pixel m and no tile is
         // partial, so there is nothing to validate.  One VGPR offset per lane; the 16 row steps of the accumulator
         // layout ride in the scalar offset of the buffer instructions (no per-row offset registers, no selects).
@@ -447,6 +498,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         const __amdgpu_buffer_rsrc_t rs_add0 = add ? rs_add : make_rsrc(out, 0);
         const __amdgpu_buffer_rsrc_t rs_mask0 = mask ? rs_mask : make_rsrc(out, 0);
         const bool nomask = mask == nullptr;
+        // side output (optional): relu(bn(y)) of the BatchNorm whose mask is recomputed here -- the activation the
+        // forward pass never stored (its consumer read y through the input transform); the filter gradient of that
+        // consumer wants it as a plain tensor.  y is in registers anyway: one more store stream, no extra read.
+        const __amdgpu_buffer_rsrc_t rs_aout = make_rsrc_at(bw.a_out ? bw.a_out : (void*)out, out_base,
+                                                            bw.a_out ? out_bytes : out_base);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -466,26 +522,18 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + av[r];
                     v = (mv[r] > 0.f || nomask) ? v : 0.f;
-                    if (bw.mscale) v = __builtin_fmaf(yv[r] - bw_mu[j], bw_sc[j], bw_sh[j]) > 0.f ? v : 0.f;
+                    const float t = __builtin_fmaf(yv[r] - bw_mu[j], bw_sc[j], bw_sh[j]);     // bn(y), bn_apply's fma
+                    if (bw.mscale) v = t > 0.f ? v : 0.f;
                     bw_s1[j] += v;
                     bw_s2[j] += v * ((yv[r] - bw_mu[j]) * bw_rs[j]);
                     st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    // (no a_out: a zero-length descriptor drops the store)
+                    st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
                 }
-#if IO_BWE_MODE == 3
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
-#if IO_BWE_MODE == 4
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-#endif
     }
-#if IO_BWE_MODE >= 2
     if constexpr (!BWE) {
-#else
-    {
-#endif
     float ep_bias[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) ep_bias[j] = bw.bias ? bw.bias[n0 + wn * (BN / WN) + j * 32 + (lane & 31)] : 0.f;
@@ -1257,6 +1305,10 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                    "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group");
     }
     IO_REQUIRE(!(stem && bws.y), IO_ERR_SHAPE, "conv_nt: the stem has no BatchNorm-backward epilogue");
+    IO_REQUIRE(!bws.a_out || (bws.y && bws.mscale && bws.mshift), IO_ERR_SHAPE,
+               "conv_nt: the activation side output needs the BatchNorm-backward epilogue with its mask tables");
+    IO_REQUIRE(!bws.in_scale || (!stem && !bws.y && bws.in_shift && bws.in_Mg > 0 && bws.in_Mg % 128 == 0 && !g.gw),
+               IO_ERR_SHAPE, "conv_nt: the input transform needs a regular forward convolution and 128 | rows per group");
     IO_REQUIRE((st_mean == nullptr) == (st_m2 == nullptr), IO_ERR_SHAPE, "conv_nt: statistics outputs come in pairs");
     IO_REQUIRE(!st_mean || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && !add && !mask), IO_ERR_SHAPE,
                "conv_nt: fused statistics need a plain dense forward convolution");
@@ -1297,24 +1349,25 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
                          (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
                      st);
-#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_)                                               \
+#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_)                                          \
     do {                                                                                                     \
         const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
             (void)hipFuncSetAttribute(                                                                       \
-                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_>,                    \
+                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_>,               \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                      \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_>), grid, block, ldsz, \
-                           st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,               \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_>), grid, block,  \
+                           ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,         \
                            (const TO_*)mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);        \
     } while (0)
 #define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
     do {                                                                                                     \
-        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0));            \
-        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false);                                       \
+        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0), false);     \
+        else if (STEM_ == 0 && bws.in_scale) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, (STEM_ == 0)); \
+        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false);                                \
     } while (0)
     // 128-wide tiles run single-buffered (36.9 KB of LDS, a second barrier per k-tile) with the register allocator held
     // to three blocks per CU: three waves per SIMD keep the matrix pipe fuller than two even on the MFMA-bound layers

@@ -109,10 +109,20 @@ struct IoBwStats {
     const float *mean, *rstd, *mscale, *mshift;
     float *p1, *p2;     // [M/128][C] tile partials
     int Mg;
+    void* a_out;        // optional (needs mscale / mshift): relu(bn(y)) written next to the gradient, same shape and type
     // Independent of the above (y may be null): inference epilogue out = [relu](acc + bias[o] (+ add)) -- the
     // BatchNorm of an eval-mode forward folded into the convolution (filters pre-scaled by gamma * rstd).
     const float* bias;
     int relu;
+    // Independent again: INPUT transform of a forward convolution.  The A operand is read through the BatchNorm + ReLU of
+    // the layer that produced it -- in = relu((in_raw - in_mean[g][c]) * in_scale[g][c] + in_shift[g][c]), zero in the
+    // padding -- so that layer's normalised activation is never written to memory.  Tables [G][Ci] exactly as
+    // bn_apply_kernel takes them (mean, scale = gamma * rstd, shift = beta; in_mean may be null = 0), evaluated with the
+    // same fma, so the ReLU mask the backward recomputes from the raw tensor agrees bit for bit; in_Mg: OUTPUT rows per
+    // BatchNorm group (a multiple of 128: a tile never straddles two groups; the rows a tile gathers belong to the
+    // samples of its output rows).
+    const float *in_mean, *in_scale, *in_shift;
+    int in_Mg;
 };
 
 // internal launchers shared between the C ABI and the network executor
@@ -136,7 +146,9 @@ int io_bn_bwd_t(const void* dout, const void* act, const float* mask_scale, cons
                 int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
                 float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef,
                 hipStream_t st, int dt);
-int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt);
+// xm / xs / xh (optional): [G][C] tables -- the pooled tensor is relu((x - xm) * xs + xh), evaluated on the fly
+int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt,
+                     const float* xs = nullptr, const float* xh = nullptr, int G = 1, const float* xm = nullptr);
 int io_maxpool_bwd_t(const void* dy, const uint32_t* idx, int N, int H, int W, int C, void* dx, hipStream_t st, int dt);
 int io_avgpool_fc_fwd_t(const void* x, int N, int HW, int C, const float* w0, const float* b0, int K0,
                         const float* w1, const float* b1, int K1, float* pooled, float* logits, hipStream_t st,

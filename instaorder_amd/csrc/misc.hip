@@ -46,10 +46,16 @@ __global__ __launch_bounds__(kThreads) void pack_planes_kernel(PackArgs a, int n
 // ---- max-pool 3x3 stride 2 pad 1 (resnet_cls.py:144), NHWC -----------------------------------
 // idx keeps, per output element, which of the 9 window taps won (first maximum in (kh,kw) scan
 // order, as the PyTorch CPU kernel); one byte per element, 4 channels packed per uint32.
-template <typename T>
+// XF: the pooled tensor is relu((x - xm[g][c]) * xs[g][c] + xh[g][c]) -- the BatchNorm + ReLU in front of the pooling
+// (resnet_cls.py:205-208: bn1 -> relu -> maxpool) evaluated on the fly, so that activation is never stored; g = sample
+// n / (N / G).  The arg-max is taken over the transformed values (scale may be negative).
+template <typename T, bool XF = false>
 __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W,
                                                               int C, T* __restrict__ out,
-                                                              uint32_t* __restrict__ idx) {
+                                                              uint32_t* __restrict__ idx,
+                                                              const float* __restrict__ xs,
+                                                              const float* __restrict__ xh, int npg,
+                                                              const float* __restrict__ xm) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
     const size_t total = (size_t)N * Ho * Wo * C4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -60,6 +66,13 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restri
         t /= Wo;
         const int ho = (int)(t % Ho);
         const int n = (int)(t / Ho);
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (XF) {
+            const int gi = n / npg;
+            if (xm) mu = *reinterpret_cast<const f32x4*>(xm + (size_t)gi * C + q * 4);
+            sc = *reinterpret_cast<const f32x4*>(xs + (size_t)gi * C + q * 4);
+            sh = *reinterpret_cast<const f32x4*>(xh + (size_t)gi * C + q * 4);
+        }
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         uint32_t bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -70,7 +83,11 @@ __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restri
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * 2 - 1 + kw;
                 if ((unsigned)w >= (unsigned)W) continue;
-                const f32x4 v = ld4(x + (((size_t)n * H + h) * W + w) * C + q * 4);
+                f32x4 v = ld4(x + (((size_t)n * H + h) * W + w) * C + q * 4);
+                if constexpr (XF) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(__builtin_fmaf(v[k] - mu[k], sc[k], sh[k]), 0.f);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
@@ -358,17 +375,33 @@ extern "C" int io_pack_planes_nhwc8(const float* const* planes, const long* samp
     return io_pack_planes_t(planes, sample_strides, nplanes, N, H, W, out, st, IO_F32);
 }
 
-int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt) {
+int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, hipStream_t st, int dt,
+                     const float* xs, const float* xh, int G, const float* xm) {
     IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
+    IO_REQUIRE(!xs || (xh && G >= 1 && N % G == 0), IO_ERR_SHAPE, "maxpool: input transform needs both tables and G | N");
     const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, (double)io_dtype_bytes(dt) * N * H * W * C * 1.3125, st);
-    if (dt == IO_BF16)
-        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const bf16_t*)x,
-                           N, H, W, C, (bf16_t*)out, idx);
-    else
-        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const float*)x, N,
-                           H, W, C, (float*)out, idx);
+    const int npg = xs ? N / G : 1;
+#define IO_MP(T_, XF_)                                                                                              \
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T_, XF_>), dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const T_*)x, N, H, \
+                       W, C, (T_*)out, idx, xs, xh, npg, xm)
+    if (dt == IO_BF16) {
+        if (xs) IO_MP(bf16_t, true);
+        else IO_MP(bf16_t, false);
+    } else {
+        if (xs) IO_MP(float, true);
+        else IO_MP(float, false);
+    }
+#undef IO_MP
     return io_check_launch("maxpool_fwd");
+}
+
+extern "C" int io_maxpool_fwd_xf_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int G,
+                                    const float* in_mean, const float* in_scale, const float* in_shift, int dtype,
+                                    hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "maxpool_fwd_xf: unknown dtype %d", dtype);
+    IO_REQUIRE(in_scale && in_shift, IO_ERR_SHAPE, "maxpool_fwd_xf: in_scale / in_shift are required");
+    return io_maxpool_fwd_t(x, N, H, W, C, out, idx, st, dtype, in_scale, in_shift, G, in_mean);
 }
 
 extern "C" int io_maxpool_fwd(const float* x, int N, int H, int W, int C, float* out, uint32_t* idx,

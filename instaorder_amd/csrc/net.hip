@@ -99,8 +99,9 @@ BnL add_bn(io_net* net, const char* name, int C) {
 }
 
 // ---- workspace plan ---------------------------------------------------------------------------
+constexpr size_t kNoBuf = ~(size_t)0;
 struct BlockBufs {
-    size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets
+    size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets (a1 / a2 = kNoBuf: never materialised, see fuse_in)
 };
 struct Plan {
     size_t y0, a0, p0, idx0, pooled;
@@ -109,6 +110,8 @@ struct Plan {
     size_t bn_partial, bn_partial_floats, coef;
     size_t tile_mean, tile_m2;   // fused-statistics partials written by the conv epilogue (training)
     size_t gbuf[5];      // gradient scratch (training only)
+    size_t aside;        // fp32 training: relu(bn(y)) of ONE layer at a time, rebuilt by the data-gradient epilogue for
+                         // the filter gradient that wants it (see fuse_in)
     size_t wt, wg_partial, wg_partial_bytes;
     size_t wop;          // bf16 mode: operand copy of the whole flat parameter buffer (same element offsets)
     size_t stem_wp, stem_dwp;   // fp32: exact-K stem filter / filter gradient, [64][io_stem_kp]
@@ -155,7 +158,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     p.blk.resize(net->blocks.size());
     if (training) {
         p.y0 = a.take(maxact);
-        p.a0 = a.take(maxact);
+        p.a0 = kNoBuf;          // relu(bn1(conv1)) is evaluated inside the max-pooling kernel, never stored
         p.p0 = a.take((size_t)N * H1 * H1 * 64 * e);
         p.idx0 = a.take((size_t)N * H1 * H1 * 16 * sizeof(uint32_t));
         int H = H1;
@@ -163,16 +166,23 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
             const Block& b = net->blocks[i];
             const int Ho = H / b.stride;
             BlockBufs& bb = p.blk[i];
+            // fp32: relu(bn1(y1)) / relu(bn2(y2)) are applied to the operand of conv2 / conv3 (and of their filter
+            // gradients) as it is staged; the tensors exist only where that cannot run -- bf16 mode (the VALU work
+            // does not hide under the 16x faster MFMA: measured) and shapes whose BatchNorm groups do not
+            // fill whole 128-row tiles for some group count G | 8
+            const long Mo = (long)N * Ho * Ho;
+            const bool never = net->dtype == IO_F32 && Mo % kMaxGroups == 0 && (Mo / kMaxGroups) % kIoStatTileRows == 0;
             bb.y1 = a.take((size_t)N * H * H * b.planes * e);
-            bb.a1 = a.take((size_t)N * H * H * b.planes * e);
+            bb.a1 = (never && b.stride == 1) ? kNoBuf : a.take((size_t)N * H * H * b.planes * e);
             bb.y2 = a.take((size_t)N * Ho * Ho * b.planes * e);
-            bb.a2 = a.take((size_t)N * Ho * Ho * b.planes * e);
+            bb.a2 = never ? kNoBuf : a.take((size_t)N * Ho * Ho * b.planes * e);
             bb.y3 = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
             bb.yd = b.down ? a.take((size_t)N * Ho * Ho * b.planes * 4 * e) : 0;
             bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
             H = Ho;
         }
         for (int i = 0; i < 5; ++i) p.gbuf[i] = a.take(maxact);
+        p.aside = net->dtype == IO_F32 ? a.take(maxact / 2) : kNoBuf;    // the largest a1 / a2: N x (S/4)^2 x 128 (layer2.0)
         // filter-gradient split-K partials: largest over all convs
         size_t wg = 0, wtmax = 0;
         {
@@ -210,6 +220,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
             const size_t t = xin; xin = xout; xout = t;
         }
         for (int i = 0; i < 5; ++i) p.gbuf[i] = 0;
+        p.aside = kNoBuf;
         p.wg_partial = p.wt = 0;
         p.wg_partial_bytes = 0;
     }
@@ -292,7 +303,9 @@ struct Ctx {
 // re-packed per pass (64 x 256 floats)
 bool stem_exact(const Ctx& c, const ConvL& L) { return L.cin_store == 8 && c.net->dtype == IO_F32; }
 
-int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false) {
+// xf: the BatchNorm whose (training) scale / shift tables + ReLU are applied to x while it is staged
+int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false, const BnL* xf = nullptr,
+             int Mout = 0) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
     const void* w = c.wop(L.w_off);
@@ -301,9 +314,17 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         IO_TRY(io_stem_pack_filter(c.params + L.w_off, c.buf(c.plan.stem_wp), L.cout, L.k * L.k, L.cin, c.st));
         w = c.buf(c.plan.stem_wp);
     }
+    IoBwStats ep{};
+    if (xf) {
+        Tables t = c.tables(*xf);
+        ep.in_mean = t.mean;
+        ep.in_scale = t.scale;
+        ep.in_shift = t.shift;
+        ep.in_Mg = Mout / c.G;
+    }
     return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, stem, c.st,
-                             stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr, nullptr,
-                             c.dt(), c.dt());
+                             stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
+                             xf ? &ep : nullptr, c.dt(), c.dt());
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
@@ -324,10 +345,20 @@ int bn_prepare(const Ctx& c, const BnL& b, const void* y, int M, bool from_tiles
 
 // conv followed by the statistics of its output; the statistics ride in the conv epilogue whenever a
 // 128-row tile never straddles two BN groups
-int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout) {
+int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout,
+            const BnL* xf = nullptr) {
     const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
-    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse));
+    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout));
     return bn_prepare(c, b, y, Mout, fuse);
+}
+
+// Does conv2 / conv3 of a block with Mout output rows read its input through the producer's BatchNorm + ReLU instead of
+// from a stored activation?  fp32 with whole 128-row tiles per BatchNorm group; the forward then never writes
+// relu(bn(y)), and the backward gets it back for the one filter gradient that needs it as a side output of the
+// data-gradient launch that recomputes the ReLU mask from y anyway (IoBwStats::a_out).  (Transforming the operand of the
+// filter-gradient kernel the same way was measured: +20..35 % on the 128 x 128 tiles, which have no registers to spare.)
+bool fuse_in(const Ctx& c, int Mout) {
+    return c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
 int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, const BnL* b2, int relu,
@@ -424,9 +455,12 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         IO_TRY(io_filter_prepare_t(c.params, 1, 1, (int)net->param_floats, c.act(p.wop), 0, c.st, IO_BF16));
     // stem
     IO_TRY(conv_bn(c, net->stem, net->bn1, x8, c.act(p.y0), c.S, c.N * H0 * H0));
-    IO_TRY(bn_act(c, net->bn1, c.act(p.y0), c.N * H0 * H0, nullptr, nullptr, 1, c.act(p.a0)));
-    IO_TRY(io_maxpool_fwd_t(c.act(p.a0), c.N, H0, H0, 64, c.act(p.p0),
-                            c.training ? reinterpret_cast<uint32_t*>(c.ws + p.idx0) : nullptr, c.st, c.dt()));
+    {
+        // relu(bn1(.)) inside the pooling kernel: the 2.1 GB activation of the bench batch is neither written nor re-read
+        Tables t = c.tables(net->bn1);
+        IO_TRY(io_maxpool_fwd_t(c.act(p.y0), c.N, H0, H0, 64, c.act(p.p0), reinterpret_cast<uint32_t*>(c.ws + p.idx0),
+                                c.st, c.dt(), t.scale, t.shift, c.G, t.mean));
+    }
     const void* x = c.act(p.p0);
     int H = H1;
     for (size_t i = 0; i < net->blocks.size(); ++i) {
@@ -435,10 +469,24 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         const int Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
         IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
-        IO_TRY(bn_act(c, b.b1, c.act(bb.y1), Min, nullptr, nullptr, 1, c.act(bb.a1)));
-        IO_TRY(conv_bn(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.y2), H, Mout));
-        IO_TRY(bn_act(c, b.b2, c.act(bb.y2), Mout, nullptr, nullptr, 1, c.act(bb.a2)));
-        IO_TRY(conv_bn(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.y3), Ho, Mout));
+        // conv2 reads relu(bn1(y1)), conv3 reads relu(bn2(y2)): through the input transform straight from y1 / y2, or
+        // from a stored activation (the strided conv2 of a stage's first block keeps a1: its data gradient runs as
+        // parity classes and cannot rebuild it)
+        const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
+        IO_REQUIRE((f2 || bb.a1 != kNoBuf) && (f3 || bb.a2 != kNoBuf), IO_ERR_SHAPE,
+                   "io_net_forward: G=%d does not divide this batch into whole 128-row tiles (use G in 1, 2, 4, 8)", c.G);
+        if (f2) {
+            IO_TRY(conv_bn(c, b.c2, b.b2, c.act(bb.y1), c.act(bb.y2), H, Mout, &b.b1));
+        } else {
+            IO_TRY(bn_act(c, b.b1, c.act(bb.y1), Min, nullptr, nullptr, 1, c.act(bb.a1)));
+            IO_TRY(conv_bn(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.y2), H, Mout));
+        }
+        if (f3) {
+            IO_TRY(conv_bn(c, b.c3, b.b3, c.act(bb.y2), c.act(bb.y3), Ho, Mout, &b.b2));
+        } else {
+            IO_TRY(bn_act(c, b.b2, c.act(bb.y2), Mout, nullptr, nullptr, 1, c.act(bb.a2)));
+            IO_TRY(conv_bn(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.y3), Ho, Mout));
+        }
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
             IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
@@ -511,13 +559,16 @@ int bn_back_tiles(const Ctx& c, const BnL& b, const void* dz, const void* y, int
 // data gradient of conv L (-> dx, the gradient of relu(bn(y))), then the backward of that BN (-> dyb).
 // With a stride-1 conv the BN-backward reductions ride in the conv epilogue (which also applies the ReLU
 // mask recomputed from y), and only the apply pass remains.
+// a_out (optional, fused path only): relu(bn(y)) rebuilt next to dx
 int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H, const BnL& b, const void* y,
-                  int M, void* dyb) {
+                  int M, void* dyb, void* a_out = nullptr) {
     if (L.stride == 1 && tiles_ok(c, M)) {
         IoBwStats bw = bw_for(c, b, y, M, true);
+        bw.a_out = a_out;
         IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
         return bn_back_tiles(c, b, dx, y, M, dyb);
     }
+    IO_REQUIRE(!a_out, IO_ERR_STATE, "dgrad_then_bn: no fused epilogue to rebuild the activation in");
     IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H));
     return bn_back(c, b, dx, 1, nullptr, y, M, dyb, nullptr);
 }
@@ -566,10 +617,17 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         else
             IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.act(bb.y3), Mout, Ga, nullptr));
         have_tiles = false;
-        IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
-        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, Gc));
-        IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
-        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.act(bb.y1), Min, Gb));
+        // Where the forward read relu(bn(y)) through the input transform (fuse_in) that activation was never stored: the
+        // data-gradient launch, which recomputes the ReLU mask from y anyway, rebuilds it into the one `aside` buffer, and
+        // the filter gradient that needs it runs right after (instead of right before) that launch.
+        const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
+        void* As = f3 ? c.act(p.aside) : nullptr;
+        if (!f3) IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
+        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, Gc, f3 ? As : nullptr));
+        if (f3) IO_TRY(conv_wgrad(c, b.c3, As, Ga, Ho));
+        if (!f2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
+        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.act(bb.y1), Min, Gb, f2 ? As : nullptr));
+        if (f2) IO_TRY(conv_wgrad(c, b.c2, As, Gc, H));
         IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
         // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
@@ -710,7 +768,10 @@ extern "C" long io_net_activation_offset(const io_net* net, int N, int S, int wh
     const Plan p = make_plan(net, N, S, true);
     const int nb = (int)net->blocks.size();
     if (which == 0) return (long)p.y0;
-    if (which == 1) return (long)p.a0;
+    if (which == 1) {
+        io_set_error("io_net_activation_offset: relu(bn1(.)) is not stored (it is evaluated inside the pooling kernel)");
+        return -1;
+    }
     if (which == 2) return (long)p.p0;
     if (which >= 3 && which < 3 + nb) return (long)p.blk[which - 3].out;
     io_set_error("io_net_activation_offset: which=%d (0..%d)", which, 2 + nb);

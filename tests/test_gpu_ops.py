@@ -92,6 +92,101 @@ def test_conv_fwd(case):
     assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+XF_CASES = [((4, 16, 16, 64, 64, 3, 1, 1), 2), ((2, 16, 16, 64, 256, 1, 1, 0), 1), ((8, 16, 16, 128, 128, 3, 2, 1), 2),
+            ((2, 16, 16, 256, 128, 3, 1, 1), 1), ((4, 8, 8, 512, 2048, 1, 1, 0), 2), ((2, 12, 32, 128, 128, 3, 1, 1), 2)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case,G", XF_CASES)
+def test_conv_fwd_input_transform(case, G, dtype):
+    """io_conv2d_fwd_xf_dt: conv(relu(bn(x)), w) with the BatchNorm scale / shift + ReLU applied to the A operand while
+    it is staged == F.conv2d(F.relu(x * scale + shift), w): per-group tables, zero padding AFTER the transform (a zero
+    read from the padding must not become relu(shift)), fp32 and bf16 storage."""
+    N, H, W, Cin, Cout, k, s, p = case
+    x, w = _conv_inputs(case, 7)
+    g = torch.Generator().manual_seed(3)
+    scale = (torch.randn(G, Cin, generator=g, dtype=torch.float64) * 0.7 + 0.3)        # both signs
+    shift = torch.randn(G, Cin, generator=g, dtype=torch.float64) * 0.5 + 0.4           # relu(shift) > 0 mostly
+    mean = torch.randn(G, Cin, generator=g, dtype=torch.float64) * 0.3
+    bf = dtype == "bf16"
+    if bf:
+        x, w = x.bfloat16().double(), w.bfloat16().double()
+    per = N // G
+    v4 = lambda t, gi: t[gi].view(1, -1, 1, 1)      # noqa: E731
+    xa = torch.cat([F.relu((x[gi * per:(gi + 1) * per] - v4(mean, gi)) * v4(scale, gi) + v4(shift, gi)) for gi in range(G)])
+    if bf:
+        xa = xa.bfloat16().double()              # the kernel rounds the transformed operand to bf16 for the MFMA
+    ref = F.conv2d(xa, w, stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+    td = torch.bfloat16 if bf else torch.float32
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV, dtype=td)
+    _lib.check(L().io_conv2d_fwd_xf_dt(P(nhwc(x).to(td)), P(krsc(w).to(td)), P(y), N, H, W, Cin, Cout, k, k, s, p, G,
+                                       P(mean.float().to(DEV)), P(scale.float().to(DEV)), P(shift.float().to(DEV)),
+                                       None, None, None, None, 0.1, 1e-5, None, None, None, None, None, 0,
+                                       1 if bf else 0, ST()), "conv_xf")
+    assert relerr(y.float().permute(0, 3, 1, 2), ref) < (6e-3 if bf else 2e-5)
+    # with statistics: the tables of the NEXT BatchNorm from the same launch
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean2, rstd, sc2, sh2 = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+    nws = L().io_conv2d_bnstats_workspace_floats(N, H, W, Cout, k, k, s, p, G)
+    ws = torch.empty(nws, device=DEV)
+    y2 = torch.empty_like(y)
+    _lib.check(L().io_conv2d_fwd_xf_dt(P(nhwc(x).to(td)), P(krsc(w).to(td)), P(y2), N, H, W, Cin, Cout, k, k, s, p, G,
+                                       P(mean.float().to(DEV)), P(scale.float().to(DEV)), P(shift.float().to(DEV)),
+                                       P(gamma.to(DEV)), P(beta.to(DEV)), P(rm), P(rv), 0.1, 1e-5, P(mean2), P(rstd),
+                                       P(sc2), P(sh2), P(ws), nws, 1 if bf else 0, ST()), "conv_xf+stats")
+    assert torch.equal(y2, y)
+    mref = torch.stack([ref[gi * per:(gi + 1) * per].mean((0, 2, 3)) for gi in range(G)])
+    vref = torch.stack([ref[gi * per:(gi + 1) * per].var((0, 2, 3), unbiased=False) for gi in range(G)])
+    assert relerr(mean2.view(G, Cout), mref) < (6e-3 if bf else 2e-5)
+    assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < (6e-3 if bf else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,H,W,C,G", [(4, 16, 16, 64, 2), (2, 9, 13, 64, 1), (6, 32, 32, 64, 2)])
+def test_maxpool_input_transform(N, H, W, C, G, dtype):
+    """io_maxpool_fwd_xf_dt == F.max_pool2d(relu(x * scale + shift), 3, 2, 1) incl. indices that route the backward."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    bf = dtype == "bf16"
+    if bf:
+        x = x.bfloat16().double()
+    scale = torch.randn(G, C, generator=g, dtype=torch.float64).float().double()
+    shift = (torch.randn(G, C, generator=g, dtype=torch.float64) * 0.5).float().double()
+    mean = (torch.randn(G, C, generator=g, dtype=torch.float64) * 0.3).float().double()
+    per = N // G
+    v4 = lambda t, gi: t[gi].view(1, -1, 1, 1)      # noqa: E731
+    xa = torch.cat([F.relu((x[gi * per:(gi + 1) * per] - v4(mean, gi)) * v4(scale, gi) + v4(shift, gi))
+                    for gi in range(G)]).requires_grad_(True)
+    ref = F.max_pool2d(xa, 3, 2, 1)
+    Ho, Wo = ref.shape[2:]
+    td = torch.bfloat16 if bf else torch.float32
+    out = torch.empty(N, Ho, Wo, C, device=DEV, dtype=td)
+    idx = torch.empty(N * Ho * Wo * C // 4, device=DEV, dtype=torch.int32)
+    _lib.check(L().io_maxpool_fwd_xf_dt(P(nhwc(x).to(td)), N, H, W, C, P(out), P(idx), G, P(mean.float().to(DEV)),
+                                        P(scale.float().to(DEV)), P(shift.float().to(DEV)), 1 if bf else 0, ST()),
+               "maxpool_xf")
+    assert relerr(out.float().permute(0, 3, 1, 2), ref.detach()) < (4e-3 if bf else 1e-6)
+    if not bf:      # the stored arg-max indices scatter a gradient exactly as autograd does (ties aside: relu zeros)
+        dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+        ref.backward(dy)
+        dx = torch.empty(N, H, W, C, device=DEV)
+        _lib.check(L().io_maxpool_bwd(P(nhwc(dy)), P(idx), N, H, W, C, P(dx), ST()), "maxpool_bwd")
+        # where several window entries are clipped to the same 0 the winner is a convention; compare the pooled sums
+        got = dx.permute(0, 3, 1, 2).double().cpu()
+        assert abs(float(got.sum()) - float(xa.grad.sum())) < 1e-3 * float(xa.grad.abs().sum())
+        nz = (ref.detach() > 0)                                  # windows with a positive maximum have a unique winner
+        want = torch.zeros_like(x)
+        # recompute autograd's routing restricted to those windows
+        xa2 = xa.detach().clone().requires_grad_(True)
+        (F.max_pool2d(xa2, 3, 2, 1) * dy * nz).sum().backward()
+        dy_nz = (dy * nz)
+        dx2 = torch.empty(N, H, W, C, device=DEV)
+        _lib.check(L().io_maxpool_bwd(P(nhwc(dy_nz)), P(idx), N, H, W, C, P(dx2), ST()), "maxpool_bwd")
+        assert relerr(dx2.permute(0, 3, 1, 2), xa2.grad) < 1e-6
+
+
 @pytest.mark.parametrize("case,G", [((4, 16, 16, 64, 64, 1, 1, 0), 2), ((2, 16, 16, 64, 256, 3, 1, 1), 1),
                                     ((8, 16, 16, 256, 128, 3, 2, 1), 2), ((64, 8, 8, 512, 2048, 1, 1, 0), 2)])
 def test_conv_fwd_with_fused_bn_statistics(case, G):

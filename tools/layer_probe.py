@@ -22,6 +22,8 @@ def acts(net, x8, N, S, G):
             dims.append((H, planes * 4))
     el = 2 if net.dtype == "bf16" else 4
     for i, (h, c) in enumerate(dims):
+        if i == 1:
+            continue                  # relu(bn1(.)) lives only inside the pooling kernel
         off = net.plan.activation_offset(N, S, i)
         n = N * h * h * c
         raw = ws[off:off + n * el]
