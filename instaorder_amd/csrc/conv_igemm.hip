@@ -126,8 +126,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // convolutions, plain data gradients -- runs the BWE = false build, whose register allocation does not pay for it.
 // XF: the instantiation whose A operand goes through an input transform (IoBwStats::in_scale): BatchNorm scale / shift +
 // ReLU applied to the staged chunk between its global load and its LDS store.
+// LIN: dense 1x1 stride-1 GEMM on whole tiles (row m of the output IS pixel m of the input, 128 | M): no row decoding, no
+// validity, k offsets and output row steps ride in the scalar offset of the buffer instructions.  The generic path spends
+// ~800 VALU + ~500 SALU instructions per wave and tile on addressing; with a bf16 tile of K <= 512 worth only 16..128
+// MFMAs the SIMDs were instruction-issue bound on exactly these layers (measured: 69 % issue utilisation, 19 % MFMA).
 template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false,
-          bool XF = false>
+          bool XF = false, bool LIN = false>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -175,23 +179,32 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
     // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
     // unit returns zeros.
-    const int n_lo = fdiv(m0, g.fd_howo);        // first sample of this tile: every offset below is relative to it
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * ES),
-                                                      in_bytes);
+    static_assert(!LIN || STEM == 0, "LIN: regular 1x1 convolutions");
+    // first sample of this tile: every offset below is relative to it (LIN: relative to the tile's first row)
+    const int n_lo = LIN ? 0 : fdiv(m0, g.fd_howo);
+    const __amdgpu_buffer_rsrc_t rs_in =
+        make_rsrc_at(in, LIN ? (size_t)m0 * (size_t)(g.Ci * ES) : (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * ES),
+                     in_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wgt, w_bytes);
     unsigned rowv[AR];
     int hi0[AR], wi0[AR];
     bool rvalid[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        const int m = m0 + lr + RS * j;
-        rvalid[j] = m < M;
-        const int mm = rvalid[j] ? m : 0;
-        const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
-        const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
-        hi0[j] = ho * g.is;
-        wi0[j] = wo * g.is;
-        rowv[j] = (unsigned)((((n - n_lo) * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
+        if constexpr (LIN) {
+            rvalid[j] = true;
+            hi0[j] = wi0[j] = 0;
+            rowv[j] = (unsigned)((lr + RS * j) * g.Ci + kq * VE) * (unsigned)ES;
+        } else {
+            const int m = m0 + lr + RS * j;
+            rvalid[j] = m < M;
+            const int mm = rvalid[j] ? m : 0;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+            hi0[j] = ho * g.is;
+            wi0[j] = wo * g.is;
+            rowv[j] = (unsigned)((((n - n_lo) * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
+        }
     }
     unsigned wv[BR];
 #pragma unroll
@@ -249,6 +262,26 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             for (int j = 0; j < BR; ++j) rb[j] = bld4(rs_w, wv[j] + (unsigned)kt * 128u);
             return;
         }
+        if constexpr (LIN) {
+            const unsigned koff = (unsigned)(cc * BK) * (unsigned)ES;        // scalar: the channel chunk of this k-tile
+            if constexpr (XF) {
+                const unsigned coff = (unsigned)(cc * BK + kq * VE) * 4u;
+#pragma unroll
+                for (int q = 0; q < XC; ++q) {
+                    xm[q] = bld4(rs_xm, coff + 16u * q);
+                    xs[q] = bld4(rs_xs, coff + 16u * q);
+                    xh[q] = bld4(rs_xh, coff + 16u * q);
+                }
+                xok = ~0u;
+            }
+#pragma unroll
+            for (int j = 0; j < AR; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, rowv[j], koff, 0));
+#pragma unroll
+            for (int j = 0; j < BR; ++j)
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv[j], koff, 0));
+            return;
+        }
         int dh, dw;
         unsigned aoff, woff;     // wave-uniform for the regular path
         bool tapok = true;
@@ -291,6 +324,10 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         for (int j = 0; j < BR; ++j) rb[j] = bld4(rs_w, tapok ? wv[j] + woff : kInvalidOff);
     };
     auto advance = [&](bool really) {    // step the (th, tw, cc) counters unless we are re-fetching
+        if constexpr (LIN) {
+            cc += really ? 1 : 0;
+            return;
+        }
         if (!STEM) {
             const int c1 = cc + 1;
             const bool wrapc = c1 == nkc;
@@ -471,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // their stores are dropped and their `add` loads return 0); the `add` variant issues all its loads
     // before the stores.
     const bool dense = (g.os == 1) && (g.Ho == g.outH) && (g.Wo == g.outW);
-    const int opix_lo = n_lo * g.outH * g.outW;           // < 2^31: it is a pixel count, not a byte count
+    const int opix_lo = LIN ? m0 : n_lo * g.outH * g.outW;   // < 2^31: it is a pixel count, not a byte count
     const size_t out_base = (size_t)opix_lo * (size_t)(g.Co * OS);
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_at(out, out_base, out_bytes);
     const __amdgpu_buffer_rsrc_t rs_add = make_rsrc_at(add ? (const void*)add : (const void*)out, out_base, out_bytes);
@@ -537,6 +574,45 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     float ep_bias[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) ep_bias[j] = bw.bias ? bw.bias[n0 + wn * (BN / WN) + j * 32 + (lane & 31)] : 0.f;
+    if constexpr (LIN) {
+        // dense output, whole tiles: one VGPR offset per lane and column block, the 16 row steps of the accumulator
+        // layout in the scalar offset (as in the fused BatchNorm-backward epilogue above)
+        const unsigned rowstep = (unsigned)g.Co * (unsigned)OS;
+        const unsigned lane_base = (unsigned)((wm * 64 + 4 * (lane >> 5)) * g.Co + n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned voff = lane_base + (unsigned)(i * 32) * rowstep + (unsigned)j * 32u * OS;
+                if (add) {
+                    float av[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) av[r] = ld_el_s<TO>(rs_add, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += av[r];
+                }
+                if (bw.bias) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r] + ep_bias[j];
+                        acc[i][j][r] = (bw.relu && v < 0.f) ? 0.f : v;
+                    }
+                }
+                if (mask) {
+                    float mv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mv[r] = ld_el_s<TO>(rs_mask, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r];
+                    st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                }
+            }
+        }
+    } else {
     const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
     constexpr unsigned JS = 32u * OS;     // byte step between a lane's column blocks
 #pragma unroll
@@ -613,6 +689,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             }
         }
     }
+    }   // !LIN
     }   // generic epilogue
     if constexpr (BWE) {
         __syncthreads();
@@ -1342,6 +1419,10 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const long tiles = (long)io_cdiv(M, 128) * ntn;
     IO_REQUIRE(tiles < (1L << 31), IO_ERR_SHAPE, "conv_nt: grid too large");
     dim3 grid((unsigned)tiles), block(kThreads);
+    // dense 1x1 stride-1 GEMM on whole tiles: the addressing-free instantiation (LIN)
+    const bool lin = !stem && !g.gw && g.Th * g.Tw == 1 && g.is == 1 && g.os == 1 && g.dh0 == 0 && g.dw0 == 0 &&
+                     g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo && M % 128 == 0 &&
+                     128.0 * g.Ci * es < 4.0e9 && 128.0 * g.Co * os < 4.0e9;
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
@@ -1349,25 +1430,31 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
                          (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
                      st);
-#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_)                                          \
+#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_, LIN_)                                    \
     do {                                                                                                     \
         const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
             (void)hipFuncSetAttribute(                                                                       \
-                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_>,               \
+                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_>,         \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                      \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_>), grid, block,  \
-                           ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,         \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_>), grid,   \
+                           block, ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,  \
                            (const TO_*)mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);        \
+    } while (0)
+#define IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, LIN_)                                             \
+    do {                                                                                                     \
+        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0), false, LIN_); \
+        else if (STEM_ == 0 && bws.in_scale)                                                                 \
+            IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, (STEM_ == 0), LIN_);                    \
+        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_);                          \
     } while (0)
 #define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
     do {                                                                                                     \
-        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0), false);     \
-        else if (STEM_ == 0 && bws.in_scale) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, (STEM_ == 0)); \
-        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false);                                \
+        if (STEM_ == 0 && lin) IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0));             \
+        else IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false);                                      \
     } while (0)
     // 128-wide tiles run single-buffered (36.9 KB of LDS, a second barrier per k-tile) with the register allocator held
     // to three blocks per CU: three waves per SIMD keep the matrix pipe fuller than two even on the MFMA-bound layers
@@ -1399,6 +1486,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         else IO_LAUNCH_NT(float, float, 64, 0, 1, 4);
     }
 #undef IO_LAUNCH_NT
+#undef IO_LAUNCH_NT__
 #undef IO_LAUNCH_NT_
     return io_check_launch("conv_nt");
 }
