@@ -431,12 +431,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     }
     __syncthreads();
     if (nk > 0) read_frags(0, 0, fa, fb);
-    for (int kt = 0; kt < nk; ++kt) {
+    // All k-tiles but the last: fetch tile kt+1 under the MFMAs of tile kt.  The last tile runs in a peeled block without
+    // loads, LDS refill or barriers: the loop used to be ONE body whose last trip re-fetched the final tile and waited
+    // for it before the refill it then discarded -- one full memory latency per output tile, which is 1/3 of the chain
+    // of a K = 64 fp32 tile and 1/2 of a K = 64 bf16 one.
+    for (int kt = 0; kt + 1 < nk; ++kt) {
         const int buf = NBUF == 2 ? kt & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
-        const bool more = kt + 1 < nk;
-        advance(more);
-        load_tile(more ? kt + 1 : kt);
+        advance(true);
+        load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             f32x4 na[TI], nb[TJ];
@@ -452,13 +455,27 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         store_tile(nbuf);
         __syncthreads();
         f32x4 na[TI], nb[TJ];
-        read_frags(nbuf, 0, na, nb);       // first fragments of tile kt+1 (unused after the last tile)
+        read_frags(nbuf, 0, na, nb);           // first fragments of tile kt+1
         __builtin_amdgcn_sched_barrier(0);
         mma16(fa, fb);                         // group 4 of tile kt, operands already in registers
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+    }
+    if (nk > 0) {
+        const int buf = NBUF == 2 ? (nk - 1) & 1 : 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            f32x4 na[TI], nb[TJ];
+            read_frags(buf, kk + 1, na, nb);
+            mma16(fa, fb);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = na[i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+        }
+        mma16(fa, fb);
     }
 
     // Fused BatchNorm statistics (forward convs in training mode): per (row tile, channel) the mean of the
@@ -1015,10 +1032,11 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_kernel(IoConvGeom g
     }
     __syncthreads();
     if (kt0 < kt1) read_frags(0, 0, fa, fb);
-    for (int kt = kt0; kt < kt1; ++kt) {
+    // (the last k-tile runs in a peeled block without loads, LDS refill or barriers, as in the NT kernel)
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
         const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
-        load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
+        load_tile(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         prep(kt + 2 < kt1 ? kt + 2 : kt);           // rows past M read zeros anyway; clamp keeps it branch-free
 #pragma unroll
@@ -1049,6 +1067,23 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_kernel(IoConvGeom g
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[s4][j] = nb[s4][j];
         }
+    }
+    if (kt0 < kt1) {
+        const int buf = NBUF == 2 ? (kt1 - 1 - kt0) & 1 : 0;
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            float na[4][TI], nb[4][TJ];
+            read_frags(buf, grp + 1, na, nb);
+            mma16(fa, fb);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa[s4][i] = na[s4][i];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) fb[s4][j] = nb[s4][j];
+            }
+        }
+        mma16(fa, fb);
     }
 
     // epilogue: rows = output channel o, cols = input channel (or flattened stem column)
@@ -1241,10 +1276,10 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvG
     }
     __syncthreads();
     if (kt0 < kt1) read_frags(0, 0, fa, fb);
-    for (int kt = kt0; kt < kt1; ++kt) {
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
         const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
-        load_tile(kt + 1 < kt1 ? kt + 1 : kt);      // last iteration re-fetches, unused
+        load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             f32x4 na[TI], nb[TJ];
@@ -1265,6 +1300,20 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvG
         for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+    }
+    if (kt0 < kt1) {                           // last k-tile: peeled, nothing to fetch
+        const int buf = NBUF == 2 ? (kt1 - 1 - kt0) & 1 : 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            f32x4 na[TI], nb[TJ];
+            read_frags(buf, kk + 1, na, nb);
+            mma(fa, fb);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = na[i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+        }
+        mma(fa, fb);
     }
 
     const int kwid = g.gw ? g.gw : g.Ci;
