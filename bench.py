@@ -67,6 +67,43 @@ def cpu_baseline(sd, S):
                       "mean of %d step(s) after 1 warm-up" % (cb, S, S, cores, nrep)}
 
 
+def cpu_baseline_depthnet(algo, S, cfg):
+    """CPU oracle of the MiDaS-based nets (oracle/midas_oracle.py, pinned by tests/golden/depthnet_*.npz): one training
+    step -- both mask orders forward, the five loss terms, backward -- on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from instaorder_amd import synthetic
+    from oracle import midas_oracle as mo                          # CPU baseline leg only
+    cores = min(usable_cores(), 32)
+    torch.set_num_threads(cores)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "depthnet_od_S64_B2.npz" if algo == "InstaDepthNet_od"
+                             else "depthnet_d_S64_B2.npz"), allow_pickle=False)
+    spec = [(str(k), tuple(int(d) for d in str(s_).split(",") if d), (str(a) or None))
+            for k, s_, a in zip(g["keys"], g["shapes"], g["aliases"])]
+    sd = synthetic.make_spec_state_dict(3, spec, prefix="module.")
+    variant = "od" if algo == "InstaDepthNet_od" else "d"
+
+    def step(B, S_):
+        st = mo.state_from_numpy(sd, prefix="module.")
+        t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(2000, B, S_).items()}
+        o1 = mo.forward(st, t["rgb"], t["modal1"], t["modal2"], True, variant=variant)
+        o2 = mo.forward(st, t["rgb"], t["modal2"], t["modal1"], True, variant=variant)
+        _, total = mo.losses(o1, o2, t, cfg, variant=variant)
+        total.backward()
+
+    t0 = time.perf_counter()
+    step(1, S // 2)                                                # calibration on a 4x cheaper problem
+    probe = time.perf_counter() - t0
+    cb = 2 if probe * 8 < 15.0 else 1
+    step(cb, S)                                                    # warm-up
+    c0 = time.perf_counter()
+    step(cb, S)
+    cdt = time.perf_counter() - c0
+    return {"value": cb / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pair(s) at %dx%d, %s fwd+bwd (two full passes per pair, as the reference), PyTorch-CPU fp32 "
+                      "oracle, %d threads, 1 step after 1 warm-up" % (cb, S, S, algo, cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,30 +317,43 @@ def main():
         name, d = dom
         avg_ms = d["total_ms"] / d["launches"]
         tfl = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
-        traffic = None        # HBM bytes per launch from the committed PMC run of this command (not live)
+        # HBM bytes per launch from the newest committed PMC run of this command (profiles/rNN_pmc_traffic.json, made
+        # by tools/collect_traffic.sh + tools/make_profiles.py; not live -- the file names the commit it was measured at)
+        traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+            tj = json.load(open(f))
             if tj.get("kernel") == name:
                 traffic = tj["bytes_per_launch_corrected"]
+                traffic_src = "%s (measured at commit %s)" % (os.path.basename(f), tj.get("commit", "round 1"))
         except Exception:
             pass
         # the wgrad kernel runs the fp32 MFMA in both modes; the NT kernel (fwd / dgrad) follows --dtype
         peak = PEAK_BF16_MFMA_TFLOPS if (args.dtype == "bf16" and "wgrad" not in name) else PEAK_FP32_MFMA_TFLOPS
         if args.dtype == "bf16":
-            traffic = None
+            traffic, traffic_src = None, None
+        gbs = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": peak,
-                              "unit": "TFLOP/s", "frac": tfl / peak, "traffic": traffic,
+                              "unit": "TFLOP/s", "frac": tfl / peak, "traffic": traffic, "traffic_source": traffic_src,
                               "launches": d["launches"], "avg_launch_ms": avg_ms,
                               "flops_per_launch": d["flops"] / d["launches"],
-                              "share_of_gpu_time": d["total_ms"] / tot_ms}
+                              "share_of_gpu_time": d["total_ms"] / tot_ms,
+                              # the other roof, always: algorithmic bytes of the same launches against HBM
+                              "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}}
+        if args.dtype == "bf16" and "wgrad" not in name and gbs / PEAK_HBM_GBS > tfl / peak:
+            # bf16 forward / data-gradient GEMMs of ResNet-50 sit below the bf16 ridge (312 FLOP/B): HBM is the roof that
+            # binds, the MFMA fraction is reported alongside
+            result["roofline"].update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
+                                      mfma={"achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak})
         result["kernel_classes"] = {
             k: {"launches": v["launches"], "ms_per_step": v["total_ms"] / args.steps,
                 "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["flops"] else None,
                 "gbs": v["bytes"] / (v["total_ms"] * 1e-3) / 1e9}
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train" and not depthnet:
-        result["cpu_baseline"] = cpu_baseline(sd, S)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
+        result["cpu_baseline"] = cpu_baseline_depthnet(args.algo, S, cfg) if depthnet else cpu_baseline(sd, S)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

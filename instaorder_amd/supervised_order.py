@@ -269,17 +269,35 @@ class _DepthBase(SingleStageModel):
         super(_DepthBase, self).__init__(params, dist_model)
         self.params = params
         self.use_rgb = params.get("use_rgb", False)
+        # hipGraph replay of forward + losses + backward + gradient gathering: the MiDaS-based nets are ~3000 launches of
+        # mostly small kernels per step, built op by op (instaorder_amd.ops under the autograd tape), so an eager step is
+        # bound by the host; the second step of a shape is captured, later ones are replayed (IO_NO_GRAPH=1: always eager)
+        self._use_graph = os.environ.get("IO_NO_GRAPH", "0") != "1"
+        self._graph = None
+        self._graph_key = None
+        self._seen_key = None
+        self._static = {}
 
     # inputs ----------------------------------------------------------------------------------------------------------
+    def _keep(self, name, t):
+        """Inputs and labels live in persistent device tensors so that a captured step can be replayed on new data."""
+        cur = self._static.get(name)
+        if cur is None or cur.shape != t.shape or cur.dtype != t.dtype or cur.device != t.device:
+            cur = torch.empty_like(t)
+            self._static[name] = cur
+            self._graph = None
+        cur.copy_(t)
+        return cur
+
     def _set_common(self, rgb, modal1, modal2, depth_order, count, is_overlap):
-        self.rgb = _dev(rgb, torch.float32).contiguous()
-        self.modal1 = _dev(modal1, torch.float32).contiguous()
-        self.modal2 = _dev(modal2, torch.float32).contiguous()
-        self.depth_order1 = _dev(depth_order, torch.long)
+        self.rgb = self._keep("rgb", _dev(rgb, torch.float32).contiguous())
+        self.modal1 = self._keep("modal1", _dev(modal1, torch.float32).contiguous())
+        self.modal2 = self._keep("modal2", _dev(modal2, torch.float32).contiguous())
+        self.depth_order1 = self._keep("depth_order1", _dev(depth_order, torch.long))
         self.depth_order2 = _mirror_classes(self.depth_order1)
         self.count = _dev(count)
-        self.is_overlap = _dev(is_overlap, torch.long).contiguous()
-        self._dep_t = torch.cat([self.depth_order1, self.depth_order2], 0)
+        self.is_overlap = self._keep("is_overlap", _dev(is_overlap, torch.long).contiguous())
+        self._dep_t = self._keep("dep_t", torch.cat([self.depth_order1, self.depth_order2], 0))
         self.B = self.rgb.shape[0]
 
     # losses ----------------------------------------------------------------------------------------------------------
@@ -378,7 +396,8 @@ class _DepthBase(SingleStageModel):
             logs, loss, _, _ = self._losses(outs, False)
         return logs, {"loss": loss}
 
-    def step(self):
+    def _fwd_loss_bwd(self):
+        """forward (both mask orders) + the five loss terms + backward + gradients gathered into the flat buffer"""
         outs = self._run(True)
         logs, loss, heads, loss_smooth = self._losses(outs, True)
         self.optim.zero_grad()
@@ -387,11 +406,39 @@ class _DepthBase(SingleStageModel):
             roots.append(loss_smooth)
             grads.append(torch.ones_like(loss_smooth))
         torch.autograd.backward(roots, grads)
-        flat = self.optim.gather_grads()
+        self.optim.gather_grads()
+        logs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in logs.items()}
+        return logs, (loss.detach() if torch.is_tensor(loss) else loss)
+
+    def step(self):
+        if not self.model.training:
+            raise RuntimeError("step() needs switch_to('train')")
+        key = (tuple(self.rgb.shape), self.rgb.data_ptr(), self.PAIR_MODE, self.optim.flat_params.data_ptr())
+        if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
+            self._graph.replay()
+            logs, loss = self._graph_out
+        elif self._use_graph and self._seen_key == key and not engine.prof_active():
+            # second step with this shape (the first ran eagerly and warmed every kernel): capture, then run it
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                self.optim.zero_grad()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    logs, loss = self._fwd_loss_bwd()
+                self._graph, self._graph_key, self._graph_out = g, key, (logs, loss)
+                g.replay()
+            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
+                self._use_graph = False
+                self._graph = None
+                print("instaorder_amd: hipGraph capture of the MiDaS step disabled (%s)" % ex)
+                logs, loss = self._fwd_loss_bwd()
+        else:
+            logs, loss = self._fwd_loss_bwd()
+            self._seen_key = key
         if self.world_size > 1:
-            distributed_utils.allreduce_flat(flat)
+            distributed_utils.allreduce_flat(self.optim.flat_grads)
         self.optim.step(gathered=True)
-        return logs, {"loss": loss.detach() if torch.is_tensor(loss) else loss}
+        return logs, {"loss": loss}
 
 
 class InstaDepthNet_od(_DepthBase):
@@ -403,7 +450,7 @@ class InstaDepthNet_od(_DepthBase):
         self._set_common(rgb, modal1, modal2, depth_order, count, is_overlap)
         self.occ_order1 = _dev(occ_order, torch.float32)
         self.occ_order2 = _mirror_occ(self.occ_order1)
-        self._occ_t = torch.cat([self.occ_order1, self.occ_order2], 0).contiguous()
+        self._occ_t = self._keep("occ_t", torch.cat([self.occ_order1, self.occ_order2], 0).contiguous())
 
 
 class InstaDepthNet_d(_DepthBase):

@@ -318,3 +318,28 @@ def test_midasnet_alone_and_midas_pretrained_method():
         for j in range(i + 1, 4):
             a = inference.net_forward_midas_pretrained(d2, masks[i], masks[j], "median")
             assert (order[i, j], order[j, i]) == {0: (1, 0), 1: (0, 1), 2: (2, 2)}[a]
+
+
+def test_graph_replay_equals_eager_steps():
+    """The captured MiDaS step (forward + losses + backward + gradient gathering as one hipGraph, replayed on new
+    inputs) takes exactly the steps the eager path takes: three steps on three different batches, bit-identical
+    parameters, momentum, running statistics and logged losses."""
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    S, B, seed = (int(v) for v in g["meta"])
+    res = []
+    for use_graph in (False, True):
+        m, _ = build(algo, g, spec)
+        m._use_graph = use_graph
+        m.switch_to("train")
+        logs_all = []
+        for it in range(4):
+            t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(seed + 500 + it, B, S).items()}
+            feed(m, algo, t)
+            logs, l = m.step()
+            logs_all.append([float(v) for v in logs.values()] + [float(l["loss"])])
+        assert (m._graph is not None) == use_graph
+        rm = torch.cat([b.reshape(-1).float() for k, b in m.model.named_buffers()])
+        res.append((m.optim.flat_params.clone(), m.optim._buf.clone(), rm, logs_all))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3]

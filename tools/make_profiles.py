@@ -10,6 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 rnd = "r%02d" % (int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+import subprocess
+try:
+    COMMIT = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    COMMIT = "unknown"
 
 
 def last_json(path):
@@ -28,13 +33,30 @@ for m in ("fwd", "infer"):
         if os.path.exists(src):
             json.dump(last_json(src), open(os.path.join(P, "%s_bench_%s_%s.json" % (rnd, m, d)), "w"), indent=1)
 
-raw = os.path.join(G, "kernel_stats_raw.csv")
-if os.path.exists(raw):
-    csv.field_size_limit(1 << 30)
+for src, dst in (("bench_c2.json", "bench_config2_od_bf16_1024.json"), ("bench_c3.json", "bench_config3_od_bf16_images20_n1.json"),
+                 ("bench_c4.json", "bench_config4_depthnet_od_bf16_b16.json"),
+                 ("bench_c4_prof.json", "bench_config4_depthnet_od_bf16_b16_kernel_classes.json"),
+                 ("bench_c4_fp32.json", "bench_config4_depthnet_od_fp32_b16.json")):
+    if os.path.exists(os.path.join(G, src)):
+        try:
+            json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (rnd, dst)), "w"), indent=1)
+        except Exception as ex:
+            print("skipped", src, ex)
+
+csv.field_size_limit(1 << 30)
+for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv", "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
+                              ("kernel_stats_bf16_raw.csv", "_bench_bf16_kernel_stats.csv",
+                               "python3 bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline"),
+                              ("kernel_stats_depthnet_bf16_raw.csv", "_bench_depthnet_od_bf16_kernel_stats.csv",
+                               "python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --no-prof "
+                               "--steps 5 --warmup 2 --no-cpu-baseline")):
+    raw = os.path.join(G, rawname)
+    if not os.path.exists(raw):
+        continue
     rows = list(csv.DictReader(open(raw)))
-    with open(os.path.join(P, rnd + "_bench_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  "
-                "(1x MI355X, 7 steps incl. warm-up)\n# kernel names shortened (namespaces / argument lists dropped); "
+    with open(os.path.join(P, rnd + outname), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- " + cmd + "  "
+                "(1x MI355X, 7 steps incl. warm-up; commit " + COMMIT + ")\n# kernel names shortened (namespaces / argument lists dropped); "
                 "durations in ns\nName,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             n = r["Name"]
@@ -60,10 +82,32 @@ if len(vals) == 2:
                     "counters report KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts wide "
                     "coalesced reads at half their size, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; the raw "
                     "(uncorrected) sum is kept alongside.",
-        "kernel": b["roofline"]["kernel"], "launches_profiled": vals["FETCH_SIZE"][0],
+        "commit": COMMIT, "kernel": b["roofline"]["kernel"], "launches_profiled": vals["FETCH_SIZE"][0],
         "fetch_size_kib_mean": fz, "write_size_kib_mean": wz,
         "bytes_per_launch_corrected": int((2 * fz + wz) * 1024), "bytes_per_launch_raw": int((fz + wz) * 1024),
         "algorithmic_bytes_per_launch": int(b["kernel_classes"][b["roofline"]["kernel"]]["gbs"] * 1e6
                                             * b["roofline"]["avg_launch_ms"]),
     }, open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
+# matrix-pipe occupancy (tools/collect_traffic.sh, second part)
+mf = {}
+for tag in ("nt", "wgrad"):
+    p = os.path.join(G, "mfma_busy_%s.txt" % tag)
+    if os.path.exists(p):
+        txt = open(p).read()
+        c = {m.group(1): (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+             for m in re.finditer(r"(\w+): n=(\d+) mean=([0-9.e+]+) sum=([0-9.e+]+)", txt)}
+        if "VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            busy, gui, cu = c["VALU_MFMA_BUSY_CYCLES"][2], c["GRBM_GUI_ACTIVE"][2], c.get("BUSY_CU_CYCLES", (0, 0, 0))[2]
+            mf[tag] = {"kernel_family": txt.splitlines()[0].strip(), "launches_profiled": c["VALU_MFMA_BUSY_CYCLES"][0],
+                       "SQ_VALU_MFMA_BUSY_CYCLES_sum": busy, "GRBM_GUI_ACTIVE_sum": gui, "SQ_BUSY_CU_CYCLES_sum": cu,
+                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs: /8 = kernel cycles; 1024 SIMDs carry a matrix pipe each
+                       "mfma_busy_fraction_of_all_simd_cycles": busy / (gui / 8.0 * 1024.0),
+                       "mfma_busy_fraction_of_busy_cu_cycles": busy / (4.0 * cu) if cu else None,
+                       "wave_cycles_wait_any_frac": c["WAIT_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_ANY" in c else None,
+                       "wave_cycles_wait_inst_any_frac": c["WAIT_INST_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_INST_ANY" in c else None}
+if mf:
+    json.dump({"_comment": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE ... over `bench.py --steps 2 "
+                           "--warmup 1` (fp32 headline configuration), counters only; sums over every launch of the family.  "
+                           "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (64 per v_mfma_f32_32x32x2_f32).",
+               "commit": COMMIT, **mf}, open(os.path.join(P, rnd + "_pmc_mfma_busy.json"), "w"), indent=1)
 print("profiles refreshed:", sorted(os.listdir(P)))

@@ -16,7 +16,7 @@ for f in files:
         name = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
         if only and only not in name:
             continue
-        key = name if only else name + " grid=" + r["Grid_Size"]
+        key = only if only else name + " grid=" + r["Grid_Size"]       # every instantiation of the family in one row
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in acc.items():
     print(name[:100])

@@ -4,6 +4,7 @@
 #   bench_n1_bf16.json       the bf16 configuration (configs[2] shape at 256 pairs)
 #   kernel_stats_raw.csv     rocprofv3 --kernel-trace --stats of the same bench command
 #   traffic_*.txt            PMC HBM traffic of the dominant kernel (separate passes, see collect_traffic.sh)
+#   mfma_busy_*.txt          matrix-pipe occupancy counters of the two dominant kernels (same script)
 # tools/make_profiles.py (run in the repo afterwards) turns them into profiles/rNN_*.
 # usage: bash tools/refresh_profiles.sh
 export TMPDIR=/tmp
@@ -24,4 +25,18 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats_raw.csv
 cd $R
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1
+# secondary workloads (BASELINE configs[2], [3], [4]); the MiDaS-based net without the per-launch event profiler too
+python3 bench.py --algo InstaOrderNet_od --dtype bf16 --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench_n1.err
+python3 bench.py --algo InstaOrderNet_od --dtype bf16 --workload images20 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c3.json 2>> $O/bench_n1.err
+python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 4 --warmup 2 > $O/bench_c4_prof.json 2>> $O/bench_n1.err
+python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 6 --warmup 3 --no-prof --no-cpu-baseline > $O/bench_c4.json 2>> $O/bench_n1.err
+python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype fp32 --steps 4 --warmup 3 --no-prof --no-cpu-baseline > $O/bench_c4_fp32.json 2>> $O/bench_n1.err
+cd /tmp
+rm -rf /tmp/kt4
+rocprofv3 --kernel-trace --stats -d /tmp/kt4 -o kt --output-format csv -- python3 $R/bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --no-prof --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt4.log 2>&1
+cp $(find /tmp/kt4 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_depthnet_bf16_raw.csv
+rm -rf /tmp/kt2
+rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o kt --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt2.log 2>&1
+cp $(find /tmp/kt2 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_bf16_raw.csv
+cd $R
 tail -3 $O/bench_n1.err
