@@ -275,6 +275,17 @@ int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                         float* mean, float* rstd, float* scale, float* shift, float* workspace, size_t workspace_floats,
                         int dtype, hipStream_t stream);
+/* All filters of a module tree in one launch (the op-by-op graphs of instaorder_amd.ops; midas/midas_net.py's ~200 dense
+ * convolutions): `table` is a DEVICE array of n io_weight_desc.  io_weights_prepare writes, for every entry, the
+ * [Cop][T][Cip] operand (element type dtype, zero where o >= Co or c >= Ci) of the OIHW fp32 master at params + src to
+ * ops + dst_op and, if dst_t >= 0, its transpose [Cip][T][Cop] (the data-gradient operand) to ops + dst_t;
+ * io_weights_unpack_grads copies the filter gradients [Cop][T][Cip] at gk + dst_g back to OIHW at grads + src. */
+typedef struct io_weight_desc {
+    long src, dst_op, dst_t, dst_g;
+    int Co, Ci, T, Cop, Cip;
+} io_weight_desc;
+int io_weights_prepare(const void* table, int n, const float* params, void* ops, int dtype, hipStream_t stream);
+int io_weights_unpack_grads(const void* table, int n, const float* gk, float* grads, hipStream_t stream);
 /* The stem's pooling over a transformed input (see io_conv2d_fwd_xf_dt; tables [G][C], group = sample / (N / G)):
  * nn.MaxPool2d(3, 2, 1) over relu(bn1(x)) (resnet_cls.py:205-208) with the arg-max indices io_maxpool_bwd consumes. */
 int io_maxpool_fwd_xf_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int G,

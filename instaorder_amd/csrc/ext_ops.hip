@@ -292,6 +292,67 @@ extern "C" int io_gconv_unpack_grad(const float* dwc, int C, int cg, int taps, f
     return io_check_launch("gconv_unpack_grad");
 }
 
+// ---- all filters of a module tree in one launch ------------------------------------------------------------------
+// The op-by-op graphs (instaorder_amd.ops) re-lay every filter out per call: OIHW fp32 master -> [Cout'][taps][Cin']
+// operand (activation type, channels zero-padded) for the forward / filter-gradient kernels, its transpose
+// [Cin'][taps][Cout'] for the data gradient, and the filter gradient back to OIHW -- three to six tiny launches per
+// convolution, ~1300 per step of the MiDaS-based nets.  One table-driven launch per direction does all of them.
+struct IoWeightDesc {
+    long src;            // float offset of the OIHW master in the flat parameter / gradient buffer
+    long dst_op, dst_t;  // element offsets of the operand and of its transpose in the operand buffer (dst_t < 0: none)
+    long dst_g;          // float offset of the [Cout'][taps][Cin'] filter gradient in the gradient staging buffer
+    int Co, Ci, T, Cop, Cip;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void weights_prepare_kernel(const IoWeightDesc* __restrict__ tab,
+                                                             const float* __restrict__ params, T* __restrict__ ops) {
+    const IoWeightDesc d = tab[blockIdx.y];
+    const long total = (long)d.Cop * d.T * d.Cip;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % d.Cip);
+        const long r = i / d.Cip;
+        const int t = (int)(r % d.T), o = (int)(r / d.T);
+        const float v = (o < d.Co && c < d.Ci) ? params[d.src + ((long)o * d.Ci + c) * d.T + t] : 0.f;
+        if constexpr (sizeof(T) == 2) {
+            ops[d.dst_op + i] = io_f2bf(v);
+            if (d.dst_t >= 0) ops[d.dst_t + ((long)c * d.T + t) * d.Cop + o] = io_f2bf(v);
+        } else {
+            ops[d.dst_op + i] = v;
+            if (d.dst_t >= 0) ops[d.dst_t + ((long)c * d.T + t) * d.Cop + o] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void weights_unpack_grads_kernel(const IoWeightDesc* __restrict__ tab,
+                                                                  const float* __restrict__ gk,
+                                                                  float* __restrict__ grads) {
+    const IoWeightDesc d = tab[blockIdx.y];
+    const long total = (long)d.Co * d.Ci * d.T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % d.T);
+        const long r = i / d.T;
+        const int c = (int)(r % d.Ci), o = (int)(r / d.Ci);
+        grads[d.src + i] = gk[d.dst_g + ((long)o * d.T + t) * d.Cip + c];
+    }
+}
+
+extern "C" int io_weights_prepare(const void* table, int n, const float* params, void* ops, int dt, hipStream_t st) {
+    IO_DT_REQUIRE(dt);
+    IO_REQUIRE(n > 0 && n < 65536 && table && params && ops, IO_ERR_SHAPE, "weights_prepare: bad table (n=%d)", n);
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 0.0, st);
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL(weights_prepare_kernel<T_>, dim3(64, n), dim3(256), 0, st,
+                                       (const IoWeightDesc*)table, params, (T_*)ops));
+    return io_check_launch("weights_prepare");
+}
+
+extern "C" int io_weights_unpack_grads(const void* table, int n, const float* gk, float* grads, hipStream_t st) {
+    IO_REQUIRE(n > 0 && n < 65536 && table && gk && grads, IO_ERR_SHAPE, "weights_unpack_grads: bad table (n=%d)", n);
+    IoProfScope prof(IO_PROF_TRANSPOSE, 0.0, 0.0, st);
+    hipLaunchKernelGGL(weights_unpack_grads_kernel, dim3(64, n), dim3(256), 0, st, (const IoWeightDesc*)table, gk, grads);
+    return io_check_launch("weights_unpack_grads");
+}
+
 static IoConvGeom gconv_geom(int N, int H, int W, int C, int R, int S, int stride, int pad) {
     IoConvGeom g = io_geom_fwd(N, H, W, C, C, R, S, stride, pad);
     g.gw = 64;

@@ -26,6 +26,85 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _WeightDesc(C.Structure):        # io_weight_desc of include/instaorder_hip.h
+    _fields_ = [("src", C.c_long), ("dst_op", C.c_long), ("dst_t", C.c_long), ("dst_g", C.c_long), ("Co", C.c_int),
+                ("Ci", C.c_int), ("T", C.c_int), ("Cop", C.c_int), ("Cip", C.c_int)]
+
+
+class WeightPlan(object):
+    """Every dense filter of a module tree re-laid out in ONE launch per training step, instead of three to six tiny
+    launches per convolution (OIHW master -> [Cout'][taps][Cin'] operand + its transpose for the data gradient; filter
+    gradient back to OIHW): ``prepare()`` before the forward, ``unpack_grads()`` after the backward, and in between
+    ``_Conv`` / ``_ConvBn`` pick their operands up as views of the plan's buffers (the filter gradient is written into
+    the plan's staging buffer and the node returns no gradient for ``w``).
+
+    Built from a RECORDING of one eager training step (which filters are used, with which stored channel counts), so
+    it needs no knowledge of the module tree; a filter used more than once per step stays on the per-call path (its
+    gradients must accumulate).  Only for parameters that live in a flat buffer (optim.FlatSGD)."""
+    active = None          # the plan convolutions consult (set for the duration of a training step)
+    _recording = None      # id(w) -> [w, Cip, Cop, uses] while a step is being recorded
+
+    @classmethod
+    def start_recording(cls):
+        cls._recording = {}
+
+    @classmethod
+    def note(cls, w, Cip, Cop):
+        if cls._recording is not None:
+            r = cls._recording.setdefault(id(w), [w, Cip, Cop, 0])
+            r[3] += 1
+            if (r[1], r[2]) != (Cip, Cop):
+                r[3] += 100        # used with two layouts: never plan it
+
+    @classmethod
+    def stop_recording(cls):
+        recs, cls._recording = cls._recording, None
+        return [r for r in (recs or {}).values() if r[3] == 1]
+
+    def __init__(self, optim, recs, dtype):
+        spans = {id(p): off for p, (off, k) in zip(optim._params, optim._spans)}
+        dev = optim.flat_params.device
+        self.optim, self.dtype = optim, dtype
+        self.entries = {}
+        rows, n_op, n_g = [], 0, 0
+        for w, Cip, Cop, _ in recs:
+            if id(w) not in spans or w.dim() != 4:
+                continue
+            Co, Ci, R, S = w.shape
+            T = R * S
+            sz = Cop * T * Cip
+            need_t = Cip != 8                       # the packed 8-channel stems have no data gradient
+            rows.append((w, _WeightDesc(spans[id(w)], n_op, n_op + sz if need_t else -1, n_g, Co, Ci, T, Cop, Cip)))
+            n_op += sz * (2 if need_t else 1)
+            n_g += sz
+        self.n = len(rows)
+        self.ops = torch.zeros(max(n_op, 1), device=dev, dtype=dtype)
+        self.gk = torch.zeros(max(n_g, 1), device=dev, dtype=torch.float32)
+        tab = (_WeightDesc * max(self.n, 1))(*[d for _, d in rows])
+        self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        for w, d in rows:
+            sz = d.Cop * d.T * d.Cip
+            self.entries[id(w)] = (d.Cip, d.Cop,
+                                   self.ops[d.dst_op:d.dst_op + sz].view(d.Cop, d.T, d.Cip),
+                                   self.ops[d.dst_t:d.dst_t + sz].view(d.Cip, d.T, d.Cop) if d.dst_t >= 0 else None,
+                                   self.gk[d.dst_g:d.dst_g + sz].view(d.Cop, d.T, d.Cip))
+
+    def lookup(self, w, Cip, Cop, dtype):
+        e = self.entries.get(id(w))
+        return e if (e is not None and e[0] == Cip and e[1] == Cop and dtype == self.dtype) else None
+
+    def prepare(self):
+        if self.n:
+            _lib.check(_L().io_weights_prepare(_p(self.table), self.n, _p(self.optim.flat_params), _p(self.ops),
+                                               1 if self.dtype == torch.bfloat16 else 0, _st()), "io_weights_prepare")
+
+    def unpack_grads(self):
+        """after optim.gather_grads(): the planned filters' gradients into their OIHW places in the flat buffer"""
+        if self.n:
+            _lib.check(_L().io_weights_unpack_grads(_p(self.table), self.n, _p(self.gk), _p(self.optim.flat_grads), _st()),
+                       "io_weights_unpack_grads")
+
+
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -72,13 +151,19 @@ class _Conv(torch.autograd.Function):
         N, H, W_, Cs = x.shape
         Co, Ci, R, S = w.shape
         Cop = ((Co + 63) // 64) * 64 if co_pad else Co
-        wk = torch.zeros((Cop, R * S, Cs), device=x.device, dtype=x.dtype)
-        wk[:Co, :, :Ci] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Ci)
+        WeightPlan.note(w, Cs, Cop)
+        ent = WeightPlan.active.lookup(w, Cs, Cop, x.dtype) if WeightPlan.active is not None else None
+        if ent is not None:
+            wk = ent[2]
+        else:
+            wk = torch.zeros((Cop, R * S, Cs), device=x.device, dtype=x.dtype)
+            wk[:Co, :, :Ci] = w.detach().permute(0, 2, 3, 1).reshape(Co, R * S, Ci)
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W_ + 2 * pad - S) // stride + 1
         y = torch.empty((N, Ho, Wo, Cop), device=x.device, dtype=x.dtype)
         _lib.check(_L().io_conv2d_fwd_dt(_p(x), _p(wk), _p(y), N, H, W_, Cs, Cop, R, S, stride, pad, _dt(x), _dt(x), _st()),
                    "io_conv2d_fwd_dt")
         ctx.save_for_backward(x, wk)
+        ctx.ent = ent
         ctx.geom = (N, H, W_, Cs, Cop, Co, Ci, R, S, stride, pad)
         return y
 
@@ -92,18 +177,21 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if Cs == 8:
                 raise RuntimeError("ops.conv2d: no data gradient for the packed 8-channel stem input")
-            wt = wk.permute(2, 1, 0).contiguous()            # [Cin][taps][Cout], a few MB at most
+            ent = ctx.ent
+            wt = ent[3] if ent is not None else wk.permute(2, 1, 0).contiguous()     # [Cin][taps][Cout]
             dx = torch.empty_like(x)
             _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Cop, R, S, stride, pad, _dt(x),
                                             _st()), "io_conv2d_dgrad_dt")
         dw = None
         if ctx.needs_input_grad[1]:
+            ent = ctx.ent
             nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Cop, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
-            dwk = torch.empty((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
+            dwk = ent[4] if ent is not None else torch.empty((Cop, R * S, Cs), device=x.device, dtype=torch.float32)
             _lib.check(L.io_conv2d_wgrad_dt(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Cop, R, S, stride, pad, _p(ws), nb, _dt(x),
                                             _dt(x), _st()), "io_conv2d_wgrad_dt")
-            dw = dwk[:Co, :, :Ci].reshape(Co, R, S, Ci).permute(0, 3, 1, 2).contiguous()
+            if ent is None:        # (planned filters: WeightPlan.unpack_grads delivers the gradient)
+                dw = dwk[:Co, :, :Ci].reshape(Co, R, S, Ci).permute(0, 3, 1, 2).contiguous()
         return dx, dw, None, None, None
 
 
@@ -261,9 +349,16 @@ class _ConvBn(torch.autograd.Function):
             fscale = gamma.detach() / torch.sqrt(running_var + 1e-5)
             fbias = (beta.detach() - running_mean * fscale).contiguous()
             wsrc = wsrc * fscale.view(-1, 1, 1, 1)
+        ent = None
         if dense:
-            wop = torch.zeros((Co, R * S, Cs), device=dev, dtype=x.dtype)
-            wop[:, :, :Cig] = wsrc.permute(0, 2, 3, 1).reshape(Co, R * S, Cig)
+            if training:
+                WeightPlan.note(w, Cs, Co)
+                ent = WeightPlan.active.lookup(w, Cs, Co, x.dtype) if WeightPlan.active is not None else None
+            if ent is not None:
+                wop = ent[2]
+            else:
+                wop = torch.zeros((Co, R * S, Cs), device=dev, dtype=x.dtype)
+                wop[:, :, :Cig] = wsrc.permute(0, 2, 3, 1).reshape(Co, R * S, Cig)
             wback = wop
         else:
             if Co != Cs or Co // groups != Cig:
@@ -312,6 +407,7 @@ class _ConvBn(torch.autograd.Function):
         _lib.check(L.io_bn_apply_dt(_p(y), M, Co, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
                                     None, None, int(relu), _p(out), dt, _st()), "io_bn_apply_dt")
         ctx.save_for_backward(x, wback, y, out, gamma, mean, rstd)
+        ctx.ent = ent
         ctx.cfg = (N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, bool(relu), identity is not None, bool(training))
         return out
 
@@ -334,20 +430,22 @@ class _ConvBn(torch.autograd.Function):
                                   _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dy), _p(dz), _p(part), npart, _p(coef), dt,
                                   _st()), "io_bn_bwd_dt")
         dx = None
+        ent = getattr(ctx, "ent", None)
         if dense:
             if ctx.needs_input_grad[0]:
                 if Cs == 8:
                     raise RuntimeError("ops.conv_bn: no data gradient for the packed 8-channel stem input")
-                wt = wback.permute(2, 1, 0).contiguous()
+                wt = ent[3] if ent is not None else wback.permute(2, 1, 0).contiguous()
                 dx = torch.empty_like(x)
                 _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Co, R, S, stride, pad, dt,
                                                 _st()), "io_conv2d_dgrad_dt")
             nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Co, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
-            dwk = torch.empty((Co, R * S, Cs), device=dev, dtype=torch.float32)
+            dwk = ent[4] if ent is not None else torch.empty((Co, R * S, Cs), device=dev, dtype=torch.float32)
             _lib.check(L.io_conv2d_wgrad_dt(_p(x), _p(dy), _p(dwk), N, H, W_, Cs, Co, R, S, stride, pad, _p(ws), nb, dt, dt,
                                             _st()), "io_conv2d_wgrad_dt")
-            dw = dwk[:, :, :Cig].reshape(Co, R, S, Cig).permute(0, 3, 1, 2).contiguous()
+            # (planned filters: WeightPlan.unpack_grads delivers the gradient)
+            dw = None if ent is not None else dwk[:, :, :Cig].reshape(Co, R, S, Cig).permute(0, 3, 1, 2).contiguous()
         else:
             dx = torch.empty_like(x)
             _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wback), _p(dx), N, H, W_, Co, R, S, stride, pad, dt, _st()),

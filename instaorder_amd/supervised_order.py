@@ -277,6 +277,7 @@ class _DepthBase(SingleStageModel):
         self._graph_key = None
         self._seen_key = None
         self._static = {}
+        self._wplan = None          # ops.WeightPlan, built from a recording of the first training step (False: none)
 
     # inputs ----------------------------------------------------------------------------------------------------------
     def _keep(self, name, t):
@@ -398,15 +399,31 @@ class _DepthBase(SingleStageModel):
 
     def _fwd_loss_bwd(self):
         """forward (both mask orders) + the five loss terms + backward + gradients gathered into the flat buffer"""
-        outs = self._run(True)
-        logs, loss, heads, loss_smooth = self._losses(outs, True)
-        self.optim.zero_grad()
-        roots, grads = [h for h, _ in heads], [g for _, g in heads]
-        if torch.is_tensor(loss_smooth) and loss_smooth.requires_grad:
-            roots.append(loss_smooth)
-            grads.append(torch.ones_like(loss_smooth))
-        torch.autograd.backward(roots, grads)
+        from . import ops
+        plan = self._wplan if (self._wplan and self.PAIR_MODE and self._wplan.dtype == self.net._act_dtype()) else None
+        recording = self._wplan is None and self.PAIR_MODE and hasattr(self.optim, "_spans")
+        if recording:
+            ops.WeightPlan.start_recording()
+        if plan is not None:
+            plan.prepare()                       # every dense filter of the net, one launch
+        ops.WeightPlan.active = plan
+        try:
+            outs = self._run(True)
+            logs, loss, heads, loss_smooth = self._losses(outs, True)
+            self.optim.zero_grad()
+            roots, grads = [h for h, _ in heads], [g for _, g in heads]
+            if torch.is_tensor(loss_smooth) and loss_smooth.requires_grad:
+                roots.append(loss_smooth)
+                grads.append(torch.ones_like(loss_smooth))
+            torch.autograd.backward(roots, grads)
+        finally:
+            ops.WeightPlan.active = None
+            recs = ops.WeightPlan.stop_recording() if recording else None
         self.optim.gather_grads()
+        if plan is not None:
+            plan.unpack_grads()                  # ... and their gradients back, one launch
+        if recording:
+            self._wplan = ops.WeightPlan(self.optim, recs, self.net._act_dtype()) if recs else False
         logs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in logs.items()}
         return logs, (loss.detach() if torch.is_tensor(loss) else loss)
 
