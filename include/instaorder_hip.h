@@ -263,6 +263,12 @@ int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H
                              float* running_var, float momentum, float eps, float* mean, float* rstd, float* scale,
                              float* shift, float* workspace, size_t workspace_floats, int dtype, int gw,
                              hipStream_t stream);
+/* io_conv2d_dgrad_bnbwd for either storage type (dy, wt, dz, y, dyb of `dtype`) and for the grouped window form (gw = 64:
+ * wt = wtc of io_gconv_pack, Cin == Cout); gw = 0 is the dense convolution */
+int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz, int N, int H, int W, int Cin, int Cout, int R, int S,
+                             int pad, const void* y, int G, const float* gamma, const float* mean, const float* rstd,
+                             const float* scale, const float* shift, float* dgamma, float* dbeta, void* dyb,
+                             float* workspace, size_t workspace_floats, int dtype, int gw, hipStream_t stream);
 /* conv(relu((x - in_mean[g][c]) * in_scale[g][c] + in_shift[g][c]), w): the BatchNorm + ReLU between two convolutions of a Bottleneck
  * (models/backbone/resnet_cls.py:99-111: out = relu(bn1(conv1(x))); out = conv2(out)) applied to the operand of the
  * SECOND convolution while it is staged, so relu(bn1(.)) is never written to memory.  Padding is zero AFTER the

@@ -354,6 +354,31 @@ extern "C" int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, i
 }
 
 
+/* io_conv2d_dgrad_bnbwd for either storage type and for the grouped window form (gw = 64: wt = wtc of io_gconv_pack, Cin
+ * == Cout) */
+extern "C" int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz, int N, int H, int W, int Cin, int Cout,
+                                        int R, int S, int pad, const void* y, int G, const float* gamma, const float* mean,
+                                        const float* rstd, const float* scale, const float* shift, float* dgamma,
+                                        float* dbeta, void* dyb, float* workspace, size_t workspace_floats, int dtype,
+                                        int gw, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_dgrad_bnbwd: unknown dtype %d", dtype);
+    IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad_bnbwd: Cin=%d must be a multiple of 64", Cin);
+    const int M = N * H * W;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_dgrad_bnbwd: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    const size_t tiles = (size_t)M / kIoStatTileRows;
+    const size_t per = (tiles + tiles / 64 + G + 2) * (size_t)Cin;
+    IO_REQUIRE(workspace_floats >= 2 * per + 2 * (size_t)G * Cin, IO_ERR_WORKSPACE,
+               "conv2d_dgrad_bnbwd: workspace %zu < %zu floats", workspace_floats, 2 * per + 2 * (size_t)G * Cin);
+    IoBwStats bw{};
+    bw.y = y; bw.mean = mean; bw.rstd = rstd; bw.mscale = scale; bw.mshift = shift;
+    bw.p1 = workspace; bw.p2 = workspace + per; bw.Mg = M / G;
+    int rc = io_run_dgrad(dy, wt, dz, nullptr, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, st, &bw, dtype, gw);
+    if (rc) return rc;
+    return io_bn_bwd_from_tiles(bw.p1, bw.p2, dz, y, M, Cin, G, gamma, mean, rstd, dgamma, dbeta, dyb,
+                                workspace + 2 * per, st, dtype);
+}
+
 /* Forward convolution whose INPUT goes through the BatchNorm + ReLU of the layer that produced it, applied while the
  * operand is staged (the normalised activation never exists in memory): y = conv(relu((x - in_mean[g]) * in_scale[g] +
  * in_shift[g]), w) -- bn_apply's expression, in_mean optional (NULL = 0) --

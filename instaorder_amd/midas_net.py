@@ -96,12 +96,14 @@ class BatchNorm2d(nn.Module):
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                               identity, _BnMode.groups, _BnMode.repeat)
 
-    def after(self, conv, x, relu=False, identity=None):
-        """bn(conv(x)) (+ identity) (+ ReLU) as one fused node (statistics in the convolution's epilogue)."""
+    def after(self, conv, x, relu=False, identity=None, sole=False):
+        """bn(conv(x)) (+ identity) (+ ReLU) as one fused node (statistics in the convolution's epilogue).  sole: this is
+        the only use of x (ops.conv_bn then runs the backward of x's own BatchNorm inside its data-gradient launch)."""
         if self.training:
             _Counters.bump(self.num_batches_tracked, _BnMode.groups * _BnMode.repeat)
         return ops.conv_bn(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, conv.stride,
-                           conv.padding, conv.groups, self.training, relu, identity, _BnMode.groups, _BnMode.repeat)
+                           conv.padding, conv.groups, self.training, relu, identity, _BnMode.groups, _BnMode.repeat,
+                           sole=sole)
 
 
 class _Fn(nn.Module):
@@ -132,11 +134,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = self.bn1.after(self.conv1, x, relu=True)
-        out = self.bn2.after(self.conv2, out, relu=True)
+        out = self.bn2.after(self.conv2, out, relu=True, sole=True)          # relu(bn1(.)) feeds conv2 only
         identity = x
         if self.downsample is not None:
             identity = self.downsample[1].after(self.downsample[0], x)
-        return self.bn3.after(self.conv3, out, relu=True, identity=identity)
+        return self.bn3.after(self.conv3, out, relu=True, identity=identity, sole=True)   # relu(bn2(.)) feeds conv3 only
 
 
 def _make_layer(inplanes, planes, blocks, stride, groups, base_width):

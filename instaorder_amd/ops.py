@@ -319,8 +319,11 @@ class _ConvBn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
-                bn_groups, repeat):
+                bn_groups, repeat, prev):
         _chk(x, "x")
+        ctx.prev = None
+        ctx.link = None
+        _ConvBn.last_offer = None
         L = _L()
         dev, dt = x.device, _dt(x)
         N, H, W_, Cs = x.shape
@@ -409,6 +412,15 @@ class _ConvBn(torch.autograd.Function):
         ctx.save_for_backward(x, wback, y, out, gamma, mean, rstd)
         ctx.ent = ent
         ctx.cfg = (N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, bool(relu), identity is not None, bool(training))
+        # Cross-node fusion of the BatchNorm backward (see conv_bn's `sole`): as PRODUCER of relu(bn(y)) this node offers
+        # what a consumer's data-gradient epilogue needs; as CONSUMER of such a tensor it keeps the producer's offer.
+        if training and relu and identity is None and M % G == 0 and (M // G) % 128 == 0 and Co % 64 == 0:
+            ctx.link = {}
+            _ConvBn.last_offer = (ctx.link, y, mean, rstd, scale, shift, gamma.detach(), G, M, Co)
+        else:
+            _ConvBn.last_offer = None
+        if prev is not None and stride == 1 and prev[8] == N * H * W_ and prev[9] == Cs and (dense or Co == Cs):
+            ctx.prev = prev
         return out
 
     @staticmethod
@@ -424,21 +436,48 @@ class _ConvBn(torch.autograd.Function):
         part = torch.empty(npart, device=dev, dtype=torch.float32)
         coef = torch.empty(2 * G * Co, device=dev, dtype=torch.float32)
         dgamma, dbeta = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
-        dy = torch.empty_like(y)
-        dz = torch.empty_like(y) if has_id else None
-        _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(y), M, Co, G, _p(gamma.detach()),
-                                  _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dy), _p(dz), _p(part), npart, _p(coef), dt,
-                                  _st()), "io_bn_bwd_dt")
+        link = ctx.link
+        if link is not None and "dy" in link:
+            # the sole consumer of this node's output already ran this BatchNorm's backward in its data-gradient launch
+            dy, dgamma, dbeta = link.pop("dy"), link.pop("dgamma"), link.pop("dbeta")
+            dz = None
+        else:
+            dy = torch.empty_like(y)
+            dz = torch.empty_like(y) if has_id else None
+            _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(y), M, Co, G, _p(gamma.detach()),
+                                      _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dy), _p(dz), _p(part), npart, _p(coef),
+                                      dt, _st()), "io_bn_bwd_dt")
         dx = None
         ent = getattr(ctx, "ent", None)
+        prev = ctx.prev
+
+        def fused_dgrad(wt_op, gw):
+            """data gradient + the PRODUCER's BatchNorm backward: ReLU mask recomputed from its y, its two reductions in
+            the epilogue of this launch, then only the apply pass -- the producer node finds its results in the link"""
+            link, yp, mean_p, rstd_p, scale_p, shift_p, gamma_p, Gp, Mp, Cp = prev
+            tiles = Mp // 128
+            nws = 2 * ((tiles + tiles // 64 + Gp + 2) * Cp) + 2 * Gp * Cp
+            wsf = torch.empty(nws, device=dev, dtype=torch.float32)
+            dz = torch.empty_like(x)
+            dyb = torch.empty_like(x)
+            dg, db = torch.empty(Cp, device=dev), torch.empty(Cp, device=dev)
+            _lib.check(L.io_conv2d_dgrad_bnbwd_dt(_p(dy), _p(wt_op), _p(dz), N, H, W_, Cs, Co, R, S, pad, _p(yp), Gp,
+                                                  _p(gamma_p), _p(mean_p), _p(rstd_p), _p(scale_p), _p(shift_p), _p(dg),
+                                                  _p(db), _p(dyb), _p(wsf), nws, dt, gw, _st()), "io_conv2d_dgrad_bnbwd_dt")
+            link["dy"], link["dgamma"], link["dbeta"] = dyb, dg, db
+            return dz
+
         if dense:
             if ctx.needs_input_grad[0]:
                 if Cs == 8:
                     raise RuntimeError("ops.conv_bn: no data gradient for the packed 8-channel stem input")
                 wt = ent[3] if ent is not None else wback.permute(2, 1, 0).contiguous()
-                dx = torch.empty_like(x)
-                _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Co, R, S, stride, pad, dt,
-                                                _st()), "io_conv2d_dgrad_dt")
+                if prev is not None:
+                    dx = fused_dgrad(wt, 0)
+                else:
+                    dx = torch.empty_like(x)
+                    _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Co, R, S, stride, pad,
+                                                    dt, _st()), "io_conv2d_dgrad_dt")
             nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Co, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
             dwk = ent[4] if ent is not None else torch.empty((Co, R * S, Cs), device=dev, dtype=torch.float32)
@@ -447,9 +486,12 @@ class _ConvBn(torch.autograd.Function):
             # (planned filters: WeightPlan.unpack_grads delivers the gradient)
             dw = None if ent is not None else dwk[:, :, :Cig].reshape(Co, R, S, Cig).permute(0, 3, 1, 2).contiguous()
         else:
-            dx = torch.empty_like(x)
-            _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wback), _p(dx), N, H, W_, Co, R, S, stride, pad, dt, _st()),
-                       "io_gconv2d_dgrad")
+            if prev is not None:
+                dx = fused_dgrad(wback, 64)
+            else:
+                dx = torch.empty_like(x)
+                _lib.check(L.io_gconv2d_dgrad(_p(dy), _p(wback), _p(dx), N, H, W_, Co, R, S, stride, pad, dt, _st()),
+                           "io_gconv2d_dgrad")
             nb = int(L.io_gconv2d_wgrad_workspace_bytes(N, H, W_, Co, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
             dwc = torch.empty((Co, R * S, 64), device=dev, dtype=torch.float32)
@@ -457,15 +499,28 @@ class _ConvBn(torch.autograd.Function):
                        "io_gconv2d_wgrad")
             dw = torch.empty((Co, Cig, R, S), device=dev, dtype=torch.float32)
             _lib.check(L.io_gconv_unpack_grad(_p(dwc), Co, Cig, R * S, _p(dw), _st()), "io_gconv_unpack_grad")
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, dz, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, dz, None, None, None
+
+
+_ConvBn.last_offer = None
 
 
 def conv_bn(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu=False, identity=None,
-            bn_groups=1, repeat=1):
+            bn_groups=1, repeat=1, sole=False):
+    """``sole=True``: the caller promises that THIS call is the only consumer of ``x`` (as conv2 / conv3 of a Bottleneck
+    are of relu(bn1(.)) / relu(bn2(.)), resnet_cls.py:99-111).  If ``x`` came out of a conv_bn with ReLU, the backward of
+    that BatchNorm then runs inside this node's data-gradient launch (mask recomputed from the producer's conv output,
+    reductions in the epilogue, io_conv2d_dgrad_bnbwd_dt) instead of as separate reduce + apply passes."""
     if repeat > 1 and bn_groups > 1:
         raise ValueError("conv_bn: repeat and bn_groups are exclusive")
-    return _ConvBn.apply(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
-                         bn_groups, repeat)
+    prev = getattr(x, "_io_offer", None) if (sole and training) else None
+    if prev is not None and prev[7] != (int(bn_groups) if training else 1):
+        prev = None
+    out = _ConvBn.apply(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
+                        bn_groups, repeat, prev)
+    if _ConvBn.last_offer is not None:
+        out._io_offer, _ConvBn.last_offer = _ConvBn.last_offer, None
+    return out
 
 
 # ---- pooling / heads --------------------------------------------------------------------------------------------------

@@ -109,13 +109,15 @@ class FlatSGD(torch.optim.Optimizer):
                 self._spans.append((off, k))
                 off += ((k + 63) // 64) * 64
 
-    def gather_grads(self):
-        """Per-tensor autograd gradients -> the flat gradient buffer (missing gradients count as zero)."""
+    def gather_grads(self, skip=None):
+        """Per-tensor autograd gradients -> the flat gradient buffer (missing gradients count as zero).  ``skip``: ids of
+        parameters whose slice somebody else fills right afterwards (ops.WeightPlan.unpack_grads)."""
         with torch.no_grad():
             dst, src = [], []
             for p, (off, k) in zip(self._params, self._spans):
                 if p.grad is None:
-                    self.flat_grads[off:off + k].zero_()
+                    if skip is None or id(p) not in skip:
+                        self.flat_grads[off:off + k].zero_()
                 else:
                     dst.append(self.flat_grads[off:off + k].view(p.shape))
                     src.append(p.grad)

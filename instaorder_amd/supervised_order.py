@@ -419,7 +419,7 @@ class _DepthBase(SingleStageModel):
         finally:
             ops.WeightPlan.active = None
             recs = ops.WeightPlan.stop_recording() if recording else None
-        self.optim.gather_grads()
+        self.optim.gather_grads(skip=plan.entries if plan is not None else None)
         if plan is not None:
             plan.unpack_grads()                  # ... and their gradients back, one launch
         if recording:
