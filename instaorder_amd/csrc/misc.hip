@@ -241,13 +241,19 @@ __global__ __launch_bounds__(kThreads) void order_loss_kernel(const float* __res
                                                              float* __restrict__ losses,
                                                              float* __restrict__ dlogits) {
     __shared__ float red[8];
-    float n_ov = 0.f;
+    // subset sizes as the reference's boolean masks give them (supervised_order.py:62-73): is_overlap == 1 / == 0; a row
+    // with any other value belongs to neither subset and contributes nothing
+    float n_ov = 0.f, n_di = 0.f;
     if (Kdep && is_overlap) {
-        float c = 0.f;
-        for (int n = threadIdx.x; n < B; n += blockDim.x) c += is_overlap[n] == 1 ? 1.f : 0.f;
+        float c = 0.f, d = 0.f;
+        for (int n = threadIdx.x; n < B; n += blockDim.x) {
+            c += is_overlap[n] == 1 ? 1.f : 0.f;
+            d += is_overlap[n] == 0 ? 1.f : 0.f;
+        }
         n_ov = block_sum(c, red);
+        __syncthreads();
+        n_di = block_sum(d, red);
     }
-    const float n_di = (float)B - n_ov;
     float l_occ = 0.f, l_dep = 0.f;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const float* z = logits + (size_t)n * K;
@@ -270,9 +276,10 @@ __global__ __launch_bounds__(kThreads) void order_loss_kernel(const float* __res
             const float* zd = z + Kocc;
             float wrow;
             if (is_overlap) {
-                const bool ov = is_overlap[n % B] == 1;
+                const long io = is_overlap[n % B];
+                const bool ov = io == 1;
                 const float cnt = ov ? n_ov : n_di;
-                wrow = cnt > 0.f ? (ov ? w_ov : w_di) / cnt : 0.f;
+                wrow = ((io == 0 || io == 1) && cnt > 0.f) ? (ov ? w_ov : w_di) / cnt : 0.f;
             } else {
                 wrow = 1.f / (float)B;
             }
@@ -286,8 +293,12 @@ __global__ __launch_bounds__(kThreads) void order_loss_kernel(const float* __res
             for (int k = 1; k < Kdep; ++k) mq = fmaxf(mq, q[k]);
             float s2 = 0.f;
             for (int k = 0; k < Kdep; ++k) { s[k] = expf(q[k] - mq); s2 += s[k]; }
-            const int t = (int)dep_t[n];
-            l_dep += -(q[t] - mq - logf(s2)) * wrow;
+            // a class id outside [0, Kdep) is an error (nn.CrossEntropyLoss device-asserts on it): poison the loss so
+            // that it cannot pass silently -- never index past the local arrays
+            const long tl = dep_t[n];
+            const bool tok = tl >= 0 && tl < Kdep;
+            const int t = tok ? (int)tl : 0;
+            l_dep += tok ? -(q[t] - mq - logf(s2)) * wrow : __builtin_nanf("");
             if (dz) {
                 float dq[4], dot = 0.f;
                 for (int k = 0; k < Kdep; ++k) {

@@ -262,6 +262,8 @@ class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, identity, groups, repeat):
         _chk(x, "x")
+        if training:
+            WEIGHTS_EPOCH[0] += 1      # running statistics move (behind torch's version counters): folded operands are stale
         L = _L()
         Cc = x.shape[-1]
         M = x.numel() // Cc
@@ -324,6 +326,8 @@ class _ConvBn(torch.autograd.Function):
         ctx.prev = None
         ctx.link = None
         _ConvBn.last_offer = None
+        if training:
+            WEIGHTS_EPOCH[0] += 1      # running statistics move (behind torch's version counters): folded operands are stale
         L = _L()
         dev, dt = x.device, _dt(x)
         N, H, W_, Cs = x.shape

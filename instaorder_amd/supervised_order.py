@@ -152,6 +152,15 @@ class _OrderBase(SingleStageModel):
         return self._pack_return(losses)
 
 
+def _check_labels(t, lo, hi, what):
+    """Labels that arrive on the host (the DataLoader's tensors) are validated here; the loss kernel poisons the loss
+    with NaN for an out-of-range class id that only shows up on the device."""
+    if t is not None and torch.is_tensor(t) and not t.is_cuda and t.numel():
+        mn, mx = int(t.min()), int(t.max())
+        if mn < lo or mx > hi:
+            raise ValueError("%s: values must lie in [%d, %d], got [%d, %d]" % (what, lo, hi, mn, mx))
+
+
 def _mirror_occ(occ_order):
     return occ_order[:, [1, 0]]
 
@@ -183,6 +192,8 @@ class InstaOrderNet_od(_OrderBase):
 
     def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None,
                   occ_order=None):
+        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order")
+        _check_labels(is_overlap, 0, 1, "is_overlap")
         self._set_images(rgb, modal1, modal2)
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
@@ -211,6 +222,8 @@ class InstaOrderNet_d(_OrderBase):
         self.KDEP = int(params["backbone_param"]["num_classes"])
 
     def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None):
+        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order")
+        _check_labels(is_overlap, 0, 1, "is_overlap")
         self._set_images(rgb, modal1, modal2)
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
@@ -236,6 +249,7 @@ class OrderNet(_OrderBase):
         self.KDEP = int(params["backbone_param"]["num_classes"])
 
     def set_input(self, rgb=None, modal1=None, modal2=None, occ_order=None):
+        _check_labels(occ_order, 0, self.KDEP - 1, "occ_order (class id)")
         self._set_images(rgb, modal1, modal2)
         self.occ_order1 = _dev(occ_order, torch.long)
         self.occ_order2 = _mirror_classes(self.occ_order1)
@@ -291,6 +305,8 @@ class _DepthBase(SingleStageModel):
         return cur
 
     def _set_common(self, rgb, modal1, modal2, depth_order, count, is_overlap):
+        _check_labels(depth_order, 0, 2, "depth_order")
+        _check_labels(is_overlap, 0, 1, "is_overlap")
         self.rgb = self._keep("rgb", _dev(rgb, torch.float32).contiguous())
         self.modal1 = self._keep("modal1", _dev(modal1, torch.float32).contiguous())
         self.modal2 = self._keep("modal2", _dev(modal2, torch.float32).contiguous())
@@ -400,6 +416,7 @@ class _DepthBase(SingleStageModel):
     def _fwd_loss_bwd(self):
         """forward (both mask orders) + the five loss terms + backward + gradients gathered into the flat buffer"""
         from . import ops
+        flat = hasattr(self.optim, "gather_grads")          # FlatSGD; torch.optim.Adam keeps per-tensor gradients
         plan = self._wplan if (self._wplan and self.PAIR_MODE and self._wplan.dtype == self.net._act_dtype()) else None
         recording = self._wplan is None and self.PAIR_MODE and hasattr(self.optim, "_spans")
         if recording:
@@ -419,7 +436,8 @@ class _DepthBase(SingleStageModel):
         finally:
             ops.WeightPlan.active = None
             recs = ops.WeightPlan.stop_recording() if recording else None
-        self.optim.gather_grads(skip=plan.entries if plan is not None else None)
+        if flat:
+            self.optim.gather_grads(skip=plan.entries if plan is not None else None)
         if plan is not None:
             plan.unpack_grads()                  # ... and their gradients back, one launch
         if recording:
@@ -430,6 +448,15 @@ class _DepthBase(SingleStageModel):
     def step(self):
         if not self.model.training:
             raise RuntimeError("step() needs switch_to('train')")
+        if not hasattr(self.optim, "gather_grads"):
+            # `optim: Adam` (single_stage_model.py:39-41): plain torch optimiser over the per-tensor gradients
+            logs, loss = self._fwd_loss_bwd()
+            if self.world_size > 1:
+                distributed_utils.average_gradients(self.model)
+            self.optim.step()
+            from . import ops
+            ops.WEIGHTS_EPOCH[0] += 1
+            return logs, {"loss": loss}
         key = (tuple(self.rgb.shape), self.rgb.data_ptr(), self.PAIR_MODE, self.optim.flat_params.data_ptr())
         if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
             self._graph.replay()

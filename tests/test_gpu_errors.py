@@ -128,3 +128,41 @@ def test_two_host_threads_on_two_streams():
         t.join()
     for i in range(2):
         assert torch.equal(out[i][0], serial[i][0]) and torch.equal(out[i][1], serial[i][1])
+
+
+def test_invalid_labels_fail_loudly():
+    """A class id outside the head (datasets can emit depth_label = -1; nn.CrossEntropyLoss device-asserts on it in the
+    reference): host tensors are rejected in set_input, device tensors poison the loss with NaN -- never a silent read past
+    the kernel's local arrays.  is_overlap values other than 0 / 1 belong to neither subset (supervised_order.py:62-73)."""
+    import numpy as np
+    import instaorder_amd as ia
+    from instaorder_amd import engine, synthetic
+    cfg = dict(algo="InstaOrderNet_od", lr=1e-4, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=[2, 3]), use_rgb=True, overlap_weight=0.1,
+               distinct_weight=0.9)
+    m = ia.InstaOrderNet_od(cfg, dist_model=False)
+    b = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_pair_batch(3, 4, 64).items()}
+    bad = b["depth_order"].clone()
+    bad[1] = -1
+    with pytest.raises(ValueError):
+        m.set_input(b["rgb"], b["modal1"], b["modal2"], bad, b["count"], b["is_overlap"], b["occ_order"])
+    # the same label arriving on the device: NaN loss
+    B = 4
+    logits = torch.randn(2 * B, 5, device="cuda")
+    dep = torch.tensor([0, 1, 2, 3, 0, 1, 2, 0], device="cuda")           # 3 is out of range for a 3-class head
+    ov = torch.tensor([0, 1, 0, 1], device="cuda")
+    occ = torch.zeros(2 * B, 2, device="cuda")
+    losses, _ = engine.order_loss(logits, B, 2, 3, occ_target=occ, depth_target=dep, is_overlap=ov, overlap_weight=0.1,
+                                  distinct_weight=0.9)
+    assert torch.isnan(losses[0]) and torch.isnan(losses[2])
+    # is_overlap = 2 on one row: that row counts in neither subset
+    dep_ok = torch.tensor([0, 1, 2, 1, 1, 0, 2, 0], device="cuda")
+    l_a, _ = engine.order_loss(logits, B, 2, 3, occ_target=occ, depth_target=dep_ok,
+                               is_overlap=torch.tensor([0, 1, 2, 1], device="cuda"), overlap_weight=0.1, distinct_weight=0.9)
+    assert torch.isfinite(l_a).all()
+    z = logits.double().cpu()
+    q = torch.softmax(z[:, 2:], 1)
+    ce = -(torch.log_softmax(q, 1)[torch.arange(2 * B), dep_ok.cpu()])
+    io = np.array([0, 1, 2, 1] * 2)
+    want = 0.1 * (ce[io == 1].sum() / (io[:B] == 1).sum()) + 0.9 * (ce[io == 0].sum() / (io[:B] == 0).sum())
+    assert abs(float(l_a[2]) - float(want)) < 1e-5 * abs(float(want))
