@@ -160,7 +160,9 @@ def test_network_bf16_vs_fp32_oracle(algo, S, B):
     zh = torch.cat(zh, 1) if isinstance(zh, tuple) else zh
     e = rel_err(zh.cpu().numpy(), zo.numpy())
     print("bf16 train-mode logits rel err vs fp32 oracle: %.3e" % e)
-    assert e < 3e-2
+    # <= 2e-2 on logits.  Measured 0.8e-2 at 4 x 128^2 and 2.0e-2 at 4 x 64^2, where a BatchNorm of the last
+    # stage normalises over 16 values per channel and the batch statistics themselves carry the bf16 noise
+    assert e < (2e-2 if S >= 128 else 2.5e-2)
     m.switch_to("eval")
     with torch.no_grad():
         zo = orc.resnet_forward(state, x1, False)
@@ -169,7 +171,7 @@ def test_network_bf16_vs_fp32_oracle(algo, S, B):
     zh = torch.cat(zh, 1) if isinstance(zh, tuple) else zh
     e = rel_err(zh.cpu().numpy(), zo.numpy())
     print("bf16 eval-mode logits rel err vs fp32 oracle: %.3e" % e)
-    assert e < 3e-2
+    assert e < 1e-2
     # a training step: loss close to the fp32 oracle's, gradients well aligned with it
     m.switch_to("train")
     m.optim.param_groups[0]["lr"] = 0.0
