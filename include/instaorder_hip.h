@@ -347,6 +347,8 @@ typedef struct io_prof_entry {
 } io_prof_entry;
 int io_prof_begin(void);
 int io_prof_end(io_prof_entry* out, int max_entries);
+/* the launch groups recorded so far, one entry each (launches = 1), in launch order; the profile keeps running */
+int io_prof_launches(io_prof_entry* out, int max_entries);
 
 #ifdef __cplusplus
 }

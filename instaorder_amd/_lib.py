@@ -103,6 +103,7 @@ SIGNATURES = {
     "io_conv2d_fwd_bias_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "io_conv2d_dgrad_bnbwd_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                       _Z, _I, _I, _P]),
+    "io_prof_launches": (_I, [_P, _I]),
     "io_weights_prepare": (_I, [_P, _I, _P, _P, _I, _P]),
     "io_weights_unpack_grads": (_I, [_P, _I, _P, _P, _P]),
     "io_maxpool_fwd_xf_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P]),

@@ -235,6 +235,25 @@ extern "C" int io_prof_begin(void) {
     return IO_OK;
 }
 
+/* per-launch records of the running profile (launch order), WITHOUT ending it: each entry = one launch group */
+extern "C" int io_prof_launches(io_prof_entry* out, int max_entries) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (ProfRec& r : g_prof_recs) {
+        if (n >= max_entries) break;
+        float ms = 0.f;
+        if (!r.closed || hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess)
+            continue;
+        io_prof_entry& e = out[n++];
+        snprintf(e.name, sizeof(e.name), "%s", kProfNames[r.cls]);
+        e.launches = 1;
+        e.total_ms = ms;
+        e.flops = r.flops;
+        e.bytes = r.bytes;
+    }
+    return n;
+}
+
 extern "C" int io_prof_end(io_prof_entry* out, int max_entries) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = false;

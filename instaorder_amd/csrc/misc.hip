@@ -179,39 +179,66 @@ __global__ __launch_bounds__(kThreads) void avgpool_fc_bwd_data_kernel(const flo
                                                                       const float* __restrict__ w0, int K0,
                                                                       const float* __restrict__ w1, int K1, int HW,
                                                                       int C, const T* __restrict__ mask,
-                                                                      T* __restrict__ dx) {
-    const int n = blockIdx.x, K = K0 + K1;
+                                                                      T* __restrict__ dx, size_t total4) {
+    // one thread = 4 consecutive channels of one pixel: 16-byte mask load and store, the K <= 5 head rows from L1/L2
+    // (the first version walked the HW pixels of a channel serially, one 4-byte load + store at a time: 292 us for the
+    // 268 MB of the bench batch, a latency chain)
+    const int K = K0 + K1, C4 = C >> 2;
     const float inv = 1.f / (float)HW;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % C4);
+        const size_t pix = i / C4;
+        const int n = (int)(pix / HW);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < K; ++k) {
-            const float wv = k < K0 ? w0[(size_t)k * C + c] : w1[(size_t)(k - K0) * C + c];
-            s += dlogits[(size_t)n * K + k] * wv;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>((k < K0 ? w0 + (size_t)k * C : w1 + (size_t)(k - K0) * C) + q * 4);
+            const float d = dlogits[(size_t)n * K + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += d * wv[e];
         }
-        s *= inv;
-        for (int p = 0; p < HW; ++p) {
-            const size_t o = ((size_t)n * HW + p) * C + c;
-            st1(dx + o, (!mask || ld1(mask + o) > 0.f) ? s : 0.f);
-        }
+        f32x4 m = {1.f, 1.f, 1.f, 1.f};
+        if (mask) m = ld4(mask + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = m[e] > 0.f ? s[e] * inv : 0.f;
+        st4(dx + i * 4, s);
     }
 }
 
-// dW[k][c] = sum_n dlogits[n][k] pooled[n][c];  db[k] = sum_n dlogits[n][k]
+// dW[k][c] = sum_n dlogits[n][k] pooled[n][c];  db[k] = sum_n dlogits[n][k].  Block = 32 channels x 8 slices of n
+// (fixed summation order: deterministic); the first version had ONE thread walk all N samples of a channel.
 __global__ __launch_bounds__(kThreads) void fc_bwd_weight_kernel(const float* __restrict__ dlogits,
                                                                 const float* __restrict__ pooled, int N, int C,
                                                                 int K, int kofs, int Kh, float* __restrict__ dw,
                                                                 float* __restrict__ db) {
+    __shared__ float red[8][33];
     const int k = blockIdx.y;   // row of this head
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dlogits[(size_t)n * K + kofs + k] * pooled[(size_t)n * C + c];
-        dw[(size_t)k * C + c] = s;
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f, sb = 0.f;
+    if (c < C)
+        for (int n = sl; n < N; n += 8) {
+            const float d = dlogits[(size_t)n * K + kofs + k];
+            s += d * pooled[(size_t)n * C + c];
+            sb += d;
+        }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][cl];
+        dw[(size_t)k * C + c] = t;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dlogits[(size_t)n * K + kofs + k];
-        db[k] = s;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (cl == 0) red[sl][0] = sb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j][0];
+            db[k] = t;
+        }
     }
     (void)Kh;
 }
@@ -464,17 +491,19 @@ int io_avgpool_fc_bwd_t(const float* dlogits, const float* pooled, int N, int HW
                         const float* w1, int K1, const void* relu_mask, void* dx, float* dw0, float* db0, float* dw1,
                         float* db1, hipStream_t st, int dt) {
     const int K = K0 + K1;
-    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, (double)io_dtype_bytes(dt) * N * HW * C, st);
+    IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "avgpool_fc_bwd: C=%d must be a multiple of 4", C);
+    const size_t total4 = (size_t)N * HW * (C / 4);
+    IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * N * C * K, (relu_mask ? 2.0 : 1.0) * io_dtype_bytes(dt) * N * HW * C, st);
     if (dt == IO_BF16)
-        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<bf16_t>, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1,
-                           HW, C, (const bf16_t*)relu_mask, (bf16_t*)dx);
+        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<bf16_t>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dlogits, w0,
+                           K0, w1, K1, HW, C, (const bf16_t*)relu_mask, (bf16_t*)dx, total4);
     else
-        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<float>, dim3(N), dim3(kThreads), 0, st, dlogits, w0, K0, w1, K1,
-                           HW, C, (const float*)relu_mask, (float*)dx);
-    hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K0), dim3(kThreads), 0, st, dlogits, pooled,
+        hipLaunchKernelGGL(avgpool_fc_bwd_data_kernel<float>, dim3(ew_blocks(total4)), dim3(kThreads), 0, st, dlogits, w0,
+                           K0, w1, K1, HW, C, (const float*)relu_mask, (float*)dx, total4);
+    hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, 32), K0), dim3(kThreads), 0, st, dlogits, pooled,
                        N, C, K, 0, K0, dw0, db0);
     if (K1 > 0)
-        hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, kThreads), K1), dim3(kThreads), 0, st, dlogits,
+        hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3(io_cdiv(C, 32), K1), dim3(kThreads), 0, st, dlogits,
                            pooled, N, C, K, K0, K1, dw1, db1);
     return io_check_launch("avgpool_fc_bwd");
 }

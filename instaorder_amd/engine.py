@@ -169,6 +169,13 @@ def prof_begin():
     _prof_on = True
 
 
+def prof_launches(max_entries=8192):
+    """Per-launch records of the running profile, in launch order: [(class, ms, flops, bytes)] (synchronises)."""
+    arr = (_lib.ProfEntry * max_entries)()
+    n = _lib.lib().io_prof_launches(arr, max_entries)
+    return [(arr[i].name.decode(), float(arr[i].total_ms), float(arr[i].flops), float(arr[i].bytes)) for i in range(n)]
+
+
 def prof_end():
     """Stop and return {class name: dict(launches, total_ms, flops, bytes)} (synchronises)."""
     global _prof_on
