@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC counters of one convolution shape: tools/pmc_one.sh <tag> "<one_conv args>" "<counters pass 1>" ["<counters pass 2>" ...]
+# KERNEL=<substring> selects the kernel family (default conv_nt_kernel)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG="$1"; ARGS="$2"; shift 2
@@ -10,12 +11,12 @@ for CNT in "$@"; do
   rm -rf /tmp/pmc_$TAG_$i
   rocprofv3 --pmc $CNT -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- python3 $R/tools/one_conv.py $ARGS > /tmp/pmc_${TAG}_$i.log 2>&1
   f=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | head -1)
-  python3 - "$f" "$CNT" <<'PY' >> $R/gpurun_out/pmc_$TAG.txt
+  python3 - "$f" "${KERNEL:-conv_nt_kernel}" <<'PY' >> $R/gpurun_out/pmc_$TAG.txt
 import csv, sys, collections
 csv.field_size_limit(1 << 30)
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "conv_nt_kernel" in r["Kernel_Name"]:
+    if sys.argv[2] in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     v = v[3:] if len(v) > 3 else v
