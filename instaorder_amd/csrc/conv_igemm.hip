@@ -1205,11 +1205,13 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvG
                 const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
                 const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
                 const int hi = ho * g.is + dh, wi0 = wo * g.is + dw;
-                const bool okh = ok0 && (unsigned)hi < (unsigned)g.Hi;
+                const bool okh = ok0 & ((unsigned)hi < (unsigned)g.Hi);
                 const int base = (((n - n_lo) * g.Hi + hi) * g.Wi + wi0) * g.Ci + xcol;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const bool ok = okh && (unsigned)(wi0 + r * g.is) < (unsigned)g.Wi;
+                    // `&`, not `&&`: the short-circuit form makes hipcc split the r = 0 load into an if / else pair
+                    // of loads to the same registers with an s_waitcnt vmcnt(0) between them
+                    const bool ok = okh & ((unsigned)(wi0 + r * g.is) < (unsigned)g.Wi);
                     rr[r] = __builtin_amdgcn_raw_buffer_load_b128(
                         rs_in, ok ? (unsigned)(base + r * g.is * g.Ci) * 2u : kInvalidOff, 0, 0);
                 }
