@@ -57,6 +57,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #ifndef IO_ST_AUX
 #define IO_ST_AUX 2
 #endif
+#ifndef IO_WGRAD_TR
+#define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -1345,6 +1348,234 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvG
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN kernel on the bf16 MFMA, LDS-DMA + transpose-read form
+// ------------------------------------------------------------------------------------------
+// Same product as conv_wgrad_bf16_kernel, without its register staging: the two operands go from global memory
+// STRAIGHT into LDS (`buffer_load_dwordx4 ... lds`, 16 bytes per lane, no VGPRs, no LDS store instructions) as
+// row-major images [64 m][channels] -- exactly what memory holds -- and the MFMA fragments (8 consecutive m per lane)
+// come out of `ds_read_b64_tr_b16`, gfx950's transposing LDS read: per 16-lane group, lane 4 j + q points at columns
+// 4q..4q+3 of row j of a [4 m][16 channel] block and lane c receives column c of the four rows.  That removes the 32
+// v_perm_b32 + 8 ds_write_b128 + the per-row gather arithmetic per k-tile and thread that made the staged kernel
+// instruction-issue bound (profiles/r02_pmc_bf16_wgrad_3x3.txt).
+//   * An LDS-DMA instruction writes 64 lanes x 16 B = 1 KiB contiguously (lane i -> M0 base + 16 i), a "chunk": 4 rows
+//     of a 128-channel operand, 8 rows of a 64-channel one.  WHICH (row, 16-byte channel slot) a lane fetches is free,
+//     so the image is swizzled on the way in (tr_chunk_pos): the four rows a transpose-read touches, 64 bytes each, then
+//     sit in four different 64-byte bank groups -- conflict-free (tools/tr_probe.hip measures it on the hardware).
+//   * Addresses: the lane part of a fetch (in-chunk row, channel slot) is constant for the whole kernel (voffset), the
+//     k-tile / chunk part is wave-uniform and goes into the scalar offset -- computed on the scalar unit, zero vector
+//     instructions for dY, three (the left / right image border) for X.  soffset is not range-checked and must not be
+//     negative: the X descriptor starts `padpx` pixels early; border lanes get an out-of-range voffset = zeros in LDS.
+//   * One barrier per k-tile: wait for the own fetches of tile kt, barrier (tile kt complete, every wave done with
+//     tile kt - 1), request tile kt + 1 into the other stage, multiply tile kt.
+// Shapes: 64 | Ho*Wo (a k-tile lies in one sample), rows-per-chunk | Wo (a chunk lies in one output row), 64 | M; the
+// launcher sends everything else (and the stem) to the staged kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char* lds_cptr;
+
+// One LDS-DMA instruction: 16 bytes per lane from descriptor `rs` at voff (per lane, range-checked) + soff (uniform,
+// not range-checked) to LDS byte address lds_addr + 16 * lane.  Inline asm, NOT __builtin_amdgcn_raw_ptr_buffer_load_lds:
+// hipcc tracks the builtin as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next LDS read that may
+// alias it -- every read of the OTHER stage -- which serialises fetch and multiply.  The asm form is invisible to that
+// pass, so the one wait it needs (before the barrier that publishes the tile) is written by hand: dma_wait_all().
+__device__ __forceinline__ u32x4 dma_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes,
+                     0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void dma16(u32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr)
+                 : "memory");          // (m0 is reserved: hipcc never keeps a value in it across statements)
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// 16-byte slot of (in-chunk row r, channel slot cs) inside a chunk of a W-channel image
+template <int W> __device__ __forceinline__ int tr_chunk_pos(int r, int cs) {
+    if (W == 128) return r * 16 + ((cs + 4 * r) & 15);                     // 4 rows x 16 slots, row r rotated by 4 r
+    return (2 * r + ((cs >> 2) ^ ((r >> 1) & 1))) * 4 + (cs & 3);           // 8 rows x 2 halves, halves swapped in rows 2,3,6,7
+}
+// ... and its inverse: which (row, slot) DMA lane `pos` fetches
+template <int W> __device__ __forceinline__ void tr_chunk_src(int pos, int& r, int& cs) {
+    if (W == 128) {
+        r = pos >> 4;
+        cs = ((pos & 15) - 4 * r) & 15;
+    } else {
+        const int P = pos >> 2;
+        r = P >> 1;
+        cs = (((P & 1) ^ ((r >> 1) & 1)) << 2) + (pos & 3);
+    }
+}
+
+template <int BMO, int BNC, bool STEM = false, int MINB = 2>
+__global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
+                                                                     const bf16_t* __restrict__ dy,
+                                                                     float* __restrict__ dst, int ntile_c, int tiles,
+                                                                     int kps, size_t in_bytes, size_t dy_bytes) {
+    constexpr int BKM = 64;
+    constexpr int TI = BMO / 64, TJ = BNC / 64;
+    constexpr int A_BYTES = BMO * BKM * 2, B_BYTES = BNC * BKM * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int RA = 512 / BMO, RB = 512 / BNC;              // rows per 1 KiB chunk
+    constexpr int CA = BKM / RA / 4, CB = BKM / RB / 4;        // chunks per wave and k-tile
+    constexpr int KKA = BMO == 128 ? 4096 : 2048, HA = BMO == 128 ? 1024 : 512;   // bytes per 16-row k-step / 4-row half
+    constexpr int KKB = BNC == 128 ? 4096 : 2048, HB = BNC == 128 ? 1024 : 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const lds_cptr lds = (lds_cptr)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = g.Ho * g.Wo;
+    const int M = g.N * HoWo;
+    const int T = g.Th * g.Tw;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    // tile -> (o tile, tap, channel tile); stem: the columns are the flattened (tap, 8 channels) axis of the packed
+    // input, a 16-byte slot of the X image is one tap of one pixel, so the tap is a LANE constant there
+    const int per_o = STEM ? ntile_c : T * ntile_c;
+    const int ot = tile / per_o, rem0 = tile - ot * per_o;
+    const int o0 = ot * BMO;
+    const int tap = STEM ? 0 : rem0 / ntile_c;
+    const int c0 = STEM ? rem0 * BNC : g.gw ? o0 : (rem0 - tap * ntile_c) * BNC;   // grouped: only the diagonal tiles
+    const int th = tap / g.Tw, tw = tap - th * g.Tw;
+    const int widx = STEM ? 0 : (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
+
+    const int nkt = M / BKM;
+    const int kt0 = split * kps;
+    const int kt1 = min(kt0 + kps, nkt);
+    const int mfirst = kt0 * BKM;                // descriptors start at this split's first row / first sample
+    const int n_lo = fdiv(mfirst, g.fd_howo);
+    // the tap shift (dh, dw) lives in the lane offset, which must not be negative: the X descriptor starts `padh` rows
+    // and `padw` pixels before the split's first sample (address arithmetic only -- lanes that would read there are
+    // border lanes and get an out-of-range offset)
+    const int padh = g.dh0 < 0 ? -g.dh0 : 0, padw = g.dw0 < 0 ? -g.dw0 : 0;
+    u32x4 rs_dy, rs_in;
+    {
+        const size_t abase = (size_t)mfirst * (size_t)(g.Co * 2);
+        rs_dy = dma_rsrc(reinterpret_cast<const char*>(dy) + abase, dy_bytes > abase ? dy_bytes - abase : 0);
+        const size_t base = (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * 2);
+        const size_t pad = (size_t)(padh * g.Wi + padw) * (size_t)(g.Ci * 2);
+        rs_in = dma_rsrc(reinterpret_cast<const char*>(in) + base - pad, (in_bytes > base ? in_bytes - base : 0) + pad);
+    }
+    const unsigned lds0 = (unsigned)(size_t)lds;       // LDS byte address of the dynamic region
+
+    // lane constants of the fetches
+    int ra_, csa, rb_, csb;
+    tr_chunk_src<BMO>(lane, ra_, csa);
+    tr_chunk_src<BNC>(lane, rb_, csb);
+    int dh, dw;
+    bool tapok = true;
+    if (STEM) {
+        const int tp = (c0 >> 3) + csb;
+        tapok = tp < g.wT;
+        const int r = tp / g.S, sx = tp - r * g.S;
+        dh = g.dh0 + g.dhs * r;
+        dw = g.dw0 + g.dws * sx;
+    } else {
+        dh = g.dh0 + g.dhs * th;
+        dw = g.dw0 + g.dws * tw;
+    }
+    const unsigned va = (unsigned)(ra_ * g.Co + o0 + csa * 8) * 2u;
+    const unsigned vb =
+        (unsigned)(((dh + padh) * g.Wi + rb_ * g.is + dw + padw) * g.Ci + (STEM ? 0 : c0 + csb * 8)) * 2u;
+    const int wib = rb_ * g.is + dw;             // + wo * is = input column of the lane's row
+
+    auto issue = [&](int kt, int stage) {
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+        const int m0 = kt * BKM;
+#pragma unroll
+        for (int u = 0; u < CA; ++u) {
+            const int chunk = wave * CA + u;
+            const unsigned soff = (unsigned)((m0 + chunk * RA - mfirst) * g.Co) * 2u;
+            dma16(rs_dy, sb + (unsigned)(chunk * 1024), va, soff);
+        }
+        const int n = fdiv(m0, g.fd_howo), p_tile = m0 - n * HoWo;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int chunk = wave * CB + u;
+            const int pc = p_tile + chunk * RB;
+            const int ho = fdiv(pc, g.fd_wo), wo = pc - ho * g.Wo;
+            const unsigned soff = (unsigned)((((n - n_lo) * g.Hi + ho * g.is) * g.Wi + wo * g.is) * g.Ci) * 2u;
+            const bool ok = tapok & ((unsigned)(ho * g.is + dh) < (unsigned)g.Hi) &
+                            ((unsigned)(wo * g.is + wib) < (unsigned)g.Wi);
+            dma16(rs_in, sb + (unsigned)(A_BYTES + chunk * 1024), ok ? vb : kInvalidOff, soff);
+        }
+    };
+
+    // lane constants of the fragment reads
+    const int g4 = lane >> 4, fj = (lane >> 2) & 3, fq = lane & 3;
+    unsigned fa[TI], fb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int c = wm * (BMO / 2) + i * 32 + (g4 & 1) * 16 + 4 * fq;
+        fa[i] = (unsigned)((g4 >> 1) * (BMO == 128 ? 2048 : 1024) + tr_chunk_pos<BMO>(fj, c >> 3) * 16 + (c & 7) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int c = wn * (BNC / 2) + j * 32 + (g4 & 1) * 16 + 4 * fq;
+        fb[j] = (unsigned)(A_BYTES + (g4 >> 1) * (BNC == 128 ? 2048 : 1024) + tr_chunk_pos<BNC>(fj, c >> 3) * 16 + (c & 7) * 2);
+    }
+    auto frag = [&](lds_cptr sb, unsigned off, int half_bytes) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + off));
+        const s16x4 hi =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + off + half_bytes));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) issue(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int stage = (kt - kt0) & 1;
+        dma_wait_all();                  // the own fetches of tile kt have landed ...
+        __syncthreads();                 // ... everybody's have, and every wave is done reading the other stage
+        if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+        const lds_cptr sb = lds + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = frag(sb, fa[i] + kk * KKA, HA);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = frag(sb, fb[j] + kk * KKB, HB);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int kwid = g.gw ? g.gw : g.Ci;
+    const size_t wrow = (size_t)g.wT * kwid;
+    float* base = dst + (size_t)split * g.Co * wrow;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int cl = wn * (BNC / 2) + j * 32 + (lane & 31);
+                if (STEM) {
+                    if (c0 + cl < (int)wrow) base[(size_t)o * wrow + c0 + cl] = acc[i][j][r];
+                } else {
+                    base[(size_t)o * wrow + (size_t)widx * kwid + (g.gw ? 0 : c0) + cl] = acc[i][j][r];
+                }
+            }
+        }
+}
+
 // dst[i] = sum_z partial[z][i]: block = 32 float4 columns x 8 split lanes (8 loads in flight per lane),
 // fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
@@ -1667,11 +1898,34 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         if (!STEM_ && w8) IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, !STEM_, 2, 1);                                       \
         else IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, false, 2, 1);                                                     \
     } while (0)
-        if (stem) IO_LAUNCH_WGB(64, 64, true);
+        // LDS-DMA + transpose-read form where its shape conditions hold (see the kernel)
+        const int rb_rows = 512 / p.bnc;
+        const bool trk = IO_WGRAD_TR && !(stem && g.cr) && (long)Md % 64 == 0 && (g.Ho * g.Wo) % 64 == 0 &&
+                         g.Wo % rb_rows == 0;
+#define IO_LAUNCH_WGTR(BMO_, BNC_, STEM_)                                                                               \
+    do {                                                                                                         \
+        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 64 * 2;                                                   \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_>,                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_>), grid1, block, lds, st, g,             \
+                           (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes,       \
+                           dy_bytes);                                                                            \
+    } while (0)
+        if (trk && stem) IO_LAUNCH_WGTR(64, 64, true);
+        else if (trk && p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGTR(128, 128, false);
+        else if (trk && p.bmo == 128) IO_LAUNCH_WGTR(128, 64, false);
+        else if (trk && p.bnc == 128) IO_LAUNCH_WGTR(64, 128, false);
+        else if (trk) IO_LAUNCH_WGTR(64, 64, false);
+        else if (stem) IO_LAUNCH_WGB(64, 64, true);
         else if (p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGB(128, 128, false);
         else if (p.bmo == 128) IO_LAUNCH_WGB(128, 64, false);
         else if (p.bnc == 128) IO_LAUNCH_WGB(64, 128, false);
         else IO_LAUNCH_WGB(64, 64, false);
+#undef IO_LAUNCH_WGTR
 #undef IO_LAUNCH_WGB
 #undef IO_LAUNCH_WGB_
     } else {

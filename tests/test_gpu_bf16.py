@@ -28,7 +28,12 @@ def to_bf_dev(t_nhwc):
 
 
 CASES = [(2, 16, 16, 64, 64, 1, 1, 0), (3, 10, 14, 64, 256, 1, 1, 0), (2, 16, 16, 256, 128, 3, 1, 1),
-         (2, 12, 20, 128, 128, 3, 2, 1), (2, 16, 16, 256, 512, 1, 2, 0), (1, 8, 8, 512, 2048, 1, 1, 0)]
+         (2, 12, 20, 128, 128, 3, 2, 1), (2, 16, 16, 256, 512, 1, 2, 0), (1, 8, 8, 512, 2048, 1, 1, 0),
+         # shapes of the LDS-DMA / transpose-read filter-gradient kernel (64 | Ho*Wo, chunk rows | Wo) in each of its four
+         # tile forms, stride 2, the 8-wide map, several k-tiles per split -- the cases above with 64 !| Ho*Wo stay on the
+         # staged kernel
+         (2, 32, 32, 128, 128, 3, 2, 1), (2, 16, 16, 64, 128, 3, 1, 1), (2, 16, 16, 128, 64, 1, 1, 0),
+         (4, 8, 8, 64, 64, 3, 1, 1), (8, 16, 16, 128, 128, 3, 1, 1), (3, 16, 32, 128, 256, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)

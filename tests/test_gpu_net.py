@@ -75,7 +75,10 @@ def unpack(ret):
 # 1. forward parity vs oracle
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("algo,style,S,B", [("InstaOrderNet_o", "kaiming", 64, 4), ("InstaOrderNet_od", "kaiming", 96, 3),
-                                            ("InstaOrderNet_o", "xavier", 128, 2), ("InstaOrderNet_o", "kaiming", 256, 2)])
+                                            ("InstaOrderNet_o", "xavier", 128, 2), ("InstaOrderNet_o", "kaiming", 256, 2),
+                                            # 384: the input_size of the reference's own _od configuration
+                                            # (experiments/InstaOrder/InstaOrderNet_od/config.yaml:35); 12 x 12 at layer 4
+                                            ("InstaOrderNet_od", "kaiming", 384, 2)])
 def test_forward_train_and_eval_vs_oracle(algo, style, S, B):
     m = build(algo, 31, style)
     state = oracle_state(31, algo, style)
@@ -149,7 +152,8 @@ def test_backward_tight_on_relu_free_network(algo, S, B):
     print("relu-free backward: worst per-tensor rel L2 err vs fp64: HIP %.2e, torch-CPU-fp32 %.2e" % (worst, worst_cpu))
 
 
-@pytest.mark.parametrize("algo,style,S,B", [("InstaOrderNet_o", "kaiming", 64, 8), ("InstaOrderNet_od", "xavier", 128, 4)])
+@pytest.mark.parametrize("algo,style,S,B", [("InstaOrderNet_o", "kaiming", 64, 8), ("InstaOrderNet_od", "xavier", 128, 4),
+                                            ("InstaOrderNet_od", "kaiming", 384, 2)])    # the reference _od input_size
 def test_backward_statistical_vs_fp64_anchor(algo, style, S, B):
     sd = synthetic.make_state_dict(43, 5, ALGO_CLASSES[algo], style=style)
     st32 = orc.state_from_numpy(sd)

@@ -34,6 +34,7 @@ for m in ("fwd", "infer"):
             json.dump(last_json(src), open(os.path.join(P, "%s_bench_%s_%s.json" % (rnd, m, d)), "w"), indent=1)
 
 for src, dst in (("bench_c2.json", "bench_config2_od_bf16_1024.json"), ("bench_c3.json", "bench_config3_od_bf16_images20_n1.json"),
+                 ("bench_c2_384.json", "bench_config2_od_bf16_384_b256.json"),
                  ("bench_c4.json", "bench_config4_depthnet_od_bf16_b16.json"),
                  ("bench_c4_prof.json", "bench_config4_depthnet_od_bf16_b16_kernel_classes.json"),
                  ("bench_c4_fp32.json", "bench_config4_depthnet_od_fp32_b16.json")):

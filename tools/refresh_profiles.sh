@@ -27,6 +27,8 @@ cd $R
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1
 # secondary workloads (BASELINE configs[2], [3], [4]); the MiDaS-based net without the per-launch event profiler too
 python3 bench.py --algo InstaOrderNet_od --dtype bf16 --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench_n1.err
+# the reference's own _od input_size (InstaOrderNet_od/config.yaml:35), SURVEY 8(d) secondary row
+python3 bench.py --algo InstaOrderNet_od --dtype bf16 --size 384 --batch 256 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2_384.json 2>> $O/bench_n1.err
 python3 bench.py --algo InstaOrderNet_od --dtype bf16 --workload images20 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c3.json 2>> $O/bench_n1.err
 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 4 --warmup 2 > $O/bench_c4_prof.json 2>> $O/bench_n1.err
 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 6 --warmup 3 --no-prof --no-cpu-baseline > $O/bench_c4.json 2>> $O/bench_n1.err
