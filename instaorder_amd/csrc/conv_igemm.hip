@@ -1576,6 +1576,11 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
         }
 }
 
+// (An fp32 sibling -- LDS-DMA into a row-major [m][channels] image, ds_read_b32 fragments, no transposes at all because
+// v_mfma_f32_32x32x2_f32 takes one reduction index per lane -- was built and measured: 112.9 TF/s with 32-row k-tiles at
+// two blocks per CU, 117.8 with 16-row k-tiles at four, against 118.3 for the register-staged kernel at three; the
+// fp32 filter gradient is bound by the matrix pipe, not by its staging, so it stays on conv_wgrad_kernel.)
+
 // dst[i] = sum_z partial[z][i]: block = 32 float4 columns x 8 split lanes (8 loads in flight per lane),
 // fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,

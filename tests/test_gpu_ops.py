@@ -71,6 +71,8 @@ CONV_CASES = [
     (1, 64, 64, 64, 128, 3, 2, 1),      # the same through a strided 3x3 with a 128 x 64 tile
     (1, 12, 12, 256, 128, 3, 1, 1),     # 4 | Wo on 128 x 128 tiles with rows that wrap inside a k-tile (Wo = 12)
     (8, 64, 64, 128, 512, 1, 1, 0),     # 1024 tiles of a 1x1 GEMM: the grid that keeps the two-block NT build
+    (2, 32, 32, 128, 128, 3, 2, 1),     # LDS-DMA filter gradient: strided 3x3, 128 x 128 tiles
+    (3, 16, 32, 128, 256, 3, 1, 1),     # ... non-square map, three samples, several k-tiles per split
 ]
 
 
