@@ -57,6 +57,10 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #ifndef IO_ST_AUX
 #define IO_ST_AUX 2
 #endif
+#ifndef IO_TR_BKM
+#define IO_TR_BKM 64       // rows (output pixels) per k-tile of the LDS-DMA filter-gradient kernel ...
+#define IO_TR_MINB 2       // ... and the blocks per CU asked of the register allocator
+#endif
 #ifndef IO_WGRAD_TR
 #define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
 #endif
@@ -1410,12 +1414,11 @@ template <int W> __device__ __forceinline__ void tr_chunk_src(int pos, int& r, i
     }
 }
 
-template <int BMO, int BNC, bool STEM = false, int MINB = 2>
+template <int BMO, int BNC, bool STEM = false, int MINB = 2, int BKM = 64>
 __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
                                                                      const bf16_t* __restrict__ dy,
                                                                      float* __restrict__ dst, int ntile_c, int tiles,
                                                                      int kps, size_t in_bytes, size_t dy_bytes) {
-    constexpr int BKM = 64;
     constexpr int TI = BMO / 64, TJ = BNC / 64;
     constexpr int A_BYTES = BMO * BKM * 2, B_BYTES = BNC * BKM * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int RA = 512 / BMO, RB = 512 / BNC;              // rows per 1 KiB chunk
@@ -1484,25 +1487,54 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
         (unsigned)(((dh + padh) * g.Wi + rb_ * g.is + dw + padw) * g.Ci + (STEM ? 0 : c0 + csb * 8)) * 2u;
     const int wib = rb_ * g.is + dw;             // + wo * is = input column of the lane's row
 
+    // Scalar side of the fetches.  The wave's chunks sit at fixed pixel offsets q inside a k-tile (64 consecutive output
+    // pixels of one sample, starting at a multiple of 64).  When Wo divides 64 or 64 divides Wo (every power-of-two map)
+    // a chunk's (row, column) is the tile's plus a per-chunk CONSTANT, so a k-tile costs two divisions and each fetch one
+    // scalar add; other widths decode every chunk (the general path below).  This matters: with the decode per chunk the
+    // kernel issued 7.4 scalar instructions per MFMA and spent 27 % of its wave cycles on them.
+    const bool fastrow = (g.Wo % BKM == 0) || (BKM % g.Wo == 0);
+    const bool wo_small = BKM % g.Wo == 0;
+    int dho[CB], wou[CB];
+    unsigned cso[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+        const int q = (wave * CB + u) * RB;
+        dho[u] = wo_small ? q / g.Wo : 0;
+        wou[u] = wo_small ? q - dho[u] * g.Wo : q;
+        cso[u] = (unsigned)((dho[u] * g.is * g.Wi + wou[u] * g.is) * g.Ci) * 2u;
+    }
     auto issue = [&](int kt, int stage) {
         const unsigned sb = lds0 + (unsigned)(stage * STAGE);
         const int m0 = kt * BKM;
+        const unsigned asoff = (unsigned)((m0 - mfirst) * g.Co) * 2u;
 #pragma unroll
         for (int u = 0; u < CA; ++u) {
             const int chunk = wave * CA + u;
-            const unsigned soff = (unsigned)((m0 + chunk * RA - mfirst) * g.Co) * 2u;
-            dma16(rs_dy, sb + (unsigned)(chunk * 1024), va, soff);
+            dma16(rs_dy, sb + (unsigned)(chunk * 1024), va, asoff + (unsigned)(chunk * RA * g.Co) * 2u);
         }
         const int n = fdiv(m0, g.fd_howo), p_tile = m0 - n * HoWo;
+        if (fastrow) {
+            const int ho_t = fdiv(p_tile, g.fd_wo), wo_t = p_tile - ho_t * g.Wo;
+            const unsigned tsoff = (unsigned)((((n - n_lo) * g.Hi + ho_t * g.is) * g.Wi + wo_t * g.is) * g.Ci) * 2u;
 #pragma unroll
-        for (int u = 0; u < CB; ++u) {
-            const int chunk = wave * CB + u;
-            const int pc = p_tile + chunk * RB;
-            const int ho = fdiv(pc, g.fd_wo), wo = pc - ho * g.Wo;
-            const unsigned soff = (unsigned)((((n - n_lo) * g.Hi + ho * g.is) * g.Wi + wo * g.is) * g.Ci) * 2u;
-            const bool ok = tapok & ((unsigned)(ho * g.is + dh) < (unsigned)g.Hi) &
-                            ((unsigned)(wo * g.is + wib) < (unsigned)g.Wi);
-            dma16(rs_in, sb + (unsigned)(A_BYTES + chunk * 1024), ok ? vb : kInvalidOff, soff);
+            for (int u = 0; u < CB; ++u) {
+                const int chunk = wave * CB + u;
+                const int ho = ho_t + dho[u], wo = wo_t + wou[u];
+                const bool ok = tapok & ((unsigned)(ho * g.is + dh) < (unsigned)g.Hi) &
+                                ((unsigned)(wo * g.is + wib) < (unsigned)g.Wi);
+                dma16(rs_in, sb + (unsigned)(A_BYTES + chunk * 1024), ok ? vb : kInvalidOff, tsoff + cso[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int chunk = wave * CB + u;
+                const int pc = p_tile + chunk * RB;
+                const int ho = fdiv(pc, g.fd_wo), wo = pc - ho * g.Wo;
+                const unsigned soff = (unsigned)((((n - n_lo) * g.Hi + ho * g.is) * g.Wi + wo * g.is) * g.Ci) * 2u;
+                const bool ok = tapok & ((unsigned)(ho * g.is + dh) < (unsigned)g.Hi) &
+                                ((unsigned)(wo * g.is + wib) < (unsigned)g.Wi);
+                dma16(rs_in, sb + (unsigned)(A_BYTES + chunk * 1024), ok ? vb : kInvalidOff, soff);
+            }
         }
     };
 
@@ -1542,7 +1574,7 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
         if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
         const lds_cptr sb = lds + stage * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < BKM / 16; ++kk) {
             bf16x8 a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) a[i] = frag(sb, fa[i] + kk * KKA, HA);
@@ -1909,16 +1941,16 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                          g.Wo % rb_rows == 0;
 #define IO_LAUNCH_WGTR(BMO_, BNC_, STEM_)                                                                               \
     do {                                                                                                         \
-        const size_t lds = (size_t)2 * (BMO_ + BNC_) * 64 * 2;                                                   \
+        const size_t lds = (size_t)2 * (BMO_ + BNC_) * IO_TR_BKM * 2;                                            \
         static bool attr_done = false;                                                                           \
         if (!attr_done) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_>,                 \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
             attr_done = true;                                                                                    \
         }                                                                                                        \
-        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_>), grid1, block, lds, st, g,             \
-                           (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64, in_bytes,       \
-                           dy_bytes);                                                                            \
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>), grid1, block,  \
+                           lds, st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles,            \
+                           kps64 * (64 / IO_TR_BKM), in_bytes, dy_bytes);                                        \
     } while (0)
         if (trk && stem) IO_LAUNCH_WGTR(64, 64, true);
         else if (trk && p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGTR(128, 128, false);
