@@ -61,6 +61,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #define IO_TR_BKM 64       // rows (output pixels) per k-tile of the LDS-DMA filter-gradient kernel ...
 #define IO_TR_MINB 2       // ... and the blocks per CU asked of the register allocator
 #endif
+#ifndef IO_EP_ROWS
+#define IO_EP_ROWS 1       // bf16 epilogues of the dense 1x1 GEMMs store whole rows through LDS (0: one column per lane)
+#endif
 #ifndef IO_WGRAD_TR
 #define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
 #endif
@@ -610,6 +613,47 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         // layout in the scalar offset (as in the fused BatchNorm-backward epilogue above)
         const unsigned rowstep = (unsigned)g.Co * (unsigned)OS;
         const unsigned lane_base = (unsigned)((wm * 64 + 4 * (lane >> 5)) * g.Co + n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
+        if constexpr (OS == 2 && BN == 128 && IO_EP_ROWS) {
+            // bf16 output without residual / mask: the accumulator layout gives a lane ONE column, i.e. 2-byte stores
+            // that reach memory as 64-byte half lines -- 3.3 TB/s with the non-temporal bit against 5.6+ for whole
+            // lines (profiles/r02_store_and_shortk_probes.txt), and the p -> 4p layers write four times what they read.
+            // So each wave turns its quadrant through its own slice of the (now idle) operand LDS, 32 rows at a time: fp32
+            // in column order, out as 4 consecutive channels of a row per lane -> 8-byte stores, 16 lanes = one 128-byte
+            // line.  LDS traffic of a wave stays in order, so the slice needs no barrier after the first one.  (128-wide
+            // tiles only: a 64-wide tile's rows are 64-byte segments either way, measured 4 % slower this way.)
+            // Isolated, rotating buffers: 64 -> 256 0.384 -> 0.306 ms, 128 -> 512 0.258 -> 0.183, 256 -> 1024 0.128 ->
+            // 0.111; in the bf16 step the NT class 21.49 -> 20.97 ms (a timing-only build with 16-byte stores and no LDS
+            // trip bounds the idea at 20.41).
+            if (!add && !mask) {
+                constexpr int WC = BN / WN, EPP = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NI = 32 / RPI;
+                __syncthreads();                 // every wave is done with the operand tiles
+                float* ep = smem + wave * (32 * EPP);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[i][j][r];
+                            if (bw.bias) {
+                                v += ep_bias[j];
+                                v = (bw.relu && v < 0.f) ? 0.f : v;
+                            }
+                            ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = v;
+                        }
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 4;
+                        const f32x4 q = ld4(ep + row * EPP + cc);
+                        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                        const u32x2_ pk = {io_f2bf2(q[0], q[1]), io_f2bf2(q[2], q[3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(
+                            pk, rs_out, (unsigned)((wm * 64 + i * 32 + row) * g.Co + n0 + wn * WC + cc) * 2u, 0, IO_ST_AUX);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
