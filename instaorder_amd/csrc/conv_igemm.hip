@@ -574,6 +574,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         // consumer wants it as a plain tensor.  y is in registers anyway: one more store stream, no extra read.
         const __amdgpu_buffer_rsrc_t rs_aout = make_rsrc_at(bw.a_out ? bw.a_out : (void*)out, out_base,
                                                             bw.a_out ? out_bytes : out_base);
+        // bf16, 128-wide tiles, no activation side output: dz leaves through the wave's LDS slice as whole rows (see the
+        // plain 1x1 epilogue below for the why)
+        constexpr bool ROWS = OS == 2 && BN == 128 && IO_EP_ROWS;
+        constexpr int WC = BN / WN, EPP = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NI = 32 / RPI;
+        const bool rows = ROWS && !bw.a_out;
+        float* ep = smem + wave * (32 * EPP);
+        if (rows) __syncthreads();               // every wave is done with the operand tiles
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -597,12 +604,29 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     if (bw.mscale) v = t > 0.f ? v : 0.f;
                     bw_s1[j] += v;
                     bw_s2[j] += v * ((yv[r] - bw_mu[j]) * bw_rs[j]);
-                    st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
-                    // (no a_out: a zero-length descriptor drops the store)
-                    st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    if (ROWS && rows) {
+                        ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = v;
+                    } else {
+                        st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                        // (no a_out: a zero-length descriptor drops the store)
+                        st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    }
+                }
+            }
+            if (ROWS && rows) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 4;
+                    const f32x4 q = ld4(ep + row * EPP + cc);
+                    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                    const u32x2_ pk = {io_f2bf2(q[0], q[1]), io_f2bf2(q[2], q[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        pk, rs_out, (unsigned)((m0 - opix_lo + wm * 64 + i * 32 + row) * g.Co + n0 + wn * WC + cc) * 2u, 0,
+                        IO_ST_AUX);
                 }
             }
         }
+        // (the reduction of the partial sums below starts with a barrier before it reuses LDS)
     }
     if constexpr (!BWE) {
     float ep_bias[TJ];
