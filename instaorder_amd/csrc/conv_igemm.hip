@@ -574,13 +574,12 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         // consumer wants it as a plain tensor.  y is in registers anyway: one more store stream, no extra read.
         const __amdgpu_buffer_rsrc_t rs_aout = make_rsrc_at(bw.a_out ? bw.a_out : (void*)out, out_base,
                                                             bw.a_out ? out_bytes : out_base);
-        // bf16, 128-wide tiles, no activation side output: dz leaves through the wave's LDS slice as whole rows (see the
-        // plain 1x1 epilogue below for the why)
+        // bf16, 128-wide tiles: dz leaves through the wave's LDS slice as whole rows (see the plain 1x1 epilogue below for
+        // the why); the optional activation side output keeps its column stores
         constexpr bool ROWS = OS == 2 && BN == 128 && IO_EP_ROWS;
         constexpr int WC = BN / WN, EPP = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NI = 32 / RPI;
-        const bool rows = ROWS && !bw.a_out;
         float* ep = smem + wave * (32 * EPP);
-        if (rows) __syncthreads();               // every wave is done with the operand tiles
+        if (ROWS) __syncthreads();               // every wave is done with the operand tiles
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -604,16 +603,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     if (bw.mscale) v = t > 0.f ? v : 0.f;
                     bw_s1[j] += v;
                     bw_s2[j] += v * ((yv[r] - bw_mu[j]) * bw_rs[j]);
-                    if (ROWS && rows) {
-                        ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = v;
-                    } else {
-                        st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
-                        // (no a_out: a zero-length descriptor drops the store)
-                        st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
-                    }
+                    if constexpr (ROWS) ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = v;
+                    else st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    // (no a_out: a zero-length descriptor drops the store)
+                    st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
                 }
             }
-            if (ROWS && rows) {
+            if constexpr (ROWS) {
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
                     const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 4;
