@@ -174,6 +174,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     constexpr int BR = (BN * 8) / NT;       // weight rows loaded per thread
     constexpr int RS = NT / 8;              // row step between a thread's rows
     static_assert(TJ >= 1 && BR >= 1, "tile too small for this wave count");
+    // the row-wise bf16 epilogues turn 32 x (BN / WN) fp32 values per wave through the operand LDS
+    static_assert(NBUF * (BM + BN) * LDT >= NW * 32 * (BN / WN + 4), "operand LDS too small for the row epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                       // [2][BM][LDT]
     float* sB = smem + NBUF * BM * LDT;     // [NBUF][BN][LDT]
