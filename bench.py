@@ -332,7 +332,18 @@ def main():
         # the wgrad kernel runs the fp32 MFMA in both modes; the NT kernel (fwd / dgrad) follows --dtype
         peak = PEAK_BF16_MFMA_TFLOPS if (args.dtype == "bf16" and "wgrad" not in name) else PEAK_FP32_MFMA_TFLOPS
         if args.dtype == "bf16":
+            # the bf16 step has its own PMC file (tools/collect_traffic_bf16.sh); it holds for the headline configuration
             traffic, traffic_src = None, None
+            try:
+                f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bf16.json")))[-1]
+                tj = json.load(open(f))
+                kk = [k for k in tj["kernels"] if k.startswith("conv_nt_kernel")]
+                if kk and name == "conv_nt_kernel<128,false>" and args.algo == "InstaOrderNet_o" and B == 256 and S == 256 \
+                        and args.mode == "train":
+                    traffic = tj["kernels"][kk[0]]["bytes_per_launch_corrected"]
+                    traffic_src = "%s (measured at commit %s)" % (os.path.basename(f), tj.get("commit"))
+            except Exception:
+                pass
         gbs = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tfl, "peak": peak,
                               "unit": "TFLOP/s", "frac": tfl / peak, "traffic": traffic, "traffic_source": traffic_src,
