@@ -33,7 +33,10 @@ CASES = [(2, 16, 16, 64, 64, 1, 1, 0), (3, 10, 14, 64, 256, 1, 1, 0), (2, 16, 16
          # tile forms, stride 2, the 8-wide map, several k-tiles per split -- the cases above with 64 !| Ho*Wo stay on the
          # staged kernel
          (2, 32, 32, 128, 128, 3, 2, 1), (2, 16, 16, 64, 128, 3, 1, 1), (2, 16, 16, 128, 64, 1, 1, 0),
-         (4, 8, 8, 64, 64, 3, 1, 1), (8, 16, 16, 128, 128, 3, 1, 1), (3, 16, 32, 128, 256, 3, 1, 1)]
+         (4, 8, 8, 64, 64, 3, 1, 1), (8, 16, 16, 128, 128, 3, 1, 1), (3, 16, 32, 128, 256, 3, 1, 1),
+         # ... and its general row decode: 24-wide maps (64 | Ho*Wo, but Wo neither divides 64 nor is divided by it), also
+         # strided from 48 x 48
+         (2, 24, 24, 128, 128, 3, 1, 1), (2, 48, 48, 64, 128, 3, 2, 1), (4, 24, 24, 256, 64, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("case", CASES)
