@@ -205,6 +205,64 @@ def test_checkpoint_roundtrip_with_momentum(tmp_path):
     assert torch.equal(m.optim.flat_params, m2.optim.flat_params)
 
 
+def test_backward_against_fp64_anchor():
+    """Every parameter gradient of an InstaDepthNet_od training pass (all five loss terms, both mask orders) against an
+    fp64 evaluation of the oracle on the same state and batch, each tensor measured against the distance that PyTorch-CPU
+    fp32 -- the reference's arithmetic -- has from that anchor: e <= 3 ec + 5e-3 (the floor is the price of one
+    knife-edge ReLU decision, helpers.check_against_anchor).  With 680 tensors and ~100 ReLU layers a pass usually HAS
+    such an event somewhere (PyTorch-CPU fp32 shows them too: its worst tensor sits at 2e-2), so the test runs two
+    batches: a tensor may exceed the bound in one of them (<= 2 % of the tensors do, none beyond 5e-2), never in both --
+    which is what a systematic error of 1 % in any kernel would do -- and the aggregate stays within 3 x the CPU's."""
+    from oracle import midas_oracle as mo
+    algo, tag = CASES[0]
+    g, spec = load(tag)
+    import instaorder_amd as ia
+    S, B, seed = 64, 2, 91
+    cfg = dict(algo=algo, lr=0.0, weight_decay=0.0, optim="SGD", pretrained_weight=None, use_rgb=True, **WEIGHTS)
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
+    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    names = [str(n) for n in g["names"]]
+    m.switch_to("train")
+    bad_sets = []
+    for bseed in (seed + 1, seed + 2):
+        t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(bseed, B, S).items()}
+
+        def oracle_grads(dtype):
+            st = mo.state_from_numpy(sd, prefix="module.", dtype=dtype)
+            tt = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in t.items()}
+            o1 = mo.forward(st, tt["rgb"], tt["modal1"], tt["modal2"], True, "od")
+            o2 = mo.forward(st, tt["rgb"], tt["modal2"], tt["modal1"], True, "od")
+            _, total = mo.losses(o1, o2, tt, WEIGHTS, 1, "od")
+            gr = torch.autograd.grad(total, [st[n] for n in names], allow_unused=True)
+            return {n: x.reshape(-1) for n, x in zip(names, gr) if x is not None}
+
+        g32, g64 = oracle_grads(torch.float32), oracle_grads(torch.float64)
+        feed(m, algo, t)
+        m.step()                         # lr = 0: the state (and the running statistics' effect on it) stays put
+        bad, num_h, num_c, den, worst = set(), 0.0, 0.0, 0.0, 0.0
+        for n, (off, k) in zip(names, m.optim._spans):
+            if n not in g64:
+                continue
+            ref = g64[n]
+            gh = m.optim.flat_grads[off:off + k].double().cpu()
+            nr = float(ref.norm().clamp_min(1e-300))
+            e, ec = float((gh - ref).norm()) / nr, float((g32[n].double() - ref).norm()) / nr
+            num_h += float((gh - ref).norm() ** 2)
+            num_c += float((g32[n].double() - ref).norm() ** 2)
+            den += float(ref.norm() ** 2)
+            worst = max(worst, e)
+            if e > 3 * ec + 5e-3:
+                bad.add(n)
+        eh, ec = (num_h / den) ** 0.5, (num_c / den) ** 0.5
+        print("InstaDepthNet_od grads vs fp64 (batch %d): global HIP %.2e, torch-CPU-fp32 %.2e; %d of %d tensors over their "
+              "bound, worst %.2e" % (bseed, eh, ec, len(bad), len(g64), worst))
+        assert eh < 3 * ec + 1e-3
+        assert len(bad) <= len(g64) // 50 and worst < 5e-2, sorted(bad)[:10]
+        bad_sets.append(bad)
+    assert not (bad_sets[0] & bad_sets[1]), sorted(bad_sets[0] & bad_sets[1])
+
+
 def test_larger_input_against_oracle():
     """A shape the goldens do not cover (128 x 128, 4 pairs: the fused conv + statistics path is taken down to layer3,
     the pair mode batches 8 mask orders with two statistics groups): HIP path against the CPU oracle on the same
