@@ -50,10 +50,13 @@ __device__ __forceinline__ int fdiv(int n, IoFastDiv f) {
 // (kInvalidOff, or rows beyond M) returns zeros in hardware -- no 64-bit address arithmetic, no selects.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
-// Output stores of the convolution epilogues are NON-TEMPORAL (aux bit 1 = nt): a lane owns one column of the
-// accumulator layout, so a store instruction writes 2 x 64 (bf16) or 2 x 128 (fp32) bytes -- partial or single lines
-// that the default policy keeps in L2; with nt they stream out.  Same-box A/B on the bf16 1x1 layers: 64->256 +31 %,
-// 128->512 +47 %, 256->1024 +36 % (sc0 / sc1 bits: no gain / -15 %); the tensors are far larger than L2 + MALL anyway.
+// Output stores of the convolution epilogues are NON-TEMPORAL (aux bit 1 = nt).  What is known about that bit here
+// (profiles/r02_store_and_shortk_probes.txt): on ONE re-used buffer pair (cache-warm) nt looks 31-47 % faster on the
+// bf16 1x1 layers; on rotating buffers plain stores win by 8-25 % on the write-heavy layers, because a lane owns one
+// column of the accumulator layout and nt sends its 64-byte half lines to memory unmerged (write-only probe: 3.3 TB/s
+// nt vs 5.5-6.0 plain for 2-byte stores; no such gap for 4-byte stores or whole lines); in the network the two builds are
+// indistinguishable (the BatchNorm pass that follows pays back what the convolution gains).  nt is kept; the bf16
+// epilogues that matter store whole rows through LDS instead (IO_EP_ROWS).  (sc0 / sc1 bits: no gain / -15 %.)
 #ifndef IO_ST_AUX
 #define IO_ST_AUX 2
 #endif
