@@ -269,6 +269,43 @@ int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz, int N, in
                              int pad, const void* y, int G, const float* gamma, const float* mean, const float* rstd,
                              const float* scale, const float* shift, float* dgamma, float* dbeta, void* dyb,
                              float* workspace, size_t workspace_floats, int dtype, int gw, hipStream_t stream);
+/* ---- BatchNorm backward without an apply pass: the training step's fused data-gradient launch ---------------------------
+ * autograd of `out = conv(relu(bn(y)))` chains (models/backbone/resnet_cls.py:99-113, loss.backward() at
+ * models/supervised_order.py:545).  The BatchNorm input gradient dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) is
+ * an affine function of (dz, y) per channel: dy = a[g][c]*dz + b[g][c]*y + c[g][c].  io_bn_bwd_coefs* produce dgamma /
+ * dbeta and the three [G][C] tables (coef: 3*G*C floats, a | b | c) -- from (dz, y) by a reduction pass, or from the
+ * per-tile partial sums p1 / p2 that the epilogue of io_conv2d_dgrad_fused_dt left behind (each array
+ * io_bn_tile_partial_floats(M, C, G) floats; M/G a multiple of 128) -- and io_conv2d_dgrad_fused_dt consumes them: its A
+ * operand is evaluated from dz and y while it is staged (two loads per chunk instead of one), and the blocks of the
+ * first output-channel tile write dy out once for the filter gradient.  dz must already carry its ReLU mask. */
+size_t io_bn_tile_partial_floats(int M, int C, int G);
+int io_bn_bwd_coefs_dt(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
+                       const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
+                       size_t partial_floats, int dtype, hipStream_t stream);
+int io_bn_bwd_coefs_from_tile_partials(float* p1, float* p2, int M, int C, int G, const float* gamma, const float* mean,
+                                       const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t stream);
+/* Everything one data-gradient launch of the training step can carry (all optional; zero-initialise the struct):
+ *  operand side   xb_y / xb_coef / xb_dy_out: `dy` is the masked gradient dz of the BatchNorm output behind the convolution,
+ *                 xb_y that BatchNorm's input, xb_coef its tables (above); xb_dy_out (optional) receives dy [N,Ho,Wo,Cout].
+ *                 Needs a stride-1 same-size convolution (1x1, or 3x3 pad 1) and M/G a multiple of 128.
+ *  epilogue       add (may alias dx) / relu_mask as io_conv2d_dgrad;
+ *                 ep_y: the BatchNorm whose OUTPUT gradient dx is (y = its input [N,H,W,Cin], ep_mean / ep_rstd [G][Cin]):
+ *                 per-tile sums of dx and dx*xhat go to ep_p1 / ep_p2 for io_bn_bwd_coefs_from_tile_partials; with
+ *                 ep_scale / ep_shift dx is first masked by [relu(bn(y)) > 0] recomputed from y, and ep_act_out
+ *                 (optional) receives relu(bn(y)).  Needs M/G a multiple of 128. */
+typedef struct io_dgrad_fused {
+    const void* xb_y;
+    const float* xb_coef;
+    void* xb_dy_out;
+    const void* add;
+    const void* relu_mask;
+    const void* ep_y;
+    const float *ep_mean, *ep_rstd, *ep_scale, *ep_shift;
+    void* ep_act_out;
+    float *ep_p1, *ep_p2;
+} io_dgrad_fused;
+int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout, int R,
+                             int S, int pad, int G, const io_dgrad_fused* f, int dtype, hipStream_t stream);
 /* conv(relu((x - in_mean[g][c]) * in_scale[g][c] + in_shift[g][c]), w): the BatchNorm + ReLU between two convolutions of a Bottleneck
  * (models/backbone/resnet_cls.py:99-111: out = relu(bn1(conv1(x))); out = conv2(out)) applied to the operand of the
  * SECOND convolution while it is staged, so relu(bn1(.)) is never written to memory.  Padding is zero AFTER the

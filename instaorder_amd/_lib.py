@@ -27,6 +27,12 @@ class PairDesc(C.Structure):
                 ("flip", C.c_int32), ("interp", C.c_int32)]
 
 
+class DgradFused(C.Structure):
+    """io_dgrad_fused of include/instaorder_hip.h (device pointers as integers, None = NULL)"""
+    _fields_ = [(n, C.c_void_p) for n in ("xb_y", "xb_coef", "xb_dy_out", "add", "relu_mask", "ep_y", "ep_mean", "ep_rstd",
+                                          "ep_scale", "ep_shift", "ep_act_out", "ep_p1", "ep_p2")]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -101,6 +107,10 @@ SIGNATURES = {
     "io_conv2d_fwd_bnstats_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P,
                                       _P, _P, _P, _P, _Z, _I, _I, _P]),
     "io_conv2d_fwd_bias_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "io_bn_tile_partial_floats": (_Z, [_I, _I, _I]),
+    "io_bn_bwd_coefs_dt": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "io_bn_bwd_coefs_from_tile_partials": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "io_conv2d_dgrad_fused_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(DgradFused), _I, _P]),
     "io_conv2d_dgrad_bnbwd_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                       _Z, _I, _I, _P]),
     "io_prof_launches": (_I, [_P, _I]),

@@ -395,7 +395,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                              const float* __restrict__ p2, int nb, int G, int Mg,
                                                              int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ c1,
-                                                             float* __restrict__ c2) {
+                                                             float* __restrict__ c2,
+                                                             const float* __restrict__ xgamma = nullptr,
+                                                             const float* __restrict__ xmean = nullptr,
+                                                             const float* __restrict__ xrstd = nullptr,
+                                                             float* __restrict__ c3 = nullptr) {
     constexpr int U = 16, MAXG = 8;
     __shared__ double sh[2][32][8];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;     // tx: channel, ty: partial lane (0..31)
@@ -424,8 +428,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
             for (int k = 1; k < 32; ++k) { a += sh[0][k][tx]; b2 += sh[1][k][tx]; }
             db += a;
             dg += b2;
-            c1[g * C + c] = (float)(a / Mg);
-            c2[g * C + c] = (float)(b2 / Mg);
+            if (c3) {
+                // coefficient form for the operand transform of the data-gradient kernel (IoBwStats::xb_a/b/c):
+                // dy = gamma*rstd*(dz - m1 - (y - mean)*rstd*m2) = A*dz + B*y + Cc
+                const double rs = (double)xrstd[g * C + c];
+                const double A = (double)xgamma[c] * rs, B = -A * rs * (b2 / Mg);
+                c1[g * C + c] = (float)A;
+                c2[g * C + c] = (float)B;
+                c3[g * C + c] = (float)(-A * (a / Mg) - B * (double)xmean[g * C + c]);
+            } else {
+                c1[g * C + c] = (float)(a / Mg);
+                c2[g * C + c] = (float)(b2 / Mg);
+            }
         }
         __syncthreads();
     }
@@ -679,6 +693,29 @@ int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, in
     return io_check_launch("bn_bwd_from_tiles");
 }
 
+int io_bn_bwd_coefs_from_tiles(float* p1, float* p2, int M, int C, int G, const float* gamma, const float* mean,
+                               const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    IO_REQUIRE(C % 4 == 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd_coefs_from_tiles: C=%d unsupported", C);
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "bn_bwd_coefs_from_tiles: rows per group must be a multiple of %d", kIoStatTileRows);
+    const int Mg = M / G, nt = Mg / kIoStatTileRows;
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, 8.0 * (double)(M / kIoStatTileRows) * C, st);
+    const float* q1 = p1;
+    const float* q2 = p2;
+    int nb = nt;
+    if (nt > 64) {
+        const int chunk = 64, nch = io_cdiv(nt, chunk);
+        float* o1 = p1 + (size_t)G * nt * C;
+        float* o2 = p2 + (size_t)G * nt * C;
+        hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3(io_cdiv(C, 32), G, nch), dim3(256), 0, st, p1, p2, nt, C, chunk, o1,
+                           o2);
+        q1 = o1; q2 = o2; nb = nch;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, q1, q2, nb, G, Mg, C, dgamma,
+                       dbeta, coef, coef + (size_t)G * C, gamma, mean, rstd, coef + (size_t)2 * G * C);
+    return io_check_launch("bn_bwd_coefs_from_tiles");
+}
+
 static int bn_rows_per_block(int Mg, int G, int* nb) {
     int want = 1024 / (G > 0 ? G : 1);
     if (want < 1) want = 1;
@@ -815,4 +852,30 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_
                          size_t partial_floats, float* coef, hipStream_t st) {
     return io_bn_bwd_t(dout, act, mask_scale, mask_shift, y, M, C, G, gamma, mean, rstd, dgamma, dbeta, dy, dz_out,
                        partial, partial_floats, coef, st, IO_F32);
+}
+
+int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
+                      const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
+                      size_t partial_floats, hipStream_t st, int dt) {
+    const int sh = ilog2_exact(C / 4);
+    IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd_coefs: C=%d unsupported", C);
+    IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_bwd_coefs: M=%d not divisible by G=%d", M, G);
+    IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_bwd_coefs: partial too small");
+    const int Mg = M / G;
+    int nb;
+    const int rpb = bn_rows_per_block(Mg, G, &nb);
+    float* p1 = partial;
+    float* p2 = partial + (size_t)G * nb * C;
+    IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C * 2.0, st);
+    if (dt == IO_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb, G), dim3(kThreads), 0, st, (const bf16_t*)dz,
+                           (const bf16_t*)nullptr, (const bf16_t*)y, Mg, C, rpb, mean, rstd, (const float*)nullptr,
+                           (const float*)nullptr, p1, p2);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, G), dim3(kThreads), 0, st, (const float*)dz,
+                           (const float*)nullptr, (const float*)y, Mg, C, rpb, mean, rstd, (const float*)nullptr,
+                           (const float*)nullptr, p1, p2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C, dgamma, dbeta,
+                       coef, coef + (size_t)G * C, gamma, mean, rstd, coef + (size_t)2 * G * C);
+    return io_check_launch("bn_bwd_coefs");
 }

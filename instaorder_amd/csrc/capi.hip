@@ -412,6 +412,54 @@ extern "C" int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz
                                 workspace + 2 * per, st, dtype);
 }
 
+extern "C" size_t io_bn_tile_partial_floats(int M, int C, int G) {
+    if (M <= 0 || C <= 0 || G <= 0) return 0;
+    const size_t tiles = (size_t)(M + kIoStatTileRows - 1) / kIoStatTileRows;
+    return (tiles + tiles / 64 + (size_t)G + 2) * (size_t)C;
+}
+
+extern "C" int io_bn_bwd_coefs_dt(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
+                                  const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
+                                  size_t partial_floats, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "bn_bwd_coefs: unknown dtype %d", dtype);
+    return io_bn_bwd_coefs_t(dz, y, M, C, G, gamma, mean, rstd, dgamma, dbeta, coef, partial, partial_floats, st, dtype);
+}
+
+extern "C" int io_bn_bwd_coefs_from_tile_partials(float* p1, float* p2, int M, int C, int G, const float* gamma,
+                                                  const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                                  float* coef, hipStream_t st) {
+    return io_bn_bwd_coefs_from_tiles(p1, p2, M, C, G, gamma, mean, rstd, dgamma, dbeta, coef, st);
+}
+
+/* the data-gradient launch of the training step with everything it can carry (include/instaorder_hip.h) */
+extern "C" int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout,
+                                        int R, int S, int pad, int G, const io_dgrad_fused* f, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_dgrad_fused: unknown dtype %d", dtype);
+    IO_REQUIRE(f != nullptr, IO_ERR_SHAPE, "conv2d_dgrad_fused: the option struct is required");
+    IO_REQUIRE(Cin % 64 == 0, IO_ERR_SHAPE, "conv2d_dgrad_fused: Cin=%d must be a multiple of 64", Cin);
+    const int M = N * H * W;
+    const bool grouped = f->xb_coef || f->ep_y;
+    IO_REQUIRE(!grouped || (G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0), IO_ERR_SHAPE,
+               "conv2d_dgrad_fused: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    IO_REQUIRE(!f->xb_coef || f->xb_y, IO_ERR_SHAPE, "conv2d_dgrad_fused: xb_coef needs xb_y");
+    IO_REQUIRE(!f->ep_y || (f->ep_mean && f->ep_rstd && f->ep_p1 && f->ep_p2 && (f->ep_scale == nullptr) == (f->ep_shift == nullptr)),
+               IO_ERR_SHAPE, "conv2d_dgrad_fused: ep_y needs ep_mean / ep_rstd / ep_p1 / ep_p2 (and scale / shift as a pair)");
+    IO_REQUIRE(!f->ep_act_out || (f->ep_y && f->ep_scale), IO_ERR_SHAPE,
+               "conv2d_dgrad_fused: ep_act_out needs ep_y with ep_scale / ep_shift");
+    IoBwStats bw{};
+    if (f->ep_y) {
+        bw.y = f->ep_y; bw.mean = f->ep_mean; bw.rstd = f->ep_rstd; bw.mscale = f->ep_scale; bw.mshift = f->ep_shift;
+        bw.p1 = f->ep_p1; bw.p2 = f->ep_p2; bw.Mg = M / G; bw.a_out = f->ep_act_out;
+    }
+    if (f->xb_coef) {
+        const size_t gs = (size_t)G * Cout;
+        bw.xb_y = f->xb_y; bw.xb_a = f->xb_coef; bw.xb_b = f->xb_coef + gs; bw.xb_c = f->xb_coef + 2 * gs;
+        bw.xb_out = f->xb_dy_out; bw.xb_Mg = M / G;
+    }
+    return io_run_dgrad(dy, wt, dx, f->add, f->relu_mask, N, H, W, Cin, Cout, R, S, 1, pad, st, grouped ? &bw : nullptr,
+                        dtype);
+}
+
 /* Forward convolution whose INPUT goes through the BatchNorm + ReLU of the layer that produced it, applied while the
  * operand is staged (the normalised activation never exists in memory): y = conv(relu((x - in_mean[g]) * in_scale[g] +
  * in_shift[g]), w) -- bn_apply's expression, in_mean optional (NULL = 0) --

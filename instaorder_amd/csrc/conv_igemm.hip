@@ -67,6 +67,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #ifndef IO_EP_ROWS
 #define IO_EP_ROWS 1       // bf16 epilogues of the dense 1x1 GEMMs store whole rows through LDS (0: one column per lane)
 #endif
+#ifndef IO_EARLY_LOADS
+#define IO_EARLY_LOADS 0
+#endif
 #ifndef IO_WGRAD_TR
 #define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
 #endif
@@ -146,12 +149,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // convolutions, plain data gradients -- runs the BWE = false build, whose register allocation does not pay for it.
 // XF: the instantiation whose A operand goes through an input transform (IoBwStats::in_scale): BatchNorm scale / shift +
 // ReLU applied to the staged chunk between its global load and its LDS store.
+// XB: the BACKWARD operand transform of a data-gradient launch (IoBwStats::xb_a): the A operand is the gradient of a
+// BatchNorm INPUT, dy = a[c] * dz + b[c] * y + c[c], evaluated from the masked gradient dz (= `in`) and that BatchNorm's
+// input y while the chunk is staged -- two 16-byte loads per chunk instead of one -- so BatchNorm backward has no apply
+// pass of its own; the blocks of the first output-channel tile also write dy out (centre tap) for the filter gradient.
 // LIN: dense 1x1 stride-1 GEMM on whole tiles (row m of the output IS pixel m of the input, 128 | M): no row decoding, no
 // validity, k offsets and output row steps ride in the scalar offset of the buffer instructions.  The generic path spends
 // ~800 VALU + ~500 SALU instructions per wave and tile on addressing; with a bf16 tile of K <= 512 worth only 16..128
 // MFMAs the SIMDs were instruction-issue bound on exactly these layers (measured: 69 % issue utilisation, 19 % MFMA).
 template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false,
-          bool XF = false, bool LIN = false>
+          bool XF = false, bool LIN = false, bool XB = false>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -239,18 +246,31 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     f32x4 ra[AR], rb[BR];
     // XF: per-channel coefficients of the chunk being loaded (they change with the k-tile) and the validity of its rows
     static_assert(!XF || STEM == 0, "input transform: regular convolutions");
+    static_assert(!XB || (STEM == 0 && !XF), "backward operand transform: regular data gradients, not combined with XF");
+    constexpr bool XT = XF || XB;           // some operand transform
     constexpr int XC = ES == 4 ? 1 : 2;     // 16-byte coefficient loads per 16-byte operand chunk (4 floats or 8 bf16)
-    f32x4 xm[XC], xs[XC], xh[XC];
-    unsigned xok = 0;
-    const int xgrp = XF ? m0 / bw.in_Mg : 0;
-    const __amdgpu_buffer_rsrc_t rs_xs = make_rsrc(XF ? (const void*)(bw.in_scale + (size_t)xgrp * g.Ci) : (const void*)wgt,
-                                                   XF ? (unsigned)g.Ci * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rs_xh = make_rsrc(XF ? (const void*)(bw.in_shift + (size_t)xgrp * g.Ci) : (const void*)wgt,
-                                                   XF ? (unsigned)g.Ci * 4u : 0u);
+    f32x4 xm[XC], xs[XC], xh[XC];           // XF: mean, scale, shift.  XB: b (times y), a (times dz), c
+    f32x4 ry[XB ? AR : 1];                  // XB: the chunk of y that goes with ra
+    unsigned xok = 0, xaoff = 0;            // XB: xaoff = the k-tile's wave-uniform offset (side output goes where dz came from)
+    bool xside = false;                     // XB: this k-tile is the centre tap (every pixel exactly once)
+    const int xgrp = XF ? m0 / bw.in_Mg : XB ? m0 / bw.xb_Mg : 0;
+    const float* const xt_s = XF ? bw.in_scale : bw.xb_a;
+    const float* const xt_h = XF ? bw.in_shift : bw.xb_c;
+    const float* const xt_m = XF ? bw.in_mean : bw.xb_b;
+    const __amdgpu_buffer_rsrc_t rs_xs = make_rsrc(XT ? (const void*)(xt_s + (size_t)xgrp * g.Ci) : (const void*)wgt,
+                                                   XT ? (unsigned)g.Ci * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_xh = make_rsrc(XT ? (const void*)(xt_h + (size_t)xgrp * g.Ci) : (const void*)wgt,
+                                                   XT ? (unsigned)g.Ci * 4u : 0u);
     // (no mean table: a zero-length descriptor, whose loads return 0)
-    const __amdgpu_buffer_rsrc_t rs_xm = make_rsrc((XF && bw.in_mean) ? (const void*)(bw.in_mean + (size_t)xgrp * g.Ci)
-                                                                      : (const void*)wgt,
-                                                   (XF && bw.in_mean) ? (unsigned)g.Ci * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_xm = make_rsrc((XT && xt_m) ? (const void*)(xt_m + (size_t)xgrp * g.Ci)
+                                                                : (const void*)wgt,
+                                                   (XT && xt_m) ? (unsigned)g.Ci * 4u : 0u);
+    // XB: y is addressed exactly like `in`; the side output too, through a descriptor that is EMPTY (stores dropped)
+    // unless this block owns the first output-channel tile
+    const size_t xb_base = LIN ? (size_t)m0 * (size_t)(g.Ci * ES) : (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * ES);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc_at(XB ? bw.xb_y : (const void*)in, xb_base, XB ? in_bytes : xb_base);
+    const __amdgpu_buffer_rsrc_t rs_side =
+        make_rsrc_at((XB && bw.xb_out) ? bw.xb_out : (void*)out, xb_base, (XB && bw.xb_out && n0 == 0) ? in_bytes : xb_base);
     int th = 0, tw = 0, cc = 0;   // tap / channel-chunk counters of the k-tile being LOADED (non-stem)
     // Loads are branch-free and the loop body below is ONE basic block (the last iteration simply
     // re-fetches the final k-tile and discards it), so the scheduler is free to sink the address
@@ -286,7 +306,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         }
         if constexpr (LIN) {
             const unsigned koff = (unsigned)(cc * BK) * (unsigned)ES;        // scalar: the channel chunk of this k-tile
-            if constexpr (XF) {
+            if constexpr (XB) {
+                xaoff = koff;
+#pragma unroll
+                for (int j = 0; j < AR; ++j)
+                    ry[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, rowv[j], koff, 0));
+            }
+            if constexpr (XT) {
                 const unsigned coff = (unsigned)(cc * BK + kq * VE) * 4u;
 #pragma unroll
                 for (int q = 0; q < XC; ++q) {
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             aoff = (unsigned)((dh * g.Wi + dw) * g.Ci + cbase + cc * BK) * (unsigned)ES;
             woff = (unsigned)(widx * kw + cc * BK) * (unsigned)ES;
         }
-        if constexpr (XF) {
+        if constexpr (XT) {
             const unsigned coff = (unsigned)(cbase + cc * BK + kq * VE) * 4u;
 #pragma unroll
             for (int q = 0; q < XC; ++q) {
@@ -339,8 +365,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 const int hi = hi0[j] + dh, wi = wi0[j] + dw;
                 ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
             }
-            if constexpr (XF) xok |= ok ? (1u << j) : 0u;
+            if constexpr (XT) xok |= ok ? (1u << j) : 0u;
             ra[j] = bld4(rs_in, ok ? rowv[j] + aoff : kInvalidOff);
+            if constexpr (XB) ry[j] = bld4(rs_y, ok ? rowv[j] + aoff : kInvalidOff);
+        }
+        if constexpr (XB) {
+            xaoff = aoff;
+            xside = dh == 0 && dw == 0;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) rb[j] = bld4(rs_w, tapok ? wv[j] + woff : kInvalidOff);
@@ -390,6 +421,46 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     }
                     ra[j] = __builtin_bit_cast(f32x4, o);
                 }
+            }
+        }
+        if constexpr (XB) {
+            // dy = a * dz + (b * y + c) on the staged chunk; padding rows stay zero (their transform would be c)
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = (xok >> j) & 1u;
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(ra[j][e], xs[0][e], __builtin_fmaf(ry[j][e], xm[0][e], xh[0][e]));
+                        ra[j][e] = ok ? v : 0.f;
+                    }
+                } else {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]), rwy = __builtin_bit_cast(u32x4, ry[j]);
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
+                        const int q = d >> 1, e0 = (d & 1) * 2;
+                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
+                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
+                        const float yl = __builtin_bit_cast(float, rwy[d] << 16);
+                        const float yh = __builtin_bit_cast(float, rwy[d] & 0xffff0000u);
+                        const float vl = __builtin_fmaf(lo, xs[q][e0], __builtin_fmaf(yl, xm[q][e0], xh[q][e0]));
+                        const float vh = __builtin_fmaf(hi, xs[q][e0 + 1], __builtin_fmaf(yh, xm[q][e0 + 1], xh[q][e0 + 1]));
+                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
+                    }
+                    ra[j] = __builtin_bit_cast(f32x4, o);
+                }
+            }
+            // side output: the transformed chunk goes back out where dz came from (first output-channel tile, centre tap)
+            if constexpr (LIN) {
+#pragma unroll
+                for (int j = 0; j < AR; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ra[j]), rs_side, rowv[j], xaoff, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AR; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ra[j]), rs_side,
+                                                           (xside && ((xok >> j) & 1u)) ? rowv[j] + xaoff : kInvalidOff, 0, 0);
             }
         }
 #pragma unroll
@@ -462,6 +533,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         advance(true);
         load_tile(kt + 1);
+#if IO_EARLY_LOADS
+        __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
+#endif
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             f32x4 na[TI], nb[TJ];
@@ -1773,8 +1847,19 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     memset(&bws, 0, sizeof(bws));
     if (bw) {
         bws = *bw;
-        IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg % 128 == 0), IO_ERR_SHAPE,
-                   "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group");
+        const long Mchk = (long)g.N * g.Ho * g.Wo;
+        // the fused epilogue addresses whole tiles without validating rows: no partial tile, no tile across two groups
+        IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg > 0 && bws.Mg % 128 == 0 &&
+                              Mchk % 128 == 0 && Mchk % bws.Mg == 0),
+                   IO_ERR_SHAPE, "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group | M");
+        IO_REQUIRE(!bws.xb_a || (bws.xb_b && bws.xb_c && bws.xb_y && !bws.in_scale && !stem && !g.gw && g.is == 1 &&
+                                 g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo &&
+                                 bws.xb_Mg > 0 && bws.xb_Mg % 128 == 0 && Mchk % bws.xb_Mg == 0 && g.dhs * g.dhs == 1 &&
+                                 g.dws * g.dws == 1 && g.dh0 * (g.dh0 + g.dhs * (g.Th - 1)) <= 0 &&
+                                 g.dw0 * (g.dw0 + g.dws * (g.Tw - 1)) <= 0),
+                   IO_ERR_SHAPE,
+                   "conv_nt: the backward operand transform needs a stride-1 same-size data gradient whose taps include "
+                   "the centre, and 128 | rows per group | M");
     }
     IO_REQUIRE(!(stem && bws.y), IO_ERR_SHAPE, "conv_nt: the stem has no BatchNorm-backward epilogue");
     IO_REQUIRE(!bws.a_out || (bws.y && bws.mscale && bws.mshift), IO_ERR_SHAPE,
@@ -1823,28 +1908,32 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
-                         (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
+                         (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci * ((bw && bw->xb_a) ? (bw->xb_out ? 3.0 : 2.0) : 1.0) +
+                                       (double)g.Co * kred),
                      st);
-#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_, LIN_)                                    \
+#define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_, LIN_, XB_)                               \
     do {                                                                                                     \
         const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
             (void)hipFuncSetAttribute(                                                                       \
-                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_>,         \
+                (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_, XB_>,    \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                      \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_>), grid,   \
-                           block, ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out, (const TO_*)add,  \
-                           (const TO_*)mask, ntn, in_bytes, w_bytes, out_bytes, st_mean, st_m2, bws);        \
+        hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_, XB_>),    \
+                           grid, block, ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out,             \
+                           (const TO_*)add, (const TO_*)mask, ntn, in_bytes, w_bytes, out_bytes, st_mean,    \
+                           st_m2, bws);                                                                      \
     } while (0)
 #define IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, LIN_)                                             \
     do {                                                                                                     \
-        if (STEM_ == 0 && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, (STEM_ == 0), false, LIN_); \
-        else if (STEM_ == 0 && bws.in_scale)                                                                 \
-            IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, (STEM_ == 0), LIN_);                    \
-        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_);                          \
+        constexpr bool R_ = STEM_ == 0, XBOK_ = R_ && sizeof(TI_) == sizeof(TO_);                            \
+        if (XBOK_ && bws.xb_a && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, XBOK_); \
+        else if (XBOK_ && bws.xb_a) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XBOK_);  \
+        else if (R_ && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, false);     \
+        else if (R_ && bws.in_scale) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, R_, LIN_, false); \
+        else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, false);                   \
     } while (0)
 #define IO_LAUNCH_NT(TI_, TO_, BN_, STEM_, NBUF_, MINB_)                                                     \
     do {                                                                                                     \

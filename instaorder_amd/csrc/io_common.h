@@ -123,6 +123,18 @@ struct IoBwStats {
     // samples of its output rows).
     const float *in_mean, *in_scale, *in_shift;
     int in_Mg;
+    // Independent again: BACKWARD operand transform of a stride-1 data-gradient launch.  `in` is then not the gradient dy
+    // of the convolution's output but the (ReLU-masked) gradient dz of the BatchNorm output behind it, and the A operand
+    // is that BatchNorm's input gradient evaluated while the chunk is staged: dy = xb_a[g][c] * dz + xb_b[g][c] * y +
+    // xb_c[g][c] with y (xb_y, shaped like `in`) the BatchNorm input and the [G][Ci] tables of io_bn_bwd_coefs* (a =
+    // gamma * rstd, b = -a * rstd * mean(dz * xhat), c = -a * mean(dz) - b * mean) -- zero in the padding -- so the
+    // BatchNorm backward has no apply pass.  xb_out (optional): dy as a tensor shaped like `in`, written by the blocks of
+    // the first output-channel tile (centre tap), for the filter gradient that runs next.  xb_Mg: rows per BatchNorm
+    // group (a multiple of 128; input and output grids of the launch coincide).
+    const void* xb_y;
+    const float *xb_a, *xb_b, *xb_c;
+    void* xb_out;
+    int xb_Mg;
 };
 
 // internal launchers shared between the C ABI and the network executor
@@ -134,6 +146,14 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, int M, int C, int G,
                          const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                          void* dy, float* coef, hipStream_t st, int dt = IO_F32);
+// the same without the apply pass: dgamma / dbeta and the three [G][C] coefficient tables of IoBwStats::xb_a/b/c
+// (coef: 3*G*C floats, a | b | c)
+int io_bn_bwd_coefs_from_tiles(float* p1, float* p2, int M, int C, int G, const float* gamma, const float* mean,
+                               const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
+// ... and from (dz, y) themselves: reduction pass + finalize, no apply.  dz must already carry the ReLU mask.
+int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
+                      const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
+                      size_t partial_floats, hipStream_t st, int dt);
 // storage-typed internals behind the fp32 C entry points of the same name (dt: IoDType of the tensors)
 int io_bn_stats_finalize_t(const void* y, int M, int C, int G, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean,

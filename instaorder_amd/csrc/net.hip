@@ -146,7 +146,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
     p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
-    p.coef = a.take((size_t)2 * kMaxGroups * 2048 * f);
+    p.coef = a.take((size_t)3 * kMaxGroups * 2048 * f);
     p.pooled = a.take((size_t)N * 2048 * f);
     {
         // per (128-row tile, channel) partials of the widest conv output + room for the level-1 merge
@@ -533,7 +533,18 @@ int conv_dgrad(const Ctx& c, const ConvL& L, const void* dy, void* dx, const voi
     return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st, bw, c.dt());
 }
 
-bool tiles_ok(const Ctx& c, int M) { return (M / c.G) % kIoStatTileRows == 0; }
+bool tiles_ok(const Ctx& c, int M) { return M % c.G == 0 && (M / c.G) % kIoStatTileRows == 0; }
+
+// Does the BatchNorm backward of a layer with M rows leave its apply pass to the data-gradient kernel that consumes dy
+// (IoBwStats::xb_a: dy = a * dz + b * y + c evaluated on the staged operand, written out once for the filter gradient)?
+// fp32 only: there the transform hides under the MFMAs (as the forward one does); whole 128-row tiles per group.
+#ifndef IO_XB
+#define IO_XB 1
+#endif
+#ifndef IO_XB_C2
+#define IO_XB_C2 0      // ... also into conv2's 3x3 data gradient (measured: a loss, see run_backward)
+#endif
+bool xb_ok(const Ctx& c, int M) { return IO_XB && c.net->dtype == IO_F32 && tiles_ok(c, M); }
 
 IoBwStats bw_for(const Ctx& c, const BnL& b, const void* y, int M, bool mask_from_y) {
     Tables t = c.tables(b);
@@ -549,6 +560,31 @@ IoBwStats bw_for(const Ctx& c, const BnL& b, const void* y, int M, bool mask_fro
     return bw;
 }
 
+// BatchNorm backward WITHOUT the apply pass: dgamma / dbeta and the coefficient tables of the operand transform, from the
+// tile partials the epilogue of the launch that completed dz left behind, or (have_tiles false) from a reduction pass
+// over (dz, y); dz already carries its ReLU mask.
+int bn_back_coefs(const Ctx& c, const BnL& b, const void* dz, const void* y, int M, bool have_tiles) {
+    Tables t = c.tables(b);
+    if (have_tiles)
+        return io_bn_bwd_coefs_from_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), M, b.C, c.G,
+                                          c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off, c.grads + b.b_off,
+                                          c.buf(c.plan.coef), c.st);
+    return io_bn_bwd_coefs_t(dz, y, M, b.C, c.G, c.params + b.g_off, t.mean, t.rstd, c.grads + b.g_off,
+                             c.grads + b.b_off, c.buf(c.plan.coef), c.buf(c.plan.bn_partial), c.plan.bn_partial_floats,
+                             c.st, c.dt());
+}
+
+// the operand-transform part of a data-gradient launch whose A operand is that BatchNorm's input gradient
+void xb_fill(const Ctx& c, IoBwStats& bw, const BnL& b, const void* y, int M, void* dy_out) {
+    const size_t gs = (size_t)c.G * b.C;
+    bw.xb_y = y;
+    bw.xb_a = c.buf(c.plan.coef);
+    bw.xb_b = c.buf(c.plan.coef) + gs;
+    bw.xb_c = c.buf(c.plan.coef) + 2 * gs;
+    bw.xb_out = dy_out;
+    bw.xb_Mg = M / c.G;
+}
+
 int bn_back_tiles(const Ctx& c, const BnL& b, const void* dz, const void* y, int M, void* dy) {
     Tables t = c.tables(b);
     return io_bn_bwd_from_tiles(c.buf(c.plan.tile_mean), c.buf(c.plan.tile_m2), dz, y, M, b.C, c.G,
@@ -560,14 +596,21 @@ int bn_back_tiles(const Ctx& c, const BnL& b, const void* dz, const void* y, int
 // With a stride-1 conv the BN-backward reductions ride in the conv epilogue (which also applies the ReLU
 // mask recomputed from y), and only the apply pass remains.
 // a_out (optional, fused path only): relu(bn(y)) rebuilt next to dx
+// xb (optional, fused path only): `dy` is NOT the gradient of the conv output but the masked gradient dz of the BatchNorm
+// behind it, whose coefficients are in plan.coef: the launch evaluates dy on its operand and writes it to xb_out
+// dyb == nullptr: stop after the data gradient -- the tile partials of b are left for bn_back_coefs
 int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H, const BnL& b, const void* y,
-                  int M, void* dyb, void* a_out = nullptr) {
+                  int M, void* dyb, void* a_out = nullptr, const BnL* xb = nullptr, const void* xb_y = nullptr,
+                  int xb_M = 0, void* xb_out = nullptr) {
     if (L.stride == 1 && tiles_ok(c, M)) {
         IoBwStats bw = bw_for(c, b, y, M, true);
         bw.a_out = a_out;
+        if (xb) xb_fill(c, bw, *xb, xb_y, xb_M, xb_out);
         IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
+        if (!dyb) return IO_OK;
         return bn_back_tiles(c, b, dx, y, M, dyb);
     }
+    IO_REQUIRE(!xb && dyb, IO_ERR_STATE, "dgrad_then_bn: the operand transform needs the fused path");
     IO_REQUIRE(!a_out, IO_ERR_STATE, "dgrad_then_bn: no fused epilogue to rebuild the activation in");
     IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H));
     return bn_back(c, b, dx, 1, nullptr, y, M, dyb, nullptr);
@@ -612,7 +655,22 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         // whose gradient is not masked here)
         const void* xmask = ii == 0 ? nullptr : xin;
         // bn3: Gd holds dz = d(out) * [out > 0]; dy3 -> Ga
-        if (have_tiles)
+        // Where xb_ok, the apply pass of a BatchNorm backward (read dz, read y, write dy) does not exist: the reductions
+        // become three coefficient tables and the data-gradient launch that consumes dy evaluates it on its operand --
+        // dz and y are loaded side by side, dy = a * dz + b * y + c in registers -- and writes it out once (first
+        // output-channel tile only) for the filter gradient, which therefore runs AFTER that launch.
+        // Measured per shape at the bench batch (tools/xb_bench.py, profiles/r03_xb_microbench_fp32.txt): the 1x1 data
+        // gradients pay +0.00..0.17 ms for the doubled operand load (+0.54 on the HBM-bound 256 -> 64 layer) and save an
+        // apply pass of 0.04..1.29 ms -- a gain on every conv3 and conv1; a 3x3 data gradient stages every chunk nine
+        // times (once per tap), pays +0.21..0.61 ms and saves 0.04..0.32: bn2 keeps its apply pass (IO_XB_C2).
+        const bool x3 = xb_ok(c, Mout);                          // bn3 -> conv3's data gradient
+        const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
+        const bool x2 = IO_XB_C2 && x3 && b.stride == 1;         // bn2 -> conv2's (a strided one runs as parity classes)
+        // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
+        const bool x1 = b.stride == 1 && xb_ok(c, Min) && tiles_ok(c, Mout);
+        if (x3)
+            IO_TRY(bn_back_coefs(c, b.b3, Gd, c.act(bb.y3), Mout, have_tiles));
+        else if (have_tiles)
             IO_TRY(bn_back_tiles(c, b.b3, Gd, c.act(bb.y3), Mout, Ga));
         else
             IO_TRY(bn_back(c, b.b3, Gd, 0, nullptr, c.act(bb.y3), Mout, Ga, nullptr));
@@ -620,15 +678,19 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         // Where the forward read relu(bn(y)) through the input transform (fuse_in) that activation was never stored: the
         // data-gradient launch, which recomputes the ReLU mask from y anyway, rebuilds it into the one `aside` buffer, and
         // the filter gradient that needs it runs right after (instead of right before) that launch.
-        const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
         void* As = f3 ? c.act(p.aside) : nullptr;
-        if (!f3) IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
-        IO_TRY(dgrad_then_bn(c, b.c3, Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, Gc, f3 ? As : nullptr));
-        if (f3) IO_TRY(conv_wgrad(c, b.c3, As, Ga, Ho));
-        if (!f2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
-        IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.act(bb.y1), Min, Gb, f2 ? As : nullptr));
-        if (f2) IO_TRY(conv_wgrad(c, b.c2, As, Gc, H));
-        IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
+        if (!f3 && !x3) IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
+        // conv3: (dy3 | dz3 + y3) -> Gb = dz2 (+ bn2's partials); without x2 also Gc = dy2
+        IO_TRY(dgrad_then_bn(c, b.c3, x3 ? Gd : Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, x2 ? nullptr : Gc, f3 ? As : nullptr,
+                             x3 ? &b.b3 : nullptr, c.act(bb.y3), Mout, Ga));
+        if (f3 || x3) IO_TRY(conv_wgrad(c, b.c3, f3 ? As : c.act(bb.a2), Ga, Ho));
+        if (x2) IO_TRY(bn_back_coefs(c, b.b2, Gb, c.act(bb.y2), Mout, true));
+        if (!f2 && !x2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
+        // conv2: (dy2 | dz2 + y2) -> Ga = dz1 (+ bn1's partials); without x1 also Gb = dy1
+        IO_TRY(dgrad_then_bn(c, b.c2, x2 ? Gb : Gc, Ga, H, b.b1, c.act(bb.y1), Min, x1 ? nullptr : Gb, f2 ? As : nullptr,
+                             x2 ? &b.b2 : nullptr, c.act(bb.y2), Mout, Gc));
+        if (f2 || x2) IO_TRY(conv_wgrad(c, b.c2, f2 ? As : c.act(bb.a1), Gc, H));
+        if (!x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
         // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
         // the previous block's bn3.  With one, the mask is idempotent and is applied by both kernels (the
@@ -638,19 +700,24 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         // that completes d(x_in) and can carry the previous block's bn3 reductions there too.
         const void* partial = Gd;          // what conv1's data gradient accumulates onto: the identity path ...
         if (b.down) {
-            IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.act(bb.yd), Mout, Ga, nullptr));
-            IO_TRY(conv_wgrad(c, b.cd, xin, Ga, H));
-            IO_TRY(conv_dgrad(c, b.cd, Ga, Ge, nullptr, nullptr, H));
+            // (Gc: dy2 has been consumed by conv2's data and filter gradients; with x1, Ga still holds dz1)
+            IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.act(bb.yd), Mout, Gc, nullptr));
+            IO_TRY(conv_wgrad(c, b.cd, xin, Gc, H));
+            IO_TRY(conv_dgrad(c, b.cd, Gc, Ge, nullptr, nullptr, H));
             partial = Ge;                  // ... or the downsample path
         }
-        if (ii > 0 && tiles_ok(c, Min)) {
-            const Block& pb = net->blocks[ii - 1];
-            IoBwStats bw = bw_for(c, pb.b3, c.act(p.blk[ii - 1].y3), Min, false);
-            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, partial, xmask, H, &bw));
-            have_tiles = true;
-        } else {
-            IO_TRY(conv_dgrad(c, b.c1, Gb, Ge, partial, xmask, H));
+        // conv1: (dy1 | dz1 + y1) -> Ge = d(x_in).  (bn1's tables only now: the downsample BatchNorm's backward above
+        // uses the same coefficient scratch; bn1's tile partials are untouched by it)
+        if (x1) IO_TRY(bn_back_coefs(c, b.b1, Ga, c.act(bb.y1), Min, true));
+        {
+            IoBwStats bw{};
+            const bool carry = ii > 0 && tiles_ok(c, Min);
+            if (carry) bw = bw_for(c, net->blocks[ii - 1].b3, c.act(p.blk[ii - 1].y3), Min, false);
+            if (x1) xb_fill(c, bw, b.b1, c.act(bb.y1), Min, Gb);
+            IO_TRY(conv_dgrad(c, b.c1, x1 ? Ga : Gb, Ge, partial, xmask, H, (carry || x1) ? &bw : nullptr));
+            have_tiles = carry;
         }
+        if (x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         void* t = Gd; Gd = Ge; Ge = t;
     }
     // Gd = d(maxpool output)

@@ -304,6 +304,122 @@ def test_conv_dgrad_with_fused_bn_backward(N, H, Cin, Cout, k, G):
     assert relerr(dz.permute(0, 3, 1, 2), dz_ref) < 3e-5
 
 
+XB_CASES = [(4, 16, 64, 256, 1, 2, False), (4, 16, 128, 128, 3, 2, False), (8, 8, 512, 64, 1, 2, False),
+            (2, 16, 64, 64, 3, 1, False), (4, 16, 256, 64, 1, 2, True), (2, 32, 64, 128, 3, 2, True),
+            (16, 8, 128, 2048, 1, 2, False)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,H,Cin,Cout,k,G,resid", XB_CASES)
+def test_conv_dgrad_fused_operand_transform(N, H, Cin, Cout, k, G, resid, dtype):
+    """The data-gradient launch of the training step, everything on: autograd through
+    z = bn_b(conv(relu(bn_a(y_a)))) given the (masked) gradient dz_b of z.  BatchNorm b's backward has no apply pass --
+    io_bn_bwd_coefs_dt turns its reductions into per-channel tables and io_conv2d_dgrad_fused_dt evaluates
+    dy_b = a*dz_b + b*y_b + c on its staged operand (side output: dy_b for the filter gradient); the epilogue masks with
+    relu(bn_a(y_a)) > 0 recomputed from y_a (or, `resid`: adds a residual gradient and masks with a stored activation, as
+    conv1's data gradient does), rebuilds that activation, and leaves the tile partials from which
+    io_bn_bwd_coefs_from_tile_partials makes BatchNorm a's tables.  Against torch autograd in fp64."""
+    bf = dtype == "bf16"
+    td = torch.bfloat16 if bf else torch.float32
+    rt = (lambda t: t.bfloat16().double()) if bf else (lambda t: t.float().double())
+    g = torch.Generator().manual_seed(N * H + Cin + k)
+    y_a = rt(torch.randn(N, Cin, H, H, generator=g, dtype=torch.float64) * 0.7 + 0.2).requires_grad_(True)
+    gam_a = (1 + 0.2 * torch.randn(Cin, generator=g, dtype=torch.float64)).float().double().requires_grad_(True)
+    bet_a = (0.2 * torch.randn(Cin, generator=g, dtype=torch.float64)).float().double().requires_grad_(True)
+    gam_b = (1 + 0.2 * torch.randn(Cout, generator=g, dtype=torch.float64)).float().double().requires_grad_(True)
+    bet_b = (0.2 * torch.randn(Cout, generator=g, dtype=torch.float64)).float().double().requires_grad_(True)
+    w = rt(torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k))
+    per = N // G
+    bn = lambda t, ga, be: torch.cat([F.batch_norm(t[i * per:(i + 1) * per], None, None, ga, be, True, 0.1, 1e-5)   # noqa: E731
+                                      for i in range(G)])
+    t_a = bn(y_a, gam_a, bet_a)
+    t_a.retain_grad()
+    if resid:      # conv1's form: the tensor the gradient belongs to is a block input with its own stored activation
+        act = rt(torch.randn(N, Cin, H, H, generator=g, dtype=torch.float64))
+        a = t_a
+    else:
+        a = F.relu(t_a)
+    y_b = rt(F.conv2d(a, w, padding=k // 2).detach()).requires_grad_(True)     # what the forward stored (rounded once)
+    z = bn(y_b, gam_b, bet_b)
+    dz_b = rt(torch.randn(z.shape, generator=g, dtype=torch.float64) *
+              (torch.rand(z.shape, generator=g, dtype=torch.float64) > 0.4))
+    dyb_ref, dgb_ref, dbb_ref = torch.autograd.grad(z, [y_b, gam_b, bet_b], dz_b)
+    f = lambda t: t.detach().float().to(DEV).contiguous()    # noqa: E731
+    M = N * H * H
+    lib = L()
+    dt = 1 if bf else 0
+    # forward tables of both BatchNorms
+    def tables(yt, C, ga, be):
+        mean, rstd, scale, shift = (torch.empty(G * C, device=DEV) for _ in range(4))
+        npart = lib.io_bn_partial_floats(M, C, G)
+        part = torch.empty(npart, device=DEV)
+        _lib.check(lib.io_bn_stats_finalize_dt(P(yt), M, C, G, P(f(ga)), P(f(be)), None, None, 0.1, 1e-5, P(mean), P(rstd),
+                                               P(scale), P(shift), P(part), npart, dt, ST()), "stats")
+        return mean, rstd, scale, shift
+    ya_d, yb_d = nhwc(y_a.detach()).to(td), nhwc(y_b.detach()).to(td)
+    mean_a, rstd_a, scale_a, shift_a = tables(ya_d, Cin, gam_a, bet_a)
+    mean_b, rstd_b, scale_b, shift_b = tables(yb_d, Cout, gam_b, bet_b)
+    # BatchNorm b: reductions -> tables (no apply pass)
+    dzb_d = nhwc(dz_b).to(td)
+    coef_b = torch.empty(3 * G * Cout, device=DEV)
+    dgb, dbb = torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
+    npart = lib.io_bn_partial_floats(M, Cout, G)
+    part = torch.empty(npart, device=DEV)
+    _lib.check(lib.io_bn_bwd_coefs_dt(P(dzb_d), P(yb_d), M, Cout, G, P(f(gam_b)), P(mean_b), P(rstd_b), P(dgb), P(dbb),
+                                      P(coef_b), P(part), npart, dt, ST()), "bn_bwd_coefs")
+    tol = 2e-2 if bf else 3e-5
+    assert relerr(dgb, dgb_ref) < tol and relerr(dbb, dbb_ref) < tol
+    # the fused launch
+    wt = krsc(w).view(Cout, k * k, Cin).permute(2, 1, 0).contiguous().to(td)
+    nt = lib.io_bn_tile_partial_floats(M, Cin, G)
+    p1, p2 = torch.empty(nt, device=DEV), torch.empty(nt, device=DEV)
+    dx = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=td)
+    dyb_out = torch.full((N, H, H, Cout), float("nan"), device=DEV, dtype=td)
+    opt = _lib.DgradFused()
+    opt.xb_y, opt.xb_coef, opt.xb_dy_out = yb_d.data_ptr(), coef_b.data_ptr(), dyb_out.data_ptr()
+    opt.ep_y, opt.ep_mean, opt.ep_rstd, opt.ep_p1, opt.ep_p2 = (ya_d.data_ptr(), mean_a.data_ptr(), rstd_a.data_ptr(),
+                                                                p1.data_ptr(), p2.data_ptr())
+    keep = [ya_d, yb_d, coef_b, mean_a, rstd_a, scale_a, shift_a]
+    if resid:
+        base = rt(torch.randn(N, Cin, H, H, generator=g, dtype=torch.float64))
+        base_d, act_d = nhwc(base).to(td), nhwc(act).to(td)
+        opt.add, opt.relu_mask = base_d.data_ptr(), act_d.data_ptr()
+        keep += [base_d, act_d]
+        aout = None
+    else:
+        aout = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=td)
+        opt.ep_scale, opt.ep_shift, opt.ep_act_out = scale_a.data_ptr(), shift_a.data_ptr(), aout.data_ptr()
+    _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dzb_d), P(wt), P(dx), N, H, H, Cin, Cout, k, k, k // 2, G, C.byref(opt), dt,
+                                            ST()), "dgrad_fused")
+    assert relerr(dyb_out.float().permute(0, 3, 1, 2), dyb_ref) < (1e-2 if bf else 3e-5)
+    # gradient of bn_a's output: conv data gradient of dy_b (the kernel's own, rounded dy_b in bf16), masked
+    dyb_used = dyb_out.float().permute(0, 3, 1, 2).double().cpu() if bf else dyb_ref
+    a2 = a.detach().requires_grad_(True)
+    da = torch.autograd.grad(F.conv2d(a2, w, padding=k // 2), a2, dyb_used)[0]
+    dza_ref = (da + base) * (act > 0) if resid else da * (t_a.detach() > 0)
+    if bf and not resid:     # knife-edge mask decisions of a bf16-rounded bn(y): compare where the sign is certain
+        sure = (t_a.detach().abs() > 2e-2)
+        assert relerr(dx.float().permute(0, 3, 1, 2).cpu() * sure, dza_ref * sure) < 1e-2
+    else:
+        assert relerr(dx.float().permute(0, 3, 1, 2), dza_ref) < (1e-2 if bf else 3e-5)
+    if aout is not None:
+        assert relerr(aout.float().permute(0, 3, 1, 2), F.relu(t_a.detach())) < (1e-2 if bf else 3e-5)
+    # BatchNorm a from the tile partials: dgamma / dbeta and the tables that give dy_a
+    coef_a = torch.empty(3 * G * Cin, device=DEV)
+    dga, dba = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+    _lib.check(lib.io_bn_bwd_coefs_from_tile_partials(P(p1), P(p2), M, Cin, G, P(f(gam_a)), P(mean_a), P(rstd_a), P(dga),
+                                                      P(dba), P(coef_a), ST()), "coefs_from_tiles")
+    dza_k = dx.float().permute(0, 3, 1, 2).double().cpu()        # the kernel's own dz_a (fp64 reference chain from it)
+    dya_ref, dga_ref, dba_ref = torch.autograd.grad(t_a, [y_a, gam_a, bet_a], dza_k)
+    assert relerr(dga, dga_ref) < (2e-2 if bf else 5e-5) and relerr(dba, dba_ref) < (2e-2 if bf else 5e-5)
+    ca = coef_a.view(3, G, Cin).double().cpu()
+    grp = torch.arange(N) // per
+    v = lambda t: t[grp].view(N, Cin, 1, 1)          # noqa: E731
+    dya = v(ca[0]) * dza_k + v(ca[1]) * y_a.detach() + v(ca[2])
+    assert relerr(dya, dya_ref) < (5e-3 if bf else 5e-5)
+    del keep
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_wgrad(case):
     N, H, W, Cin, Cout, k, s, p = case
