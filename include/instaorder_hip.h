@@ -269,6 +269,19 @@ int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz, int N, in
                              int pad, const void* y, int G, const float* gamma, const float* mean, const float* rstd,
                              const float* scale, const float* shift, float* dgamma, float* dbeta, void* dyb,
                              float* workspace, size_t workspace_floats, int dtype, int gw, hipStream_t stream);
+/* The 7x7 / 2 stem (resnet_cls.py:140) in EXACT-K mode, fp32 -- what the executor launches for the fp32 step: the packed
+ * x8 input carries `real_channels` (1..8, here 5) real channels, and the reduction runs over k = tap * real_channels +
+ * channel only (245 instead of 392 products per output).  w / dw: [64][49][8] as for io_conv2d_fwd / io_conv2d_wgrad
+ * (pad channels of dw are written as zeros); packed: scratch of io_stem_packed_floats() floats. */
+size_t io_stem_packed_floats(int real_channels);
+size_t io_stem_wgrad_exact_workspace_bytes(int N, int H, int W, int real_channels);
+int io_stem_fwd_bnstats_exact(const float* x8, const float* w, float* y, int N, int H, int W, int real_channels, int G,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              float* workspace, size_t workspace_floats, float* packed, hipStream_t stream);
+int io_stem_wgrad_exact(const float* x8, const float* dy, float* dw, int N, int H, int W, int real_channels,
+                        void* workspace, size_t workspace_bytes, float* packed, hipStream_t stream);
+
 /* ---- BatchNorm backward without an apply pass: the training step's fused data-gradient launch ---------------------------
  * autograd of `out = conv(relu(bn(y)))` chains (models/backbone/resnet_cls.py:99-113, loss.backward() at
  * models/supervised_order.py:545).  The BatchNorm input gradient dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) is

@@ -412,6 +412,48 @@ extern "C" int io_conv2d_dgrad_bnbwd_dt(const void* dy, const void* wt, void* dz
                                 workspace + 2 * per, st, dtype);
 }
 
+/* the stem in exact-K mode (fp32): what net.hip launches for the fp32 step */
+extern "C" size_t io_stem_packed_floats(int real_channels) { return (size_t)64 * io_stem_kp(49, real_channels); }
+static IoConvGeom stem_geom_exact(int N, int H, int W, int cr) {
+    IoConvGeom g = io_geom_fwd(N, H, W, 8, 64, 7, 7, 2, 3);
+    g.cr = cr;
+    return g;
+}
+extern "C" size_t io_stem_wgrad_exact_workspace_bytes(int N, int H, int W, int real_channels) {
+    return io_conv_wgrad_partial_bytes(stem_geom_exact(N, H, W, real_channels), 1);
+}
+extern "C" int io_stem_fwd_bnstats_exact(const float* x8, const float* w, float* y, int N, int H, int W, int real_channels,
+                                         int G, const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, float momentum, float eps, float* mean, float* rstd,
+                                         float* scale, float* shift, float* workspace, size_t workspace_floats,
+                                         float* packed, hipStream_t st) {
+    IO_REQUIRE(real_channels >= 1 && real_channels <= 8, IO_ERR_SHAPE, "stem_exact: real_channels=%d (1..8)", real_channels);
+    IoConvGeom g = stem_geom_exact(N, H, W, real_channels);
+    const int M = N * g.Ho * g.Wo;
+    IO_REQUIRE(G >= 1 && M % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "stem_exact: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, 64, 7, 7, 2, 3, G);
+    IO_REQUIRE(workspace_floats >= need && packed, IO_ERR_WORKSPACE, "stem_exact: workspace %zu < %zu floats",
+               workspace_floats, need);
+    int rc = io_stem_pack_filter(w, packed, 64, 49, real_channels, st);
+    if (rc) return rc;
+    float* tmean = workspace;
+    float* tm2 = workspace + need / 2;
+    rc = io_launch_conv_nt(g, x8, packed, y, nullptr, nullptr, 1, st, tmean, tm2);
+    if (rc) return rc;
+    return io_bn_finalize_tiles(tmean, tm2, M, 64, G, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd,
+                                scale, shift, st);
+}
+extern "C" int io_stem_wgrad_exact(const float* x8, const float* dy, float* dw, int N, int H, int W, int real_channels,
+                                   void* ws, size_t ws_bytes, float* packed, hipStream_t st) {
+    IO_REQUIRE(real_channels >= 1 && real_channels <= 8 && packed, IO_ERR_SHAPE, "stem_wgrad_exact: real_channels=%d (1..8)",
+               real_channels);
+    IoConvGeom g = stem_geom_exact(N, H, W, real_channels);
+    int rc = io_launch_conv_wgrad(g, x8, dy, packed, (float*)ws, ws_bytes, 1, st);
+    if (rc) return rc;
+    return io_stem_unpack_grad(packed, dw, 64, 49, real_channels, st);
+}
+
 extern "C" size_t io_bn_tile_partial_floats(int M, int C, int G) {
     if (M <= 0 || C <= 0 || G <= 0) return 0;
     const size_t tiles = (size_t)(M + kIoStatTileRows - 1) / kIoStatTileRows;

@@ -325,7 +325,9 @@ __global__ __launch_bounds__(kThreads) void order_loss_kernel(const float* __res
             const long tl = dep_t[n];
             const bool tok = tl >= 0 && tl < Kdep;
             const int t = tok ? (int)tl : 0;
-            l_dep += tok ? -(q[t] - mq - logf(s2)) * wrow : __builtin_nanf("");
+            // (a row of weight 0 -- is_overlap outside {0, 1}: in neither subset, datasets/reader.py:363-380 with
+            // remove_depth_overlap -- takes no part in the loss, so its label is not looked at either)
+            l_dep += tok ? -(q[t] - mq - logf(s2)) * wrow : (wrow != 0.f ? __builtin_nanf("") : 0.f);
             if (dz) {
                 float dq[4], dot = 0.f;
                 for (int k = 0; k < Kdep; ++k) {

@@ -152,10 +152,17 @@ class _OrderBase(SingleStageModel):
         return self._pack_return(losses)
 
 
-def _check_labels(t, lo, hi, what):
+def _check_labels(t, lo, hi, what, is_overlap=None):
     """Labels that arrive on the host (the DataLoader's tensors) are validated here; the loss kernel poisons the loss
-    with NaN for an out-of-range class id that only shows up on the device."""
+    with NaN for an out-of-range class id that only shows up on the device.  Only rows that take part in the loss are
+    looked at: with ``is_overlap`` given, those whose flag is 0 or 1 -- the reference keeps -1 for overlapped pairs under
+    ``remove_depth_overlap`` (datasets/reader.py:363-380) and its boolean masks drop them (supervised_order.py:62-73)."""
     if t is not None and torch.is_tensor(t) and not t.is_cuda and t.numel():
+        if is_overlap is not None and torch.is_tensor(is_overlap) and not is_overlap.is_cuda:
+            live = (is_overlap.reshape(-1) == 0) | (is_overlap.reshape(-1) == 1)
+            t = t.reshape(-1)[live]
+            if not t.numel():
+                return
         mn, mx = int(t.min()), int(t.max())
         if mn < lo or mx > hi:
             raise ValueError("%s: values must lie in [%d, %d], got [%d, %d]" % (what, lo, hi, mn, mx))
@@ -192,8 +199,7 @@ class InstaOrderNet_od(_OrderBase):
 
     def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None,
                   occ_order=None):
-        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order")
-        _check_labels(is_overlap, 0, 1, "is_overlap")
+        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order", is_overlap)
         self._set_images(rgb, modal1, modal2)
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
@@ -222,8 +228,7 @@ class InstaOrderNet_d(_OrderBase):
         self.KDEP = int(params["backbone_param"]["num_classes"])
 
     def set_input(self, rgb=None, modal1=None, modal2=None, depth_order=None, count=None, is_overlap=None):
-        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order")
-        _check_labels(is_overlap, 0, 1, "is_overlap")
+        _check_labels(depth_order, 0, self.KDEP - 1, "depth_order", is_overlap)
         self._set_images(rgb, modal1, modal2)
         self.depth_order1 = _dev(depth_order, torch.long)
         self.depth_order2 = _mirror_classes(self.depth_order1)
@@ -305,8 +310,7 @@ class _DepthBase(SingleStageModel):
         return cur
 
     def _set_common(self, rgb, modal1, modal2, depth_order, count, is_overlap):
-        _check_labels(depth_order, 0, 2, "depth_order")
-        _check_labels(is_overlap, 0, 1, "is_overlap")
+        _check_labels(depth_order, 0, 2, "depth_order", is_overlap)
         self.rgb = self._keep("rgb", _dev(rgb, torch.float32).contiguous())
         self.modal1 = self._keep("modal1", _dev(modal1, torch.float32).contiguous())
         self.modal2 = self._keep("modal2", _dev(modal2, torch.float32).contiguous())

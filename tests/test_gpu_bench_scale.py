@@ -1,0 +1,467 @@
+"""Bench-scale parity: every convolution launch that ``bench.py`` times, at ITS OWN size.
+
+BASELINE.json configs[1] runs InstaOrderNet_o on 256 pairs = 512 samples at 256x256 (the reference's step,
+models/supervised_order.py:535-548, through models/backbone/resnet_cls.py:96-116).  The per-kernel tests of
+test_gpu_ops.py stop at M = 32 k rows; at the bench batch layer 1 has M = 2.1 M rows and the grid logic is different:
+768 / 2304 split-K slices in the filter gradient, the two-block build for 769..1024-tile grids, the XCD remap over many
+rounds, BatchNorm tile partials over 16 k tiles, descriptors rebased per tile on multi-GB tensors.  So each distinct
+convolution shape of ResNet-50 at N = 512, S = 256 is run here through the C ABI in the very configuration the executor
+(csrc/net.hip) launches it in -- forward with the operand transform + statistics epilogue, data gradient with the fused
+BatchNorm-backward epilogue (and, in fp32, the backward operand transform + side output), filter gradient at its real
+split count -- in fp32 and bf16, and checked against fp64:
+
+* SAMPLED entries (256 random outputs / filter taps per launch): the operands of each sampled dot product are gathered
+  from the very tensors the kernel read (a pure indexing op on the device), moved to the HOST and reduced there in fp64
+  with torch over the FULL reduction (K = taps x Cin for the NT launches, M = all 0.03 .. 2.1 M rows for the filter
+  gradient);
+* the per-channel BatchNorm sums the epilogues produce (mean / rstd of the output; sum dz, sum dz * xhat -> dgamma, dbeta
+  and the coefficient tables) against fp64 reductions of the kernel's own output tensor (torch reductions in fp64 on the
+  device -- an independent implementation; moving 2 GB per launch to the host would only add minutes).
+
+A wrong partition of a reduction at 2304 splits, a tile that reads its neighbour's rows, a partial that lands in the
+wrong slot: each shows up here as an O(1) error in some sample or channel.  Tolerances: fp32 2e-5 of the output scale
+(the per-kernel bar), bf16 one output rounding (6e-3)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from instaorder_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N, G, NS = 512, 2, 256          # samples per step (256 pairs, both mask orders), BatchNorm groups, sampled entries
+
+# (name, H_in, Cin, Cout, k, stride, role).  role: which launch configuration the executor uses for this layer --
+# c1: plain forward + statistics; data gradient = operand transform (fp32) + residual add + stored-activation mask + the
+#     reductions of the previous block's bn3
+# c2 / c3: forward through the producer's BatchNorm + ReLU (fp32) + statistics; data gradient masks with relu(bn(y)) > 0
+#     recomputed from y, reduces for that BatchNorm and rebuilds its activation; c3 also takes the operand transform
+# c2s: strided 3x3 on a stored activation; data gradient as parity classes
+# cd: downsample 1x1 (strided except in layer 1); plain data gradient
+SHAPES = [
+    ("l1.c1a", 64, 64, 64, 1, 1, "c1"), ("l1.c1b", 64, 256, 64, 1, 1, "c1"), ("l1.c2", 64, 64, 64, 3, 1, "c2"),
+    ("l1.c3", 64, 64, 256, 1, 1, "c3"), ("l1.cd", 64, 64, 256, 1, 1, "cd"),
+    ("l2.c1a", 64, 256, 128, 1, 1, "c1"), ("l2.c2s", 64, 128, 128, 3, 2, "c2s"), ("l2.c3", 32, 128, 512, 1, 1, "c3"),
+    ("l2.cd", 64, 256, 512, 1, 2, "cd"), ("l2.c1b", 32, 512, 128, 1, 1, "c1"), ("l2.c2", 32, 128, 128, 3, 1, "c2"),
+    ("l3.c1a", 32, 512, 256, 1, 1, "c1"), ("l3.c2s", 32, 256, 256, 3, 2, "c2s"), ("l3.c3", 16, 256, 1024, 1, 1, "c3"),
+    ("l3.cd", 32, 512, 1024, 1, 2, "cd"), ("l3.c1b", 16, 1024, 256, 1, 1, "c1"), ("l3.c2", 16, 256, 256, 3, 1, "c2"),
+    ("l4.c1a", 16, 1024, 512, 1, 1, "c1"), ("l4.c2s", 16, 512, 512, 3, 2, "c2s"), ("l4.c3", 8, 512, 2048, 1, 1, "c3"),
+    ("l4.cd", 16, 1024, 2048, 1, 2, "cd"), ("l4.c1b", 8, 2048, 512, 1, 1, "c1"), ("l4.c2", 8, 512, 512, 3, 1, "c2"),
+]
+IDS = [s[0] for s in SHAPES]
+
+
+@pytest.fixture(autouse=True)
+def _free():
+    yield
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def P(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def ST():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def td_of(dtype):
+    return torch.bfloat16 if dtype == "bf16" else torch.float32       # ("fp32", "fp32-exactK": float32)
+
+
+def gen(seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    return g
+
+
+def randn(shape, g, td, scale=1.0, shift=0.0):
+    return (torch.randn(shape, generator=g, device=DEV) * scale + shift).to(td)
+
+
+def tables(g, Cn):
+    """[G][C] fp32 tables in a BatchNorm-like range: mean, rstd, scale (= gamma * rstd), shift"""
+    mean = torch.randn(G * Cn, generator=g, device=DEV) * 0.3
+    rstd = torch.rand(G * Cn, generator=g, device=DEV) * 1.5 + 0.5
+    gamma = torch.rand(Cn, generator=g, device=DEV) + 0.5
+    scale = (gamma.repeat(G) * rstd).contiguous()
+    shift = torch.randn(G * Cn, generator=g, device=DEV) * 0.3
+    return mean, rstd, gamma, scale, shift
+
+
+def relerr(got, ref):
+    got, ref = got.double().cpu().reshape(-1), ref.double().cpu().reshape(-1)
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def out_size(H, k, s):
+    pad = k // 2
+    return (H + 2 * pad - k) // s + 1, pad
+
+
+def decode(m, Ho):
+    n = m // (Ho * Ho)
+    r = m - n * (Ho * Ho)
+    ho = r // Ho
+    return n, ho, r - ho * Ho
+
+
+def grp_of(n):
+    return n // (N // G)
+
+
+def host(t):
+    return t.double().cpu()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sampled fp64 references (operands gathered on the device, reduced on the host)
+# ---------------------------------------------------------------------------------------------------------------------
+def ref_forward(x, w, H, Cin, k, s, m, o, xf, bf):
+    """sum_{tap, c} X[pix(m, tap)][c] * W[o][tap][c] for the sampled (m, o); X = relu((x - mean) * scale + shift) when the
+    operand transform is on (zero in the padding), rounded to the operand type as the kernel rounds it"""
+    Ho, pad = out_size(H, k, s)
+    n, ho, wo = decode(m, Ho)
+    acc = torch.zeros(m.numel(), dtype=torch.float64)
+    xv = x.view(-1, Cin)
+    for tap in range(k * k):
+        r_, s_ = divmod(tap, k)
+        hi, wi = ho * s - pad + r_, wo * s - pad + s_
+        ok = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < H)
+        pix = (n * H + hi.clamp(0, H - 1)) * H + wi.clamp(0, H - 1)
+        xa = host(xv[pix])
+        if xf is not None:
+            mean, scale, shift = (host(t.view(G, Cin)[grp_of(n)]) for t in xf)
+            xa = torch.relu((xa - mean) * scale + shift)
+            if bf:
+                xa = xa.bfloat16().double()
+        xa = xa * host(ok)[:, None]
+        acc += (xa * host(w[o, tap])).sum(1)
+    return acc
+
+
+def ref_dgrad(src, wt, H, Cin, Cout, k, s, m, c):
+    """data gradient of conv(Cin -> Cout, k, stride s, pad k // 2) at the sampled input pixels m / channels c:
+    sum_{(r, s'), o} src[n, (h + pad - r) / s, (w + pad - s') / s, o] * W[o][r, s'][c] over the taps that divide.
+    src: callable(pixel index tensor of the OUTPUT grid) -> host fp64 [ns, Cout] (so that the operand transform can be
+    applied to exactly the gathered rows); wt: device [Cin][k * k][Cout]"""
+    Ho, pad = out_size(H, k, s)
+    n, h, w_ = decode(m, H)
+    acc = torch.zeros(m.numel(), dtype=torch.float64)
+    for tap in range(k * k):
+        r_, s_ = divmod(tap, k)
+        th, tw = h + pad - r_, w_ + pad - s_
+        ok = (th % s == 0) & (tw % s == 0)
+        yo, xo = th // s, tw // s
+        ok = ok & (yo >= 0) & (yo < Ho) & (xo >= 0) & (xo < Ho)
+        pix = (n * Ho + yo.clamp(0, Ho - 1)) * Ho + xo.clamp(0, Ho - 1)
+        a = src(pix, n) * host(ok)[:, None]
+        acc += (a * host(wt[c, tap])).sum(1)
+    return acc
+
+
+def ref_wgrad(x, dy, H, Cin, Cout, k, s, osel, csel, taps=None):
+    """dW[o][tap][c] = sum_m dY[m][o] * X[pix(m, tap)][c] for o in osel, c in csel, every tap: the two column subsets are
+    gathered on the device, the reduction over ALL m runs on the host in fp64"""
+    Ho, pad = out_size(H, k, s)
+    dys = host(dy.view(-1, Cout)[:, osel])                                  # [M, no]
+    xs = host(x[..., csel])                                                 # [N, H, H, nc]
+    xp = torch.zeros(N, H + 2 * pad, H + 2 * pad, csel.numel(), dtype=torch.float64)
+    xp[:, pad:pad + H, pad:pad + H] = xs
+    out = torch.zeros(osel.numel(), k * k, csel.numel(), dtype=torch.float64)
+    for tap in (range(k * k) if taps is None else taps):
+        r_, s_ = divmod(tap, k)
+        win = xp[:, r_:r_ + (Ho - 1) * s + 1:s, s_:s_ + (Ho - 1) * s + 1:s].reshape(-1, csel.numel())
+        out[:, tap] = dys.t() @ win
+    return out
+
+
+def group_sums(dz, y, mean, rstd, Cn):
+    """fp64 on the device: per group sum(dz), sum(dz * xhat) over the rows of the kernel's own tensors"""
+    M = dz.numel() // Cn
+    Mg = M // G
+    s1 = torch.zeros(G, Cn, dtype=torch.float64, device=DEV)
+    s2 = torch.zeros(G, Cn, dtype=torch.float64, device=DEV)
+    step = 1 << 17
+    for gi in range(G):
+        mu, rs = mean.view(G, Cn)[gi].double(), rstd.view(G, Cn)[gi].double()
+        for r0 in range(gi * Mg, (gi + 1) * Mg, step):
+            r1 = min(r0 + step, (gi + 1) * Mg)
+            d = dz.view(M, Cn)[r0:r1].double()
+            s1[gi] += d.sum(0)
+            s2[gi] += (d * ((y.view(M, Cn)[r0:r1].double() - mu) * rs)).sum(0)
+    return s1, s2
+
+
+def sample(g, hi, n=NS):
+    return torch.randint(0, hi, (n,), generator=g, device=DEV)
+
+
+def tol(bf, fp32=2e-5, bf16=6e-3):
+    return bf16 if bf else fp32
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# forward: [operand transform +] convolution + statistics epilogue
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_forward_launch_at_bench_size(shape, dtype):
+    name, H, Cin, Cout, k, s, role = shape
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(1000 + IDS.index(name))
+    Ho, pad = out_size(H, k, s)
+    M = N * Ho * Ho
+    x = randn((N, H, H, Cin), g, td, 0.8, 0.2)
+    w = randn((Cout, k * k, Cin), g, td, 1.0 / np.sqrt(Cin * k * k))
+    xf = None
+    if role in ("c2", "c3") and not bf:          # fp32: conv2 (stride 1) / conv3 read relu(bn(y)) through the transform
+        mean_i, _, _, scale_i, shift_i = tables(g, Cin)
+        xf = (mean_i, scale_i, shift_i)
+    gamma, beta = torch.rand(Cout, generator=g, device=DEV) + 0.5, torch.randn(Cout, generator=g, device=DEV)
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, rstd, scale, shift = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+    nws = lib.io_conv2d_bnstats_workspace_floats(N, H, H, Cout, k, k, s, pad, G)
+    ws = torch.empty(nws, device=DEV)
+    y = torch.full((N, Ho, Ho, Cout), float("nan"), device=DEV, dtype=td)
+    if xf is not None:
+        _lib.check(lib.io_conv2d_fwd_xf_dt(P(x), P(w), P(y), N, H, H, Cin, Cout, k, k, s, pad, G, P(xf[0]), P(xf[1]), P(xf[2]),
+                                           P(gamma), P(beta), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift),
+                                           P(ws), nws, int(bf), ST()), "fwd_xf")
+    else:
+        _lib.check(lib.io_conv2d_fwd_bnstats_dt(P(x), P(w), P(y), N, H, H, Cin, Cout, k, k, s, pad, G, P(gamma), P(beta),
+                                                P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift), P(ws), nws,
+                                                int(bf), 0, ST()), "fwd_stats")
+    m, o = sample(g, M), sample(g, Cout)
+    ref = ref_forward(x, w, H, Cin, k, s, m, o, xf, bf)
+    got = y.view(M, Cout)[m, o]
+    assert relerr(got, ref) < tol(bf), name
+    # statistics of the output from the epilogue's 128-row tile partials, against fp64 over the kernel's own y
+    Mg = M // G
+    yv = y.view(G, Mg, Cout)
+    mref = torch.stack([yv[gi].double().mean(0) for gi in range(G)])
+    vref = torch.stack([yv[gi].double().var(0, unbiased=False) for gi in range(G)])
+    # (bf16: the epilogue sums the fp32 accumulators, y holds their bf16 roundings: noise of 4e-3 / sqrt(rows))
+    assert relerr(mean.view(G, Cout), mref) < tol(bf, 2e-5, 2e-4), name
+    assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < 1e-4, name
+    assert relerr(scale.view(G, Cout), gamma.double() / torch.sqrt(vref + 1e-5)) < 1e-4, name
+    # running estimates advanced once per group, in group order, with the unbiased variance
+    rme, rve = torch.zeros(Cout, dtype=torch.float64, device=DEV), torch.ones(Cout, dtype=torch.float64, device=DEV)
+    for gi in range(G):
+        rme = 0.9 * rme + 0.1 * mref[gi]
+        rve = 0.9 * rve + 0.1 * vref[gi] * Mg / (Mg - 1)
+    assert relerr(rm, rme) < tol(bf, 2e-5, 2e-4) and relerr(rv, rve) < 1e-4, name
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data gradient in the executor's configuration for this layer
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_data_gradient_launch_at_bench_size(shape, dtype):
+    name, H, Cin, Cout, k, s, role = shape
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(2000 + IDS.index(name))
+    Ho, pad = out_size(H, k, s)
+    Mo, Mi = N * Ho * Ho, N * H * H
+    wt = randn((Cin, k * k, Cout), g, td, 1.0 / np.sqrt(Cout * k * k))
+    dz_in = randn((N, Ho, Ho, Cout), g, td)               # the gradient arriving at the conv output (or dz of its BN)
+    dx = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=td)
+    m, c = sample(g, Mi), sample(g, Cin)
+    n_s = decode(m, H)[0]
+    if role in ("c2s", "cd"):
+        # plain (strided) data gradient: every lattice class of dx is written
+        _lib.check(lib.io_conv2d_dgrad_dt(P(dz_in), P(wt), P(dx), None, None, N, H, H, Cin, Cout, k, k, s, pad, int(bf),
+                                          ST()), "dgrad")
+        src = lambda pix, n: host(dz_in.view(Mo, Cout)[pix])       # noqa: E731
+        ref = ref_dgrad(src, wt, H, Cin, Cout, k, s, m, c)
+        assert relerr(dx.view(Mi, Cin)[m, c], ref) < tol(bf), name
+        assert bool(torch.isfinite(dx).all()), name
+        return
+    xb = (role in ("c1", "c3")) and not bf      # fp32: BatchNorm backward's apply pass lives in the operand load
+    opt = _lib.DgradFused()
+    keep = []
+    if xb:
+        y_b = randn((N, Ho, Ho, Cout), g, td, 0.7, 0.1)
+        coef = (torch.randn(3 * G * Cout, generator=g, device=DEV) * 0.5).contiguous()
+        dy_out = torch.full((N, Ho, Ho, Cout), float("nan"), device=DEV, dtype=td)
+        opt.xb_y, opt.xb_coef, opt.xb_dy_out = y_b.data_ptr(), coef.data_ptr(), dy_out.data_ptr()
+        keep += [y_b, coef, dy_out]
+        cf = coef.view(3, G, Cout)
+
+        def src(pix, n):
+            gi = grp_of(n)
+            return host(cf[0][gi]) * host(dz_in.view(Mo, Cout)[pix]) + host(cf[1][gi]) * host(y_b.view(Mo, Cout)[pix]) + \
+                host(cf[2][gi])
+    else:
+        src = lambda pix, n: host(dz_in.view(Mo, Cout)[pix])       # noqa: E731
+    # epilogue: the BatchNorm whose output gradient dx is
+    y_a = randn((N, H, H, Cin), g, td, 0.7, 0.1)
+    mean_a, rstd_a, gamma_a, scale_a, shift_a = tables(g, Cin)
+    nt = lib.io_bn_tile_partial_floats(Mi, Cin, G)
+    p1, p2 = torch.empty(nt, device=DEV), torch.empty(nt, device=DEV)
+    opt.ep_y, opt.ep_mean, opt.ep_rstd, opt.ep_p1, opt.ep_p2 = (y_a.data_ptr(), mean_a.data_ptr(), rstd_a.data_ptr(),
+                                                                p1.data_ptr(), p2.data_ptr())
+    aout = base = act = None
+    if role == "c1":
+        base = randn((N, H, H, Cin), g, td)
+        act = randn((N, H, H, Cin), g, td)
+        opt.add, opt.relu_mask = base.data_ptr(), act.data_ptr()
+    else:
+        opt.ep_scale, opt.ep_shift = scale_a.data_ptr(), shift_a.data_ptr()
+        if not bf:                               # fp32 never stored relu(bn(y)): the epilogue rebuilds it
+            aout = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=td)
+            opt.ep_act_out = aout.data_ptr()
+    _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dz_in), P(wt), P(dx), N, H, H, Cin, Cout, k, k, pad, G, C.byref(opt), int(bf),
+                                            ST()), "dgrad_fused")
+    ref = ref_dgrad(src, wt, H, Cin, Cout, k, 1, m, c)
+    gi = grp_of(n_s)
+    if role == "c1":
+        ref = (ref + host(base.view(Mi, Cin)[m, c])) * host(act.view(Mi, Cin)[m, c] > 0)
+        sure = torch.ones(NS, dtype=torch.bool)
+    else:
+        t = (host(y_a.view(Mi, Cin)[m, c]) - host(mean_a.view(G, Cin)[gi, c])) * host(scale_a.view(G, Cin)[gi, c]) + \
+            host(shift_a.view(G, Cin)[gi, c])
+        sure = t.abs() > (2e-2 if bf else 1e-5)          # a mask decision within rounding of zero proves nothing
+        ref = ref * (t > 0)
+        if aout is not None:
+            assert relerr(aout.view(Mi, Cin)[m, c], torch.relu(t)) < 2e-5, name
+    got = host(dx.view(Mi, Cin)[m, c])
+    assert int(sure.sum()) > NS // 2
+    assert relerr(got * sure, ref * sure) < tol(bf), name
+    if xb:      # the side output: dy itself, at sampled entries, and nothing left unwritten
+        mo, co = sample(g, Mo), sample(g, Cout)
+        want = src(mo, decode(mo, Ho)[0])[torch.arange(NS), co.cpu()]
+        assert relerr(dy_out.view(Mo, Cout)[mo, co], want) < 2e-5, name
+        assert bool(torch.isfinite(dy_out).all()), name
+    # the epilogue's tile partials -> dgamma / dbeta / coefficient tables, against fp64 sums over the kernel's own dx
+    coef_a = torch.empty(3 * G * Cin, device=DEV)
+    dga, dba = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+    _lib.check(lib.io_bn_bwd_coefs_from_tile_partials(P(p1), P(p2), Mi, Cin, G, P(gamma_a), P(mean_a), P(rstd_a), P(dga),
+                                                      P(dba), P(coef_a), ST()), "coefs_from_tiles")
+    s1, s2 = group_sums(dx, y_a, mean_a, rstd_a, Cin)
+    # (bf16: the sums are taken before dx is rounded to bf16, and sums of zero-mean data are themselves of the size of
+    # sqrt(rows) roundings: one bf16 rounding is the bar)
+    assert relerr(dba, s1.sum(0)) < tol(bf, 5e-5, 6e-3), name
+    assert relerr(dga, s2.sum(0)) < tol(bf, 5e-5, 6e-3), name
+    Mg = Mi // G
+    A = gamma_a.double() * rstd_a.view(G, Cin).double()
+    Bc = -A * rstd_a.view(G, Cin).double() * (s2 / Mg)
+    Cc = -A * (s1 / Mg) - Bc * mean_a.view(G, Cin).double()
+    ca = coef_a.view(3, G, Cin)
+    assert relerr(ca[0], A) < 1e-6, name
+    # b and c are differences of O(1) quantities scaled by means that are themselves sums with cancellation: hold them
+    # to the scale of a (what matters is dy = a dz + b y + c, of the size of a * dz)
+    assert float((ca[1].double() - Bc).abs().max()) < tol(bf, 5e-5, 6e-3) * float(A.abs().max()), name
+    assert float((ca[2].double() - Cc).abs().max()) < tol(bf, 5e-5, 6e-3) * float(A.abs().max()), name
+    del keep
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# filter gradient at its real split count
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_filter_gradient_launch_at_bench_size(shape, dtype):
+    name, H, Cin, Cout, k, s, role = shape
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(3000 + IDS.index(name))
+    Ho, pad = out_size(H, k, s)
+    x = randn((N, H, H, Cin), g, td, 0.8, 0.2)
+    dy = randn((N, Ho, Ho, Cout), g, td)
+    nb = lib.io_conv2d_wgrad_workspace_bytes(N, H, H, Cin, Cout, k, k, s, pad)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((Cout, k * k, Cin), float("nan"), device=DEV)
+    _lib.check(lib.io_conv2d_wgrad_dt(P(x), P(dy), P(dw), N, H, H, Cin, Cout, k, k, s, pad, P(ws), nb, int(bf), int(bf),
+                                      ST()), "wgrad")
+    assert bool(torch.isfinite(dw).all()), name
+    osel = torch.randperm(Cout, generator=g, device=DEV)[:16]
+    csel = torch.randperm(Cin, generator=g, device=DEV)[:16]
+    ref = ref_wgrad(x, dy, H, Cin, Cout, k, s, osel, csel)                  # [16][taps][16]
+    got = dw[osel][:, :, csel]
+    # fp32 accumulation over up to 2.1 M rows in both modes (bf16 operands are exact in fp32 products)
+    assert relerr(got, ref) < 2e-5, name
+    # the whole gradient, cheaply: column sums over (o) of dW equal the filter gradient of the channel-summed dY --
+    # one more full-reduction identity that catches a slice added twice or dropped anywhere in the tensor
+    dys = dy.view(-1, Cout).double().sum(1)                                  # [M]
+    Hp = H + 2 * pad
+    xp = torch.zeros(N, Hp, Hp, Cin, dtype=torch.float64, device=DEV)
+    tot = torch.empty(k * k, Cin, dtype=torch.float64, device=DEV)
+    xp[:, pad:pad + H, pad:pad + H] = x.double()
+    for tap in range(k * k):
+        r_, s_ = divmod(tap, k)
+        win = xp[:, r_:r_ + (Ho - 1) * s + 1:s, s_:s_ + (Ho - 1) * s + 1:s].reshape(-1, Cin)
+        tot[tap] = dys @ win
+    assert relerr(dw.double().sum(0), tot) < 2e-5, name
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the stem: 7x7 / 2 on the packed 5-channel input
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32-exactK", "fp32", "bf16"])
+def test_stem_launches_at_bench_size(mode):
+    """fp32-exactK is what the fp32 step launches (reduction over the 5 real channels only); the padded form is the public
+    Cin = 8 entry point and the bf16 stem."""
+    bf = mode == "bf16"
+    exact = mode == "fp32-exactK"
+    td = td_of(mode)
+    lib = _lib.lib()
+    g = gen(4000)
+    S, Cout, k, s, pad = 256, 64, 7, 2, 3
+    Ho = S // 2
+    M = N * Ho * Ho
+    x = randn((N, S, S, 8), g, td)
+    x[..., 5:] = 0
+    w = randn((Cout, k * k, 8), g, torch.float32, 1.0 / 15.0)
+    w[..., 5:] = 0
+    wq = w.to(td)
+    gamma, beta = torch.rand(Cout, generator=g, device=DEV) + 0.5, torch.randn(Cout, generator=g, device=DEV)
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, rstd, scale, shift = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+    nws = lib.io_conv2d_bnstats_workspace_floats(N, S, S, Cout, k, k, s, pad, G)
+    ws = torch.empty(nws, device=DEV)
+    y = torch.full((N, Ho, Ho, Cout), float("nan"), device=DEV, dtype=td)
+    packed = torch.empty(lib.io_stem_packed_floats(5), device=DEV)
+    if exact:
+        _lib.check(lib.io_stem_fwd_bnstats_exact(P(x), P(w), P(y), N, S, S, 5, G, P(gamma), P(beta), P(rm), P(rv), 0.1, 1e-5,
+                                                 P(mean), P(rstd), P(scale), P(shift), P(ws), nws, P(packed), ST()),
+                   "stem fwd exact")
+    else:
+        _lib.check(lib.io_conv2d_fwd_bnstats_dt(P(x), P(wq), P(y), N, S, S, 8, Cout, k, k, s, pad, G, P(gamma), P(beta),
+                                                P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift), P(ws), nws,
+                                                int(bf), 0, ST()), "stem fwd")
+    m, o = sample(g, M), sample(g, Cout)
+    assert relerr(y.view(M, Cout)[m, o], ref_forward(x, wq, S, 8, k, s, m, o, None, bf)) < tol(bf)
+    yv = y.view(G, M // G, Cout)
+    mref = torch.stack([yv[gi].double().mean(0) for gi in range(G)])
+    vref = torch.stack([yv[gi].double().var(0, unbiased=False) for gi in range(G)])
+    # (zero-mean inputs: the channel means are ~1e-3 of the spread, so hold them to the spread)
+    assert float((mean.view(G, Cout).double() - mref).abs().max()) < tol(bf, 2e-5, 2e-4) * float(vref.sqrt().max())
+    assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < 1e-4
+    # filter gradient (the network input needs no data gradient)
+    dy = randn((N, Ho, Ho, Cout), g, td)
+    dw = torch.full((Cout, k * k, 8), float("nan"), device=DEV)
+    if exact:
+        nb = lib.io_stem_wgrad_exact_workspace_bytes(N, S, S, 5)
+        wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.io_stem_wgrad_exact(P(x), P(dy), P(dw), N, S, S, 5, P(wsb), nb, P(packed), ST()), "stem wgrad exact")
+    else:
+        nb = lib.io_conv2d_wgrad_workspace_bytes(N, S, S, 8, Cout, k, k, s, pad)
+        wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.io_conv2d_wgrad_dt(P(x), P(dy), P(dw), N, S, S, 8, Cout, k, k, s, pad, P(wsb), nb, int(bf), int(bf),
+                                          ST()), "stem wgrad")
+    osel = torch.randperm(Cout, generator=g, device=DEV)[:8]
+    csel = torch.arange(8, device=DEV)
+    taps = [0, 6, 9, 17, 24, 25, 31, 40, 42, 48]          # corners, centre, a few more: each a full reduction over 8.4 M rows
+    ref = ref_wgrad(x, dy, S, 8, Cout, k, s, osel, csel, taps)
+    assert relerr(dw[osel][:, taps], ref[:, taps]) < 2e-5
+    assert float(dw[..., 5:].abs().max()) == 0.0

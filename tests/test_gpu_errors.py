@@ -146,6 +146,19 @@ def test_invalid_labels_fail_loudly():
     bad[1] = -1
     with pytest.raises(ValueError):
         m.set_input(b["rgb"], b["modal1"], b["modal2"], bad, b["count"], b["is_overlap"], b["occ_order"])
+    # ... unless that row takes no part in the loss: is_overlap = -1 is what the reference's reader leaves on overlapped
+    # pairs under remove_depth_overlap (datasets/reader.py:363-380); its boolean masks drop the row (supervised_order.py:
+    # 62-73), so neither the flag nor the row's label is an error, and the loss is the one of the remaining rows
+    ovl = b["is_overlap"].clone()
+    ovl[1] = -1
+    m.switch_to("train")
+    m.set_input(b["rgb"], b["modal1"], b["modal2"], bad, b["count"], ovl, b["occ_order"])
+    logs_a, _ = m.forward_only()
+    ok = b["depth_order"].clone()
+    ok[1] = 2
+    m.set_input(b["rgb"], b["modal1"], b["modal2"], ok, b["count"], ovl, b["occ_order"])
+    logs_b, _ = m.forward_only()
+    assert np.isfinite(float(logs_a["loss_depth"])) and float(logs_a["loss_depth"]) == float(logs_b["loss_depth"])
     # the same label arriving on the device: NaN loss
     B = 4
     logits = torch.randn(2 * B, 5, device="cuda")

@@ -64,18 +64,32 @@ def test_conv_over_4gib_fp32():
 
 
 def test_config3_1024_pairs_bf16_step():
-    """BASELINE configs[2]: InstaOrderNet_od, bf16, 1024 pairs (2048 samples) of 256x256 on ONE GPU: ~125 GiB of
+    """BASELINE configs[2]: InstaOrderNet_od, bf16, 1024 pairs (2048 samples) of 256x256 on ONE GPU: ~121 GiB of
     workspace, layer-1 activations of exactly 4 GiB.  Eval-mode logits of the big batch must equal those of a
-    64-sample launch on the same images bit for bit (per-sample independence), and a training step must run."""
+    64-sample launch on the same images bit for bit (per-sample independence).  The TRAINING step is held to the fp32
+    HIP step on the very same 1024 pairs (220 GiB of workspace, run after the bf16 one has been freed; the fp32 path is
+    itself pinned to the oracle / the reference goldens by test_gpu_net.py and, launch by launch at this scale, by
+    test_gpu_bench_scale.py): all loss terms within 1e-2, gradient cosine > 0.995, norm within 2 % (measured 1.0000 / 1.000) -- on a
+    well-conditioned state (residual branches damped as in test_gpu_bf16.py: a random-weight BN ResNet amplifies any
+    perturbation ~1.2x per bottleneck, bf16 rounding included)."""
     _need(170)
+    import gc
     import instaorder_amd as ia
     algo, B, S = "InstaOrderNet_od", 1024, 256
-    cfg = dict(algo=algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype="bf16",
-               backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
-               distinct_weight=0.9)
-    m = getattr(ia, algo)(cfg, dist_model=False)
-    sd = synthetic.make_state_dict(11, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
-    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+
+    def model(dtype):
+        cfg = dict(algo=algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls", dtype=dtype,
+                   backbone_param=dict(in_channels=5, num_classes=ALGO_CLASSES[algo]), use_rgb=True, overlap_weight=0.1,
+                   distinct_weight=0.9)
+        m = getattr(ia, algo)(cfg, dist_model=False)
+        sd = synthetic.make_state_dict(11, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+        for k in sd:
+            if k.endswith("bn3.weight"):
+                sd[k] = (sd[k] * 0.1).astype(np.float32)
+        m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        return m
+
+    m = model("bf16")
     base = synthetic.make_pair_batch(77, 32, S)
     reps = B // 32
     t = {k: torch.from_numpy(np.concatenate([v] * reps, 0)).cuda() for k, v in base.items()}
@@ -93,10 +107,29 @@ def test_config3_1024_pairs_bf16_step():
         m.forward_only(ret_loss=False)
         small = m.last_logits
         assert torch.equal(small[:32], big[lo:lo + 32]) and torch.equal(small[32:], big[B + lo:B + lo + 32])
-    m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
-    m.switch_to("train")
-    logs, out = m.step()
-    loss = float(out["loss"])
-    assert np.isfinite(loss) and 0.5 < loss < 20.0, loss
-    gn = float(m.net.flat_grads.norm())
-    assert np.isfinite(gn) and gn > 0
+
+    def train_step(m):
+        m.switch_to("train")
+        m.optim.param_groups[0]["lr"] = 0.0
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+        logs, out = m.step()
+        torch.cuda.synchronize()
+        terms = dict(loss=float(out["loss"]), loss_occ=float(logs["loss_occ"]), loss_depth=float(logs["loss_depth"]))
+        return terms, m.net.flat_grads.detach().double().cpu()
+
+    lb, gb = train_step(m)
+    assert all(np.isfinite(v) for v in lb.values()) and bool(torch.isfinite(gb).all())
+    del m, big, small
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    assert free > 228 * 2 ** 30, "the fp32 step on the same 1024 pairs needs 220 GiB of workspace; free: %.0f GiB" % (free / 2 ** 30)
+    m = model("fp32")
+    lf, gf = train_step(m)
+    for k in lb:
+        assert abs(lb[k] - lf[k]) < 1e-2 * abs(lf[k]), (k, lb[k], lf[k])
+    cos = float(gb @ gf) / (float(gb.norm()) * float(gf.norm()))
+    ratio = float(gb.norm()) / float(gf.norm())
+    print("configs[2] bf16 vs fp32 HIP step, 1024 pairs: loss %.5f / %.5f, gradient cosine %.4f, norm ratio %.3f"
+          % (lb["loss"], lf["loss"], cos, ratio))
+    assert cos > 0.995 and abs(ratio - 1.0) < 0.02, (cos, ratio)
