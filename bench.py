@@ -304,8 +304,14 @@ def main():
                    "pair_source": "20-instance images, 190 pairs each, sharded by rank" if pair_src else "pair batch",
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
                    "hip_graph": bool(getattr(model, "_use_graph", False) and getattr(model, "_graph", None) is not None),
-                   "collective": None if world == 1 else "%s flat all-reduce, %d floats/step" % (
-                       args.backend, (model.optim if depthnet else model.net).flat_grads.numel())},
+                   "collective": None if world == 1 else (
+                       "%s all-reduce (SUM) of the %d gradient floats in %d stage buckets (%s MB: heads+layer4, layer3, "
+                       "layer2, layer1+stem), each launched when its stage of the backward pass is enqueued" % (
+                           args.backend, model.net.flat_grads.numel(), len(model.net.grad_stage_slices()),
+                           " / ".join("%.0f" % ((hi - lo) * 4 / 1e6) for lo, hi in model.net.grad_stage_slices()))
+                       if (not depthnet and getattr(model, "_overlap_comm", False)) else
+                       "%s flat all-reduce, %d floats/step" % (
+                           args.backend, (model.optim if depthnet else model.net).flat_grads.numel()))},
         "achieved_tflops_whole_step": pairs_per_s * flop_per_pair / 1e12,
         "mfma_frac_whole_step": pairs_per_s * flop_per_pair / 1e12 / (world * PEAK_FP32_MFMA_TFLOPS),
     }
@@ -319,14 +325,20 @@ def main():
         tfl = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
         # HBM bytes per launch from the newest committed PMC run of this command (profiles/rNN_pmc_traffic.json, made
         # by tools/collect_traffic.sh + tools/make_profiles.py; not live -- the file names the commit it was measured at)
+        # A PMC file is quoted only while the kernel sources are the ones it was measured on (csrc_sha = _lib.csrc_digest()
+        # recorded by tools/make_profiles.py); after any change under csrc/ traffic is null until the counters are re-collected.
         traffic, traffic_src = None, None
+        digest = _lib.csrc_digest()
         try:
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
             tj = json.load(open(f))
-            if tj.get("kernel") == name:
+            if tj.get("kernel") == name and tj.get("csrc_sha") == digest:
                 traffic = tj["bytes_per_launch_corrected"]
-                traffic_src = "%s (measured at commit %s)" % (os.path.basename(f), tj.get("commit", "round 1"))
+                traffic_src = "%s (measured at commit %s, csrc %s)" % (os.path.basename(f), tj.get("commit"), digest)
+            elif tj.get("kernel") == name:
+                traffic_src = "stale: %s was measured on other kernel sources (csrc %s, now %s)" % (
+                    os.path.basename(f), tj.get("csrc_sha", "unrecorded"), digest)
         except Exception:
             pass
         # the wgrad kernel runs the fp32 MFMA in both modes; the NT kernel (fwd / dgrad) follows --dtype
@@ -339,7 +351,7 @@ def main():
                 tj = json.load(open(f))
                 kk = [k for k in tj["kernels"] if k.startswith("conv_nt_kernel")]
                 if kk and name == "conv_nt_kernel<128,false>" and args.algo == "InstaOrderNet_o" and B == 256 and S == 256 \
-                        and args.mode == "train":
+                        and args.mode == "train" and tj.get("csrc_sha") == digest:
                     traffic = tj["kernels"][kk[0]]["bytes_per_launch_corrected"]
                     traffic_src = "%s (measured at commit %s)" % (os.path.basename(f), tj.get("commit"))
             except Exception:

@@ -179,6 +179,15 @@ int io_net_forward(io_net* net, const float* params, float* running, const void*
                    int training, void* workspace, size_t workspace_bytes, float* logits, hipStream_t stream);
 /* gradient of every parameter into grads (same layout as params; fully overwritten).  Must follow a
  * training io_net_forward with the same x8 / N / S / G / workspace. */
+/* The same pass cut into io_net_backward_num_stages() stages in execution order -- 0: heads + layer4, 1: layer3,
+ * 2: layer2, 3: layer1 + stem -- running the stages [stage_lo, stage_hi).  The parameter gradients of a stage are final
+ * when its call returns (stream order), so a data-parallel caller can start the exchange of that contiguous slice of
+ * `grads` (utils/distributed_utils.py:27-31 average_gradients) while the next stage computes.  Calling every stage once, in order,
+ * with the same arguments IS io_net_backward: nothing is carried between the calls but `workspace`. */
+int io_net_backward_num_stages(const io_net* net);
+int io_net_backward_stages(io_net* net, const float* params, float* grads, const void* x8, const float* dlogits, int N,
+                           int S, int G, void* workspace, size_t workspace_bytes, int stage_lo, int stage_hi,
+                           hipStream_t stream);
 int io_net_backward(io_net* net, const float* params, float* grads, const void* x8, const float* dlogits, int N,
                     int S, int G, void* workspace, size_t workspace_bytes, hipStream_t stream);
 

@@ -15,6 +15,20 @@ _lib = None
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, the public header), in name order: what a measurement of a
+    kernel (a PMC profile under profiles/) was taken on.  bench.py quotes such a measurement only while this matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "instaorder_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 class TensorInfo(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("kind", C.c_int), ("ndim", C.c_int), ("shape", C.c_long * 4),
                 ("offset", C.c_long), ("numel_storage", C.c_long), ("cin_storage", C.c_int),
@@ -79,6 +93,8 @@ SIGNATURES = {
     "io_net_activation_offset": (_L, [_P, _I, _I, _I]),
     "io_net_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "io_net_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "io_net_backward_num_stages": (_I, [_P]),
+    "io_net_backward_stages": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _I, _I, _P]),
     "io_net_set_dtype": (_I, [_P, _I]),
     "io_net_get_dtype": (_I, [_P]),
     "io_pack_planes_nhwc8_dt": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),

@@ -616,7 +616,13 @@ int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H,
     return bn_back(c, b, dx, 1, nullptr, y, M, dyb, nullptr);
 }
 
-int run_backward(Ctx& c, const float* dlogits, const void* x8) {
+// Backward stages, in execution order (gradients of a stage are final when its last launch has run, so a data-parallel
+// caller can start exchanging that slice of the flat gradient buffer while the next stage computes):
+//   0 = heads + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem.   Runs the stages [stage_lo, stage_hi).
+// Nothing is carried between calls but the workspace: which scratch buffer holds d(block output) and whether the tile
+// partials of a block's bn3 are waiting follow from the block index alone.
+constexpr int kBwdStages = 4;
+int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0, int stage_hi = kBwdStages) {
     const io_net* net = c.net;
     const Plan& p = c.plan;
     void* Gd = c.act(p.gbuf[0]);
@@ -633,6 +639,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
     // Gradients of block outputs are kept ALREADY MASKED by that output's ReLU: whoever writes the last
     // contribution to d(out) applies [out > 0] in its epilogue (here: the pooling backward; below: the
     // data-gradient kernels), so the BN backward of the block needs neither the activation nor a mask pass.
+    if (stage_lo == 0)
     IO_TRY(io_avgpool_fc_bwd_t(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
                                net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0,
                                c.act(p.blk[nb - 1].out), Gd, c.grads + net->fcw_off[0], c.grads + net->fcb_off[0],
@@ -644,12 +651,30 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         int H = H1;
         for (size_t i = 0; i < nb; ++i) { Hin[i] = H; H /= net->blocks[i].stride; }
     }
+    // stage of a block: the blocks of one resolution, last resolution first
+    std::vector<int> stage_of(nb);
+    {
+        int st = kBwdStages, res = -1;
+        for (size_t i = 0; i < nb; ++i) {                    // forward order: a stride-2 block opens a new stage ...
+            if (i == 0 || net->blocks[i].stride != 1) res += 1;
+            stage_of[i] = res;
+        }
+        for (size_t i = 0; i < nb; ++i) stage_of[i] = res - stage_of[i];     // ... numbered from the back
+        st = res + 1;
+        IO_REQUIRE(st == kBwdStages, IO_ERR_STATE, "run_backward: %d resolution stages, expected %d", st, kBwdStages);
+    }
     bool have_tiles = false;    // BN-backward partial sums of the current block's bn3 already produced?
     for (size_t ii = nb; ii-- > 0;) {
         const Block& b = net->blocks[ii];
         const BlockBufs& bb = p.blk[ii];
         const int H = Hin[ii], Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
+        if (stage_of[ii] < stage_lo || stage_of[ii] >= stage_hi) {
+            // not ours: only keep the bookkeeping in step (buffer roles alternate per block; the carry rule of below)
+            have_tiles = ii > 0 && tiles_ok(c, Min);
+            void* t = Gd; Gd = Ge; Ge = t;
+            continue;
+        }
         const void* xin = ii == 0 ? c.act(p.p0) : c.act(p.blk[ii - 1].out);
         // the block input is the previous block's post-ReLU output (for block 0 it is the max-pool output,
         // whose gradient is not masked here)
@@ -720,6 +745,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8) {
         if (x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         void* t = Gd; Gd = Ge; Ge = t;
     }
+    if (stage_hi < kBwdStages) return IO_OK;
     // Gd = d(maxpool output)
     IO_TRY(io_maxpool_bwd_t(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st, c.dt()));
     IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.act(p.y0), c.N * H0 * H0, Ga, nullptr));
@@ -891,3 +917,18 @@ extern "C" int io_net_backward(io_net* net, const float* params, float* grads, c
                c.plan.total);
     return run_backward(c, dlogits, x8);
 }
+
+extern "C" int io_net_backward_stages(io_net* net, const float* params, float* grads, const void* x8,
+                                      const float* dlogits, int N, int S, int G, void* ws, size_t ws_bytes,
+                                      int stage_lo, int stage_hi, hipStream_t st) {
+    IO_TRY(check_shape(N, S, G));
+    IO_REQUIRE(stage_lo >= 0 && stage_lo < stage_hi && stage_hi <= kBwdStages, IO_ERR_SHAPE,
+               "io_net_backward_stages: stages [%d, %d) outside [0, %d)", stage_lo, stage_hi, kBwdStages);
+    Ctx c;
+    fill_ctx(c, net, params, nullptr, grads, N, S, G, true, ws, st);
+    IO_REQUIRE(ws_bytes >= c.plan.total, IO_ERR_WORKSPACE, "io_net_backward_stages: workspace %zu < %zu bytes", ws_bytes,
+               c.plan.total);
+    return run_backward(c, dlogits, x8, stage_lo, stage_hi);
+}
+
+extern "C" int io_net_backward_num_stages(const io_net*) { return kBwdStages; }

@@ -48,11 +48,53 @@ def allreduce_flat(flat):
     return flat
 
 
-def average_gradients(model):
+class GradientBuckets(object):
+    """The gradient exchange of the reference (utils/distributed_utils.py:27-31: SUM all-reduce of every parameter
+    gradient, after the whole backward) cut into the stages of the backward pass and overlapped with it.
+
+    The backward runs heads + layer4 -> layer3 -> layer2 -> layer1 + stem (csrc/net.hip: io_net_backward_stages) and the
+    parameters lie in creation order in one flat buffer, so what a stage finalises is one contiguous slice of the flat
+    gradient buffer (``net.grad_stage_slices()``): 60 / 28 / 5 / 1 MB.  ``launch(stage)`` is called right after a stage
+    has been enqueued: the collective is issued asynchronously -- RCCL's stream takes a dependency on everything the
+    compute stream holds at that moment, i.e. on that stage, and the compute stream is NOT made to wait -- so layer4's
+    60 MB ride the xGMI ring under the ~80 % of the backward that is still to run.  ``finish()`` joins them before the
+    optimiser.  Per element the arithmetic is that of the flat call: one SUM over ranks of the same numbers (bit-identical
+    on two ranks, where the sum is commutative; with more ranks a ring may associate differently per chunking, as any
+    two bucketings of the reference's 161 calls would)."""
+
+    def __init__(self, net):
+        self.net = _net_of(net)
+        self.slices = self.net.grad_stage_slices()
+        self.pending = []
+
+    @property
+    def num_stages(self):
+        return len(self.slices)
+
+    def launch(self, stage):
+        lo, hi = self.slices[stage]
+        self.pending.append(dist.all_reduce(self.net.flat_grads[lo:hi], async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def all_at_once(self):
+        """every bucket, in backward order, after the fact (the arithmetic of the overlapped form without the overlap)"""
+        for s in range(self.num_stages):
+            self.launch(s)
+        self.finish()
+
+
+def average_gradients(model, bucketed=False):
     """Gradient exchange of the reference (SUM; the loss was already divided by world_size,
-    supervised_order.py:543).  One collective for the whole model."""
+    supervised_order.py:543).  One collective for the whole model, or (``bucketed``) the four stage buckets of
+    GradientBuckets -- what the training step overlaps with its backward pass."""
     net = _net_of(model)
-    if hasattr(net, "flat_grads"):
+    if hasattr(net, "flat_grads") and bucketed:
+        GradientBuckets(net).all_at_once()
+    elif hasattr(net, "flat_grads"):
         allreduce_flat(net.flat_grads)
     else:
         for param in model.parameters():

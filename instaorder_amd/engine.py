@@ -82,11 +82,23 @@ class Net(object):
                                            int(G), int(bool(training)), _ptr(ws), ws.numel() * ws.element_size(),
                                            _ptr(logits), _stream()), "io_net_forward")
 
-    def backward(self, params, grads, x8, dlogits, N, S, G, ws):
+    def backward(self, params, grads, x8, dlogits, N, S, G, ws, stages=None):
+        """stages = (lo, hi): only the backward stages [lo, hi) of io_net_backward_stages (0 = heads + layer4 .. 3 =
+        layer1 + stem); None = the whole pass"""
         _lib.require_gpu()
-        _lib.check(self.lib.io_net_backward(self.handle, _ptr(params), _ptr(grads), _ptr(x8), _ptr(dlogits),
-                                            int(N), int(S), int(G), _ptr(ws), ws.numel() * ws.element_size(),
-                                            _stream()), "io_net_backward")
+        if stages is None:
+            _lib.check(self.lib.io_net_backward(self.handle, _ptr(params), _ptr(grads), _ptr(x8), _ptr(dlogits),
+                                                int(N), int(S), int(G), _ptr(ws), ws.numel() * ws.element_size(),
+                                                _stream()), "io_net_backward")
+        else:
+            _lib.check(self.lib.io_net_backward_stages(self.handle, _ptr(params), _ptr(grads), _ptr(x8), _ptr(dlogits),
+                                                       int(N), int(S), int(G), _ptr(ws), ws.numel() * ws.element_size(),
+                                                       int(stages[0]), int(stages[1]), _stream()),
+                       "io_net_backward_stages")
+
+    @property
+    def backward_stages(self):
+        return int(self.lib.io_net_backward_num_stages(self.handle))
 
 
 TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16}

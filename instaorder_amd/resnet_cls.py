@@ -215,8 +215,21 @@ class ResNet(nn.Module):
             self.bump_batches_tracked(G)
         return logits, ws
 
-    def _run_backward(self, x8, dlogits, N, S, G, ws):
-        self.plan.backward(self._flat, self._flat_grad, x8, dlogits, N, S, G, ws)
+    def _run_backward(self, x8, dlogits, N, S, G, ws, stages=None):
+        self.plan.backward(self._flat, self._flat_grad, x8, dlogits, N, S, G, ws, stages)
+
+    def grad_stage_slices(self):
+        """[lo, hi) element ranges of the flat gradient buffer, one per backward stage in EXECUTION order (heads +
+        layer4, layer3, layer2, layer1 + stem): what becomes final when that stage of the backward pass has run.  The
+        parameters lie in creation order (conv1, bn1, layer1 .. layer4, heads), so the ranges are contiguous and tile
+        the buffer -- the buckets of the overlapped gradient exchange (distributed_utils.GradientBuckets)."""
+        first = {}
+        for t in self.plan.tensors:
+            stage = t["name"].split(".")[0]
+            first.setdefault(stage, t["offset"])
+        cuts = [first["layer4"], first["layer3"], first["layer2"], 0]
+        his = [self.plan.param_floats] + cuts[:-1]
+        return [(lo, hi) for lo, hi in zip(cuts, his)]
 
     def forward_packed(self, x8, groups=1):
         """x8[N,S,S,8] (already packed NHWC) -> raw logits [N, K].  In training mode the batch is

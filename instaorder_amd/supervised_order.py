@@ -48,6 +48,10 @@ class _OrderBase(SingleStageModel):
         self._graph_key = None
         self._seen_key = None
         self._static = {}
+        # world_size > 1: the gradient all-reduce in stage buckets under the backward pass (IO_COMM_OVERLAP=0: one flat
+        # all-reduce after it, the round-1/2 behaviour)
+        self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
+        self._buckets = None
         if load_pretrain is not None:
             self.load_pretrain(load_pretrain)
 
@@ -112,6 +116,24 @@ class _OrderBase(SingleStageModel):
         net._run_backward(self._x8, dlogits, N, S, 2, ws)
         return logits, losses, ws
 
+    def _step_overlapped(self, N, S):
+        """world_size > 1: forward, loss, then the backward stage by stage with the all-reduce of each stage's slice of
+        the flat gradient buffer launched as soon as that stage is enqueued (distributed_utils.GradientBuckets) -- the
+        exchange of the reference (average_gradients after loss.backward(), supervised_order.py:545-546) overlapped
+        with the rest of the backward pass.  Eager launches: the collectives sit between the stages."""
+        net = self.net
+        if self._buckets is None:
+            self._buckets = distributed_utils.GradientBuckets(net)
+        bk = self._buckets
+        logits, ws = net._run_forward(self._x8, N, S, 2, True)
+        losses, dlogits = self._loss(logits, True, True)
+        for s in range(bk.num_stages):
+            net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(s, s + 1))
+            bk.launch(s)
+        bk.finish()
+        net._pool.give(ws)
+        return logits, losses
+
     def step(self):
         net = self.net
         if not net.training:
@@ -119,6 +141,12 @@ class _OrderBase(SingleStageModel):
         N = 2 * self.B
         S = self._x8.shape[1]
         key = (N, S, self._x8.data_ptr(), net.flat_params.data_ptr())
+        if self.world_size > 1 and self._overlap_comm:
+            logits, losses = self._step_overlapped(N, S)
+            self.last_logits = logits
+            net.attach_grads()
+            self.optim.step()
+            return self._pack_return(losses)
         if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
             self._graph.replay()
             logits, losses = self._graph_out

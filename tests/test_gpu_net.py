@@ -377,6 +377,29 @@ def test_properties_larger_batch():
     # (d) determinism: same launch twice -> identical bits
     net._run_backward(x8, dl, 2 * B, S, 2, ws)
     assert torch.equal(net.flat_grads, g1)
+    # (e) the backward cut into its stages (io_net_backward_stages: what the data-parallel step interleaves with the
+    # bucketed gradient all-reduce) IS the backward: stage by stage, or in two halves, bit for bit -- and after stage s
+    # the slice of the flat gradient buffer that grad_stage_slices() names for it is already final
+    ns = net.plan.backward_stages
+    sl = net.grad_stage_slices()
+    assert ns == 4 and len(sl) == ns
+    real = torch.zeros(net.flat_grads.numel(), dtype=torch.bool, device="cuda")      # (tensors are padded to 256 bytes)
+    for t_ in net.plan.tensors:
+        real[t_["offset"]:t_["offset"] + t_["numel_storage"]] = True
+    mark = 12345.0
+    net.flat_grads.fill_(mark)
+    for s_ in range(ns):
+        net._run_backward(x8, dl, 2 * B, S, 2, ws, stages=(s_, s_ + 1))
+        lo, hi = sl[s_]
+        assert torch.equal(net.flat_grads[lo:hi][real[lo:hi]], g1[lo:hi][real[lo:hi]]), s_
+        if s_ + 1 < ns:
+            later = sl[s_ + 1][1]
+            assert bool((net.flat_grads[:later] == mark).all())                       # nothing of the later stages yet
+    assert torch.equal(net.flat_grads[real], g1[real])
+    net.flat_grads.fill_(mark)
+    net._run_backward(x8, dl, 2 * B, S, 2, ws, stages=(0, 2))
+    net._run_backward(x8, dl, 2 * B, S, 2, ws, stages=(2, 4))
+    assert torch.equal(net.flat_grads[real], g1[real])
     net._pool.give(ws)
 
 
