@@ -884,7 +884,39 @@ def case_tester(tag):
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
 
 
+def case_init_stats(tag):
+    """utils/common_utils.py:35-65 as models/single_stage_model.py:24 applies it (init_weights(net, 'xavier'), gain
+    0.02) to the reference's resnet50_cls: per-tensor std / mean of every parameter over `reps` seeded draws, pooled
+    (the statistics are what a port must reproduce; the draws themselves depend on torch's generator)."""
+    from models.backbone import resnet_cls
+    from utils import common_utils
+    reps = 3
+    acc = {}
+    for r in range(reps):
+        torch.manual_seed(100 + r)
+        net = resnet_cls.resnet50_cls(in_channels=5, num_classes=[2, 3])
+        common_utils.init_weights(net, init_type="xavier")
+        for k, p in net.named_parameters():
+            a = p.detach().double().reshape(-1)
+            acc.setdefault(k, []).append((float(a.mean()), float((a * a).mean()), a.numel()))
+    names = list(acc)
+    mean = np.array([np.mean([m for m, _, _ in acc[k]]) for k in names])
+    rms = np.array([np.sqrt(np.mean([q for _, q, _ in acc[k]])) for k in names])
+    numel = np.array([acc[k][0][2] for k in names])
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), names=np.array(names), mean=mean, rms=rms, numel=numel,
+                        reps=np.int64(reps))
+    print(tag, "conv1.weight rms %.3e  bn1.weight mean %.4f rms-1 %.3e  fc_occ.weight rms %.3e" % (
+        rms[names.index("conv1.weight")], mean[names.index("bn1.weight")],
+        np.sqrt(max(rms[names.index("bn1.weight")] ** 2 - mean[names.index("bn1.weight")] ** 2, 0)),
+        rms[names.index("fc_occ.weight")]))
+
+
 CASES = {
+    "init_stats": lambda: case_init_stats("init_stats"),
+    # well-scaled states (eval logits O(0.1 .. 1), informative losses) at the bench's and the reference _od's input size
+    "o_S256_B4_k": lambda: case_train("InstaOrderNet_o", 256, 4, 25, 1, "o_S256_B4_k", "kaiming"),
+    "od_S256_B4_k": lambda: case_train("InstaOrderNet_od", 256, 4, 26, 1, "od_S256_B4_k", "kaiming"),
+    "od_S384_B2_k": lambda: case_train("InstaOrderNet_od", 384, 2, 27, 1, "od_S384_B2_k", "kaiming"),
     "tester": lambda: case_tester("tester"),
     "heuristics": lambda: case_heuristics("heuristics"),
     "dataset_items": lambda: case_dataset_items("dataset_items"),

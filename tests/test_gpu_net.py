@@ -194,7 +194,10 @@ def test_backward_statistical_vs_fp64_anchor(algo, style, S, B):
 GOLD = [("o_S64_B4", "InstaOrderNet_o", "xavier"), ("od_S64_B6", "InstaOrderNet_od", "xavier"),
         ("d_S64_B6", "InstaOrderNet_d", "xavier"), ("ordernet_S64_B4", "OrderNet", "xavier"),
         ("o_S64_B4_k", "InstaOrderNet_o", "kaiming"), ("od_S64_B6_k", "InstaOrderNet_od", "kaiming"),
-        ("o_S256_B4", "InstaOrderNet_o", "xavier"), ("od_S256_B4", "InstaOrderNet_od", "xavier")]
+        ("o_S256_B4", "InstaOrderNet_o", "xavier"), ("od_S256_B4", "InstaOrderNet_od", "xavier"),
+        # well-scaled states (eval logits O(0.1 .. 1)): the assertions below are informative on every quantity
+        ("o_S256_B4_k", "InstaOrderNet_o", "kaiming"), ("od_S256_B4_k", "InstaOrderNet_od", "kaiming"),
+        ("od_S384_B2_k", "InstaOrderNet_od", "kaiming")]
 
 
 @pytest.mark.parametrize("tag,algo,style", GOLD)
@@ -209,7 +212,9 @@ def test_golden_first_step(tag, algo, style):
     b0 = synthetic.make_pair_batch(seed + 100, B, S)
     m.switch_to("eval")
     scale = max(np.abs(g["eval0_logits"]).max(), 1e-6)
-    assert np.abs(hip_eval_logits(m, b0) - g["eval0_logits"]).max() < FWD_TOL * scale + 1e-7
+    # (absolute slack only for the xavier-gain-0.02 states, whose eval logits are ~1e-12; none where they are O(0.1))
+    slack = 1e-7 if scale < 1e-3 else 0.0
+    assert np.abs(hip_eval_logits(m, b0) - g["eval0_logits"]).max() < FWD_TOL * scale + slack
     set_input(m, algo, b0)
     ev = m.forward_only()
     assert abs(float(ev[1]["loss"]) - float(g["eval0_loss"])) < FWD_TOL * float(g["eval0_loss"])
@@ -588,9 +593,40 @@ def test_synthetic_val_accuracy_within_0p1_pp():
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "synthetic_val.py"))
     sv = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sv)
-    delta, flips = sv.run(n_images=12, n_inst=5, S=128, verbose=True)
+    # SURVEY.md 8(d) "Accuracy": >= 200 synthetic images x 3-20 instances, at the bench's input size.  (The full
+    # 200 x 5-instance run -- 4000 network evaluations, 0 differing decisions -- is profiles/r03_synthetic_val.txt.)
+    delta, flips = sv.run(n_images=200, n_inst=3, S=256, verbose=True)
     for k, v in delta.items():
         assert abs(v) <= 0.1, (k, v)
+
+
+def test_trained_model_accuracy_fp32_and_bf16():
+    """The same claim on a TRAINED network, whose decisions sit away from the thresholds (tools/trained_val.py: 400
+    iterations of the synthetic training chain, then 40 unseen 6-instance scenes through the 'patch' pre-processing; the
+    very same network inputs go to the HIP path in fp32, to the CPU oracle on the same weights, and to the HIP path in
+    bf16).  fp32: every decision is the oracle's -- 0.000 pp.  bf16 (not a reference precision): a decision may flip only
+    where the oracle's own margin is inside the bf16 noise (< 2e-3 in probability units); on this set that is ~1 decision
+    in 1200, which already moves a mean-over-40-images precision by 0.17 pp -- so the 0.1 pp bar is NOT claimed for bf16
+    (measured: profiles/r03_trained_val.txt); what is held is 0.5 pp and the margin rule."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("trained_val", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "trained_val.py"))
+    tv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tv)
+    r = tv.run(iters=400, n_val=40, verbose=True)
+    # the point of training: decisions sit away from the thresholds (the random-weight stand-in has all of them within
+    # 1e-3).  (How WELL it learned varies run to run -- F1 57 .. 92 after 400 iterations at lr 0.01 -- and is not the
+    # subject here.)
+    assert float(np.median(r["margins"])) > 0.02 and float((r["margins"] < 1e-3).mean()) < 0.02
+    assert r["mean"]["oracle"][2] > 30.0
+    assert not r["flips"]["fp32"], r["flips"]["fp32"]
+    for k, v in r["delta"]["fp32"].items():
+        assert v == 0.0, (k, v)
+    assert all(mg < 2e-3 for mg in r["flips"]["bf16"]), r["flips"]["bf16"]
+    assert len(r["flips"]["bf16"]) <= 0.01 * 2 * r["npairs"]
+    for k, v in r["delta"]["bf16"].items():
+        assert abs(v) <= 0.5, (k, v)
 
 
 # ------------------------------------------------------------------------------------------------

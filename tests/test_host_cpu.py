@@ -211,6 +211,43 @@ def test_package_surface():
         ia.SingleStageModel({"algo": "InstaOrderNet_o", "backbone_arch": "no_such_net", "backbone_param": {}})
 
 
+def test_init_weights_statistics_match_the_reference():
+    """utils/common_utils.py:35-65 as single_stage_model.py:24 applies it (xavier-normal, gain 0.02, on every Conv / Linear
+    weight; BatchNorm weight ~ N(1, 0.02), every bias 0): per-tensor rms / mean of this package's init_weights on its own
+    resnet50_cls against the statistics of the REFERENCE's function on the reference's network (tests/golden/
+    init_stats.npz, 3 pooled draws).  A sample rms over n values has relative spread 1 / sqrt(2n); 6 sigma + the golden's
+    own spread is the bar -- a wrong fan (e.g. the x8 storage of conv1 counted as fan-in), gain or distribution is 20 %
+    to 50x off."""
+    import torch
+    import instaorder_amd as ia
+    from instaorder_amd import resnet_cls
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "init_stats.npz"))
+    want = {str(k): (float(m), float(r), int(n)) for k, m, r, n in zip(g["names"], g["mean"], g["rms"], g["numel"])}
+    torch.manual_seed(5)
+    net = resnet_cls.resnet50_cls(in_channels=5, num_classes=[2, 3])
+    ia.utils.init_weights(net, init_type="xavier")
+    got = dict(net.named_parameters())
+    assert set(got) == set(want)
+    reps = int(g["reps"])
+    for k, p in got.items():
+        a = p.detach().double().reshape(-1)
+        m, r, n = want[k]
+        assert a.numel() == n, k
+        if r == 0.0:                                  # biases: exactly zero
+            assert float(a.abs().max()) == 0.0, k
+            continue
+        if k.endswith("bn1.weight") or k.endswith("bn2.weight") or k.endswith("bn3.weight") or ".downsample.1.weight" in k:
+            sd_ref = max(r * r - m * m, 0.0) ** 0.5   # N(1, 0.02)
+            assert abs(float(a.mean()) - 1.0) < 6 * 0.02 / n ** 0.5 + 1e-6, k
+            assert abs(float(a.std()) - sd_ref) < 6 * sd_ref * (1 + 1 / reps) ** 0.5 / (2 * n) ** 0.5, (k, float(a.std()), sd_ref)
+            continue
+        rms = float((a * a).mean().sqrt())
+        assert abs(rms - r) < 6 * r * (1 + 1 / reps) ** 0.5 / (2 * n) ** 0.5, (k, rms, r)
+        assert abs(float(a.mean())) < 6 * r / n ** 0.5, k
+    # the survey's two anchor numbers (SURVEY.md a12)
+    assert abs(want["conv1.weight"][1] - 4.8e-4) < 0.3e-4
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "instaorder_amd")
     for fn in os.listdir(pkg):

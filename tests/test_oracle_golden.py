@@ -58,6 +58,16 @@ def test_train_256(tag, algo):
     run_train_case(tag, algo)
 
 
+@pytest.mark.parametrize("tag,algo", [("o_S256_B4_k", "InstaOrderNet_o"), ("od_S256_B4_k", "InstaOrderNet_od"),
+                                      ("od_S384_B2_k", "InstaOrderNet_od")])
+def test_train_256_384_kaiming(tag, algo):
+    """well-scaled states at the bench's input size and at the reference _od's own 384: eval logits of O(0.1 .. 1) and
+    losses away from the constant k ln 2 (the xavier-gain-0.02 cases above have logits of 1e-12)"""
+    g = load_golden(tag)
+    assert np.abs(g["eval0_logits"]).max() > 0.05
+    run_train_case(tag, algo, "kaiming")
+
+
 def test_eval_losses():
     g = load_golden("o_S64_B4")
     S, B, seed, steps = [int(v) for v in g["meta"]]

@@ -43,16 +43,28 @@ def run(n_images=20, n_inst=5, S=256, seed=91, verbose=True, dtype="fp32"):
     items = synthetic.make_images(seed + 50, n_images, n_inst, S)
     pairs = infer.upper_pairs(n_inst)
     # oracle logits for every pair (both directions), then centre the heads on the oracle's medians
-    ologits = []
+    # (eval mode: samples are independent, so the oracle takes the pairs of several images per call -- on a many-core
+    # host a 10-sample batch leaves most threads idle and a 200-image run takes 12 minutes instead of 3)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    xs1, xs2 = [], []
     for item in items:
         rgb, masks = synthetic.image_mode_inputs(item["image"], item["modal"], S)
         r = torch.from_numpy(rgb).expand(len(pairs), -1, -1, -1)
         mi = torch.from_numpy(np.stack([masks[i] for i, j in pairs]))[:, None]
         mj = torch.from_numpy(np.stack([masks[j] for i, j in pairs]))[:, None]
+        xs1.append(torch.cat([mi, mj, r], 1))
+        xs2.append(torch.cat([mj, mi, r], 1))
+    per_call = max(1, 48 // max(len(pairs), 1))
+    ologits = []
+    for i0 in range(0, len(items), per_call):
+        x = torch.cat(xs1[i0:i0 + per_call] + xs2[i0:i0 + per_call], 0)
         with torch.no_grad():
-            z1 = torch.cat(orc.resnet_forward(state, torch.cat([mi, mj, r], 1), False), 1)
-            z2 = torch.cat(orc.resnet_forward(state, torch.cat([mj, mi, r], 1), False), 1)
-        ologits.append((z1, z2))
+            z = torch.cat(orc.resnet_forward(state, x, False), 1)
+        k = len(xs1[i0:i0 + per_call])
+        z1, z2 = z[:k * len(pairs)], z[k * len(pairs):]
+        for q in range(k):
+            ologits.append((z1[q * len(pairs):(q + 1) * len(pairs)], z2[q * len(pairs):(q + 1) * len(pairs)]))
+    del xs1, xs2
     med = -torch.cat([torch.cat(p, 0) for p in ologits], 0).median(0).values
     state["fc_occ.bias"] += med[:2]
     state["fc_depth.bias"] += med[2:]
