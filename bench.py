@@ -263,7 +263,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_prof:
-        engine.prof_begin()
+        # the ResNet executor issues nothing but library launches: consecutive groups share an event; the MiDaS nets run
+        # op by op with torch kernels in between: own start events, so the class times are kernel times, not wall shares
+        engine.prof_begin(share_events=not depthnet)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()

@@ -405,6 +405,11 @@ typedef struct io_prof_entry {
     double bytes;
 } io_prof_entry;
 int io_prof_begin(void);
+/* share_events != 0 (what io_prof_begin uses): a launch group's start event is the previous group's end event -- half the
+ * event records, right for the network executor, where the library's launches follow each other on the stream.
+ * share_events == 0: every group gets its own start event -- for callers that put other work (kernels of their own, host
+ * gaps) between the library's launches, which would otherwise be charged to the next class. */
+int io_prof_begin_ex(int share_events);
 int io_prof_end(io_prof_entry* out, int max_entries);
 /* the launch groups recorded so far, one entry each (launches = 1), in launch order; the profile keeps running */
 int io_prof_launches(io_prof_entry* out, int max_entries);

@@ -145,6 +145,7 @@ SIGNATURES = {
     "io_avgpool_fc_fwd_dt": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P]),
     "io_avgpool_fc_bwd_dt": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "io_prof_begin": (_I, []),
+    "io_prof_begin_ex": (_I, [_I]),
     "io_prof_end": (_I, [C.POINTER(ProfEntry), _I]),
 }
 

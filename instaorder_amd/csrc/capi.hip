@@ -186,6 +186,7 @@ namespace {
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; bool own0, closed; hipStream_t st; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+bool g_prof_share = true;       // consecutive scopes share one event (see IoProfScope); off when foreign launches interleave
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[IO_PROF_NCLASS] = {"conv_nt_kernel<128,false>", "conv_nt_kernel<64,false>",
@@ -206,7 +207,7 @@ IoProfScope::IoProfScope(int cls, double flops, double bytes, hipStream_t stream
     ProfRec r;
     r.cls = cls; r.flops = flops; r.bytes = bytes;
     r.st = st; r.closed = false;
-    if (!g_prof_recs.empty() && g_prof_recs.back().closed && g_prof_recs.back().st == st) {
+    if (g_prof_share && !g_prof_recs.empty() && g_prof_recs.back().closed && g_prof_recs.back().st == st) {
         r.e0 = g_prof_recs.back().e1;
         r.own0 = false;
     } else {
@@ -225,6 +226,18 @@ IoProfScope::~IoProfScope() {
         (void)hipEventRecord(g_prof_recs[idx].e1, st);
         g_prof_recs[idx].closed = true;
     }
+}
+
+extern "C" int io_prof_begin(void);
+/* share_events = 0: every launch group gets its own start event -- for callers that put OTHER work (torch kernels of an
+ * op-by-op graph, host gaps) between the library's launches; with shared events that time would be charged to the next
+ * class and the classes would always sum to wall time. */
+extern "C" int io_prof_begin_ex(int share_events) {
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_share = share_events != 0;
+    }
+    return io_prof_begin();
 }
 
 extern "C" int io_prof_begin(void) {

@@ -174,10 +174,12 @@ def prof_active():
     return _prof_on
 
 
-def prof_begin():
-    """Start HIP-event timing of every library launch (per kernel class, on the launch stream)."""
+def prof_begin(share_events=True):
+    """Start HIP-event timing of every library launch (per kernel class, on the launch stream).  share_events=False:
+    own start event per launch group -- for op-by-op graphs (instaorder_amd.ops), where torch kernels and host gaps sit
+    between the library's launches and must not be charged to them."""
     global _prof_on
-    _lib.check(_lib.lib().io_prof_begin(), "io_prof_begin")
+    _lib.check(_lib.lib().io_prof_begin_ex(1 if share_events else 0), "io_prof_begin_ex")
     _prof_on = True
 
 

@@ -95,6 +95,9 @@ class WeightPlan(object):
 
     def prepare(self):
         if self.n:
+            # A planned filter whose gradient kernel does not run in this step (a loss weight switched to 0 after the plan
+            # was recorded) must deliver zero, not the previous step's gradient: unpack_grads() copies every entry of gk.
+            self.gk.zero_()
             _lib.check(_L().io_weights_prepare(_p(self.table), self.n, _p(self.optim.flat_params), _p(self.ops),
                                                1 if self.dtype == torch.bfloat16 else 0, _st()), "io_weights_prepare")
 

@@ -149,7 +149,9 @@ class _OrderBase(SingleStageModel):
             return self._pack_return(losses)
         if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
             self._graph.replay()
-            logits, losses = self._graph_out
+            # the graph writes the same output tensors on every replay: hand out copies, so that a caller who keeps the
+            # previous step's loss (to average later) does not see it change under them, as in the eager path
+            logits, losses = (t.clone() for t in self._graph_out)
         elif self._use_graph and self._seen_key == key and not engine.prof_active():
             # second step with this shape (the first ran eagerly and warmed every kernel): capture, then run it
             try:
@@ -162,6 +164,7 @@ class _OrderBase(SingleStageModel):
                     logits, losses, ws_keep = self._fwd_loss_bwd(N, S)
                 self._graph, self._graph_key, self._graph_out, self._graph_ws = g, key, (logits, losses), ws_keep
                 g.replay()
+                logits, losses = logits.clone(), losses.clone()
             except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
                 self._use_graph = False
                 self._graph = None
@@ -493,6 +496,7 @@ class _DepthBase(SingleStageModel):
         if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
             self._graph.replay()
             logs, loss = self._graph_out
+            logs, loss = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logs.items()}, loss.clone()
         elif self._use_graph and self._seen_key == key and not engine.prof_active():
             # second step with this shape (the first ran eagerly and warmed every kernel): capture, then run it
             try:
@@ -503,6 +507,7 @@ class _DepthBase(SingleStageModel):
                     logs, loss = self._fwd_loss_bwd()
                 self._graph, self._graph_key, self._graph_out = g, key, (logs, loss)
                 g.replay()
+                logs, loss = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logs.items()}, loss.clone()
             except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
                 self._use_graph = False
                 self._graph = None
