@@ -340,6 +340,16 @@ int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                         float* mean, float* rstd, float* scale, float* shift, float* workspace, size_t workspace_floats,
                         int dtype, hipStream_t stream);
+/* y = conv1x1(out, w) with out = relu((y3 - in_mean[g]) * in_scale[g] + in_shift[g] + identity) evaluated on the staged
+ * operand and written to `out` (may be NULL) by the blocks of the first output-channel tile: the residual BatchNorm +
+ * ReLU that ends a Bottleneck (resnet_cls.py:108-114) fused into the first convolution of the next one (:99) -- io_bn_apply's
+ * expression, bit for bit.  fp32; y3 / identity / out [N,H,W,Cin]; N*H*W/G a multiple of 128.  workspace != NULL: also the
+ * training statistics of y (as io_conv2d_fwd_xf_dt). */
+int io_conv2d_fwd_resid(const float* y3, const float* identity, const float* w, float* y, float* out, int N, int H, int W,
+                        int Cin, int Cout, int G, const float* in_mean, const float* in_scale, const float* in_shift,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                        float eps, float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                        size_t workspace_floats, hipStream_t stream);
 /* All filters of a module tree in one launch (the op-by-op graphs of instaorder_amd.ops; midas/midas_net.py's ~200 dense
  * convolutions): `table` is a DEVICE array of n io_weight_desc.  io_weights_prepare writes, for every entry, the
  * [Cop][T][Cip] operand (element type dtype, zero where o >= Co or c >= Ci) of the OIHW fp32 master at params + src to

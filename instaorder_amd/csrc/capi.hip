@@ -549,6 +549,34 @@ extern "C" int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N,
                                 rstd, scale, shift, st);
 }
 
+/* 1x1 convolution whose INPUT is a Bottleneck output that does not exist yet: conv(relu(bn3(y3) + identity), w), with
+ * that tensor written to `out` on the way (resnet_cls.py:108-114 out = relu(bn3(conv3(.)) + identity); then the next block's
+ * conv1, :99).  fp32, H*W*N/G a multiple of 128.  Statistics of y as in io_conv2d_fwd_xf_dt. */
+extern "C" int io_conv2d_fwd_resid(const float* y3, const float* identity, const float* w, float* y, float* out, int N,
+                                   int H, int W, int Cin, int Cout, int G, const float* in_mean, const float* in_scale,
+                                   const float* in_shift, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* mean, float* rstd, float* scale,
+                                   float* shift, float* workspace, size_t workspace_floats, hipStream_t st) {
+    IO_REQUIRE(in_mean && in_scale && in_shift && identity, IO_ERR_SHAPE, "conv2d_fwd_resid: tables and identity are required");
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, 1, 1, 1, 0);
+    const int M = N * H * W;
+    IO_REQUIRE(G >= 1 && N % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_fwd_resid: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    IoBwStats ep{};
+    ep.xb_y = identity; ep.xb_a = in_scale; ep.xb_b = in_mean; ep.xb_c = in_shift; ep.xb_out = out; ep.xb_Mg = M / G;
+    ep.xb_res = 1;
+    if (!workspace) return io_launch_conv_nt(g, y3, w, y, nullptr, nullptr, 0, st, nullptr, nullptr, &ep);
+    const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, Cout, 1, 1, 1, 0, G);
+    IO_REQUIRE(workspace_floats >= need, IO_ERR_WORKSPACE, "conv2d_fwd_resid: workspace %zu < %zu floats", workspace_floats,
+               need);
+    float* tmean = workspace;
+    float* tm2 = workspace + need / 2;
+    int rc = io_launch_conv_nt(g, y3, w, y, nullptr, nullptr, 0, st, tmean, tm2, &ep);
+    if (rc) return rc;
+    return io_bn_finalize_tiles(tmean, tm2, M, Cout, G, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                rstd, scale, shift, st);
+}
+
 /* convolution with an inference epilogue: y = [relu](conv(x, w) + bias[o] (+ add)) -- a BatchNorm in eval mode folded
  * into pre-scaled filters, or a biased nn.Conv2d; dense (gw = 0) or grouped-window (gw = 64) */
 extern "C" int io_conv2d_fwd_bias_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,

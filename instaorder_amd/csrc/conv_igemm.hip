@@ -153,12 +153,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BatchNorm INPUT, dy = a[c] * dz + b[c] * y + c[c], evaluated from the masked gradient dz (= `in`) and that BatchNorm's
 // input y while the chunk is staged -- two 16-byte loads per chunk instead of one -- so BatchNorm backward has no apply
 // pass of its own; the blocks of the first output-channel tile also write dy out (centre tap) for the filter gradient.
+// XB = 2: the FORWARD sibling with the same two-load staging and side output -- the A operand of a block's conv1 is the
+// previous block's output relu(bn3(y3) + identity), evaluated from y3 (= `in`) and the identity tensor (xb_y) with
+// bn_apply_kernel's own expression (tables a = scale, b = mean, c = shift) and written out once as that block's output
+// tensor: the residual BatchNorm pass `out = relu(bn3(conv3(.)) + identity)` (resnet_cls.py:108-114) has no launch of its own.
 // LIN: dense 1x1 stride-1 GEMM on whole tiles (row m of the output IS pixel m of the input, 128 | M): no row decoding, no
 // validity, k offsets and output row steps ride in the scalar offset of the buffer instructions.  The generic path spends
 // ~800 VALU + ~500 SALU instructions per wave and tile on addressing; with a bf16 tile of K <= 512 worth only 16..128
 // MFMAs the SIMDs were instruction-issue bound on exactly these layers (measured: 69 % issue utilisation, 19 % MFMA).
 template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false,
-          bool XF = false, bool LIN = false, bool XB = false>
+          bool XF = false, bool LIN = false, int XB = 0>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // XF: per-channel coefficients of the chunk being loaded (they change with the k-tile) and the validity of its rows
     static_assert(!XF || STEM == 0, "input transform: regular convolutions");
     static_assert(!XB || (STEM == 0 && !XF), "backward operand transform: regular data gradients, not combined with XF");
+    static_assert(XB != 2 || (ES == 4 && !BWE), "the residual form is an fp32 forward path");
     constexpr bool XT = XF || XB;           // some operand transform
     constexpr int XC = ES == 4 ? 1 : 2;     // 16-byte coefficient loads per 16-byte operand chunk (4 floats or 8 bf16)
     f32x4 xm[XC], xs[XC], xh[XC];           // XF: mean, scale, shift.  XB: b (times y), a (times dz), c
@@ -428,7 +433,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const bool ok = (xok >> j) & 1u;
-                if constexpr (ES == 4) {
+                if constexpr (XB == 2) {
+                    // relu(bn(y) + identity): bn_apply_kernel's expression (MODE 1), so the tensor is bit for bit the one a
+                    // separate pass would have written
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]) + ry[j][e];
+                        ra[j][e] = (ok && v > 0.f) ? v : 0.f;
+                    }
+                } else if constexpr (ES == 4) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = __builtin_fmaf(ra[j][e], xs[0][e], __builtin_fmaf(ry[j][e], xm[0][e], xh[0][e]));
@@ -1852,6 +1865,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg > 0 && bws.Mg % 128 == 0 &&
                               Mchk % 128 == 0 && Mchk % bws.Mg == 0),
                    IO_ERR_SHAPE, "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group | M");
+        IO_REQUIRE(!bws.xb_res || (bws.xb_a && !bws.y && dt_in == IO_F32 && dt_out == IO_F32), IO_ERR_SHAPE,
+                   "conv_nt: the residual operand form is an fp32 forward path (no BatchNorm-backward epilogue)");
         IO_REQUIRE(!bws.xb_a || (bws.xb_b && bws.xb_c && bws.xb_y && !bws.in_scale && !stem && !g.gw && g.is == 1 &&
                                  g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo &&
                                  bws.xb_Mg > 0 && bws.xb_Mg % 128 == 0 && Mchk % bws.xb_Mg == 0 && g.dhs * g.dhs == 1 &&
@@ -1903,6 +1918,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const bool lin = !stem && !g.gw && g.Th * g.Tw == 1 && g.is == 1 && g.os == 1 && g.dh0 == 0 && g.dw0 == 0 &&
                      g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo && M % 128 == 0 &&
                      128.0 * g.Ci * es < 4.0e9 && 128.0 * g.Co * os < 4.0e9;
+    IO_REQUIRE(!bws.xb_res || lin, IO_ERR_SHAPE, "conv_nt: the residual operand form needs a dense 1x1 stride-1 GEMM on whole tiles");
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
@@ -1929,8 +1945,10 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 #define IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, LIN_)                                             \
     do {                                                                                                     \
         constexpr bool R_ = STEM_ == 0, XBOK_ = R_ && sizeof(TI_) == sizeof(TO_);                            \
-        if (XBOK_ && bws.xb_a && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, XBOK_); \
-        else if (XBOK_ && bws.xb_a) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XBOK_);  \
+        constexpr int XB1_ = XBOK_ ? 1 : 0, XB2_ = (XBOK_ && sizeof(TI_) == 4 && LIN_) ? 2 : XB1_;           \
+        if (XBOK_ && bws.xb_a && bws.xb_res) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB2_); \
+        else if (XBOK_ && bws.xb_a && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, XB1_); \
+        else if (XBOK_ && bws.xb_a) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB1_);  \
         else if (R_ && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, false);     \
         else if (R_ && bws.in_scale) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, R_, LIN_, false); \
         else IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, false);                   \

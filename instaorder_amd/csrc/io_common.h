@@ -135,6 +135,11 @@ struct IoBwStats {
     const float *xb_a, *xb_b, *xb_c;
     void* xb_out;
     int xb_Mg;
+    // xb_res != 0: the same staging for a FORWARD 1x1 convolution (fp32, dense, whole tiles): `in` is the raw output y3 of
+    // the previous block's conv3, xb_y that block's identity tensor, and the operand is the block output relu((y3 -
+    // xb_b) * xb_a + xb_c + identity) -- xb_a / xb_b / xb_c = the scale / mean / shift tables of bn3, bn_apply's expression
+    // -- with xb_out receiving it as a tensor (the next block's identity, the backward's mask and filter-gradient operand).
+    int xb_res;
 };
 
 // internal launchers shared between the C ABI and the network executor

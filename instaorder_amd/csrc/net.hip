@@ -304,8 +304,10 @@ struct Ctx {
 bool stem_exact(const Ctx& c, const ConvL& L) { return L.cin_store == 8 && c.net->dtype == IO_F32; }
 
 // xf: the BatchNorm whose (training) scale / shift tables + ReLU are applied to x while it is staged
+// xr: x is the raw conv3 output of the PREVIOUS block and xr its bn3: the operand is that block's output relu(bn3(x) +
+// xr_id), evaluated while it is staged and written to xr_out (IoBwStats::xb_res)
 int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false, const BnL* xf = nullptr,
-             int Mout = 0) {
+             int Mout = 0, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
     const void* w = c.wop(L.w_off);
@@ -322,9 +324,19 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         ep.in_shift = t.shift;
         ep.in_Mg = Mout / c.G;
     }
+    if (xr) {
+        Tables t = c.tables(*xr);
+        ep.xb_y = xr_id;
+        ep.xb_a = t.scale;
+        ep.xb_b = t.mean;
+        ep.xb_c = t.shift;
+        ep.xb_out = xr_out;
+        ep.xb_Mg = Mout / c.G;       // (a 1x1 stride-1 convolution: operand rows = output rows)
+        ep.xb_res = 1;
+    }
     return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, stem, c.st,
                              stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
-                             xf ? &ep : nullptr, c.dt(), c.dt());
+                             (xf || xr) ? &ep : nullptr, c.dt(), c.dt());
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
@@ -346,9 +358,9 @@ int bn_prepare(const Ctx& c, const BnL& b, const void* y, int M, bool from_tiles
 // conv followed by the statistics of its output; the statistics ride in the conv epilogue whenever a
 // 128-row tile never straddles two BN groups
 int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout,
-            const BnL* xf = nullptr) {
+            const BnL* xf = nullptr, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr) {
     const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
-    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout));
+    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout, xr, xr_id, xr_out));
     return bn_prepare(c, b, y, Mout, fuse);
 }
 
@@ -357,6 +369,17 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 // relu(bn(y)), and the backward gets it back for the one filter gradient that needs it as a side output of the
 // data-gradient launch that recomputes the ReLU mask from y anyway (IoBwStats::a_out).  (Transforming the operand of the
 // filter-gradient kernel the same way was measured: +20..35 % on the 128 x 128 tiles, which have no registers to spare.)
+// Is the output of a block with Mout rows -- out = relu(bn3(y3) + identity) -- built by the NEXT block's conv1 while it
+// stages its operand (conv_fwd's xr) instead of by a pass of its own?  fp32 (there the transform hides under the MFMAs),
+// whole 128-row tiles per group; the caller also needs an identity that is a plain tensor (no downsample branch) and a
+// next block.  Like the backward form: a 12 B / element pass becomes 8 B / element inside a GEMM.
+#ifndef IO_XR
+#define IO_XR 1
+#endif
+bool xr_ok(const Ctx& c, int Mout) {
+    return IO_XR && c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
+}
+
 bool fuse_in(const Ctx& c, int Mout) {
     return c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
@@ -463,12 +486,23 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
     }
     const void* x = c.act(p.p0);
     int H = H1;
+    // a block output whose construction was left to the next block's conv1 (xr_ok): bn3, y3, identity of that block
+    const BnL* pend_bn = nullptr;
+    const void *pend_y3 = nullptr, *pend_id = nullptr;
     for (size_t i = 0; i < net->blocks.size(); ++i) {
         const Block& b = net->blocks[i];
         const BlockBufs& bb = p.blk[i];
         const int Ho = H / b.stride;
         const int Min = c.N * H * H, Mout = c.N * Ho * Ho;
-        IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
+        if (pend_bn) {
+            // x = the previous block's output does not exist yet: conv1 evaluates it from (y3, identity) on its operand
+            // and writes it out (first output-channel tile); everything below that reads x comes after this launch
+            IO_TRY(conv_bn(c, b.c1, b.b1, pend_y3, c.act(bb.y1), H, Min, nullptr, pend_bn, pend_id,
+                           c.act(p.blk[i - 1].out)));
+            pend_bn = nullptr;
+        } else {
+            IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
+        }
         // conv2 reads relu(bn1(y1)), conv3 reads relu(bn2(y2)): through the input transform straight from y1 / y2, or
         // from a stored activation (the strided conv2 of a stage's first block keeps a1: its data gradient runs as
         // parity classes and cannot rebuild it)
@@ -490,6 +524,10 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
             IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
+        } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout)) {
+            pend_bn = &b.b3;                 // built by the next block's conv1
+            pend_y3 = c.act(bb.y3);
+            pend_id = x;
         } else {
             IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, x, nullptr, 1, c.act(bb.out)));
         }

@@ -258,6 +258,49 @@ def test_forward_launch_at_bench_size(shape, dtype):
     assert relerr(rm, rme) < tol(bf, 2e-5, 2e-4) and relerr(rv, rve) < 1e-4, name
 
 
+XR_SHAPES = [s for s in SHAPES if s[6] == "c1" and s[0] != "l1.c1a"]
+
+
+@pytest.mark.parametrize("shape", XR_SHAPES, ids=[s[0] for s in XR_SHAPES])
+def test_forward_residual_operand_at_bench_size(shape):
+    """fp32: conv1 of a block whose predecessor has no downsample branch reads (y3, identity) of that predecessor and
+    builds its output relu(bn3(y3) + identity) on the staged operand, writing it out on the way (io_conv2d_fwd_resid).
+    Sampled outputs against fp64 over the full reduction, the side output against fp64 element-wise on a sample and
+    for completeness (no element left unwritten), statistics against fp64 over the kernel's own y."""
+    name, H, Cin, Cout, k, s, role = shape
+    lib = _lib.lib()
+    g = gen(5000 + IDS.index(name))
+    M = N * H * H
+    y3 = randn((N, H, H, Cin), g, torch.float32, 0.8, 0.1)
+    idt = torch.relu(randn((N, H, H, Cin), g, torch.float32))
+    w = randn((Cout, 1, Cin), g, torch.float32, 1.0 / np.sqrt(Cin))
+    mean_i, _, _, scale_i, shift_i = tables(g, Cin)
+    gamma, beta = torch.rand(Cout, generator=g, device=DEV) + 0.5, torch.randn(Cout, generator=g, device=DEV)
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, rstd, scale, shift = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+    nws = lib.io_conv2d_bnstats_workspace_floats(N, H, H, Cout, 1, 1, 1, 0, G)
+    ws = torch.empty(nws, device=DEV)
+    y = torch.full((N, H, H, Cout), float("nan"), device=DEV)
+    out = torch.full((N, H, H, Cin), float("nan"), device=DEV)
+    _lib.check(lib.io_conv2d_fwd_resid(P(y3), P(idt), P(w), P(y), P(out), N, H, H, Cin, Cout, G, P(mean_i), P(scale_i),
+                                       P(shift_i), P(gamma), P(beta), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale),
+                                       P(shift), P(ws), nws, ST()), "fwd_resid")
+    m, o = sample(g, M), sample(g, Cout)
+    n_s = decode(m, H)[0]
+    gi = grp_of(n_s)
+    op = torch.relu((host(y3.view(M, Cin)[m]) - host(mean_i.view(G, Cin)[gi])) * host(scale_i.view(G, Cin)[gi])
+                    + host(shift_i.view(G, Cin)[gi]) + host(idt.view(M, Cin)[m]))                      # [NS, Cin] fp64
+    ref = (op * host(w[o, 0])).sum(1)
+    assert relerr(y.view(M, Cout)[m, o], ref) < 2e-5, name
+    assert relerr(out.view(M, Cin)[m], op) < 1e-6, name
+    assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0, name
+    yv = y.view(G, M // G, Cout)
+    mref = torch.stack([yv[i].double().mean(0) for i in range(G)])
+    vref = torch.stack([yv[i].double().var(0, unbiased=False) for i in range(G)])
+    assert relerr(mean.view(G, Cout), mref) < 2e-5, name
+    assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < 1e-4, name
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # data gradient in the executor's configuration for this layer
 # ---------------------------------------------------------------------------------------------------------------------

@@ -304,6 +304,52 @@ def test_conv_dgrad_with_fused_bn_backward(N, H, Cin, Cout, k, G):
     assert relerr(dz.permute(0, 3, 1, 2), dz_ref) < 3e-5
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,G", [(4, 16, 256, 64, 2), (8, 8, 512, 128, 2), (2, 16, 1024, 256, 1), (16, 8, 2048, 512, 2)])
+def test_conv_fwd_residual_operand(N, H, Cin, Cout, G):
+    """io_conv2d_fwd_resid: the block output relu(bn3(y3) + identity) built on the staged operand of the next block's
+    conv1 and written out on the way == io_bn_apply (bit for bit) followed by the plain convolution (bit for bit: the
+    same operand values go through the same GEMM), incl. the statistics of the result."""
+    g = torch.Generator().manual_seed(N + Cin)
+    y3 = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+    idt = torch.randn(N, H, H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 1, Cin, generator=g) / np.sqrt(Cin)).to(DEV)
+    mean = (torch.randn(G * Cin, generator=g) * 0.3).to(DEV)
+    scale = (torch.randn(G * Cin, generator=g) * 0.7 + 0.3).to(DEV)
+    shift = (torch.randn(G * Cin, generator=g) * 0.5).to(DEV)
+    M = N * H * H
+    out_ref = torch.empty_like(y3)
+    _lib.check(L().io_bn_apply(P(y3), M, Cin, G, 1, P(mean), P(scale), P(shift), P(idt), None, None, None, 1, P(out_ref), ST()),
+               "bn_apply")
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    nws = L().io_conv2d_bnstats_workspace_floats(N, H, H, Cout, 1, 1, 1, 0, G)
+
+    def stats():
+        return [torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)] + [torch.empty(G * Cout, device=DEV) for _ in range(4)]
+    sa, sb = stats(), stats()
+    y_ref = torch.empty(N, H, H, Cout, device=DEV)
+    ws = torch.empty(nws, device=DEV)
+    _lib.check(L().io_conv2d_fwd_bnstats(P(out_ref), P(w), P(y_ref), N, H, H, Cin, Cout, 1, 1, 1, 0, G, P(gamma), P(beta),
+                                         P(sa[0]), P(sa[1]), 0.1, 1e-5, P(sa[2]), P(sa[3]), P(sa[4]), P(sa[5]), P(ws), nws, ST()),
+               "conv+stats")
+    y = torch.full_like(y_ref, float("nan"))
+    out = torch.full_like(y3, float("nan"))
+    ws2 = torch.empty(nws, device=DEV)
+    _lib.check(L().io_conv2d_fwd_resid(P(y3), P(idt), P(w), P(y), P(out), N, H, H, Cin, Cout, G, P(mean), P(scale), P(shift),
+                                       P(gamma), P(beta), P(sb[0]), P(sb[1]), 0.1, 1e-5, P(sb[2]), P(sb[3]), P(sb[4]), P(sb[5]),
+                                       P(ws2), nws, ST()), "conv_resid")
+    assert torch.equal(out, out_ref)
+    assert torch.equal(y, y_ref)
+    for a, b in zip(sa, sb):
+        assert torch.equal(a, b)
+    # and against fp64 torch, end to end
+    per = N // G
+    o64 = torch.cat([F.relu((y3[i * per:(i + 1) * per].double().cpu() - mean.view(G, Cin)[i].double().cpu())
+                            * scale.view(G, Cin)[i].double().cpu() + shift.view(G, Cin)[i].double().cpu()
+                            + idt[i * per:(i + 1) * per].double().cpu()) for i in range(G)])
+    ref = F.conv2d(o64.permute(0, 3, 1, 2), w.double().cpu().view(Cout, Cin, 1, 1))
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 XB_CASES = [(4, 16, 64, 256, 1, 2, False), (4, 16, 128, 128, 3, 2, False), (8, 8, 512, 64, 1, 2, False),
             (2, 16, 64, 64, 3, 1, False), (4, 16, 256, 64, 1, 2, True), (2, 32, 64, 128, 3, 2, True),
             (16, 8, 128, 2048, 1, 2, False)]
