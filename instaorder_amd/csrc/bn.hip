@@ -879,3 +879,25 @@ int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const 
                        coef, coef + (size_t)G * C, gamma, mean, rstd, coef + (size_t)2 * G * C);
     return io_check_launch("bn_bwd_coefs");
 }
+
+namespace {
+__global__ __launch_bounds__(256) void bn_resid2_tables_kernel(const float* __restrict__ m3, const float* __restrict__ s3,
+                                                              const float* __restrict__ h3, const float* __restrict__ md,
+                                                              const float* __restrict__ sd, const float* __restrict__ hd,
+                                                              int n, float* __restrict__ coef) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    coef[i] = s3[i];
+    coef[n + i] = sd[i];
+    coef[2 * n + i] = (float)(((double)h3[i] - (double)m3[i] * (double)s3[i]) + ((double)hd[i] - (double)md[i] * (double)sd[i]));
+}
+}  // namespace
+
+int io_bn_resid2_tables(const float* mean3, const float* scale3, const float* shift3, const float* meand,
+                        const float* scaled, const float* shiftd, int G, int C, float* coef, hipStream_t st) {
+    const int n = G * C;
+    IoProfScope prof(IO_PROF_BN_STATS, 0.0, 36.0 * n, st);
+    hipLaunchKernelGGL(bn_resid2_tables_kernel, dim3(io_cdiv(n, 256)), dim3(256), 0, st, mean3, scale3, shift3, meand, scaled,
+                       shiftd, n, coef);
+    return io_check_launch("bn_resid2_tables");
+}

@@ -87,7 +87,9 @@ IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, i
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st, const IoBwStats* bw,
                  int dt, int gw) {
-    IO_REQUIRE(!bw || stride == 1, IO_ERR_SHAPE, "dgrad: fused BN-backward reductions need a stride-1 convolution");
+    IO_REQUIRE(!bw || !bw->y || stride == 1, IO_ERR_SHAPE, "dgrad: fused BN-backward reductions need a stride-1 convolution");
+    IO_REQUIRE(!bw || !bw->xb_a || stride == 1 || (R == 1 && S == 1 && pad == 0), IO_ERR_SHAPE,
+               "dgrad: the operand transform needs a stride-1 convolution or a strided 1x1 one");
     for (int ph = 0; ph < stride; ++ph)
         for (int pw = 0; pw < stride; ++pw) {
             IoConvGeom g = io_geom_dgrad(N, H, W, Cin, Cout, R, S, stride, pad, ph, pw);

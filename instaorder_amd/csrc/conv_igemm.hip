@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // XF: per-channel coefficients of the chunk being loaded (they change with the k-tile) and the validity of its rows
     static_assert(!XF || STEM == 0, "input transform: regular convolutions");
     static_assert(!XB || (STEM == 0 && !XF), "backward operand transform: regular data gradients, not combined with XF");
-    static_assert(XB != 2 || (ES == 4 && !BWE), "the residual form is an fp32 forward path");
+    static_assert(XB < 2 || (ES == 4 && !BWE), "the residual forms are fp32 forward paths");
     constexpr bool XT = XF || XB;           // some operand transform
     constexpr int XC = ES == 4 ? 1 : 2;     // 16-byte coefficient loads per 16-byte operand chunk (4 floats or 8 bf16)
     f32x4 xm[XC], xs[XC], xh[XC];           // XF: mean, scale, shift.  XB: b (times y), a (times dz), c
@@ -442,10 +442,12 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                         ra[j][e] = (ok && v > 0.f) ? v : 0.f;
                     }
                 } else if constexpr (ES == 4) {
+                    // XB = 3: the affine form followed by a ReLU -- the output of a block with a downsample branch,
+                    // relu(bn3(y3) + bnd(yd)) = relu(a * y3 + b * yd + c) with the two BatchNorms folded into one table set
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = __builtin_fmaf(ra[j][e], xs[0][e], __builtin_fmaf(ry[j][e], xm[0][e], xh[0][e]));
-                        ra[j][e] = ok ? v : 0.f;
+                        ra[j][e] = (ok && (XB != 3 || v > 0.f)) ? v : 0.f;
                     }
                 } else {
                     const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]), rwy = __builtin_bit_cast(u32x4, ry[j]);
@@ -1867,8 +1869,10 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                    IO_ERR_SHAPE, "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group | M");
         IO_REQUIRE(!bws.xb_res || (bws.xb_a && !bws.y && dt_in == IO_F32 && dt_out == IO_F32), IO_ERR_SHAPE,
                    "conv_nt: the residual operand form is an fp32 forward path (no BatchNorm-backward epilogue)");
+        // (the output may sit on a strided lattice -- the one class of a strided 1x1 data gradient that has a tap; the operand
+        // side only needs the gathered grid to BE the logical output grid)
         IO_REQUIRE(!bws.xb_a || (bws.xb_b && bws.xb_c && bws.xb_y && !bws.in_scale && !stem && !g.gw && g.is == 1 &&
-                                 g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo &&
+                                 g.Hi == g.Ho && g.Wi == g.Wo &&
                                  bws.xb_Mg > 0 && bws.xb_Mg % 128 == 0 && Mchk % bws.xb_Mg == 0 && g.dhs * g.dhs == 1 &&
                                  g.dws * g.dws == 1 && g.dh0 * (g.dh0 + g.dhs * (g.Th - 1)) <= 0 &&
                                  g.dw0 * (g.dw0 + g.dws * (g.Tw - 1)) <= 0),
@@ -1946,7 +1950,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     do {                                                                                                     \
         constexpr bool R_ = STEM_ == 0, XBOK_ = R_ && sizeof(TI_) == sizeof(TO_);                            \
         constexpr int XB1_ = XBOK_ ? 1 : 0, XB2_ = (XBOK_ && sizeof(TI_) == 4 && LIN_) ? 2 : XB1_;           \
-        if (XBOK_ && bws.xb_a && bws.xb_res) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB2_); \
+        constexpr int XB3_ = XB2_ == 2 ? 3 : XB1_;                                                           \
+        if (XBOK_ && bws.xb_a && bws.xb_res == 2) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB3_); \
+        else if (XBOK_ && bws.xb_a && bws.xb_res) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB2_); \
         else if (XBOK_ && bws.xb_a && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, XB1_); \
         else if (XBOK_ && bws.xb_a) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB1_);  \
         else if (R_ && bws.y) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, R_, false, LIN_, false);     \

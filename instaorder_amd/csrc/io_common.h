@@ -139,6 +139,8 @@ struct IoBwStats {
     // the previous block's conv3, xb_y that block's identity tensor, and the operand is the block output relu((y3 -
     // xb_b) * xb_a + xb_c + identity) -- xb_a / xb_b / xb_c = the scale / mean / shift tables of bn3, bn_apply's expression
     // -- with xb_out receiving it as a tensor (the next block's identity, the backward's mask and filter-gradient operand).
+    // xb_res == 2: the block has a downsample branch -- operand = relu(xb_a * y3 + xb_b * yd + xb_c) with xb_y = yd (the
+    // downsample convolution's output) and the two BatchNorms folded into one table set (io_bn_resid2_tables).
     int xb_res;
 };
 
@@ -188,6 +190,10 @@ int io_filter_prepare_t(const float* w, int O, int T, int C, void* dst, int tran
 // exact-K stem: fp32 filter [O][T][8] -> [O][io_stem_kp(T, cr)] and the packed filter gradient back (pad channels 0)
 int io_stem_pack_filter(const float* w, float* wp, int O, int T, int cr, hipStream_t st);
 int io_stem_unpack_grad(const float* dwp, float* dw, int O, int T, int cr, hipStream_t st);
+// tables of IoBwStats::xb_res == 2 from the forward tables of bn3 and the downsample BatchNorm ([G][C] each, training
+// layout): a = scale3, b = scaled, c = shift3 - mean3 * scale3 + shiftd - meand * scaled; coef: 3*G*C floats (a | b | c)
+int io_bn_resid2_tables(const float* mean3, const float* scale3, const float* shift3, const float* meand,
+                        const float* scaled, const float* shiftd, int G, int C, float* coef, hipStream_t st);
 constexpr int kIoStatTileRows = 128;   // row-tile height of the conv kernel = granule of fused BN statistics
 int io_bn_finalize_tiles(float* tile_mean, float* tile_m2, int M, int C, int G, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,

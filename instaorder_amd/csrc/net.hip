@@ -307,7 +307,8 @@ bool stem_exact(const Ctx& c, const ConvL& L) { return L.cin_store == 8 && c.net
 // xr: x is the raw conv3 output of the PREVIOUS block and xr its bn3: the operand is that block's output relu(bn3(x) +
 // xr_id), evaluated while it is staged and written to xr_out (IoBwStats::xb_res)
 int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false, const BnL* xf = nullptr,
-             int Mout = 0, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr) {
+             int Mout = 0, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr,
+             bool xr_two = false) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
     const void* w = c.wop(L.w_off);
@@ -333,6 +334,13 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         ep.xb_out = xr_out;
         ep.xb_Mg = Mout / c.G;       // (a 1x1 stride-1 convolution: operand rows = output rows)
         ep.xb_res = 1;
+        if (xr_two) {                // previous block with a downsample branch: the folded tables wait in plan.coef
+            const size_t gs = (size_t)c.G * xr->C;
+            ep.xb_a = c.buf(c.plan.coef);
+            ep.xb_b = c.buf(c.plan.coef) + gs;
+            ep.xb_c = c.buf(c.plan.coef) + 2 * gs;
+            ep.xb_res = 2;
+        }
     }
     return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, stem, c.st,
                              stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
@@ -358,9 +366,10 @@ int bn_prepare(const Ctx& c, const BnL& b, const void* y, int M, bool from_tiles
 // conv followed by the statistics of its output; the statistics ride in the conv epilogue whenever a
 // 128-row tile never straddles two BN groups
 int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout,
-            const BnL* xf = nullptr, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr) {
+            const BnL* xf = nullptr, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr,
+            bool xr_two = false) {
     const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
-    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout, xr, xr_id, xr_out));
+    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout, xr, xr_id, xr_out, xr_two));
     return bn_prepare(c, b, y, Mout, fuse);
 }
 
@@ -375,6 +384,9 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 // next block.  Like the backward form: a 12 B / element pass becomes 8 B / element inside a GEMM.
 #ifndef IO_XR
 #define IO_XR 1
+#endif
+#ifndef IO_XR2
+#define IO_XR2 1      // ... also the outputs of the four blocks with a downsample branch (two BatchNorms folded into one table set)
 #endif
 bool xr_ok(const Ctx& c, int Mout) {
     return IO_XR && c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
@@ -489,6 +501,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
     // a block output whose construction was left to the next block's conv1 (xr_ok): bn3, y3, identity of that block
     const BnL* pend_bn = nullptr;
     const void *pend_y3 = nullptr, *pend_id = nullptr;
+    bool pend_two = false;        // ... of a block with a downsample branch: identity = bnd(yd), tables folded into plan.coef
     for (size_t i = 0; i < net->blocks.size(); ++i) {
         const Block& b = net->blocks[i];
         const BlockBufs& bb = p.blk[i];
@@ -498,7 +511,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
             // x = the previous block's output does not exist yet: conv1 evaluates it from (y3, identity) on its operand
             // and writes it out (first output-channel tile); everything below that reads x comes after this launch
             IO_TRY(conv_bn(c, b.c1, b.b1, pend_y3, c.act(bb.y1), H, Min, nullptr, pend_bn, pend_id,
-                           c.act(p.blk[i - 1].out)));
+                           c.act(p.blk[i - 1].out), pend_two));
             pend_bn = nullptr;
         } else {
             IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
@@ -523,11 +536,23 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         }
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
-            IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
+            if (IO_XR2 && i + 1 < net->blocks.size() && xr_ok(c, Mout)) {
+                // relu(bn3(y3) + bnd(yd)) = relu(a * y3 + b * yd + c): one table set, then as below
+                Tables t3 = c.tables(b.b3), td = c.tables(b.bd);
+                IO_TRY(io_bn_resid2_tables(t3.mean, t3.scale, t3.shift, td.mean, td.scale, td.shift, c.G, b.b3.C,
+                                           c.buf(c.plan.coef), c.st));
+                pend_bn = &b.b3;
+                pend_y3 = c.act(bb.y3);
+                pend_id = c.act(bb.yd);
+                pend_two = true;
+            } else {
+                IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
+            }
         } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout)) {
             pend_bn = &b.b3;                 // built by the next block's conv1
             pend_y3 = c.act(bb.y3);
             pend_id = x;
+            pend_two = false;
         } else {
             IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, x, nullptr, 1, c.act(bb.out)));
         }
@@ -578,6 +603,9 @@ bool tiles_ok(const Ctx& c, int M) { return M % c.G == 0 && (M / c.G) % kIoStatT
 // fp32 only: there the transform hides under the MFMAs (as the forward one does); whole 128-row tiles per group.
 #ifndef IO_XB
 #define IO_XB 1
+#endif
+#ifndef IO_XBD
+#define IO_XBD 1        // ... and the downsample BatchNorm's into the downsample convolution's data gradient
 #endif
 #ifndef IO_XB_C2
 #define IO_XB_C2 0      // ... also into conv2's 3x3 data gradient (measured: a loss, see run_backward)
@@ -762,8 +790,17 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // does not reach are written as zeros -- so that conv1's dense stride-1 data gradient is again the launch
         // that completes d(x_in) and can carry the previous block's bn3 reductions there too.
         const void* partial = Gd;          // what conv1's data gradient accumulates onto: the identity path ...
-        if (b.down) {
-            // (Gc: dy2 has been consumed by conv2's data and filter gradients; with x1, Ga still holds dz1)
+        if (b.down && IO_XBD && x3) {
+            // the downsample BatchNorm the same way: reductions over (dz, yd) -> tables, dy evaluated on the operand of the
+            // (strided) 1x1 data gradient -- only the lattice class that has a tap stages anything -- and written to Gc for
+            // the filter gradient.  (Gc: dy2 has been consumed by conv2's data and filter gradients; Ga may hold dz1.)
+            IO_TRY(bn_back_coefs(c, b.bd, Gd, c.act(bb.yd), Mout, false));
+            IoBwStats bw{};
+            xb_fill(c, bw, b.bd, c.act(bb.yd), Mout, Gc);
+            IO_TRY(conv_dgrad(c, b.cd, Gd, Ge, nullptr, nullptr, H, &bw));
+            IO_TRY(conv_wgrad(c, b.cd, xin, Gc, H));
+            partial = Ge;
+        } else if (b.down) {
             IO_TRY(bn_back(c, b.bd, Gd, 0, nullptr, c.act(bb.yd), Mout, Gc, nullptr));
             IO_TRY(conv_wgrad(c, b.cd, xin, Gc, H));
             IO_TRY(conv_dgrad(c, b.cd, Gc, Ge, nullptr, nullptr, H));
