@@ -604,6 +604,9 @@ bool tiles_ok(const Ctx& c, int M) { return M % c.G == 0 && (M / c.G) % kIoStatT
 #ifndef IO_XB
 #define IO_XB 1
 #endif
+#ifndef IO_XB1S
+#define IO_XB1S 1       // ... and bn1's of the three blocks whose conv2 is strided
+#endif
 #ifndef IO_XBD
 #define IO_XBD 1        // ... and the downsample BatchNorm's into the downsample convolution's data gradient
 #endif
@@ -758,7 +761,12 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
         const bool x2 = IO_XB_C2 && x3 && b.stride == 1;         // bn2 -> conv2's (a strided one runs as parity classes)
         // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
-        const bool x1 = b.stride == 1 && xb_ok(c, Min) && tiles_ok(c, Mout);
+        const bool x1d = b.stride == 1 && xb_ok(c, Min) && tiles_ok(c, Mout);
+        // a strided conv2 runs its data gradient as parity classes, which carry no BatchNorm epilogue: there the mask comes
+        // from the stored activation a1 (kept for exactly these blocks) in that launch's epilogue, bn1's sums from a
+        // reduction pass over (dz1, y1), and the apply pass again rides in conv1's operand load
+        const bool x1s = IO_XB1S && b.stride != 1 && xb_ok(c, Min) && bb.a1 != kNoBuf;
+        const bool x1 = x1d || x1s;
         if (x3)
             IO_TRY(bn_back_coefs(c, b.b3, Gd, c.act(bb.y3), Mout, have_tiles));
         else if (have_tiles)
@@ -778,8 +786,11 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         if (x2) IO_TRY(bn_back_coefs(c, b.b2, Gb, c.act(bb.y2), Mout, true));
         if (!f2 && !x2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
         // conv2: (dy2 | dz2 + y2) -> Ga = dz1 (+ bn1's partials); without x1 also Gb = dy1
-        IO_TRY(dgrad_then_bn(c, b.c2, x2 ? Gb : Gc, Ga, H, b.b1, c.act(bb.y1), Min, x1 ? nullptr : Gb, f2 ? As : nullptr,
-                             x2 ? &b.b2 : nullptr, c.act(bb.y2), Mout, Gc));
+        if (x1s)
+            IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, c.act(bb.a1), H));
+        else
+            IO_TRY(dgrad_then_bn(c, b.c2, x2 ? Gb : Gc, Ga, H, b.b1, c.act(bb.y1), Min, x1 ? nullptr : Gb,
+                                 f2 ? As : nullptr, x2 ? &b.b2 : nullptr, c.act(bb.y2), Mout, Gc));
         if (f2 || x2) IO_TRY(conv_wgrad(c, b.c2, f2 ? As : c.act(bb.a1), Gc, H));
         if (!x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
@@ -808,7 +819,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         }
         // conv1: (dy1 | dz1 + y1) -> Ge = d(x_in).  (bn1's tables only now: the downsample BatchNorm's backward above
         // uses the same coefficient scratch; bn1's tile partials are untouched by it)
-        if (x1) IO_TRY(bn_back_coefs(c, b.b1, Ga, c.act(bb.y1), Min, true));
+        if (x1) IO_TRY(bn_back_coefs(c, b.b1, Ga, c.act(bb.y1), Min, x1d));
         {
             IoBwStats bw{};
             const bool carry = ii > 0 && tiles_ok(c, Min);
