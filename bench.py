@@ -40,13 +40,31 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    """CPU model string of the host (core count AND model go into the report)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+# The oracle is plain PyTorch on oneDNN.  Its step on a 12-pair batch stops scaling beyond ~32 threads (the layers of
+# the last stages have too little work per thread), and more threads only add wake-up noise -- so the baseline uses up to
+# 32 of the usable cores and says so in its line.
+CPU_BASELINE_MAX_THREADS = 32
+
+
 def cpu_baseline(sd, S):
     """The CPU oracle (plain-PyTorch restatement of the reference step, pinned by tests/golden) timed on
     the host: a bounded sample of the same workload -- InstaOrderNet_o fwd+bwd+SGD on 256x256 pairs."""
     import torch
     from instaorder_amd import synthetic
     from oracle import resnet_oracle as orc                       # CPU baseline leg only
-    cores = min(usable_cores(), 32)          # beyond ~32 threads a 12-pair batch stops scaling on oneDNN
+    cores = min(usable_cores(), CPU_BASELINE_MAX_THREADS)
     torch.set_num_threads(cores)
     state = orc.state_from_numpy(sd, prefix="module.")
     mom = {}
@@ -63,8 +81,10 @@ def cpu_baseline(sd, S):
         orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)
     cdt = (time.perf_counter() - c0) / nrep
     return {"value": cb / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs at %dx%d, InstaOrderNet_o fwd+bwd+SGD, PyTorch-CPU fp32 oracle, %d threads, "
-                      "mean of %d step(s) after 1 warm-up" % (cb, S, S, cores, nrep)}
+            "cpu_model": cpu_model(), "usable_cores": usable_cores(),
+            "sample": "%d pairs at %dx%d, InstaOrderNet_o fwd+bwd+SGD, PyTorch-CPU fp32 oracle on %s, %d threads of %d "
+                      "usable cores (capped at %d: a 12-pair step does not scale further on oneDNN), mean of %d step(s) "
+                      "after 1 warm-up" % (cb, S, S, cpu_model(), cores, usable_cores(), CPU_BASELINE_MAX_THREADS, nrep)}
 
 
 def cpu_baseline_depthnet(algo, S, cfg):
@@ -74,7 +94,7 @@ def cpu_baseline_depthnet(algo, S, cfg):
     import torch
     from instaorder_amd import synthetic
     from oracle import midas_oracle as mo                          # CPU baseline leg only
-    cores = min(usable_cores(), 32)
+    cores = min(usable_cores(), CPU_BASELINE_MAX_THREADS)
     torch.set_num_threads(cores)
     g = np.load(os.path.join(ROOT, "tests", "golden", "depthnet_od_S64_B2.npz" if algo == "InstaDepthNet_od"
                              else "depthnet_d_S64_B2.npz"), allow_pickle=False)
@@ -100,8 +120,10 @@ def cpu_baseline_depthnet(algo, S, cfg):
     step(cb, S)
     cdt = time.perf_counter() - c0
     return {"value": cb / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "usable_cores": usable_cores(),
             "sample": "%d pair(s) at %dx%d, %s fwd+bwd (two full passes per pair, as the reference), PyTorch-CPU fp32 "
-                      "oracle, %d threads, 1 step after 1 warm-up" % (cb, S, S, algo, cores)}
+                      "oracle on %s, %d threads of %d usable cores, 1 step after 1 warm-up" % (
+                          cb, S, S, algo, cpu_model(), cores, usable_cores())}
 
 
 def main():
