@@ -619,7 +619,7 @@ def test_trained_model_accuracy_fp32_and_bf16():
     # 1e-3).  (How WELL it learned varies run to run -- F1 57 .. 92 after 400 iterations at lr 0.01 -- and is not the
     # subject here.)
     assert float(np.median(r["margins"])) > 0.02 and float((r["margins"] < 1e-3).mean()) < 0.02
-    assert r["mean"]["oracle"][2] > 30.0
+    assert r["mean"]["oracle"][2] > 60.0            # (seeded: the draw of seed 0 learns the rule -- F1 86 on unseen scenes)
     assert not r["flips"]["fp32"], r["flips"]["fp32"]
     for k, v in r["delta"]["fp32"].items():
         assert v == 0.0, (k, v)

@@ -41,7 +41,11 @@ def main(argv=None):
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--out", default="")
     ap.add_argument("--resume-at", type=int, default=0, help="stop at this iteration, reload the checkpoint, continue")
+    ap.add_argument("--seed", type=int, default=-1, help=">= 0: seed torch's generator first (init_weights draws from it; "
+                    "at lr 0.01 the trajectory -- and how well 400 iterations learn -- depends on the draw)")
     a = ap.parse_args(argv)
+    if a.seed >= 0:
+        torch.manual_seed(a.seed)
     out = a.out or tempfile.mkdtemp(prefix="io_train_")
     mcfg = dict(algo="InstaOrderNet_o", lr=0.01, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
                 backbone_param=dict(in_channels=5, num_classes=2), use_rgb=True, dtype=a.dtype,

@@ -30,16 +30,16 @@ from instaorder_amd import synthetic  # noqa: E402
 from oracle import resnet_oracle as orc  # noqa: E402      (checker only)
 
 
-def _train(iters, batch, size, out):
+def _train(iters, batch, size, out, seed):
     spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(ROOT, "tools", "train_synthetic.py"))
     ts = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ts)
-    return ts.main(["--iters", str(iters), "--batch", str(batch), "--size", str(size), "--out", out])
+    return ts.main(["--iters", str(iters), "--batch", str(batch), "--size", str(size), "--out", out, "--seed", str(seed)])
 
 
-def run(iters=400, batch=64, size=128, n_val=40, n_inst=6, verbose=True):
+def run(iters=400, batch=64, size=128, n_val=40, n_inst=6, verbose=True, seed=0):
     out = tempfile.mkdtemp(prefix="io_trained_val_")
-    f1_train = _train(iters, batch, size, out)
+    f1_train = _train(iters, batch, size, out, seed)
     cfg = dict(algo="InstaOrderNet_o", lr=0.01, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
                backbone_param=dict(in_channels=5, num_classes=2), use_rgb=True)
     models = {}
