@@ -265,6 +265,25 @@ int io_head1_fwd(const void* x, int M, int pitch, int C, const float* w, const f
                  hipStream_t stream);
 int io_head1_bwd(const float* dy, const float* out, const void* x, int M, int pitch, int C, const float* w, int relu,
                  void* dx, float* dw, float* db, float* partial, size_t partial_floats, int dtype, hipStream_t stream);
+/* ---- the two MiDaS-branch losses that are not order-head losses ---------------------------------------------------------
+ * Edge-aware smoothness (models/supervised_order.py:214-235 get_smooth_loss): disp [B,H,W] fp32 is min-max normalised
+ * ((d - min) / (max + 1e-7)), divided by its mean (+1e-7), and loss = mean(|dx n| exp(-mean_c |dx img|)) + the same in y;
+ * img [B,3,H,W] NCHW fp32.  loss[0] = out_scale * that; g [B,H,W] and workspace keep what the backward needs.
+ * io_smooth_loss_bwd: ddisp (+)= grad_out[0] * scale * dloss/ddisp (grad_out on the device: no host round trip), through
+ * both normalisations incl. the min / max elements torch's chained min(2).min(3) selects. */
+size_t io_smooth_loss_workspace_floats(int B, int H, int W);
+int io_smooth_loss_fwd(const float* disp, const float* img, int B, int H, int W, float out_scale, float* loss, float* g,
+                       float* workspace, size_t workspace_floats, hipStream_t stream);
+int io_smooth_loss_bwd(const float* g, const float* workspace, const float* grad_out, float scale, int B, int H, int W,
+                       int accumulate, float* ddisp, hipStream_t stream);
+/* Disparity-order count (supervised_order.py:152-173; a pure count, no gradient): per pair with is_overlap == 0 and
+ * depth_order1 in {0, 1}, over the 3x3-cross erosions (scipy.ndimage.binary_erosion, border 0) e1, e2 of the two masks:
+ * #{d[e1] <= max d[e2]} + #{min d[e1] <= d[e2]} on disp1 (with >= when depth_order1 != le_order) and the opposite
+ * comparison on disp2; pairs whose eroded masks are empty are skipped.  out[0] = out_scale * total / (H * W);
+ * per_sample: B floats of scratch. */
+int io_disp_order_count(const float* disp1, const float* disp2, const float* modal1, const float* modal2,
+                        const long* depth_order1, const long* is_overlap, int B, int H, int W, int le_order,
+                        float out_scale, float* out, float* per_sample, hipStream_t stream);
 /* io_conv2d_fwd_bnstats for either storage type and for the grouped window form (gw = 64; w = wc of io_gconv_pack,
  * Cin == Cout); gw = 0 is the dense convolution */
 int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,

@@ -510,3 +510,295 @@ extern "C" int io_head1_bwd(const float* dy, const float* out, const void* x, in
     hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, st, partial + C, nb, C + 1, 1, db);
     return io_check_launch("head1_bwd");
 }
+
+// =====================================================================================================================
+// Losses of the MiDaS-based nets that are not order-head losses (models/supervised_order.py:152-173, 214-235)
+// =====================================================================================================================
+namespace {
+
+constexpr float kSmoothEps = 1e-7f;
+
+struct MinMaxIdx {
+    float mn, mx, sum;
+    int imn, imx;      // keys w * H + h: torch reduces dim 2 (h) first, then dim 3 (w) -- the first w, then the first h wins a tie
+};
+__device__ __forceinline__ void mm_merge(MinMaxIdx& a, const MinMaxIdx& b) {
+    if (b.mn < a.mn || (b.mn == a.mn && b.imn < a.imn)) { a.mn = b.mn; a.imn = b.imn; }
+    if (b.mx > a.mx || (b.mx == a.mx && b.imx < a.imx)) { a.mx = b.mx; a.imx = b.imx; }
+    a.sum += b.sum;
+}
+
+// one block per sample: min / max (+ the element torch's chained min(2).min(3) selects), sum.  stats[b][8] =
+// {mn, mx, sum, key_min, key_max, -, -, -} (keys as float bit patterns of ints)
+__global__ __launch_bounds__(kThreads) void smooth_stats_kernel(const float* __restrict__ disp, int H, int W,
+                                                               float* __restrict__ stats) {
+    __shared__ MinMaxIdx sh[kThreads];
+    const int b = blockIdx.x, N = H * W;
+    const float* d = disp + (size_t)b * N;
+    MinMaxIdx a{INFINITY, -INFINITY, 0.f, 0x7fffffff, 0x7fffffff};
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+        const int h = i / W, w = i - h * W;
+        const float v = d[i];
+        MinMaxIdx e{v, v, v, w * H + h, w * H + h};
+        mm_merge(a, e);
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            MinMaxIdx t = sh[threadIdx.x];
+            mm_merge(t, sh[threadIdx.x + off]);
+            sh[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* s = stats + (size_t)b * 8;
+        s[0] = sh[0].mn; s[1] = sh[0].mx; s[2] = sh[0].sum;
+        s[3] = __int_as_float(sh[0].imn); s[4] = __int_as_float(sh[0].imx);
+    }
+}
+
+// n = ((disp - mn) * s) * r with s = 1 / (mx + eps), r = 1 / (mean((disp - mn) * s) + eps)
+struct SmoothNorm { float mn, s, r; };
+__device__ __forceinline__ SmoothNorm smooth_norm(const float* st, int N) {
+    SmoothNorm q;
+    q.mn = st[0];
+    q.s = 1.f / (st[1] + kSmoothEps);
+    const double m = ((double)st[2] - (double)N * (double)st[0]) * (double)q.s / (double)N;
+    q.r = (float)(1.0 / (m + (double)kSmoothEps));
+    return q;
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// edge weight exp(-mean_c |img(c, p) - img(c, q)|) of the pixel pair (p, q), img NCHW with 3 channels
+__device__ __forceinline__ float edge_w(const float* img, int HW, int p, int q) {
+    const float a = fabsf(img[p] - img[q]) + fabsf(img[HW + p] - img[HW + q]) + fabsf(img[2 * HW + p] - img[2 * HW + q]);
+    return expf(-a * (1.f / 3.f));
+}
+
+// grid (blocks, B).  Per pixel: its two forward edge terms (loss) and g = dL/dn from its up-to-four incident edges;
+// per block: partial sums {Lx, Ly, sum g, sum g * n} -> part[b][blk][4]
+__global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                             int H, int W, const float* __restrict__ stats, float cx,
+                                                             float cy, float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float red[4][kThreads];
+    const int b = blockIdx.y, N = H * W;
+    const float* d = disp + (size_t)b * N;
+    const float* im = img + (size_t)b * 3 * N;
+    const SmoothNorm q = smooth_norm(stats + (size_t)b * 8, N);
+    const float k = q.s * q.r;
+    float lx = 0.f, ly = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < N; i += gridDim.x * kThreads) {
+        const int h = i / W, w = i - h * W;
+        const float n0 = (d[i] - q.mn) * k;
+        float gi = 0.f;
+        if (w + 1 < W) {
+            const float df = n0 - (d[i + 1] - q.mn) * k, e = edge_w(im, N, i, i + 1);
+            lx += fabsf(df) * e;
+            gi += sgn(df) * e * cx;
+        }
+        if (w > 0) gi -= sgn((d[i - 1] - q.mn) * k - n0) * edge_w(im, N, i - 1, i) * cx;
+        if (h + 1 < H) {
+            const float df = n0 - (d[i + W] - q.mn) * k, e = edge_w(im, N, i, i + W);
+            ly += fabsf(df) * e;
+            gi += sgn(df) * e * cy;
+        }
+        if (h > 0) gi -= sgn((d[i - W] - q.mn) * k - n0) * edge_w(im, N, i - W, i) * cy;
+        g[(size_t)b * N + i] = gi;
+        a1 += gi;
+        a2 += gi * n0;
+    }
+    red[0][threadIdx.x] = lx; red[1][threadIdx.x] = ly; red[2][threadIdx.x] = a1; red[3][threadIdx.x] = a2;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int t = 0; t < 4; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) part[((size_t)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// one block: loss = sum_b,blk (Lx * cx + Ly * cy) * out_scale; stats[b][5] = sum g, stats[b][6] = sum g * n
+__global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(const float* __restrict__ part, int B, int nblk, float cx,
+                                                                  float cy, float out_scale, float* __restrict__ stats,
+                                                                  float* __restrict__ loss) {
+    __shared__ double red[kThreads];
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double l = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int j = threadIdx.x; j < nblk; j += kThreads) {
+            const float* p = part + ((size_t)b * nblk + j) * 4;
+            l += (double)p[0] * cx + (double)p[1] * cy;
+            a1 += p[2];
+            a2 += p[3];
+        }
+        double v[3] = {l, a1, a2};
+        for (int t = 0; t < 3; ++t) {
+            red[threadIdx.x] = v[t];
+            __syncthreads();
+            for (int off = kThreads / 2; off > 0; off >>= 1) {
+                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                __syncthreads();
+            }
+            v[t] = red[0];
+            __syncthreads();
+        }
+        tot += v[0];
+        if (threadIdx.x == 0) { stats[(size_t)b * 8 + 5] = (float)v[1]; stats[(size_t)b * 8 + 6] = (float)v[2]; }
+    }
+    if (threadIdx.x == 0) *loss = (float)(tot * out_scale);
+}
+
+// ddisp (+)= gscale[0] * scale * dL/ddisp: through the mean normalisation, the min / max normalisation (their
+// selected elements get the sums), see the derivation in DESIGN.md 3b
+__global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(const float* __restrict__ g, const float* __restrict__ stats,
+                                                             const float* __restrict__ gscale, float scale, int H, int W,
+                                                             int accumulate, float* __restrict__ ddisp) {
+    const int b = blockIdx.y, N = H * W;
+    const float* st = stats + (size_t)b * 8;
+    const SmoothNorm q = smooth_norm(st, N);
+    const float a1 = st[5], a2 = st[6];
+    const int kmn = __float_as_int(st[3]), kmx = __float_as_int(st[4]);
+    const float f = gscale[0] * scale, k = q.s * q.r, mean_g = a2 / (float)N;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < N; i += gridDim.x * kThreads) {
+        const int h = i / W, w = i - h * W, key = w * H + h;
+        float v = k * (g[(size_t)b * N + i] - mean_g);
+        if (key == kmn) v -= k * (a1 - a2);
+        if (key == kmx) v -= q.s * a2 * kSmoothEps * q.r;
+        float* o = ddisp + (size_t)b * N + i;
+        *o = accumulate ? *o + f * v : f * v;
+    }
+}
+
+// ---- disparity-order count (supervised_order.py:152-173): no gradient, scipy.ndimage.binary_erosion (3x3 cross, border 0)
+__device__ __forceinline__ bool eroded(const float* m, int H, int W, int h, int w) {
+    if (h == 0 || w == 0 || h == H - 1 || w == W - 1) return false;
+    const int i = h * W + w;
+    return m[i] != 0.f && m[i - 1] != 0.f && m[i + 1] != 0.f && m[i - W] != 0.f && m[i + W] != 0.f;
+}
+
+// one block per sample.  pass 0: max over eroded mask 2 / min over eroded mask 1 of both disparity maps; pass 1: the four
+// counts of each map; out[b] = the sample's contribution (0 when the pair is skipped)
+__global__ __launch_bounds__(kThreads) void disp_order_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                             const float* __restrict__ m1, const float* __restrict__ m2,
+                                                             const long* __restrict__ order, const long* __restrict__ ovl,
+                                                             int H, int W, int le_order, float* __restrict__ out) {
+    __shared__ float shf[4][kThreads];
+    __shared__ int shi[4][kThreads];
+    const int b = blockIdx.x, N = H * W;
+    const float *p1 = d1 + (size_t)b * N, *p2 = d2 + (size_t)b * N, *q1 = m1 + (size_t)b * N, *q2 = m2 + (size_t)b * N;
+    float mx2[2] = {-INFINITY, -INFINITY}, mn1[2] = {INFINITY, INFINITY};
+    int any1 = 0, any2 = 0;
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+        const int h = i / W, w = i - h * W;
+        const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
+        const float v[2] = {p1[i], p2[i]};
+        for (int t = 0; t < 2; ++t) {
+            if (e2) mx2[t] = fmaxf(mx2[t], v[t]);
+            if (e1) mn1[t] = fminf(mn1[t], v[t]);
+        }
+        any1 |= e1; any2 |= e2;
+    }
+    shf[0][threadIdx.x] = mx2[0]; shf[1][threadIdx.x] = mx2[1]; shf[2][threadIdx.x] = mn1[0]; shf[3][threadIdx.x] = mn1[1];
+    shi[0][threadIdx.x] = any1; shi[1][threadIdx.x] = any2;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            shf[0][threadIdx.x] = fmaxf(shf[0][threadIdx.x], shf[0][threadIdx.x + off]);
+            shf[1][threadIdx.x] = fmaxf(shf[1][threadIdx.x], shf[1][threadIdx.x + off]);
+            shf[2][threadIdx.x] = fminf(shf[2][threadIdx.x], shf[2][threadIdx.x + off]);
+            shf[3][threadIdx.x] = fminf(shf[3][threadIdx.x], shf[3][threadIdx.x + off]);
+            shi[0][threadIdx.x] |= shi[0][threadIdx.x + off];
+            shi[1][threadIdx.x] |= shi[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    const float MX[2] = {shf[0][0], shf[1][0]}, MN[2] = {shf[2][0], shf[3][0]};
+    const bool have = shi[0][0] && shi[1][0];
+    __syncthreads();
+    const long od = order[b];
+    // (the reference's .max() / .min() of an empty selection would raise; such pairs are skipped)
+    const bool use = ovl[b] == 0 && (od == 0 || od == 1) && have;
+    int le[2] = {0, 0}, ge[2] = {0, 0};
+    if (use)
+        for (int i = threadIdx.x; i < N; i += kThreads) {
+            const int h = i / W, w = i - h * W;
+            const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
+            const float v[2] = {p1[i], p2[i]};
+            for (int t = 0; t < 2; ++t) {
+                le[t] += (e1 && v[t] <= MX[t]) + (e2 && MN[t] <= v[t]);
+                ge[t] += (e1 && v[t] >= MX[t]) + (e2 && MN[t] >= v[t]);
+            }
+        }
+    shi[0][threadIdx.x] = le[0]; shi[1][threadIdx.x] = ge[0]; shi[2][threadIdx.x] = le[1]; shi[3][threadIdx.x] = ge[1];
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int t = 0; t < 4; ++t) shi[t][threadIdx.x] += shi[t][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // disp1 uses `<=` when depth_order1 == le_order and `>=` otherwise; disp2 the other way round
+        const bool le1 = od == le_order;
+        out[b] = use ? (float)((le1 ? shi[0][0] : shi[1][0]) + (le1 ? shi[3][0] : shi[2][0])) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void sum_scale_kernel(const float* __restrict__ v, int n, float scale,
+                                                            float* __restrict__ out) {
+    __shared__ double red[kThreads];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) a += v[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (float)(red[0] * scale);
+}
+
+int smooth_blocks(int N) {
+    int b = (N + kThreads * 4 - 1) / (kThreads * 4);
+    return b < 1 ? 1 : (b > 512 ? 512 : b);
+}
+
+}  // namespace
+
+extern "C" size_t io_smooth_loss_workspace_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * 8 + (size_t)B * smooth_blocks(H * W) * 4;
+}
+
+extern "C" int io_smooth_loss_fwd(const float* disp, const float* img, int B, int H, int W, float out_scale, float* loss,
+                                  float* g, float* workspace, size_t workspace_floats, hipStream_t st) {
+    IO_REQUIRE(B > 0 && H > 1 && W > 1 && (double)H * W < 2.0e9, IO_ERR_SHAPE, "smooth_loss: B=%d H=%d W=%d", B, H, W);
+    IO_REQUIRE(workspace_floats >= io_smooth_loss_workspace_floats(B, H, W), IO_ERR_WORKSPACE, "smooth_loss: workspace too small");
+    const int N = H * W, nblk = smooth_blocks(N);
+    float* stats = workspace;
+    float* part = workspace + (size_t)B * 8;
+    const float cx = 1.f / ((float)B * H * (W - 1)), cy = 1.f / ((float)B * (H - 1) * W);
+    hipLaunchKernelGGL(smooth_stats_kernel, dim3(B), dim3(kThreads), 0, st, disp, H, W, stats);
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nblk, B), dim3(kThreads), 0, st, disp, img, H, W, stats, cx, cy, g, part);
+    hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(kThreads), 0, st, part, B, nblk, cx, cy, out_scale, stats, loss);
+    return io_check_launch("smooth_loss_fwd");
+}
+
+extern "C" int io_smooth_loss_bwd(const float* g, const float* workspace, const float* grad_out, float scale, int B, int H,
+                                  int W, int accumulate, float* ddisp, hipStream_t st) {
+    IO_REQUIRE(B > 0 && H > 1 && W > 1, IO_ERR_SHAPE, "smooth_loss_bwd: B=%d H=%d W=%d", B, H, W);
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(smooth_blocks(H * W), B), dim3(kThreads), 0, st, g, workspace, grad_out, scale,
+                       H, W, accumulate, ddisp);
+    return io_check_launch("smooth_loss_bwd");
+}
+
+extern "C" int io_disp_order_count(const float* disp1, const float* disp2, const float* modal1, const float* modal2,
+                                   const long* depth_order1, const long* is_overlap, int B, int H, int W, int le_order,
+                                   float out_scale, float* out, float* per_sample, hipStream_t st) {
+    IO_REQUIRE(B > 0 && H > 2 && W > 2, IO_ERR_SHAPE, "disp_order_count: B=%d H=%d W=%d", B, H, W);
+    hipLaunchKernelGGL(disp_order_kernel, dim3(B), dim3(kThreads), 0, st, disp1, disp2, modal1, modal2, depth_order1,
+                       is_overlap, H, W, le_order, per_sample);
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(kThreads), 0, st, per_sample, B, out_scale / ((float)H * (float)W), out);
+    return io_check_launch("disp_order_count");
+}

@@ -714,3 +714,53 @@ class _Head1(torch.autograd.Function):
 
 def head1(x, w, b, relu):
     return _Head1.apply(x, w, b, relu)
+
+
+class _SmoothLoss(torch.autograd.Function):
+    """Edge-aware smoothness loss (models/supervised_order.py:214-235) of a disparity map disp[B,1,H,W] against the image
+    img[B,3,H,W]: three launches forward, one backward (io_smooth_loss_*), the incoming scalar gradient read on the device.
+    ``times``: the loss evaluated that many times on the same map (pair mode: both mask orders share the disparity)."""
+
+    @staticmethod
+    def forward(ctx, disp, img, times):
+        if not (disp.is_cuda and disp.dtype == torch.float32 and img.dtype == torch.float32):
+            raise RuntimeError("instaorder_amd.ops.smooth_loss: fp32 tensors on the GPU (no CPU fallback)")
+        B, _, H, W_ = disp.shape
+        d, im = disp.detach().contiguous(), img.detach().contiguous()
+        L = _L()
+        nws = int(L.io_smooth_loss_workspace_floats(B, H, W_))
+        ws = torch.empty(nws, device=d.device, dtype=torch.float32)
+        g = torch.empty((B, H, W_), device=d.device, dtype=torch.float32)
+        loss = torch.empty((), device=d.device, dtype=torch.float32)
+        _lib.check(L.io_smooth_loss_fwd(_p(d), _p(im), B, H, W_, float(times), _p(loss), _p(g), _p(ws), nws, _st()),
+                   "io_smooth_loss_fwd")
+        ctx.save_for_backward(g, ws)
+        ctx.cfg = (B, H, W_, float(times), tuple(disp.shape))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        g, ws = ctx.saved_tensors
+        B, H, W_, times, shape = ctx.cfg
+        dd = torch.empty((B, H, W_), device=g.device, dtype=torch.float32)
+        _lib.check(_L().io_smooth_loss_bwd(_p(g), _p(ws), _p(dl.float().contiguous()), times, B, H, W_, 0, _p(dd), _st()),
+                   "io_smooth_loss_bwd")
+        return dd.view(shape), None, None
+
+
+def smooth_loss(disp, img, times=1):
+    return _SmoothLoss.apply(disp, img, times)
+
+
+def disp_order_count(disp1, disp2, modal1, modal2, depth_order1, is_overlap, le_order=0, scale=1.0):
+    """supervised_order.py:152-173 for the whole batch in two launches (io_disp_order_count): erosion, masked max / min,
+    comparisons and counts on the device, no host round trip; returns a 0-dim tensor = scale * total / (H * W)."""
+    B, _, H, W_ = disp1.shape
+    dev = disp1.device
+    out = torch.empty((), device=dev, dtype=torch.float32)
+    per = torch.empty(B, device=dev, dtype=torch.float32)
+    f = lambda t: t.detach().float().contiguous()       # noqa: E731
+    _lib.check(_L().io_disp_order_count(_p(f(disp1)), _p(f(disp2)), _p(f(modal1)), _p(f(modal2)),
+                                        _p(depth_order1.long().contiguous()), _p(is_overlap.long().contiguous()), B, H, W_,
+                                        int(le_order), float(scale), _p(out), _p(per), _st()), "io_disp_order_count")
+    return out

@@ -296,18 +296,6 @@ class OrderNet(_OrderBase):
 
 
 # ---- MiDaS-based nets (supervised_order.py:97-367 of the reference) --------------------------------------------------
-def _erode_cross(m):
-    """scipy.ndimage.binary_erosion with its default 3x3 cross structuring element and border_value 0
-    (supervised_order.py:156-157), on a [B,H,W] bool tensor."""
-    z = torch.zeros_like(m)
-    up, down, left, right = z.clone(), z.clone(), z.clone(), z.clone()
-    up[:, 1:] = m[:, :-1]
-    down[:, :-1] = m[:, 1:]
-    left[:, :, 1:] = m[:, :, :-1]
-    right[:, :, :-1] = m[:, :, 1:]
-    return m & up & down & left & right
-
-
 class _DepthBase(SingleStageModel):
     """Shared machinery of InstaDepthNet_od / InstaDepthNet_d: two directional passes of the MiDaS-based net
     (HIP operators, instaorder_amd.ops), order-head losses through io_order_loss, and the two disparity losses --
@@ -353,43 +341,19 @@ class _DepthBase(SingleStageModel):
         self.B = self.rgb.shape[0]
 
     # losses ----------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def min_max_norm(disp):
-        mn = disp.min(2, True)[0].min(3, True)[0]
-        mx = disp.max(2, True)[0].max(3, True)[0]
-        return (disp - mn) / (mx + 1e-7)
+    def get_smooth_loss(self, disp, img, times=1):
+        """supervised_order.py:214-235 (min-max normalisation, division by the mean, edge-aware gradient penalty): HIP
+        kernels behind an autograd function (ops.smooth_loss); ``times`` = how many of the reference's two evaluations
+        fall on this very map."""
+        from . import ops
+        return ops.smooth_loss(disp, img, times)
 
-    def get_smooth_loss(self, disp, img):
-        """supervised_order.py:214-235."""
-        disp = self.min_max_norm(disp)
-        mean_disp = disp.mean(2, True).mean(3, True)
-        disp = disp / (mean_disp + 1e-7)
-        gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-        gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
-        gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
-        giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
-        return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
-
-    def _disp_order_count(self, disp1, disp2):
+    def _disp_order_count(self, disp1, disp2, scale=1.0):
         """supervised_order.py:152-173 (no gradient flows through these counts in the reference either), for the whole
-        batch at once and without a host round trip: per-sample masked max / min, comparisons, masked counts."""
-        with torch.no_grad():
-            e1 = _erode_cross(self.modal1[:, 0] != 0)
-            e2 = _erode_cross(self.modal2[:, 0] != 0)
-            order = self.depth_order1
-            # the reference's .max()/.min() of an empty selection would raise; such pairs are skipped here
-            use = (self.is_overlap == 0) & ((order == 0) | (order == 1)) & e1.flatten(1).any(1) & e2.flatten(1).any(1)
-            inf = float("inf")
-            total = torch.zeros((), device=disp1.device, dtype=torch.float32)
-            for d, flip in ((disp1[:, 0], False), (disp2[:, 0], True)):
-                mx2 = d.masked_fill(~e2, -inf).amax((1, 2))[:, None, None]       # max over eroded mask 2
-                mn1 = d.masked_fill(~e1, inf).amin((1, 2))[:, None, None]        # min over eroded mask 1
-                le = (((d <= mx2) & e1).sum((1, 2)) + ((mn1 <= d) & e2).sum((1, 2))).float()
-                ge = (((d >= mx2) & e1).sum((1, 2)) + ((mn1 >= d) & e2).sum((1, 2))).float()
-                # disp1 uses `<=` when depth_order1 == 0 and `>=` when it is 1; disp2 the other way round
-                use_le = (order == self._LE_ORDER) != flip
-                total = total + (torch.where(use_le, le, ge) * use.float()).sum()
-            return total / float(disp1.shape[2] * disp1.shape[3])
+        batch in two launches: erosion of both masks, per-sample masked max / min, comparisons, masked counts."""
+        from . import ops
+        return ops.disp_order_count(disp1, disp2, self.modal1, self.modal2, self.depth_order1, self.is_overlap,
+                                    self._LE_ORDER, scale)
 
     _LE_ORDER = 0     # both reference classes use `<=` on disp1 when depth_order1 == 0 (supervised_order.py:158-162, 289-293)
 
@@ -428,11 +392,14 @@ class _DepthBase(SingleStageModel):
             heads.append((occ, g_oc))
         loss_smooth = 0
         if p["smooth_weight"] != 0:
-            loss_smooth = (self.get_smooth_loss(disp1, self.rgb) + self.get_smooth_loss(disp2, self.rgb)) \
-                * p["smooth_weight"] * inv
+            sw = p["smooth_weight"] * inv            # (the weight rides in the kernel's output scale)
+            if disp1 is disp2:       # pair mode: one disparity map serves both mask orders -- the same term twice
+                loss_smooth = self.get_smooth_loss(disp1, self.rgb, 2 * sw)
+            else:
+                loss_smooth = self.get_smooth_loss(disp1, self.rgb, sw) + self.get_smooth_loss(disp2, self.rgb, sw)
         loss_disp_order = 0
         if p["dorder_weight"] != 0:
-            loss_disp_order = self._disp_order_count(disp1, disp2) * p["dorder_weight"] * inv
+            loss_disp_order = self._disp_order_count(disp1, disp2, p["dorder_weight"] * inv)
         loss = loss_overlap + loss_distinct + loss_occ + loss_smooth + loss_disp_order
         logs = {"loss_overlap": loss_overlap, "loss_distinct": loss_distinct}
         if self.HAS_OCC:

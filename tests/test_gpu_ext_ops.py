@@ -171,3 +171,58 @@ def test_grouped_conv_and_decoder_ops_bf16():
     part, sm = torch.empty(npart, device=DEV), torch.empty(Cc, device=DEV)
     _lib.check(L().io_colsum(P(bdev(v)), M, Cc, P(sm), P(part), npart, 1, ST()), "colsum")
     assert relerr(sm, v.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (3, 64, 64), (1, 33, 17)])
+def test_smooth_loss_value_and_gradient(B, H, W):
+    """ops.smooth_loss (io_smooth_loss_fwd / _bwd) == the oracle's restatement of get_smooth_loss
+    (models/supervised_order.py:214-235) in fp64, value and gradient -- incl. the gradient that reaches the elements the
+    min / max normalisation selects, and an output scale (the loss weight / world size / the pair-mode factor 2)."""
+    from instaorder_amd import ops
+    from oracle import midas_oracle as mo
+    g = torch.Generator().manual_seed(B * H + W)
+    disp = torch.rand(B, 1, H, W, generator=g) * 3.0 + 0.2
+    img = torch.randn(B, 3, H, W, generator=g)
+    d64 = disp.double().requires_grad_(True)
+    ref = mo.smooth_loss(d64, img.double()) * 0.7
+    ref.backward()
+    dd = disp.cuda().requires_grad_(True)
+    got = ops.smooth_loss(dd, img.cuda(), 0.7)
+    assert got.shape == () and abs(float(got) - float(ref)) < 1e-5 * abs(float(ref))
+    (got * 1.5).backward()
+    gref = d64.grad * 1.5
+    err = (dd.grad.double().cpu() - gref).abs().max() / gref.abs().max()
+    assert float(err) < 2e-4, float(err)
+    # the two selected elements carry sums over the whole map: check them explicitly
+    for b in range(B):
+        flat = disp[b, 0].reshape(-1)
+        for idx in (int(flat.argmin()), int(flat.argmax())):
+            a, r = float(dd.grad[b, 0].reshape(-1)[idx]), float(gref[b, 0].reshape(-1)[idx])
+            assert abs(a - r) < 2e-4 * float(gref.abs().max()) + 1e-3 * abs(r), (b, idx, a, r)
+
+
+@pytest.mark.parametrize("B,H,W", [(6, 32, 48), (4, 64, 64)])
+def test_disp_order_count(B, H, W):
+    """ops.disp_order_count (io_disp_order_count) == the oracle's restatement of supervised_order.py:152-173 with
+    scipy.ndimage.binary_erosion: every (is_overlap, depth_order) combination, an empty erosion (pair skipped), two
+    different disparity maps."""
+    from instaorder_amd import ops
+    from oracle import midas_oracle as mo
+    g = torch.Generator().manual_seed(H + B)
+    d1 = torch.rand(B, 1, H, W, generator=g)
+    d2 = torch.rand(B, 1, H, W, generator=g)
+    m1, m2 = torch.zeros(B, 1, H, W), torch.zeros(B, 1, H, W)
+    for b in range(B):
+        y0, x0 = 2 + b, 3 + 2 * b
+        m1[b, 0, y0:y0 + 10, x0:x0 + 12] = 1
+        m2[b, 0, H - 14 - b:H - 3, 5:W - 6] = 1
+    m2[B - 1] = 0
+    m2[B - 1, 0, 4, 4:9] = 1                 # a one-pixel-high mask: its erosion is empty -> the pair is skipped
+    order = torch.tensor([0, 1, 2, 0, 1, 0][:B])
+    ovl = torch.tensor([0, 0, 0, 1, 0, 0][:B])
+    ref = mo.disp_order_count(d1, d2, m1, m2, order[:B - 1].tolist() + [0], ovl[:B - 1].tolist() + [1])   # skip the last in the oracle
+    got = ops.disp_order_count(d1.cuda(), d2.cuda(), m1.cuda(), m2.cuda(), order.cuda(), ovl.cuda(), 0, 1.0)
+    assert abs(float(got) - ref) < 1e-6 * max(1.0, abs(ref)), (float(got), ref)
+    assert ref > 0
+    got2 = ops.disp_order_count(d1.cuda(), d2.cuda(), m1.cuda(), m2.cuda(), order.cuda(), ovl.cuda(), 0, 0.25)
+    assert abs(float(got2) - 0.25 * ref) < 1e-6 * max(1.0, abs(ref))
