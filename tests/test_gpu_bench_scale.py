@@ -18,6 +18,10 @@ split count -- in fp32 and bf16, and checked against fp64:
   and the coefficient tables) against fp64 reductions of the kernel's own output tensor (torch reductions in fp64 on the
   device -- an independent implementation; moving 2 GB per launch to the host would only add minutes).
 
+The streaming kernels the step still runs (BatchNorm backward of bn2 / the stem, the remaining BatchNorm apply forms,
+the stem's pooling and its backward, average pool + heads, the fused SGD update on the 23.5 M-float buffer, pair packing,
+the order loss) are run at the same batch at the end of the file.
+
 A wrong partition of a reduction at 2304 splits, a tile that reads its neighbour's rows, a partial that lands in the
 wrong slot: each shows up here as an O(1) error in some sample or channel.  Tolerances: fp32 2e-5 of the output scale
 (the per-kernel bar), bf16 one output rounding (6e-3)."""
@@ -508,3 +512,208 @@ def test_stem_launches_at_bench_size(mode):
     ref = ref_wgrad(x, dy, S, 8, Cout, k, s, osel, csel, taps)
     assert relerr(dw[osel][:, taps], ref[:, taps]) < 2e-5
     assert float(dw[..., 5:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the streaming kernels the step still runs, at the bench batch (grid strides that are not powers of two, 8 M rows)
+# ---------------------------------------------------------------------------------------------------------------------
+def _bn_ref_tables(y, Cn, gamma):
+    """fp64 batch statistics per group of a [M, C] tensor -> the fp32 tables the kernels take"""
+    M = y.numel() // Cn
+    yv = y.view(G, M // G, Cn)
+    mean = torch.stack([yv[i].double().mean(0) for i in range(G)])
+    var = torch.stack([yv[i].double().var(0, unbiased=False) for i in range(G)])
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    return (mean.float().reshape(-1).contiguous(), rstd.float().reshape(-1).contiguous(),
+            (gamma.double() * rstd).float().reshape(-1).contiguous())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,Cn,masked", [(128, 64, True), (64, 64, False), (32, 128, False), (8, 512, False)],
+                         ids=["stem-bn1", "l1-bn2", "l2-bn2", "l4-bn2"])
+def test_bn_backward_passes_at_bench_size(H, Cn, masked, dtype):
+    """io_bn_bwd_dt -- reduction, finalize and apply pass -- on the BatchNorm shapes that still run it in the fp32 step
+    (bn2 of every block; the stem's bn1 with its ReLU mask recomputed from y): dgamma / dbeta against fp64 sums over the
+    whole tensor, dy against fp64 at every element of a row sample."""
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(6000 + H + Cn)
+    M = N * H * H
+    y = randn((M, Cn), g, td, 0.7, 0.2)
+    dz = randn((M, Cn), g, td)
+    gamma, beta = torch.rand(Cn, generator=g, device=DEV) + 0.5, torch.randn(Cn, generator=g, device=DEV) * 0.3
+    mean, rstd, scale = _bn_ref_tables(y, Cn, gamma)
+    shift = beta.repeat(G).contiguous()
+    npart = lib.io_bn_partial_floats(M, Cn, G)
+    part, coef = torch.empty(npart, device=DEV), torch.empty(2 * G * Cn, device=DEV)
+    dy = torch.full((M, Cn), float("nan"), device=DEV, dtype=td)
+    dga, dbe = torch.empty(Cn, device=DEV), torch.empty(Cn, device=DEV)
+    _lib.check(lib.io_bn_bwd_dt(P(dz), None, P(scale) if masked else None, P(shift) if masked else None, P(y), M, Cn, G,
+                                P(gamma), P(mean), P(rstd), P(dga), P(dbe), P(dy), None, P(part), npart, P(coef), int(bf),
+                                ST()), "bn_bwd")
+    Mg = M // G
+    s1 = torch.zeros(G, Cn, dtype=torch.float64, device=DEV)
+    s2 = torch.zeros(G, Cn, dtype=torch.float64, device=DEV)
+    # mask decisions within fp32 rounding of zero may fall either way (the kernel evaluates bn(y) as one fp32 fma): what
+    # such elements could move the sums by is allowed on top of the tolerance (8.4 M rows: a few dozen per channel)
+    k1 = torch.zeros(Cn, dtype=torch.float64, device=DEV)
+    k2 = torch.zeros(Cn, dtype=torch.float64, device=DEV)
+    step = 1 << 18
+    for gi in range(G):
+        mu, rs = mean.view(G, Cn)[gi].double(), rstd.view(G, Cn)[gi].double()
+        sc, sh = scale.view(G, Cn)[gi].double(), shift.view(G, Cn)[gi].double()
+        for r0 in range(gi * Mg, (gi + 1) * Mg, step):
+            r1 = min(r0 + step, (gi + 1) * Mg)
+            d, yy = dz[r0:r1].double(), y[r0:r1].double()
+            xh = (yy - mu) * rs
+            if masked:
+                t = (yy - mu) * sc + sh
+                edge = t.abs() < (2e-2 if bf else 2e-6)
+                k1 += (d.abs() * edge).sum(0)
+                k2 += ((d * xh).abs() * edge).sum(0)
+                d = d * (t > 0)
+            s1[gi] += d.sum(0)
+            s2[gi] += (d * xh).sum(0)
+    e1 = (dbe.double() - s1.sum(0)).abs() - k1
+    e2 = (dga.double() - s2.sum(0)).abs() - k2
+    assert float(e1.max()) < 5e-5 * float(s1.sum(0).abs().max()), (H, Cn, float(e1.max()))
+    assert float(e2.max()) < 5e-5 * float(s2.sum(0).abs().max()), (H, Cn, float(e2.max()))
+    rows = sample(g, M, 2048)
+    gi = rows // Mg
+    mu, rs = host(mean.view(G, Cn)[gi]), host(rstd.view(G, Cn)[gi])
+    d, yy = host(dz[rows]), host(y[rows])
+    if masked:
+        t = (yy - mu) * host(scale.view(G, Cn)[gi]) + host(shift.view(G, Cn)[gi])
+        sure = t.abs() > (2e-2 if bf else 1e-5)
+        d = d * (t > 0)
+    else:
+        sure = torch.ones_like(d, dtype=torch.bool)
+    xh = (yy - mu) * rs
+    ref = host(gamma) * rs * (d - host(s1[gi]) / Mg - xh * host(s2[gi]) / Mg)
+    assert relerr(host(dy[rows]) * sure, ref * sure) < tol(bf, 2e-5, 6e-3), (H, Cn)
+    assert bool(torch.isfinite(dy).all())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_residual_bn_apply_at_bench_size(dtype):
+    """io_bn_apply_dt in its three forms at the sizes the step still runs them: relu(bn(y)) of a strided block's conv1
+    (2.1 M x 128), the last block's relu(bn3(y3) + identity) (32 k x 2048) and, for the bf16 step, a layer-1 block output
+    (2.1 M x 256) -- exact element-wise against the same expression in torch (fp32 fma chain is the kernel's; compare at
+    one output rounding)."""
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(6100)
+    for H, Cn, with_id in ((64, 128, False), (8, 2048, True), (64, 256, True)):
+        M = N * H * H
+        y = randn((M, Cn), g, td, 0.8, 0.1)
+        idt = torch.relu(randn((M, Cn), g, td)) if with_id else None
+        mean, _, _, scale, shift = tables(g, Cn)
+        out = torch.full((M, Cn), float("nan"), device=DEV, dtype=td)
+        _lib.check(lib.io_bn_apply_dt(P(y), M, Cn, G, 1, P(mean), P(scale), P(shift), P(idt), None, None, None, 1, P(out),
+                                      int(bf), ST()), "bn_apply")
+        Mg = M // G
+        for gi in range(G):
+            sl = slice(gi * Mg, (gi + 1) * Mg)
+            ref = (y[sl].double() - mean.view(G, Cn)[gi].double()) * scale.view(G, Cn)[gi].double() + \
+                shift.view(G, Cn)[gi].double()
+            if with_id:
+                ref = ref + idt[sl].double()
+            ref = torch.relu(ref)
+            err = float((out[sl].double() - ref).abs().max() / ref.abs().max())
+            assert err < tol(bf, 1e-6, 4e-3), (H, Cn, gi, err)
+        del y, idt, out
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pooling_and_heads_at_bench_size(dtype):
+    """The stem's max-pool over relu(bn1(y)) evaluated on the fly (512 x 128 x 128 x 64 -> 64 x 64) with its backward, and
+    the average pool + heads (512 x 8 x 8 x 2048) forward / backward."""
+    import torch.nn.functional as F
+    bf = dtype == "bf16"
+    td = td_of(dtype)
+    lib = _lib.lib()
+    g = gen(6200)
+    H, Cn = 128, 64
+    y = randn((N, H, H, Cn), g, td, 0.8, 0.1)
+    mean, _, _, scale, shift = tables(g, Cn)
+    Ho = H // 2
+    out = torch.empty(N, Ho, Ho, Cn, device=DEV, dtype=td)
+    idx = torch.empty(N * Ho * Ho * Cn // 4, device=DEV, dtype=torch.int32)
+    _lib.check(lib.io_maxpool_fwd_xf_dt(P(y), N, H, H, Cn, P(out), P(idx), G, P(mean), P(scale), P(shift), int(bf), ST()),
+               "maxpool_xf")
+    per = N // G
+    for n0 in range(0, N, 64):              # reference in slices (fp32 torch on the device; max-pooling is exact)
+        gi = n0 // per
+        a = torch.relu((y[n0:n0 + 64].float() - mean.view(G, Cn)[gi]) * scale.view(G, Cn)[gi] + shift.view(G, Cn)[gi])
+        if bf:
+            a = a.bfloat16().float()
+        ref = F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+        err = float((out[n0:n0 + 64].float() - ref).abs().max())
+        assert err < (2e-2 if bf else 1e-5), (n0, err)           # (fma vs mul + add in the affine part)
+    dyp = randn((N, Ho, Ho, Cn), g, td)
+    dx = torch.full((N, H, H, Cn), float("nan"), device=DEV, dtype=td)
+    _lib.check(lib.io_maxpool_bwd_dt(P(dyp), P(idx), N, H, H, Cn, P(dx), int(bf), ST()), "maxpool_bwd")
+    # every pooled gradient is routed to exactly one input element: the sums agree exactly in fp64 per (sample, channel)
+    assert relerr(dx.double().sum((1, 2)), dyp.double().sum((1, 2))) < tol(bf, 1e-6, 2e-3)
+    assert bool(torch.isfinite(dx).all())
+    # heads
+    HW, Cc, K0 = 64, 2048, 2
+    x = torch.relu(randn((N, 8, 8, Cc), g, td))
+    w0 = randn((K0, Cc), g, torch.float32, 0.02)
+    b0 = randn((K0,), g, torch.float32, 0.1)
+    pooled, logits = torch.empty(N, Cc, device=DEV), torch.empty(N, K0, device=DEV)
+    _lib.check(lib.io_avgpool_fc_fwd_dt(P(x), N, HW, Cc, P(w0), P(b0), K0, None, None, 0, P(pooled), P(logits), int(bf), ST()),
+               "avgpool_fc")
+    pref = x.double().mean((1, 2))
+    assert relerr(pooled, pref) < 1e-6
+    assert relerr(logits, pref @ w0.double().t() + b0.double()) < 1e-5
+    dl = randn((N, K0), g, torch.float32)
+    dxh = torch.empty(N, 8, 8, Cc, device=DEV, dtype=td)
+    dw, db = torch.empty(K0, Cc, device=DEV), torch.empty(K0, device=DEV)
+    _lib.check(lib.io_avgpool_fc_bwd_dt(P(dl), P(pooled), N, HW, Cc, P(w0), K0, None, 0, P(x), P(dxh), P(dw), P(db), None, None,
+                                        int(bf), ST()), "avgpool_fc_bwd")
+    dref = ((dl.double() @ w0.double()) / HW)[:, None, None, :] * (x > 0)
+    assert relerr(dxh, dref) < tol(bf, 1e-5, 4e-3)
+    assert relerr(dw, dl.double().t() @ pref) < 1e-5 and relerr(db, dl.double().sum(0)) < 1e-5
+
+
+def test_sgd_pack_and_loss_at_bench_size():
+    """The rest of the step at its real size: the fused SGD update on the 23.5 M-float flat buffer (torch.optim.SGD's
+    formula, three steps), the pair packing of 256 pairs at 256 x 256 (both mask orders into [512, 256, 256, 8]), the
+    BCE order loss and its gradient for 512 rows."""
+    import torch.nn.functional as F
+    from instaorder_amd import engine
+    g = gen(6300)
+    n = 23527872
+    p0 = torch.randn(n, generator=g, device=DEV)
+    par = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([par], lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    dp, buf = p0.clone(), torch.zeros(n, device=DEV)
+    for it in range(3):
+        gr = torch.randn(n, generator=g, device=DEV)
+        par.grad = gr.clone()
+        opt.step()
+        engine.sgd_momentum(dp, gr, buf, 1e-3, 0.9, 1e-4)
+    assert float((dp - par.detach()).abs().max()) < 1e-6 * float(par.detach().abs().max())
+    B, S = 256, 256
+    rgb = torch.randn(B, 3, S, S, generator=g, device=DEV)
+    m1 = (torch.rand(B, 1, S, S, generator=g, device=DEV) > 0.6).float()
+    m2 = (torch.rand(B, 1, S, S, generator=g, device=DEV) > 0.6).float()
+    x8 = engine.pack_pair_directions(rgb, m1, m2)
+    assert x8.shape == (2 * B, S, S, 8)
+    ref1 = torch.cat([m1, m2, rgb], 1).permute(0, 2, 3, 1)
+    ref2 = torch.cat([m2, m1, rgb], 1).permute(0, 2, 3, 1)
+    assert torch.equal(x8[:B, ..., :5], ref1) and torch.equal(x8[B:, ..., :5], ref2)
+    assert float(x8[..., 5:].abs().max()) == 0.0
+    z = torch.randn(2 * B, 2, generator=g, device=DEV)
+    occ = (torch.rand(2 * B, 2, generator=g, device=DEV) > 0.7).float()
+    losses, dlog = engine.order_loss(z, B, 2, 0, occ_target=occ)
+    z64 = z.double().cpu().requires_grad_(True)
+    ref = F.binary_cross_entropy(torch.sigmoid(z64[:B]), occ[:B].double().cpu()) + \
+        F.binary_cross_entropy(torch.sigmoid(z64[B:]), occ[B:].double().cpu())
+    ref.backward()
+    assert abs(float(losses[0]) - float(ref)) < 1e-5 * float(ref)
+    assert relerr(dlog, z64.grad) < 1e-5
