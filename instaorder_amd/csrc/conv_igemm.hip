@@ -70,6 +70,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #ifndef IO_EARLY_LOADS
 #define IO_EARLY_LOADS 0
 #endif
+#ifndef IO_XB_PIPE
+#define IO_XB_PIPE 1
+#endif
 #ifndef IO_WGRAD_TR
 #define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
 #endif
@@ -397,38 +400,10 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         }
     };
     const int wchunk = SWZ ? (kq ^ ((lr >> 1) & 7)) : kq;      // (the row step RS = 32 leaves bits 1..3 alone)
-    auto store_tile = [&](int buf) {
-        float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
-        float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
-        if constexpr (XF) {
-            // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
-            // the zeros the buffer unit returned would be relu(shift)
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                const bool ok = (xok >> j) & 1u;
-                if constexpr (ES == 4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaxf(__builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
-                        ra[j][e] = ok ? v : 0.f;
-                    }
-                } else {
-                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]);
-                    u32x4 o;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
-                        const int q = d >> 1, e0 = (d & 1) * 2;
-                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
-                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
-                        const float vl = fmaxf(__builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]), 0.f);
-                        const float vh = fmaxf(__builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]), 0.f);
-                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
-                    }
-                    ra[j] = __builtin_bit_cast(f32x4, o);
-                }
-            }
-        }
-        if constexpr (XB) {
+    // XB: the operand transform of the tile in (ra, ry) + its side output.  Its own step so that the loop can run it under
+    // the MFMAs of the previous tile instead of inside the barrier-to-barrier section of store_tile (IO_XB_PIPE).
+    auto xform_tile = [&]() {
+        if constexpr (XB != 0) {
             // dy = a * dz + (b * y + c) on the staged chunk; padding rows stay zero (their transform would be c)
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
@@ -477,6 +452,41 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ra[j]), rs_side,
                                                            (xside && ((xok >> j) & 1u)) ? rowv[j] + xaoff : kInvalidOff, 0, 0);
             }
+        }
+    };
+    auto store_tile = [&](int buf, bool xdone = false) {
+        float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
+        float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
+        if constexpr (XF) {
+            // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
+            // the zeros the buffer unit returned would be relu(shift)
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = (xok >> j) & 1u;
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(__builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
+                        ra[j][e] = ok ? v : 0.f;
+                    }
+                } else {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]);
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
+                        const int q = d >> 1, e0 = (d & 1) * 2;
+                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
+                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
+                        const float vl = fmaxf(__builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]), 0.f);
+                        const float vh = fmaxf(__builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]), 0.f);
+                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
+                    }
+                    ra[j] = __builtin_bit_cast(f32x4, o);
+                }
+            }
+        }
+        if constexpr (XB != 0) {
+            if (!xdone) xform_tile();
         }
 #pragma unroll
         for (int j = 0; j < AR; ++j) st4(a + RS * j * LDT, ra[j]);
@@ -547,7 +557,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         const int buf = NBUF == 2 ? kt & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         advance(true);
-        load_tile(kt + 1);
+        constexpr bool PIPE = XB != 0 && IO_XB_PIPE;
+        if constexpr (!PIPE) load_tile(kt + 1);
 #if IO_EARLY_LOADS
         __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
 #endif
@@ -560,10 +571,19 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+            if constexpr (PIPE) {
+                // operand forms: the fetches of tile kt+1 go out behind the first MFMA group, and the transform of what
+                // they bring runs under the third -- not between the barriers, where all four waves of the block wait
+                if (kk == 0) {
+                    load_tile(kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kk == 1) xform_tile();
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
-        store_tile(nbuf);
+        store_tile(nbuf, PIPE);
         __syncthreads();
         f32x4 na[TI], nb[TJ];
         read_frags(nbuf, 0, na, nb);           // first fragments of tile kt+1
