@@ -70,6 +70,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 #ifndef IO_EARLY_LOADS
 #define IO_EARLY_LOADS 0
 #endif
+#ifndef IO_XF_PIPE
+#define IO_XF_PIPE 1       // the same for the forward input transform (fp32): NT class -0.3 ms per step, same-box
+#endif
 #ifndef IO_XB_PIPE
 #define IO_XB_PIPE 1
 #endif
@@ -403,6 +406,34 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // XB: the operand transform of the tile in (ra, ry) + its side output.  Its own step so that the loop can run it under
     // the MFMAs of the previous tile instead of inside the barrier-to-barrier section of store_tile (IO_XB_PIPE).
     auto xform_tile = [&]() {
+        if constexpr (XF) {
+            // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
+            // the zeros the buffer unit returned would be relu(shift)
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = (xok >> j) & 1u;
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(__builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
+                        ra[j][e] = ok ? v : 0.f;
+                    }
+                } else {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]);
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
+                        const int q = d >> 1, e0 = (d & 1) * 2;
+                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
+                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
+                        const float vl = fmaxf(__builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]), 0.f);
+                        const float vh = fmaxf(__builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]), 0.f);
+                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
+                    }
+                    ra[j] = __builtin_bit_cast(f32x4, o);
+                }
+            }
+        }
         if constexpr (XB != 0) {
             // dy = a * dz + (b * y + c) on the staged chunk; padding rows stay zero (their transform would be c)
 #pragma unroll
@@ -457,35 +488,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     auto store_tile = [&](int buf, bool xdone = false) {
         float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
         float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
-        if constexpr (XF) {
-            // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
-            // the zeros the buffer unit returned would be relu(shift)
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                const bool ok = (xok >> j) & 1u;
-                if constexpr (ES == 4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaxf(__builtin_fmaf(ra[j][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
-                        ra[j][e] = ok ? v : 0.f;
-                    }
-                } else {
-                    const u32x4 raw = __builtin_bit_cast(u32x4, ra[j]);
-                    u32x4 o;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {     // dword d holds elements 2d (low half) and 2d + 1 (high half)
-                        const int q = d >> 1, e0 = (d & 1) * 2;
-                        const float lo = __builtin_bit_cast(float, raw[d] << 16);
-                        const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
-                        const float vl = fmaxf(__builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]), 0.f);
-                        const float vh = fmaxf(__builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]), 0.f);
-                        o[d] = ok ? io_f2bf2(vl, vh) : 0u;
-                    }
-                    ra[j] = __builtin_bit_cast(f32x4, o);
-                }
-            }
-        }
-        if constexpr (XB != 0) {
+        if constexpr (XT) {
             if (!xdone) xform_tile();
         }
 #pragma unroll
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         const int buf = NBUF == 2 ? kt & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         advance(true);
-        constexpr bool PIPE = XB != 0 && IO_XB_PIPE;
+        constexpr bool PIPE = (XB != 0 && IO_XB_PIPE) || (XF && ES == 4 && IO_XF_PIPE);
         if constexpr (!PIPE) load_tile(kt + 1);
 #if IO_EARLY_LOADS
         __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
