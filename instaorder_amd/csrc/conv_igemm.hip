@@ -560,7 +560,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         const int buf = NBUF == 2 ? kt & 1 : 0;
         const int nbuf = NBUF == 2 ? buf ^ 1 : 0;
         advance(true);
-        constexpr bool PIPE = (XB != 0 && IO_XB_PIPE) || (XF && ES == 4 && IO_XF_PIPE);
+        // (fp32 only: in bf16 the transform is VALU-bound whatever its place and the longer live ranges spill --
+        // profiles/r03_xb_microbench_bf16.txt; the bf16 step does not use the operand forms)
+        constexpr bool PIPE = ES == 4 && ((XB != 0 && IO_XB_PIPE) || (XF && IO_XF_PIPE));
         if constexpr (!PIPE) load_tile(kt + 1);
 #if IO_EARLY_LOADS
         __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
