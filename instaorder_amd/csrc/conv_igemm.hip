@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // XF: per-channel coefficients of the chunk being loaded (they change with the k-tile) and the validity of its rows
     static_assert(!XF || STEM == 0, "input transform: regular convolutions");
     static_assert(!XB || (STEM == 0 && !XF), "backward operand transform: regular data gradients, not combined with XF");
-    static_assert(XB < 2 || (ES == 4 && !BWE), "the residual forms are fp32 forward paths");
+    static_assert(XB < 2 || !BWE, "the residual forms are forward paths");
     constexpr bool XT = XF || XB;           // some operand transform
     constexpr int XC = ES == 4 ? 1 : 2;     // 16-byte coefficient loads per 16-byte operand chunk (4 floats or 8 bf16)
     f32x4 xm[XC], xs[XC], xh[XC];           // XF: mean, scale, shift.  XB: b (times y), a (times dz), c
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const bool ok = (xok >> j) & 1u;
-                if constexpr (XB == 2) {
+                if constexpr (XB == 2 && ES == 4) {
                     // relu(bn(y) + identity): bn_apply_kernel's expression (MODE 1), so the tensor is bit for bit the one a
                     // separate pass would have written
 #pragma unroll
@@ -465,8 +465,18 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                         const float hi = __builtin_bit_cast(float, raw[d] & 0xffff0000u);
                         const float yl = __builtin_bit_cast(float, rwy[d] << 16);
                         const float yh = __builtin_bit_cast(float, rwy[d] & 0xffff0000u);
-                        const float vl = __builtin_fmaf(lo, xs[q][e0], __builtin_fmaf(yl, xm[q][e0], xh[q][e0]));
-                        const float vh = __builtin_fmaf(hi, xs[q][e0 + 1], __builtin_fmaf(yh, xm[q][e0 + 1], xh[q][e0 + 1]));
+                        float vl, vh;
+                        if constexpr (XB == 2) {        // relu(bn(y) + identity), bn_apply_kernel's expression
+                            vl = __builtin_fmaf(lo - xm[q][e0], xs[q][e0], xh[q][e0]) + yl;
+                            vh = __builtin_fmaf(hi - xm[q][e0 + 1], xs[q][e0 + 1], xh[q][e0 + 1]) + yh;
+                        } else {
+                            vl = __builtin_fmaf(lo, xs[q][e0], __builtin_fmaf(yl, xm[q][e0], xh[q][e0]));
+                            vh = __builtin_fmaf(hi, xs[q][e0 + 1], __builtin_fmaf(yh, xm[q][e0 + 1], xh[q][e0 + 1]));
+                        }
+                        if constexpr (XB >= 2) {
+                            vl = vl > 0.f ? vl : 0.f;
+                            vh = vh > 0.f ? vh : 0.f;
+                        }
                         o[d] = ok ? io_f2bf2(vl, vh) : 0u;
                     }
                     ra[j] = __builtin_bit_cast(f32x4, o);
@@ -1892,8 +1902,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         IO_REQUIRE(!bws.y || (g.os == 1 && g.Ho == g.outH && g.Wo == g.outW && bws.Mg > 0 && bws.Mg % 128 == 0 &&
                               Mchk % 128 == 0 && Mchk % bws.Mg == 0),
                    IO_ERR_SHAPE, "conv_nt: fused BN-backward reductions need a dense output and 128 | rows per group | M");
-        IO_REQUIRE(!bws.xb_res || (bws.xb_a && !bws.y && dt_in == IO_F32 && dt_out == IO_F32), IO_ERR_SHAPE,
-                   "conv_nt: the residual operand form is an fp32 forward path (no BatchNorm-backward epilogue)");
+        IO_REQUIRE(!bws.xb_res || (bws.xb_a && !bws.y && dt_in == dt_out), IO_ERR_SHAPE,
+                   "conv_nt: the residual operand form is a forward path (no BatchNorm-backward epilogue)");
         // (the output may sit on a strided lattice -- the one class of a strided 1x1 data gradient that has a tap; the operand
         // side only needs the gathered grid to BE the logical output grid)
         IO_REQUIRE(!bws.xb_a || (bws.xb_b && bws.xb_c && bws.xb_y && !bws.in_scale && !stem && !g.gw && g.is == 1 &&
@@ -1974,7 +1984,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 #define IO_LAUNCH_NT__(TI_, TO_, BN_, STEM_, NBUF_, MINB_, LIN_)                                             \
     do {                                                                                                     \
         constexpr bool R_ = STEM_ == 0, XBOK_ = R_ && sizeof(TI_) == sizeof(TO_);                            \
-        constexpr int XB1_ = XBOK_ ? 1 : 0, XB2_ = (XBOK_ && sizeof(TI_) == 4 && LIN_) ? 2 : XB1_;           \
+        constexpr int XB1_ = XBOK_ ? 1 : 0, XB2_ = (XBOK_ && LIN_) ? 2 : XB1_;                               \
         constexpr int XB3_ = XB2_ == 2 ? 3 : XB1_;                                                           \
         if (XBOK_ && bws.xb_a && bws.xb_res == 2) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB3_); \
         else if (XBOK_ && bws.xb_a && bws.xb_res) IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, false, false, LIN_, XB2_); \

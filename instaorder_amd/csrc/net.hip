@@ -385,11 +385,17 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 #ifndef IO_XR
 #define IO_XR 1
 #endif
+#ifndef IO_XB_BF16_L1
+#define IO_XB_BF16_L1 1   // bf16: the operand forms on the layer-1 (64-plane) blocks only
+#endif
 #ifndef IO_XR2
 #define IO_XR2 1      // ... also the outputs of the four blocks with a downsample branch (two BatchNorms folded into one table set)
 #endif
-bool xr_ok(const Ctx& c, int Mout) {
-    return IO_XR && c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
+// bf16: only for the 64-plane blocks of layer 1 -- the form is VALU-bound next to bf16 MFMAs, but those launches are so
+// HBM-bound that dropping the pass still wins (as for the backward form, run_backward)
+bool xr_ok(const Ctx& c, int Mout, int planes) {
+    const bool dt_ok = c.net->dtype == IO_F32 || (IO_XB_BF16_L1 && planes == 64);
+    return IO_XR && c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
 bool fuse_in(const Ctx& c, int Mout) {
@@ -536,7 +542,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         }
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
-            if (IO_XR2 && i + 1 < net->blocks.size() && xr_ok(c, Mout)) {
+            if (IO_XR2 && i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
                 // relu(bn3(y3) + bnd(yd)) = relu(a * y3 + b * yd + c): one table set, then as below
                 Tables t3 = c.tables(b.b3), td = c.tables(b.bd);
                 IO_TRY(io_bn_resid2_tables(t3.mean, t3.scale, t3.shift, td.mean, td.scale, td.shift, c.G, b.b3.C,
@@ -548,7 +554,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
             } else {
                 IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
             }
-        } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout)) {
+        } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
             pend_bn = &b.b3;                 // built by the next block's conv1
             pend_y3 = c.act(bb.y3);
             pend_id = x;
@@ -757,7 +763,10 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // gradients pay +0.00..0.17 ms for the doubled operand load (+0.54 on the HBM-bound 256 -> 64 layer) and save an
         // apply pass of 0.04..1.29 ms -- a gain on every conv3 and conv1; a 3x3 data gradient stages every chunk nine
         // times (once per tap), pays +0.21..0.61 ms and saves 0.04..0.32: bn2 keeps its apply pass (IO_XB_C2).
-        const bool x3 = xb_ok(c, Mout);                          // bn3 -> conv3's data gradient
+        // (bf16: the transform is VALU-bound next to bf16 MFMAs and loses everywhere except on layer 1's 256 -> 64 data
+        // gradient, which is so HBM-bound that the saved pass still wins: -0.33 ms per launch, r03_xb_microbench_bf16.txt)
+        const bool x3 = xb_ok(c, Mout) ||                        // bn3 -> conv3's data gradient
+                        (IO_XB_BF16_L1 && c.net->dtype == IO_BF16 && b.planes == 64 && tiles_ok(c, Mout));
         const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
         const bool x2 = IO_XB_C2 && x3 && b.stride == 1;         // bn2 -> conv2's (a strided one runs as parity classes)
         // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
