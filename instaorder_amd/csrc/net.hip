@@ -385,6 +385,9 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 #ifndef IO_XR
 #define IO_XR 1
 #endif
+#ifndef IO_XB_BF16_MAXP
+#define IO_XB_BF16_MAXP 64
+#endif
 #ifndef IO_XB_BF16_L1
 #define IO_XB_BF16_L1 1   // bf16: the operand forms on the layer-1 (64-plane) blocks only
 #endif
@@ -394,7 +397,7 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 // bf16: only for the 64-plane blocks of layer 1 -- the form is VALU-bound next to bf16 MFMAs, but those launches are so
 // HBM-bound that dropping the pass still wins (as for the backward form, run_backward)
 bool xr_ok(const Ctx& c, int Mout, int planes) {
-    const bool dt_ok = c.net->dtype == IO_F32 || (IO_XB_BF16_L1 && planes == 64);
+    const bool dt_ok = c.net->dtype == IO_F32 || (IO_XB_BF16_L1 && planes <= IO_XB_BF16_MAXP);
     return IO_XR && c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
@@ -766,7 +769,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // (bf16: the transform is VALU-bound next to bf16 MFMAs and loses everywhere except on layer 1's 256 -> 64 data
         // gradient, which is so HBM-bound that the saved pass still wins: -0.33 ms per launch, r03_xb_microbench_bf16.txt)
         const bool x3 = xb_ok(c, Mout) ||                        // bn3 -> conv3's data gradient
-                        (IO_XB_BF16_L1 && c.net->dtype == IO_BF16 && b.planes == 64 && tiles_ok(c, Mout));
+                        (IO_XB_BF16_L1 && c.net->dtype == IO_BF16 && b.planes <= IO_XB_BF16_MAXP && tiles_ok(c, Mout));
         const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
         const bool x2 = IO_XB_C2 && x3 && b.stride == 1;         // bn2 -> conv2's (a strided one runs as parity classes)
         // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
