@@ -327,7 +327,8 @@ def main():
                    "inputs": ("host, " + args.host_inputs) if args.host_inputs else "resident in HBM",
                    "pair_source": "20-instance images, 190 pairs each, sharded by rank" if pair_src else "pair batch",
                    "pairs_per_gpu": B, "input_size": S, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "hip_graph": bool(getattr(model, "_use_graph", False) and getattr(model, "_graph", None) is not None),
+                   "hip_graph": bool(getattr(model, "_use_graph", False) and (getattr(model, "_graph", None) is not None
+                                                                               or getattr(model, "_dp_graphs", None))),
                    "collective": None if world == 1 else (
                        "%s all-reduce (SUM) of the %d gradient floats in %d stage buckets (%s MB: heads+layer4, layer3, "
                        "layer2, layer1+stem), each launched when its stage of the backward pass is enqueued" % (

@@ -52,6 +52,8 @@ class _OrderBase(SingleStageModel):
         # all-reduce after it, the round-1/2 behaviour)
         self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
         self._buckets = None
+        self._dp_graphs = None          # world_size > 1: one hipGraph per backward stage (the collectives sit between them)
+        self._dp_key = None
         if load_pretrain is not None:
             self.load_pretrain(load_pretrain)
 
@@ -63,6 +65,7 @@ class _OrderBase(SingleStageModel):
             cur = torch.empty_like(t)
             self._static[name] = cur
             self._graph = None
+            self._dp_graphs = None
         cur.copy_(t)
         return cur
 
@@ -74,6 +77,7 @@ class _OrderBase(SingleStageModel):
         if self._x8 is None or self._x8.shape[0] != 2 * B or self._x8.shape[1:3] != self.rgb.shape[2:]:
             self._x8 = None
             self._graph = None
+            self._dp_graphs = None
         self._x8 = engine.pack_pair_directions(self.rgb if self.use_rgb else None, self.modal1, self.modal2,
                                                self._x8, dtype=self.net.dtype)
         self.B = B
@@ -120,18 +124,56 @@ class _OrderBase(SingleStageModel):
         """world_size > 1: forward, loss, then the backward stage by stage with the all-reduce of each stage's slice of
         the flat gradient buffer launched as soon as that stage is enqueued (distributed_utils.GradientBuckets) -- the
         exchange of the reference (average_gradients after loss.backward(), supervised_order.py:545-546) overlapped
-        with the rest of the backward pass.  Eager launches: the collectives sit between the stages."""
+        with the rest of the backward pass.  The collectives sit between the stages, so the launch-bound case (small
+        per-GPU batches) is served by ONE hipGraph PER STAGE -- forward + loss + stage 0, then stages 1..3 -- replayed with
+        the all-reduces launched in between (second step with a shape: capture; the first ran eagerly and warmed every
+        kernel); identical kernels and order, so bit-identical to the eager form."""
         net = self.net
         if self._buckets is None:
             self._buckets = distributed_utils.GradientBuckets(net)
         bk = self._buckets
+        ns = bk.num_stages
+        key = (N, S, self._x8.data_ptr(), net.flat_params.data_ptr())
+        graphs_ok = self._use_graph and not engine.prof_active()
+        if graphs_ok and self._dp_graphs is not None and self._dp_key == key:
+            for s, g in enumerate(self._dp_graphs):
+                g.replay()
+                bk.launch(s)
+            bk.finish()
+            logits, losses = (t.clone() for t in self._dp_out)
+            return logits, losses
+        if graphs_ok and self._seen_key == key:
+            try:
+                torch.cuda.synchronize()
+                g0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+                    logits, ws = net._run_forward(self._x8, N, S, 2, True)
+                    losses, dlogits = self._loss(logits, True, True)
+                    net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(0, 1))
+                graphs = [g0]
+                for s in range(1, ns):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode="thread_local"):
+                        net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(s, s + 1))
+                    graphs.append(g)
+                self._dp_graphs, self._dp_key, self._dp_out, self._dp_keep = graphs, key, (logits, losses), (ws, dlogits)
+                for s, g in enumerate(graphs):
+                    g.replay()
+                    bk.launch(s)
+                bk.finish()
+                return logits.clone(), losses.clone()
+            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
+                self._use_graph = False
+                self._dp_graphs = None
+                print("instaorder_amd: per-stage hipGraph capture disabled (%s)" % ex)
         logits, ws = net._run_forward(self._x8, N, S, 2, True)
         losses, dlogits = self._loss(logits, True, True)
-        for s in range(bk.num_stages):
+        for s in range(ns):
             net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(s, s + 1))
             bk.launch(s)
         bk.finish()
         net._pool.give(ws)
+        self._seen_key = key
         return logits, losses
 
     def step(self):

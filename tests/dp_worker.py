@@ -70,6 +70,16 @@ def main():
         torch.cuda.synchronize()
         np.save(os.path.join(out_dir, "params_rank%d.npy" % rank), m.net.flat_params.cpu().numpy())
         np.save(os.path.join(out_dir, "grads_rank%d.npy" % rank), m.net.flat_grads.cpu().numpy())
+        # three more steps on the same inputs: with hipGraphs enabled the first of them is captured (one graph per backward
+        # stage, the all-reduces in between) and the next two are replays; IO_NO_GRAPH=1 runs them eagerly.  The caller
+        # compares the two forms bit for bit.
+        losses = []
+        for _ in range(3):
+            m.set_input(t["rgb"], t["modal1"], t["modal2"], t["occ_order"])
+            losses.append(float(m.step()["loss"]))
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "params4_rank%d.npy" % rank), m.net.flat_params.cpu().numpy())
+        res.update(more_losses=losses, staged_graphs=bool(getattr(m, "_dp_graphs", None)))
         res.update(ok=True, loss=loss, grad_median_err=float(np.median(gerr)))
     except Exception:   # noqa: BLE001
         import traceback

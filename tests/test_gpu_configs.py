@@ -140,10 +140,7 @@ def test_config3_sharded_training_step_equals_oracle_sum(dtype):
         assert cos > 0.97 and abs(ratio - 1) < 0.05
 
 
-def test_two_ranks_step_matches_reference_golden(tmp_path):
-    """Two real ranks through ``step()``: RCCL over two GPUs when the box has them, gloo with both ranks on GPU 0
-    otherwise.  Each rank checks itself against the reference's two-rank golden (tests/dp_worker.py); here: both
-    ranks end with bit-identical weights, and those weights moved."""
+def _run_two_ranks(out_dir, extra_env=None):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -151,22 +148,44 @@ def test_two_ranks_step_matches_reference_golden(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env.update(extra_env or {})
+    os.makedirs(out_dir, exist_ok=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)]
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), str(out_dir)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     res = []
     for r in range(2):
-        f = tmp_path / ("rank%d.json" % r)
-        assert f.exists(), "rank %d wrote no result\n%s\n%s" % (r, p.stdout[-2000:], p.stderr[-4000:])
+        f = os.path.join(out_dir, "rank%d.json" % r)
+        assert os.path.exists(f), "rank %d wrote no result\n%s\n%s" % (r, p.stdout[-2000:], p.stderr[-4000:])
         res.append(json.load(open(f)))
     for r in res:
         assert r["ok"], r.get("error")
     assert p.returncode == 0, p.stderr[-4000:]
-    print("two-rank step over", res[0]["backend"], "on", res[0]["ngpu"], "GPU(s)")
-    p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
-    g0, g1 = np.load(tmp_path / "grads_rank0.npy"), np.load(tmp_path / "grads_rank1.npy")
+    return res
+
+
+def test_two_ranks_step_matches_reference_golden(tmp_path):
+    """Two real ranks through ``step()``: RCCL over two GPUs when the box has them, gloo with both ranks on GPU 0
+    otherwise.  Each rank checks itself against the reference's two-rank golden (tests/dp_worker.py); here: both
+    ranks end with bit-identical weights, and those weights moved.  The worker then takes three more steps -- with
+    hipGraphs the overlapped step is captured as one graph per backward stage (the bucket all-reduces launched in
+    between) and replayed twice; run again with IO_NO_GRAPH=1 the same four steps are eager: the weights after step 4
+    must agree bit for bit between the two forms, and between the ranks."""
+    a, b = tmp_path / "graphs", tmp_path / "eager"
+    res = _run_two_ranks(str(a))
+    print("two-rank step over", res[0]["backend"], "on", res[0]["ngpu"], "GPU(s); staged graphs:", res[0]["staged_graphs"])
+    p0, p1 = np.load(a / "params_rank0.npy"), np.load(a / "params_rank1.npy")
+    g0, g1 = np.load(a / "grads_rank0.npy"), np.load(a / "grads_rank1.npy")
     assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
     assert np.abs(g0).sum() > 0
+    res_e = _run_two_ranks(str(b), {"IO_NO_GRAPH": "1"})
+    assert res[0]["staged_graphs"] and not res_e[0]["staged_graphs"]
+    q0, q1 = np.load(a / "params4_rank0.npy"), np.load(a / "params4_rank1.npy")
+    e0 = np.load(b / "params4_rank0.npy")
+    assert np.array_equal(q0, q1)
+    assert np.array_equal(q0, e0), float(np.abs(q0 - e0).max())
+    assert res[0]["more_losses"] == res_e[0]["more_losses"]
+    assert not np.array_equal(q0, p0)
 
 
 # ---- configs[4]: InstaDepthNet_od at 384 x 384 -----------------------------------------------------------------
