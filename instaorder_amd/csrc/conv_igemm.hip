@@ -885,25 +885,6 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = mv[r] > 0.f ? acc[i][j][r] : 0.f;
             }
         }
-        if constexpr (BWE) {
-            // BN-backward reductions of the producer BN of this gradient tensor (see IoBwStats)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                float yv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    yv[r] = ld_el<TO>(rs_bwy, rowb[r] == kInvalidOff ? kInvalidOff : rowb[r] + j * JS);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (bw.mscale) v = __builtin_fmaf(yv[r] - bw_mu[j], bw_sc[j], bw_sh[j]) > 0.f ? v : 0.f;
-                    acc[i][j][r] = v;
-                    const float vv = rowb[r] == kInvalidOff ? 0.f : v;
-                    bw_s1[j] += vv;
-                    bw_s2[j] += vv * ((yv[r] - bw_mu[j]) * bw_rs[j]);
-                }
-            }
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
