@@ -179,3 +179,67 @@ def test_invalid_labels_fail_loudly():
     io = np.array([0, 1, 2, 1] * 2)
     want = 0.1 * (ce[io == 1].sum() / (io[:B] == 1).sum()) + 0.9 * (ce[io == 0].sum() / (io[:B] == 0).sum())
     assert abs(float(l_a[2]) - float(want)) < 1e-5 * abs(float(want))
+
+
+def test_round3_entry_points_reject_bad_arguments():
+    """The fused data gradient, the residual forward form, the coefficient producers, the staged backward and the two
+    MiDaS losses: unsupported shapes are error codes with a message, nothing is launched on them."""
+    a, b, c, d = buf(1 << 18), buf(1 << 18), buf(1 << 18), buf(1 << 18)
+    t = [buf(4096) for _ in range(6)]
+    opt = _lib.DgradFused()
+    # rows per BatchNorm group not a multiple of 128 (N*H*W = 192, G = 1)
+    opt.xb_y, opt.xb_coef = b.data_ptr(), t[0].data_ptr()
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 3, 8, 8, 64, 64, 1, 1, 0, 1, C.byref(opt), 0, ST()))
+    # coefficient tables without the BatchNorm input they go with
+    opt = _lib.DgradFused()
+    opt.xb_coef = t[0].data_ptr()
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 64, 64, 1, 1, 0, 1, C.byref(opt), 0, ST()))
+    # epilogue BatchNorm without its partial-sum buffers / activation side output without the mask tables
+    opt = _lib.DgradFused()
+    opt.ep_y, opt.ep_mean, opt.ep_rstd = b.data_ptr(), t[0].data_ptr(), t[1].data_ptr()
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 64, 64, 1, 1, 0, 1, C.byref(opt), 0, ST()))
+    opt.ep_p1, opt.ep_p2, opt.ep_act_out = t[2].data_ptr(), t[3].data_ptr(), a.data_ptr()
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 64, 64, 1, 1, 0, 1, C.byref(opt), 0, ST()))
+    # the operand transform on a 5x5 window (taps without a same-size output grid are fine, but Cin must be a multiple of 64)
+    opt = _lib.DgradFused()
+    opt.xb_y, opt.xb_coef = b.data_ptr(), t[0].data_ptr()
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 48, 64, 1, 1, 0, 1, C.byref(opt), 0, ST()))
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 64, 64, 1, 1, 0, 1, None, 0, ST()))   # no option struct
+    bad(L().io_conv2d_dgrad_fused_dt(P(a), P(c), P(d), 2, 8, 8, 64, 64, 1, 1, 0, 1, C.byref(opt), 5, ST()))   # dtype
+    # residual forward form: rows per group, missing tables
+    bad(L().io_conv2d_fwd_resid(P(a), P(b), P(c), P(d), None, 3, 8, 8, 64, 64, 1, P(t[0]), P(t[1]), P(t[2]), None, None, None,
+                                None, 0.1, 1e-5, None, None, None, None, None, 0, ST()))
+    bad(L().io_conv2d_fwd_resid(P(a), P(b), P(c), P(d), None, 2, 8, 8, 64, 64, 1, None, P(t[1]), P(t[2]), None, None, None,
+                                None, 0.1, 1e-5, None, None, None, None, None, 0, ST()))
+    # coefficient producers
+    bad(L().io_bn_bwd_coefs_dt(P(a), P(b), 128, 6, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]), P(c), 1 << 18, 0,
+                               ST()))                                                       # C not 4 * 2^k
+    bad(L().io_bn_bwd_coefs_dt(P(a), P(b), 128, 64, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]), P(c), 1, 0,
+                               ST()))                                                       # partial buffer too small
+    bad(L().io_bn_bwd_coefs_from_tile_partials(P(a), P(b), 192, 64, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]),
+                                               ST()))                                       # rows not whole 128-row tiles
+    # exact-K stem
+    bad(L().io_stem_wgrad_exact(P(a), P(b), P(c), 1, 64, 64, 9, P(d), 1 << 20, P(t[0]), ST()))
+    # MiDaS losses
+    bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 1, 8, 1.0, P(t[0]), P(c), P(d), 1 << 18, ST()))          # one row: no y edges
+    bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 8, 8, 1.0, P(t[0]), P(c), P(d), 1, ST()))                # workspace
+    lab = torch.zeros(4, dtype=torch.long, device=DEV)
+    bad(L().io_disp_order_count(P(a), P(a), P(b), P(b), P(lab), P(lab), 2, 2, 8, 0, 1.0, P(t[0]), P(t[1]), ST()))
+
+
+def test_staged_backward_rejects_bad_stage_ranges():
+    import instaorder_amd as ia
+    from instaorder_amd import engine
+    cfg = dict(algo="InstaOrderNet_o", lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=2), use_rgb=True)
+    m = ia.InstaOrderNet_o(cfg, dist_model=False)
+    net = m.net
+    x8 = torch.zeros(2, 64, 64, 8, device=DEV)
+    m.switch_to("train")
+    logits, ws = net._run_forward(x8, 2, 64, 2, True)
+    dl = torch.zeros_like(logits)
+    for lo, hi in ((2, 2), (-1, 2), (0, 5), (3, 1)):
+        with pytest.raises(RuntimeError):
+            net._run_backward(x8, dl, 2, 64, 2, ws, stages=(lo, hi))
+    net._run_backward(x8, dl, 2, 64, 2, ws, stages=(0, 4))
+    net._pool.give(ws)
