@@ -389,6 +389,13 @@ def main():
                               "share_of_gpu_time": d["total_ms"] / tot_ms,
                               # the other roof, always: algorithmic bytes of the same launches against HBM
                               "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}}
+        if not depthnet and args.mode == "train" and name.startswith("conv_nt_kernel"):
+            # what the FLOP rate of this class does not show ("Round 3")
+            result["roofline"]["note"] = (
+                "algorithmic conv FLOPs only: about half of this class's launches per step also evaluate a BatchNorm pass on "
+                "their A operand while it is staged (second 16-byte load per chunk, per-channel fma, side output) -- work "
+                "that used to be separate HBM-bound kernels (bn_bwd + bn_apply 30.8 -> 8 ms per step) and adds bytes, not "
+                "algorithmic FLOPs, to these launches; mfma_frac_whole_step is the figure that reflects the trade")
         if args.dtype == "bf16" and "wgrad" not in name and gbs / PEAK_HBM_GBS > tfl / peak:
             # bf16 forward / data-gradient GEMMs of ResNet-50 sit below the bf16 ridge (312 FLOP/B): HBM is the roof that
             # binds, the MFMA fraction is reported alongside
