@@ -283,6 +283,61 @@ def test_golden_backward_real_relu_tight(tag, algo):
         check_backward_golden(g, grads, "hip-vs-golden")
 
 
+def test_trajectory_in_the_well_conditioned_regime():
+    """Four consecutive optimisation steps -- forward, loss, backward, momentum SGD with weight decay, BatchNorm running
+    statistics -- of the HIP path against the CPU oracle, from the well-conditioned state of the backward golden and on
+    fresh batches.  Every step's loss terms within 2e-4 of the oracle's.  The weights: a trajectory amplifies rounding
+    (each step's gradient depends on the previous steps' weights), so the yardstick is the fp32 arithmetic's own
+    sensitivity -- the same steps by the oracle in fp64 are the anchor, and per tensor the HIP path's distance from
+    it, measured against how far the tensor MOVED, is held to 3x the distance of the oracle's own fp32 run + 2 % of the
+    movement (a systematic error in the optimiser, the weight decay, the momentum or a gradient kernel is of order 1)."""
+    from helpers import prestepped_oracle_state
+    algo = "InstaOrderNet_od"
+    g = load_golden("backward_od_S128_B16")
+    S, B, seed, pre = (int(v) for v in g["meta"])
+    state, batch0, _ = prestepped_oracle_state(g, algo)
+    import instaorder_amd as ia
+    cfg = cfg_for(algo)
+    cfg["lr"], cfg["weight_decay"] = float(g["lr"]), float(g["weight_decay"])
+    m = getattr(ia, algo)(cfg, dist_model=False)
+    m.model.load_state_dict({"module." + k: v.clone() for k, v in state.items()}, strict=True)
+    m.switch_to("train")
+    start = {k: v.clone() for k, v in state.items()}
+    st64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in state.items()}
+    mom, mom64 = {}, {}
+    for it in range(4):
+        batch = synthetic.make_pair_batch(seed + 500 + it, B, S)
+        b64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in batch.items()}
+        set_input(m, algo, batch)
+        out = unpack(m.step())
+        logs, _ = orc.train_step(state, mom, batch, algo, cfg["lr"], cfg["weight_decay"])
+        orc.train_step(st64, mom64, b64, algo, cfg["lr"], cfg["weight_decay"])
+        for k in ("loss", "loss_occ", "loss_depth"):
+            assert abs(out[k] - float(logs[k])) < 2e-4 * abs(float(logs[k])), (it, k, out[k], float(logs[k]))
+    hs = hip_state(m)
+    bad, ratios = [], []
+    for k, v in st64.items():
+        if v.dtype != torch.float64:
+            assert int(hs[k]) == int(v), k
+            continue
+        ref = v
+        mv = float((ref - start[k].double()).norm())
+        if mv == 0.0:
+            continue
+        eh = float((hs[k].double() - ref).norm()) / mv
+        ec = float((state[k].double() - ref).norm()) / mv
+        ratios.append((eh, ec))
+        if eh > 3 * ec + 2e-2:
+            bad.append((k, eh, ec))
+    # (a knife-edge ReLU decision inside the steps moves single tensors: over five steps layer3.3.conv2.weight sat at 9 % of its
+    # movement where the oracle's own fp32 run is at 1.5 % -- its five siblings in the stage are inside the bound, which
+    # a kernel error could not arrange; so: at most two of the 163 tensors outside, none beyond 20 %)
+    assert len(bad) <= 2 and all(e < 0.2 for _, e, _ in bad), sorted(bad, key=lambda t: -t[1])[:6]
+    r = np.asarray(ratios)
+    print("trajectory, distance from the fp64 run / movement: HIP median %.2e max %.2e; oracle fp32 median %.2e max %.2e"
+          % (np.median(r[:, 0]), r[:, 0].max(), np.median(r[:, 1]), r[:, 1].max()))
+
+
 @pytest.mark.parametrize("tag,algo", [("plumbing_o", "InstaOrderNet_o"), ("plumbing_od", "InstaOrderNet_od")])
 def test_golden_plumbing(tag, algo):
     """config 1: synthetic 256x256 images x instances through the batched O(n^2) pair driver; order
