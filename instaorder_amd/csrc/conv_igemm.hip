@@ -1867,8 +1867,12 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     // sized for either storage type: the fp32 and the bf16 kernels split differently
     const int s0 = plan_wgrad(g, stem, true).splits, s1 = plan_wgrad(g, stem, false).splits;
     const int splits = s0 > s1 ? s0 : s1;
-    if (splits == 1) return 0;
-    return (size_t)splits * g.Co * io_filter_row(g) * sizeof(float);
+    size_t need = splits == 1 ? 0 : (size_t)splits * g.Co * io_filter_row(g) * sizeof(float);
+    if (stem && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g)) {      // one partial per block of the row-persistent kernel
+        const size_t rows = (size_t)io_stem_wgrad_rows_max_blocks() * g.Co * io_filter_row(g) * sizeof(float);
+        if (rows > need) need = rows;
+    }
+    return need;
 }
 
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
@@ -1992,6 +1996,11 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
             IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1, 1, 4);
         } else if (dt_out == IO_BF16) {
             IO_LAUNCH_NT(float, bf16_t, 64, 1, 2, 1);
+        } else if (g.cr && IO_STEM_ROWS && io_stem_rows_ok(g) && !add && !mask && !bws.y && !bws.in_scale) {
+            // whole 128-pixel output rows: the row-persistent kernel of stem.hip (filter resident in LDS, A fragments read
+            // straight out of a compact input patch)
+            return io_launch_stem_rows(g, (const float*)in, (const float*)wgt, (float*)out, st_mean, st_m2, bws.bias,
+                                       bws.relu, st);
         } else if (g.cr) {
             IO_LAUNCH_NT(float, float, 64, 2, 1, 4);      // (3.3 -> 3.1 ms against the double-buffered form)
         } else {
@@ -2037,6 +2046,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     float* dst = p.splits == 1 ? dw : partial;
     int splits = p.splits;
+    bool rows_path = false;
     dim3 grid((unsigned)(p.tiles * p.splits)), block(kThreads);
     // descriptors are rebased per split: what one split spans must fit 32-bit offsets, not the whole tensors
     const size_t in_bytes = (size_t)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
@@ -2098,7 +2108,12 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, 0);                    \
         else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                       \
     } while (0)
-    if (stem && dt_in == IO_F32) {
+    if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g)) {
+        // whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
+        const int rc_rows = io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, partial, partial_bytes, &splits, st);
+        if (rc_rows) return rc_rows;
+        rows_path = true;   // (always reduced, even from one block: the partial IS the only copy)
+    } else if (stem && dt_in == IO_F32) {
         if (g.cr && g.Wo % 32 == 0) {
             if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 3);
             else IO_LAUNCH_WG(float, float, 64, 64, 3);
@@ -2172,7 +2187,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 || rows_path) {
         const size_t n4 = (size_t)g.Co * io_filter_row(g) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
                            splits);

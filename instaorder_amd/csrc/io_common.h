@@ -204,6 +204,17 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
 
 IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+// stem.hip: the exact-K stem forward on whole 128-pixel output rows (row-persistent; statistics partials in the tile
+// format of io_launch_conv_nt, or the inference epilogue relu(acc + bias))
+#ifndef IO_STEM_ROWS
+#define IO_STEM_ROWS 1
+#endif
+bool io_stem_rows_ok(const IoConvGeom& g);
+int io_launch_stem_rows(const IoConvGeom& g, const float* x8, const float* wp, float* out, float* st_mean, float* st_m2,
+                        const float* bias, int relu, hipStream_t st);
+int io_stem_wgrad_rows_max_blocks();
+int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* partial, size_t partial_bytes,
+                              int* nblocks, hipStream_t st);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,

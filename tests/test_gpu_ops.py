@@ -507,6 +507,50 @@ def test_stem(N, S):
     assert float(got[:, 5:].abs().max()) == 0.0      # padded channels never receive gradient
 
 
+@pytest.mark.parametrize("N,S,G", [(2, 256, 2), (3, 256, 1), (20, 256, 2), (2, 512, 1), (2, 128, 2)])
+def test_stem_exact_k_rows(N, S, G):
+    """The fp32 step's stem: reduction over the 5 REAL channels, BatchNorm statistics from the convolution's epilogue.
+    128 | Wo runs the row-persistent kernel of csrc/stem.hip -- N = 2: one output row per block (no steady state),
+    N = 3: two rows per block, N = 20: ten (the branch-free steady-state body), S = 512: two column blocks per output row;
+    S = 128 (Wo = 64) is the generic exact-K kernel.  Every output element against an fp64 convolution, the statistics
+    against the fp64 mean / variance of the output per sample group."""
+    g = torch.Generator().manual_seed(11 + N + S)
+    x = torch.randn(N, 5, S, S, generator=g, dtype=torch.float64)
+    x[:, :2] = (x[:, :2] > 0).double()                      # the two mask planes
+    w = torch.randn(64, 5, 7, 7, generator=g, dtype=torch.float64) / 15.0
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    x8 = engine.pack_nchw(x.float().to(DEV))
+    Ho = S // 2
+    y = torch.full((N, Ho, Ho, 64), float("nan"), device=DEV)
+    gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    mean, rstd, scale, shift = (torch.full((G * 64,), float("nan"), device=DEV) for _ in range(4))
+    nws = L().io_conv2d_bnstats_workspace_floats(N, S, S, 64, 7, 7, 2, 3, G)
+    ws = torch.empty(nws, device=DEV)
+    packed = torch.empty(L().io_stem_packed_floats(5), device=DEV)
+    _lib.check(L().io_stem_fwd_bnstats_exact(P(x8), P(krsc(w, 8)), P(y), N, S, S, 5, G, P(gamma), P(beta), P(rm), P(rv), 0.1,
+                                             1e-5, P(mean), P(rstd), P(scale), P(shift), P(ws), nws, P(packed), ST()),
+               "stem exact")
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+    rg = ref.view(G, N // G, 64, Ho, Ho) if N % G == 0 else None
+    assert rg is not None
+    mref = rg.mean(dim=(1, 3, 4))
+    vref = rg.var(dim=(1, 3, 4), unbiased=False)
+    assert float((mean.view(G, 64).cpu().double() - mref).abs().max()) < 2e-5 * float(vref.sqrt().max())
+    assert relerr(rstd.view(G, 64), 1.0 / torch.sqrt(vref + 1e-5)) < 2e-5
+    # filter gradient over the same 5 real channels (row-persistent where the forward is; one partial per block)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    wq = w.clone().requires_grad_(True)
+    gref = torch.autograd.grad(F.conv2d(x, wq, stride=2, padding=3), wq, dy)[0]
+    nb = L().io_stem_wgrad_exact_workspace_bytes(N, S, S, 5)
+    wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 49, 8), float("nan"), device=DEV)
+    _lib.check(L().io_stem_wgrad_exact(P(x8), P(nhwc(dy)), P(dw), N, S, S, 5, P(wsb), nb, P(packed), ST()), "stem wgrad exact")
+    got = dw.view(64, 7, 7, 8).permute(0, 3, 1, 2)
+    assert relerr(got[:, :5], gref) < 2e-5
+    assert float(got[:, 5:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("N,H,C,G", [(4, 8, 64, 1), (4, 8, 256, 2), (6, 4, 2048, 2), (2, 16, 128, 1), (8, 1, 512, 2)])
 def test_batchnorm(N, H, C, G):
     """train-mode BN (+ReLU, + residual) forward, running statistics, backward; G groups == G
