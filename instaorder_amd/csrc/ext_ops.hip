@@ -678,19 +678,20 @@ __device__ __forceinline__ bool eroded(const float* m, int H, int W, int h, int 
     return m[i] != 0.f && m[i - 1] != 0.f && m[i + 1] != 0.f && m[i - W] != 0.f && m[i + W] != 0.f;
 }
 
-// one block per sample.  pass 0: max over eroded mask 2 / min over eroded mask 1 of both disparity maps; pass 1: the four
+constexpr int kDispThreads = 1024;
+// one block of 1024 threads per sample (a pair batch is 8..64 samples of 147 k pixels: the block size IS the parallelism).  pass 0: max over eroded mask 2 / min over eroded mask 1 of both disparity maps; pass 1: the four
 // counts of each map; out[b] = the sample's contribution (0 when the pair is skipped)
-__global__ __launch_bounds__(kThreads) void disp_order_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+__global__ __launch_bounds__(kDispThreads) void disp_order_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
                                                              const float* __restrict__ m1, const float* __restrict__ m2,
                                                              const long* __restrict__ order, const long* __restrict__ ovl,
                                                              int H, int W, int le_order, float* __restrict__ out) {
-    __shared__ float shf[4][kThreads];
-    __shared__ int shi[4][kThreads];
+    __shared__ float shf[4][kDispThreads];
+    __shared__ int shi[4][kDispThreads];
     const int b = blockIdx.x, N = H * W;
     const float *p1 = d1 + (size_t)b * N, *p2 = d2 + (size_t)b * N, *q1 = m1 + (size_t)b * N, *q2 = m2 + (size_t)b * N;
     float mx2[2] = {-INFINITY, -INFINITY}, mn1[2] = {INFINITY, INFINITY};
     int any1 = 0, any2 = 0;
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = threadIdx.x; i < N; i += kDispThreads) {
         const int h = i / W, w = i - h * W;
         const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
         const float v[2] = {p1[i], p2[i]};
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(kThreads) void disp_order_kernel(const float* __res
     shf[0][threadIdx.x] = mx2[0]; shf[1][threadIdx.x] = mx2[1]; shf[2][threadIdx.x] = mn1[0]; shf[3][threadIdx.x] = mn1[1];
     shi[0][threadIdx.x] = any1; shi[1][threadIdx.x] = any2;
     __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
+    for (int off = kDispThreads / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             shf[0][threadIdx.x] = fmaxf(shf[0][threadIdx.x], shf[0][threadIdx.x + off]);
             shf[1][threadIdx.x] = fmaxf(shf[1][threadIdx.x], shf[1][threadIdx.x + off]);
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(kThreads) void disp_order_kernel(const float* __res
     const bool use = ovl[b] == 0 && (od == 0 || od == 1) && have;
     int le[2] = {0, 0}, ge[2] = {0, 0};
     if (use)
-        for (int i = threadIdx.x; i < N; i += kThreads) {
+        for (int i = threadIdx.x; i < N; i += kDispThreads) {
             const int h = i / W, w = i - h * W;
             const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
             const float v[2] = {p1[i], p2[i]};
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void disp_order_kernel(const float* __res
         }
     shi[0][threadIdx.x] = le[0]; shi[1][threadIdx.x] = ge[0]; shi[2][threadIdx.x] = le[1]; shi[3][threadIdx.x] = ge[1];
     __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
+    for (int off = kDispThreads / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off)
             for (int t = 0; t < 4; ++t) shi[t][threadIdx.x] += shi[t][threadIdx.x + off];
         __syncthreads();
@@ -797,7 +798,7 @@ extern "C" int io_disp_order_count(const float* disp1, const float* disp2, const
                                    const long* depth_order1, const long* is_overlap, int B, int H, int W, int le_order,
                                    float out_scale, float* out, float* per_sample, hipStream_t st) {
     IO_REQUIRE(B > 0 && H > 2 && W > 2, IO_ERR_SHAPE, "disp_order_count: B=%d H=%d W=%d", B, H, W);
-    hipLaunchKernelGGL(disp_order_kernel, dim3(B), dim3(kThreads), 0, st, disp1, disp2, modal1, modal2, depth_order1,
+    hipLaunchKernelGGL(disp_order_kernel, dim3(B), dim3(kDispThreads), 0, st, disp1, disp2, modal1, modal2, depth_order1,
                        is_overlap, H, W, le_order, per_sample);
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(kThreads), 0, st, per_sample, B, out_scale / ((float)H * (float)W), out);
     return io_check_launch("disp_order_count");
