@@ -309,6 +309,17 @@ int io_stem_fwd_bnstats_exact(const float* x8, const float* w, float* y, int N, 
                               float* workspace, size_t workspace_floats, float* packed, hipStream_t stream);
 int io_stem_wgrad_exact(const float* x8, const float* dy, float* dw, int N, int H, int W, int real_channels,
                         void* workspace, size_t workspace_bytes, float* packed, hipStream_t stream);
+/* The same gradient with bn1's backward (resnet_cls.py:157: the BatchNorm behind the stem) folded into it: da[N,H/2,W/2,64]
+ * is the gradient of relu(bn1(y)) -- what the max-pool backward leaves -- and y the raw stem output.  One reduction pass
+ * produces dgamma / dbeta and the coefficient tables coef[3][G][64] (a, b, c of dy = a * dz + b * y + c, dz = da where
+ * scale * (y - mean) + shift > 0); the gradient kernel applies them while it stages its rows, so dy is never written.
+ * Needs 5 real channels, 256 | H, W and G | N (IO_ERR_SHAPE otherwise: use io_bn_bwd + io_stem_wgrad_exact).
+ * bn_partial: io_bn_partial_floats(N * H/2 * W/2, 64, G) floats; workspace as io_stem_wgrad_exact. */
+int io_stem_wgrad_exact_bn(const float* x8, const float* da, const float* y, float* dw, int N, int H, int W,
+                           int real_channels, int G, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, float* dgamma, float* dbeta, float* coef,
+                           float* bn_partial, size_t bn_partial_floats, void* workspace, size_t workspace_bytes,
+                           float* packed, hipStream_t stream);
 
 /* ---- BatchNorm backward without an apply pass: the training step's fused data-gradient launch ---------------------------
  * autograd of `out = conv(relu(bn(y)))` chains (models/backbone/resnet_cls.py:99-113, loss.backward() at

@@ -128,6 +128,8 @@ SIGNATURES = {
     "io_stem_fwd_bnstats_exact": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P,
                                        _P]),
     "io_stem_wgrad_exact": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    "io_stem_wgrad_exact_bn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P,
+                                    _P]),
     "io_conv2d_fwd_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P,
                                  _P, _P, _Z, _P]),
     "io_smooth_loss_workspace_floats": (_Z, [_I, _I, _I]),

@@ -854,12 +854,15 @@ extern "C" int io_bn_bwd(const float* dout, const float* act, const float* mask_
                        partial, partial_floats, coef, st, IO_F32);
 }
 
+// mask_scale / mask_shift != nullptr: dz is the gradient of relu(bn(y)) and the ReLU mask is recomputed from y with the
+// forward tables (as io_bn_bwd_t's mask mode does); whoever applies the coefficients must apply the same mask
 int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
                       const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
-                      size_t partial_floats, hipStream_t st, int dt) {
+                      size_t partial_floats, hipStream_t st, int dt, const float* mask_scale, const float* mask_shift) {
     const int sh = ilog2_exact(C / 4);
     IO_REQUIRE(C % 4 == 0 && sh >= 0 && C <= 2048, IO_ERR_SHAPE, "bn_bwd_coefs: C=%d unsupported", C);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_bwd_coefs: M=%d not divisible by G=%d", M, G);
+    IO_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), IO_ERR_SHAPE, "bn_bwd_coefs: the mask tables come in pairs");
     IO_REQUIRE(partial_floats >= io_bn_partial_floats(M, C, G), IO_ERR_WORKSPACE, "bn_bwd_coefs: partial too small");
     const int Mg = M / G;
     int nb;
@@ -869,12 +872,10 @@ int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const 
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C * 2.0, st);
     if (dt == IO_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb, G), dim3(kThreads), 0, st, (const bf16_t*)dz,
-                           (const bf16_t*)nullptr, (const bf16_t*)y, Mg, C, rpb, mean, rstd, (const float*)nullptr,
-                           (const float*)nullptr, p1, p2);
+                           (const bf16_t*)nullptr, (const bf16_t*)y, Mg, C, rpb, mean, rstd, mask_scale, mask_shift, p1, p2);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, G), dim3(kThreads), 0, st, (const float*)dz,
-                           (const float*)nullptr, (const float*)y, Mg, C, rpb, mean, rstd, (const float*)nullptr,
-                           (const float*)nullptr, p1, p2);
+                           (const float*)nullptr, (const float*)y, Mg, C, rpb, mean, rstd, mask_scale, mask_shift, p1, p2);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(io_cdiv(C, 8)), dim3(256), 0, st, p1, p2, nb, G, Mg, C, dgamma, dbeta,
                        coef, coef + (size_t)G * C, gamma, mean, rstd, coef + (size_t)2 * G * C);
     return io_check_launch("bn_bwd_coefs");

@@ -469,6 +469,36 @@ extern "C" int io_stem_wgrad_exact(const float* x8, const float* dy, float* dw, 
     return io_stem_unpack_grad(packed, dw, 64, 49, real_channels, st);
 }
 
+/* ... with bn1's backward evaluated while the gradient kernel stages its rows (what the fp32 step runs where 256 | H, W):
+ * da = gradient of relu(bn1(y)) (the pooling backward's output), y = the raw stem output */
+extern "C" int io_stem_wgrad_exact_bn(const float* x8, const float* da, const float* y, float* dw, int N, int H, int W,
+                                      int real_channels, int G, const float* gamma, const float* mean, const float* rstd,
+                                      const float* scale, const float* shift, float* dgamma, float* dbeta, float* coef,
+                                      float* bn_partial, size_t bn_partial_floats, void* ws, size_t ws_bytes, float* packed,
+                                      hipStream_t st) {
+    IO_REQUIRE(real_channels >= 1 && real_channels <= 8 && packed && coef, IO_ERR_SHAPE,
+               "stem_wgrad_exact_bn: real_channels=%d (1..8)", real_channels);
+    IoConvGeom g = stem_geom_exact(N, H, W, real_channels);
+    IO_REQUIRE(IO_STEM_ROWS && io_stem_rows_ok(g) && G >= 1 && N % G == 0, IO_ERR_SHAPE,
+               "stem_wgrad_exact_bn: needs 5 real channels, 256 | H, W and G | N (else: io_bn_bwd + io_stem_wgrad_exact)");
+    const int M = N * g.Ho * g.Wo;
+    int rc = io_bn_bwd_coefs_t(da, y, M, 64, G, gamma, mean, rstd, dgamma, dbeta, coef, bn_partial, bn_partial_floats, st, IO_F32,
+                               scale, shift);
+    if (rc) return rc;
+    IoStemXb xb{};
+    xb.y = y;
+    xb.a = coef;
+    xb.b = coef + (size_t)G * 64;
+    xb.c = coef + (size_t)2 * G * 64;
+    xb.mean = mean;
+    xb.scale = scale;
+    xb.shift = shift;
+    xb.G = G;
+    rc = io_launch_stem_wgrad_rows(g, x8, da, packed, (float*)ws, ws_bytes, st, &xb);
+    if (rc) return rc;
+    return io_stem_unpack_grad(packed, dw, 64, 49, real_channels, st);
+}
+
 extern "C" size_t io_bn_tile_partial_floats(int M, int C, int G) {
     if (M <= 0 || C <= 0 || G <= 0) return 0;
     const size_t tiles = (size_t)(M + kIoStatTileRows - 1) / kIoStatTileRows;

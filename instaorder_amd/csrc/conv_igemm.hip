@@ -2044,9 +2044,11 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     const size_t need = io_conv_wgrad_partial_bytes(g, stem);
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
+    // the fp32 exact-K stem on whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
+    if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g))
+        return io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, dw, partial, partial_bytes, st);
     float* dst = p.splits == 1 ? dw : partial;
     int splits = p.splits;
-    bool rows_path = false;
     dim3 grid((unsigned)(p.tiles * p.splits)), block(kThreads);
     // descriptors are rebased per split: what one split spans must fit 32-bit offsets, not the whole tensors
     const size_t in_bytes = (size_t)io_dtype_bytes(dt_in) * g.N * g.Hi * g.Wi * g.Ci;
@@ -2108,12 +2110,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         else if (p.bnc == 128) IO_LAUNCH_WG(TX_, TDY_, 64, 128, 0);                    \
         else IO_LAUNCH_WG(TX_, TDY_, 64, 64, 0);                                       \
     } while (0)
-    if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g)) {
-        // whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
-        const int rc_rows = io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, partial, partial_bytes, &splits, st);
-        if (rc_rows) return rc_rows;
-        rows_path = true;   // (always reduced, even from one block: the partial IS the only copy)
-    } else if (stem && dt_in == IO_F32) {
+    if (stem && dt_in == IO_F32) {
         if (g.cr && g.Wo % 32 == 0) {
             if (dt_dy == IO_BF16) IO_LAUNCH_WG(float, bf16_t, 64, 64, 3);
             else IO_LAUNCH_WG(float, float, 64, 64, 3);
@@ -2187,11 +2184,11 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #undef IO_LAUNCH_WG
     int rc = io_check_launch("conv_wgrad");
     if (rc) return rc;
-    if (splits > 1 || rows_path) {
-        const size_t n4 = (size_t)g.Co * io_filter_row(g) / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dw, n4,
-                           splits);
-        rc = io_check_launch("splitk_reduce");
-    }
+    if (splits > 1) rc = io_splitk_reduce(partial, dw, (size_t)g.Co * io_filter_row(g) / 4, splits, st);
     return rc;
+}
+
+int io_splitk_reduce(const float* partial, float* dst, size_t n4, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(io_cdiv((long)n4, 32)), dim3(256), 0, st, partial, dst, n4, splits);
+    return io_check_launch("splitk_reduce");
 }

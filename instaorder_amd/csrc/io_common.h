@@ -160,7 +160,8 @@ int io_bn_bwd_coefs_from_tiles(float* p1, float* p2, int M, int C, int G, const 
 // ... and from (dz, y) themselves: reduction pass + finalize, no apply.  dz must already carry the ReLU mask.
 int io_bn_bwd_coefs_t(const void* dz, const void* y, int M, int C, int G, const float* gamma, const float* mean,
                       const float* rstd, float* dgamma, float* dbeta, float* coef, float* partial,
-                      size_t partial_floats, hipStream_t st, int dt);
+                      size_t partial_floats, hipStream_t st, int dt, const float* mask_scale = nullptr,
+                      const float* mask_shift = nullptr);
 // storage-typed internals behind the fp32 C entry points of the same name (dt: IoDType of the tensors)
 int io_bn_stats_finalize_t(const void* y, int M, int C, int G, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
@@ -213,8 +214,17 @@ bool io_stem_rows_ok(const IoConvGeom& g);
 int io_launch_stem_rows(const IoConvGeom& g, const float* x8, const float* wp, float* out, float* st_mean, float* st_m2,
                         const float* bias, int relu, hipStream_t st);
 int io_stem_wgrad_rows_max_blocks();
-int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* partial, size_t partial_bytes,
-                              int* nblocks, hipStream_t st);
+// BatchNorm backward of the stem's bn1 evaluated in the staging of its filter gradient (stem.hip): y = the raw conv output,
+// a / b / c = the coefficient tables of io_bn_bwd_coefs_t, mean / scale / shift = the forward tables the ReLU mask is
+// recomputed from; all [G][64]
+struct IoStemXb {
+    const float *y, *a, *b, *c, *mean, *scale, *shift;
+    int G, tiles_per_group;
+};
+int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* dwp, float* partial,
+                              size_t partial_bytes, hipStream_t st, const IoStemXb* xb = nullptr);
+// dst[i] = sum over `splits` slabs of n4 float4, fixed order (conv_igemm.hip)
+int io_splitk_reduce(const float* partial, float* dst, size_t n4, int splits, hipStream_t st);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,

@@ -613,6 +613,9 @@ bool tiles_ok(const Ctx& c, int M) { return M % c.G == 0 && (M / c.G) % kIoStatT
 #ifndef IO_XB
 #define IO_XB 1
 #endif
+#ifndef IO_STEM_XB
+#define IO_STEM_XB 1     // bn1 (stem) backward in the staging of the stem's filter gradient (stem.hip)
+#endif
 #ifndef IO_XB1S
 #define IO_XB1S 1       // ... and bn1's of the three blocks whose conv2 is strided
 #endif
@@ -846,8 +849,34 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
     if (stage_hi < kBwdStages) return IO_OK;
     // Gd = d(maxpool output)
     IO_TRY(io_maxpool_bwd_t(Gd, reinterpret_cast<const uint32_t*>(c.ws + p.idx0), c.N, H0, H0, 64, Ge, c.st, c.dt()));
+    // stem filter gradient only: the network input needs no data gradient -- so bn1's backward has ONE reader, and on
+    // the row-persistent kernel it is evaluated while that reader stages its rows (no apply pass: reduction + tables only)
+    {
+        IoConvGeom g = io_geom_fwd(c.N, c.S, c.S, 8, 64, 7, 7, 2, 3);
+        g.cr = net->stem.cin;
+        if (IO_STEM_XB && IO_STEM_ROWS && stem_exact(c, net->stem) && io_stem_rows_ok(g) && c.N % c.G == 0) {
+            const BnL& b = net->bn1;
+            Tables t = c.tables(b);
+            IO_TRY(io_bn_bwd_coefs_t(Ge, c.act(p.y0), c.N * H0 * H0, b.C, c.G, c.params + b.g_off, t.mean, t.rstd,
+                                     c.grads + b.g_off, c.grads + b.b_off, c.buf(c.plan.coef), c.buf(c.plan.bn_partial),
+                                     c.plan.bn_partial_floats, c.st, c.dt(), t.scale, t.shift));
+            const size_t gs = (size_t)c.G * b.C;
+            IoStemXb xb{};
+            xb.y = (const float*)c.act(p.y0);
+            xb.a = c.buf(c.plan.coef);
+            xb.b = c.buf(c.plan.coef) + gs;
+            xb.c = c.buf(c.plan.coef) + 2 * gs;
+            xb.mean = t.mean;
+            xb.scale = t.scale;
+            xb.shift = t.shift;
+            xb.G = c.G;
+            IO_TRY(io_launch_stem_wgrad_rows(g, (const float*)x8, (const float*)Ge, c.buf(c.plan.stem_dwp),
+                                             c.buf(c.plan.wg_partial), c.plan.wg_partial_bytes, c.st, &xb));
+            return io_stem_unpack_grad(c.buf(c.plan.stem_dwp), c.grads + net->stem.w_off, net->stem.cout, 49,
+                                       net->stem.cin, c.st);
+        }
+    }
     IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.act(p.y0), c.N * H0 * H0, Ga, nullptr));
-    // stem filter gradient only: the network input needs no data gradient
     IO_TRY(conv_wgrad(c, net->stem, x8, Ga, c.S));
     return IO_OK;
 }

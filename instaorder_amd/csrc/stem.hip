@@ -20,6 +20,8 @@
 // Blocks take CONTIGUOUS runs of rows, so the five input rows two consecutive output rows share come out of the L2 of the
 // XCD that just fetched them.
 //
+// (filter gradient: below, with its own header)
+//
 // Measured (512 x 256 x 256, tools/one_stem.py, profiles/r03_stem_rows.txt): 2.37 ms = 111 TF/s against 3.1 ms; with
 // stores, fetch + staging and statistics compiled out (IO_STEM_ABLATE=7) the MFMA + fragment-read loop alone is 1.95 ms =
 // 135 TF/s, i.e. at what v_mfma_f32_32x32x2_f32 sustains on this part -- the remaining 0.4 ms is the epilogue work that
@@ -238,9 +240,14 @@ constexpr int kWPatch = kRounds * kNT * kCR + 40;       // floats per patch buff
 constexpr int kWDy = 128 * 64;
 constexpr size_t kWLds = (size_t)2 * (kWPatch + kWDy) * sizeof(float);
 
+// XB: `dy` is the gradient of relu(bn1(y)) as the pooling backward leaves it, and the BatchNorm backward is applied
+// while the rows are staged: dz = da where fma(y - mean, scale, shift) > 0 (bn_affine of bn.hip: the mask bit the
+// reduction pass saw), dy = a * dz + b * y + c with the [G][64] tables of io_bn_bwd_coefs_t -- the stem has no data
+// gradient, so this kernel is dy's only reader and the apply pass (read dz, read y, write dy) has no reason to exist.
+template <bool XB>
 __global__ __launch_bounds__(kNT, 1) void stem_wgrad_rows_kernel(const float* __restrict__ x8, const float* __restrict__ dy,
                                                                  float* __restrict__ partial, int Hi, int Wi, int Ho, int Wo,
-                                                                 int ntiles, int per_block) {
+                                                                 int ntiles, int per_block, IoStemXb xb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                       // [2][kWPatch]
     float* sD = smem + 2 * kWPatch;         // [2][128][64]
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kNT, 1) void stem_wgrad_rows_kernel(const float* __
     const int cbn = Wo >> 7;
 
     float pr[kRounds][kCR];
-    f32x4 dr[4];
+    f32x4 dr[4], yr[4], tb[6];              // tb: a, b, c, mean, scale, shift of this thread's 4 channels (XB)
     int p_r[kRounds], p_c[kRounds], p_off[kRounds], p_dst[kRounds];
     bool p_ok[kRounds];
 #pragma unroll
@@ -264,6 +271,8 @@ __global__ __launch_bounds__(kNT, 1) void stem_wgrad_rows_kernel(const float* __
     }
     int f_cb = t_lo % cbn, f_ho = (t_lo / cbn) % Ho, f_n = (t_lo / cbn) / Ho;
     const float* f_dy = dy + (size_t)t_lo * kWDy + tid * 4;
+    const float* f_y = XB ? xb.y + (size_t)t_lo * kWDy + tid * 4 : nullptr;
+    int f_t = t_lo;
     auto fetch = [&]() {
         const int hi0 = 2 * f_ho - 3, wi0 = 256 * f_cb - 3;
         const float* base = x8 + (((ptrdiff_t)f_n * Hi + hi0) * Wi + wi0) * 8;
@@ -286,6 +295,19 @@ __global__ __launch_bounds__(kNT, 1) void stem_wgrad_rows_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) dr[i] = *reinterpret_cast<const f32x4*>(f_dy + i * kNT * 4);
         f_dy += kWDy;
+        if constexpr (XB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yr[i] = *reinterpret_cast<const f32x4*>(f_y + i * kNT * 4);
+            f_y += kWDy;
+            const int go = (f_t / xb.tiles_per_group) * 64 + (tid & 15) * 4;     // a row belongs to one sample group
+            ++f_t;
+            tb[0] = *reinterpret_cast<const f32x4*>(xb.a + go);
+            tb[1] = *reinterpret_cast<const f32x4*>(xb.b + go);
+            tb[2] = *reinterpret_cast<const f32x4*>(xb.c + go);
+            tb[3] = *reinterpret_cast<const f32x4*>(xb.mean + go);
+            tb[4] = *reinterpret_cast<const f32x4*>(xb.scale + go);
+            tb[5] = *reinterpret_cast<const f32x4*>(xb.shift + go);
+        }
     };
     auto stage = [&](int buf) {
         float* dst = sP + buf * kWPatch;
@@ -295,7 +317,18 @@ __global__ __launch_bounds__(kNT, 1) void stem_wgrad_rows_kernel(const float* __
             for (int c = 0; c < kCR; ++c) dst[p_dst[i] + c] = p_ok[i] ? pr[i][c] : 0.f;
         float* dd = sD + buf * kWDy + tid * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dd + i * kNT * 4) = dr[i];
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = dr[i];
+            if constexpr (XB) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float act = __builtin_fmaf(yr[i][e] - tb[3][e], tb[4][e], tb[5][e]);
+                    const float dz = act > 0.f ? v[e] : 0.f;
+                    v[e] = __builtin_fmaf(tb[0][e], dz, __builtin_fmaf(tb[1][e], yr[i][e], tb[2][e]));
+                }
+            }
+            *reinterpret_cast<f32x4*>(dd + i * kNT * 4) = v;
+        }
     };
 
     fetch();
@@ -398,10 +431,11 @@ int io_launch_stem_rows(const IoConvGeom& g, const float* x8, const float* wp, f
 // blocks (= partial filter gradients) io_launch_stem_wgrad_rows may use: what the caller's workspace is sized for
 int io_stem_wgrad_rows_max_blocks() { return 256; }
 
-// The filter gradient of the same geometry: writes *nblocks partials [nblocks][64][256] (packed exact-K rows); the caller
-// reduces them.
-int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* partial, size_t partial_bytes,
-                              int* nblocks, hipStream_t st) {
+// The filter gradient of the same geometry into the packed exact-K rows dwp[64][256]: one partial per block, summed in a
+// fixed order (io_splitk_reduce).  xb != nullptr: dy is the pooling backward's output and the BatchNorm backward rides
+// in the staging (see the kernel).
+int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* dwp, float* partial,
+                              size_t partial_bytes, hipStream_t st, const IoStemXb* xb) {
     IO_REQUIRE(io_stem_rows_ok(g), IO_ERR_SHAPE, "stem_wgrad_rows: not the 7x7 stride-2 stem on whole 128-pixel output rows");
     const int ntiles = g.N * g.Ho * (g.Wo / 128);
     static int ncu = 0;
@@ -410,15 +444,33 @@ int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float*
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0 || ncu > io_stem_wgrad_rows_max_blocks()) ncu = io_stem_wgrad_rows_max_blocks();
-        (void)hipFuncSetAttribute((const void*)stem_wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+        (void)hipFuncSetAttribute((const void*)stem_wgrad_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+        (void)hipFuncSetAttribute((const void*)stem_wgrad_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
     }
     const int blocks = ntiles < ncu ? ntiles : ncu;
     const int per_block = (ntiles + blocks - 1) / blocks;
     const int grid = (ntiles + per_block - 1) / per_block;
     IO_REQUIRE(partial && partial_bytes >= (size_t)grid * 64 * 256 * sizeof(float), IO_ERR_WORKSPACE,
                "stem_wgrad_rows: workspace %zu < %zu bytes", partial_bytes, (size_t)grid * 64 * 256 * sizeof(float));
-    hipLaunchKernelGGL(stem_wgrad_rows_kernel, dim3((unsigned)grid), dim3(kNT), kWLds, st, x8, dy, partial, g.Hi, g.Wi, g.Ho,
-                       g.Wo, ntiles, per_block);
-    *nblocks = grid;
-    return io_check_launch("stem_wgrad_rows");
+    IoStemXb x{};
+    if (xb) {
+        x = *xb;
+        IO_REQUIRE(x.y && x.a && x.b && x.c && x.mean && x.scale && x.shift && x.G >= 1 && g.N % x.G == 0, IO_ERR_SHAPE,
+                   "stem_wgrad_rows: the fused BatchNorm backward needs y, six [G][64] tables and G | N");
+        x.tiles_per_group = ntiles / x.G;
+    }
+    const double Md = (double)g.N * g.Ho * g.Wo;
+    {
+        IoProfScope prof(IO_PROF_WGRAD_STEM, 2.0 * Md * 64 * 49.0 * kCR,
+                         4.0 * (Md * 64 * (xb ? 2.0 : 1.0) + (double)g.N * g.Hi * g.Wi * 8 + 64.0 * 49 * kCR), st);
+        if (xb)
+            hipLaunchKernelGGL(stem_wgrad_rows_kernel<true>, dim3((unsigned)grid), dim3(kNT), kWLds, st, x8, dy, partial, g.Hi,
+                               g.Wi, g.Ho, g.Wo, ntiles, per_block, x);
+        else
+            hipLaunchKernelGGL(stem_wgrad_rows_kernel<false>, dim3((unsigned)grid), dim3(kNT), kWLds, st, x8, dy, partial, g.Hi,
+                               g.Wi, g.Ho, g.Wo, ntiles, per_block, x);
+        const int rc = io_check_launch("stem_wgrad_rows");
+        if (rc) return rc;
+        return io_splitk_reduce(partial, dwp, (size_t)64 * 256 / 4, grid, st);
+    }
 }

@@ -512,6 +512,46 @@ def test_stem_launches_at_bench_size(mode):
     ref = ref_wgrad(x, dy, S, 8, Cout, k, s, osel, csel, taps)
     assert relerr(dw[osel][:, taps], ref[:, taps]) < 2e-5
     assert float(dw[..., 5:].abs().max()) == 0.0
+    if not exact:
+        return
+    # what the fp32 step launches since the row-persistent stem: bn1's backward evaluated in the staging of the filter
+    # gradient.  `dy` above now plays da = d relu(bn1(y)); reference: the BatchNorm-backward formula in fp64 on the device
+    # from the kernel's own y / tables (the mask is the sign of fma(y - mean, scale, shift), reproduced exactly in fp64),
+    # for the sampled output channels, then the same full-reduction gather as above.
+    Mg = M // G
+    yq, daq = y.view(G, Mg, Cout), dy.view(G, Mg, Cout)
+    mu, rs = mean.view(G, 1, Cout).double(), rstd.view(G, 1, Cout).double()
+    s1 = torch.zeros(G, Cout, dtype=torch.float64, device=DEV)
+    s2 = torch.zeros(G, Cout, dtype=torch.float64, device=DEV)
+    step = 1 << 17
+    dzf = lambda gi, r0, r1: torch.where(
+        ((yq[gi, r0:r1] - mean.view(G, Cout)[gi]).double() * scale.view(G, Cout)[gi].double() + shift.view(G, Cout)[gi].double()) > 0,
+        daq[gi, r0:r1].double(), torch.zeros((), dtype=torch.float64, device=DEV))
+    for gi in range(G):
+        for r0 in range(0, Mg, step):
+            r1 = min(r0 + step, Mg)
+            dz = dzf(gi, r0, r1)
+            s1[gi] += dz.sum(0)
+            s2[gi] += (dz * ((yq[gi, r0:r1].double() - mu[gi]) * rs[gi])).sum(0)
+    dysel = torch.empty(M, osel.numel(), dtype=torch.float64, device=DEV)
+    for gi in range(G):
+        for r0 in range(0, Mg, step):
+            r1 = min(r0 + step, Mg)
+            xh = (yq[gi, r0:r1].double() - mu[gi]) * rs[gi]
+            full = (gamma.double() * rs[gi]) * (dzf(gi, r0, r1) - s1[gi] / Mg - xh * (s2[gi] / Mg))
+            dysel[gi * Mg + r0:gi * Mg + r1] = full[:, osel]
+    npart = lib.io_bn_partial_floats(M, Cout, G)
+    part = torch.empty(npart, device=DEV)
+    coef = torch.full((3 * G * Cout,), float("nan"), device=DEV)
+    dgam, dbet = (torch.full((Cout,), float("nan"), device=DEV) for _ in range(2))
+    dw2 = torch.full((Cout, k * k, 8), float("nan"), device=DEV)
+    _lib.check(lib.io_stem_wgrad_exact_bn(P(x), P(dy), P(y), P(dw2), N, S, S, 5, G, P(gamma), P(mean), P(rstd), P(scale),
+                                          P(shift), P(dgam), P(dbet), P(coef), P(part), npart, P(wsb), nb, P(packed), ST()),
+               "stem wgrad exact + bn1 backward")
+    ref2 = ref_wgrad(x, dysel, S, 8, osel.numel(), k, s, torch.arange(osel.numel(), device=DEV), csel, taps)
+    assert relerr(dw2[osel][:, taps], ref2[:, taps]) < 1e-4
+    assert float(dw2[..., 5:].abs().max()) == 0.0
+    assert relerr(dbet, s1.sum(0)) < 1e-5 and relerr(dgam, s2.sum(0)) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -549,6 +549,42 @@ def test_stem_exact_k_rows(N, S, G):
     got = dw.view(64, 7, 7, 8).permute(0, 3, 1, 2)
     assert relerr(got[:, :5], gref) < 2e-5
     assert float(got[:, 5:].abs().max()) == 0.0
+    if S % 256:
+        return
+    # ... and with bn1's backward folded into the gradient kernel's staging (resnet_cls.py:157-158: relu(bn1(conv1(x)))):
+    # da = gradient of the ReLU output; reference = autograd through batch_norm + relu + conv in fp64, per sample group
+    gamma = (torch.rand(64, generator=g, dtype=torch.float64) + 0.5)
+    beta = torch.randn(64, generator=g, dtype=torch.float64) * 0.3
+    da = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    wq = w.clone().requires_grad_(True)
+    gq, bq = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    _lib.check(L().io_stem_fwd_bnstats_exact(P(x8), P(krsc(w, 8)), P(y), N, S, S, 5, G, P(gamma.float().to(DEV)),
+                                             P(beta.float().to(DEV)), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale),
+                                             P(shift), P(ws), nws, P(packed), ST()), "stem exact (tables)")
+    # the ReLU mask as the kernels see it: sign of fma(y - mean, scale, shift) on the fp32 output and tables (the product of
+    # two floats is exact in fp64, so this reproduces the bit; a mask from the fp64 forward flips a knife-edge element or
+    # two in 21 M, each worth 1e-3 of the largest filter-gradient entry)
+    yv = y.view(G, N // G, Ho, Ho, 64)
+    tabs = [t.view(G, 1, 1, 1, 64) for t in (mean, scale, shift)]
+    mask = ((yv - tabs[0]).double() * tabs[1].double() + tabs[2].double()) > 0
+    mask = mask.view(N, Ho, Ho, 64).permute(0, 3, 1, 2).cpu()
+    yq = F.conv2d(x, wq, stride=2, padding=3)
+    outs = [F.batch_norm(yq[k * (N // G):(k + 1) * (N // G)], None, None, gq, bq, True, 0.1, 1e-5) for k in range(G)]
+    gw, gg, gb = torch.autograd.grad(torch.cat(outs), (wq, gq, bq), da * mask)
+    M = N * Ho * Ho
+    npart = L().io_bn_partial_floats(M, 64, G)
+    part = torch.empty(npart, device=DEV)
+    coef = torch.full((3 * G * 64,), float("nan"), device=DEV)
+    dgam, dbet = torch.full((64,), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
+    dw2 = torch.full((64, 49, 8), float("nan"), device=DEV)
+    _lib.check(L().io_stem_wgrad_exact_bn(P(x8), P(nhwc(da)), P(y), P(dw2), N, S, S, 5, G, P(gamma.float().to(DEV)), P(mean),
+                                          P(rstd), P(scale), P(shift), P(dgam), P(dbet), P(coef), P(part), npart, P(wsb), nb,
+                                          P(packed), ST()), "stem wgrad exact + bn")
+    got2 = dw2.view(64, 7, 7, 8).permute(0, 3, 1, 2)
+    # (BatchNorm backward subtracts the two projections: the result is small against its terms, hence the looser bound)
+    assert relerr(got2[:, :5], gw) < 2e-4
+    assert float(got2[:, 5:].abs().max()) == 0.0
+    assert relerr(dgam, gg) < 1e-4 and relerr(dbet, gb) < 1e-4
 
 
 @pytest.mark.parametrize("N,H,C,G", [(4, 8, 64, 1), (4, 8, 256, 2), (6, 4, 2048, 2), (2, 16, 128, 1), (8, 1, 512, 2)])
