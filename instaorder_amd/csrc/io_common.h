@@ -225,6 +225,17 @@ int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float*
                               size_t partial_bytes, hipStream_t st, const IoStemXb* xb = nullptr);
 // dst[i] = sum over `splits` slabs of n4 float4, fixed order (conv_igemm.hip)
 int io_splitk_reduce(const float* partial, float* dst, size_t n4, int splits, hipStream_t st);
+// all filter transposes of a network in one launch (misc.hip): entry l = filter [O][T][C] at element offset off[l] of the
+// parameter buffer; its transpose lands at the same element offset of wt_all
+struct IoFilterTable {
+    static constexpr int kMax = 64;
+    int n;
+    int start[kMax + 1];     // first 32 x 32 tile of entry l (start[n] = grid size)
+    int O[kMax], T[kMax], C[kMax];
+    unsigned off[kMax];
+};
+int io_filter_table_add(IoFilterTable& tab, long off, int O, int T, int C);
+int io_filter_transpose_all(const IoFilterTable& tab, const float* params, void* wt_all, hipStream_t st, int dt);
 IoConvGeom io_geom_dgrad(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int ph, int pw);
 int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, const void* mask, int N, int H,
                  int W, int Cin, int Cout, int R, int S, int stride, int pad, hipStream_t st,

@@ -99,6 +99,9 @@ BnL add_bn(io_net* net, const char* name, int C) {
 }
 
 // ---- workspace plan ---------------------------------------------------------------------------
+#ifndef IO_WT_ALL
+#define IO_WT_ALL 1      // all filter transposes of a backward pass in one launch
+#endif
 constexpr size_t kNoBuf = ~(size_t)0;
 struct BlockBufs {
     size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets (a1 / a2 = kNoBuf: never materialised, see fuse_in)
@@ -115,6 +118,7 @@ struct Plan {
     size_t wt, wg_partial, wg_partial_bytes;
     size_t wop;          // bf16 mode: operand copy of the whole flat parameter buffer (same element offsets)
     size_t stem_wp, stem_dwp;   // fp32: exact-K stem filter / filter gradient, [64][io_stem_kp]
+    size_t wt_all;              // transposed copies of all filters (kNoBuf: one transpose launch per data gradient)
     size_t wfold, fbias; // eval: filters with the BatchNorm scale folded in (storage type, parameter offsets) + biases
     size_t total;
 };
@@ -208,6 +212,9 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
         p.wg_partial_bytes = wg;
         p.wg_partial = a.take(wg);
         p.wt = a.take(wtmax);
+        // every filter's transpose (the B operand of its data gradient) at the filter's own offset: one launch per
+        // backward pass instead of one per layer
+        p.wt_all = IO_WT_ALL ? a.take((size_t)net->param_floats * e) : kNoBuf;
     } else {
         // eval: rotating buffers (block input / a1 / a2 / y / yd / output)
         const size_t r0 = a.take(maxact), r1 = a.take(maxact), r2 = a.take(maxact), r3 = a.take(maxact),
@@ -222,6 +229,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
         for (int i = 0; i < 5; ++i) p.gbuf[i] = 0;
         p.aside = kNoBuf;
         p.wg_partial = p.wt = 0;
+        p.wt_all = kNoBuf;
         p.wg_partial_bytes = 0;
     }
     p.total = a.top;
@@ -598,10 +606,27 @@ int conv_wgrad(const Ctx& c, const ConvL& L, const void* x, const void* dy, int 
                                 c.st, c.dt(), c.dt());
 }
 
+// the transposes of ALL filters (io_net_backward's first stage; the staged calls of one pass share the workspace)
+int transpose_filters(const Ctx& c) {
+    if (c.plan.wt_all == kNoBuf) return IO_OK;
+    IoFilterTable tab;
+    tab.n = 0;
+    tab.start[0] = 0;
+    for (const Block& b : c.net->blocks) {
+        const ConvL* cs[4] = {&b.c1, &b.c2, &b.c3, b.down ? &b.cd : nullptr};
+        for (int j = 0; j < 4; ++j)
+            if (cs[j]) IO_TRY(io_filter_table_add(tab, cs[j]->w_off, cs[j]->cout, cs[j]->k * cs[j]->k, cs[j]->cin));
+    }
+    return io_filter_transpose_all(tab, c.params, c.act(c.plan.wt_all), c.st, c.dt());
+}
+
 int conv_dgrad(const Ctx& c, const ConvL& L, const void* dy, void* dx, const void* add, const void* mask,
                int H, const IoBwStats* bw = nullptr) {
     void* wt = c.act(c.plan.wt);
-    IO_TRY(io_filter_prepare_t(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, 1, c.st, c.dt()));
+    if (c.plan.wt_all != kNoBuf)
+        wt = (char*)c.act(c.plan.wt_all) + (size_t)L.w_off * io_dtype_bytes(c.dt());
+    else
+        IO_TRY(io_filter_prepare_t(c.params + L.w_off, L.cout, L.k * L.k, L.cin, wt, 1, c.st, c.dt()));
     return io_run_dgrad(dy, wt, dx, add, mask, c.N, H, H, L.cin, L.cout, L.k, L.k, L.stride, L.pad, c.st, bw, c.dt());
 }
 
@@ -720,6 +745,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
     // Gradients of block outputs are kept ALREADY MASKED by that output's ReLU: whoever writes the last
     // contribution to d(out) applies [out > 0] in its epilogue (here: the pooling backward; below: the
     // data-gradient kernels), so the BN backward of the block needs neither the activation nor a mask pass.
+    if (stage_lo == 0) IO_TRY(transpose_filters(c));
     if (stage_lo == 0)
     IO_TRY(io_avgpool_fc_bwd_t(dlogits, c.buf(p.pooled), c.N, Hlast * Hlast, 2048, c.params + net->fcw_off[0],
                                net->head_dims[0], w1, net->n_heads > 1 ? net->head_dims[1] : 0,
