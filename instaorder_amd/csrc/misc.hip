@@ -2,6 +2,10 @@
 // global-average-pool + FC heads, order losses, momentum SGD, filter transposition.
 #include "io_common.h"
 
+#ifndef IO_POOL_ROWS
+#define IO_POOL_ROWS 1
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -131,6 +135,139 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
         }
         st4(dx + i * 4, acc);
     }
+}
+
+// Row forms of the two pooling kernels: one block per output row (forward) / input row (backward), threads over
+// (column, 16-byte channel chunk).  The element-indexed forms above decode (n, h, w, chunk) from a 64-bit flat index with
+// three divisions by run-time values per element and move 8 bytes per lane on bf16 tensors; here the row is decoded once
+// per block on the scalar unit, the column split is a shift when C / VEC is a power of two, and a lane always moves 16
+// bytes (4 fp32 / 8 bf16 channels).
+template <typename T> struct PoolChunk;
+template <> struct PoolChunk<float> {
+    static constexpr int NV = 1;
+    static __device__ __forceinline__ void load(const float* p, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, const f32x4* v) { *reinterpret_cast<f32x4*>(p) = v[0]; }
+};
+template <> struct PoolChunk<bf16_t> {
+    static constexpr int NV = 2;
+    static __device__ __forceinline__ void load(const bf16_t* p, f32x4* v) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k >> 1][(k & 1) * 2] = __builtin_bit_cast(float, w[k] << 16);
+            v[k >> 1][(k & 1) * 2 + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const f32x4* v) {
+        uint4 r;
+        r.x = io_f2bf2(v[0][0], v[0][1]); r.y = io_f2bf2(v[0][2], v[0][3]);
+        r.z = io_f2bf2(v[1][0], v[1][1]); r.w = io_f2bf2(v[1][2], v[1][3]);
+        *reinterpret_cast<uint4*>(p) = r;
+    }
+};
+
+template <typename T, bool XF>
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_rows_kernel(const T* __restrict__ x, int N, int H, int W, int C,
+                                                                   T* __restrict__ out, uint32_t* __restrict__ idx,
+                                                                   const float* __restrict__ xs,
+                                                                   const float* __restrict__ xh, int npg,
+                                                                   const float* __restrict__ xm, int cv_shift) {
+    constexpr int NV = PoolChunk<T>::NV, VEC = 4 * NV;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, CV = C / VEC;
+    const int ho = (int)blockIdx.x % Ho, n = (int)blockIdx.x / Ho;
+    const int gi = XF ? n / npg : 0;
+    const T* xn = x + (size_t)n * H * W * C;
+    const size_t orow = (size_t)blockIdx.x * Wo;
+    for (int j = threadIdx.x; j < Wo * CV; j += kThreads) {
+        const int wo = cv_shift >= 0 ? j >> cv_shift : j / CV;
+        const int q = j - wo * CV;
+        f32x4 mu[NV], sc[NV], sh[NV], best[NV];
+        uint32_t bi[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            mu[k] = 0.f; sc[k] = 1.f; sh[k] = 0.f; best[k] = -INFINITY; bi[k] = 0;
+            if constexpr (XF) {
+                const size_t to = (size_t)gi * C + q * VEC + 4 * k;
+                if (xm) mu[k] = *reinterpret_cast<const f32x4*>(xm + to);
+                sc[k] = *reinterpret_cast<const f32x4*>(xs + to);
+                sh[k] = *reinterpret_cast<const f32x4*>(xh + to);
+            }
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * 2 - 1 + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                f32x4 v[NV];
+                PoolChunk<T>::load(xn + ((size_t)h * W + w) * C + q * VEC, v);
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = v[k][e];
+                        if constexpr (XF) a = fmaxf(__builtin_fmaf(a - mu[k][e], sc[k][e], sh[k][e]), 0.f);
+                        if (a > best[k][e] || a != a) {
+                            best[k][e] = a;
+                            bi[k] = (bi[k] & ~(0xffu << (8 * e))) | ((uint32_t)(kh * 3 + kw) << (8 * e));
+                        }
+                    }
+            }
+        }
+        const size_t o = (orow + wo) * CV + q;
+        PoolChunk<T>::store(out + o * VEC, best);
+        if (idx) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) idx[o * NV + k] = bi[k];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_rows_kernel(const T* __restrict__ dy,
+                                                                   const uint32_t* __restrict__ idx, int N, int H, int W,
+                                                                   int C, T* __restrict__ dx, int cv_shift) {
+    constexpr int NV = PoolChunk<T>::NV, VEC = 4 * NV;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, CV = C / VEC;
+    const int h = (int)blockIdx.x % H, n = (int)blockIdx.x / H;
+    const size_t irow = (size_t)blockIdx.x * W;
+    for (int j = threadIdx.x; j < W * CV; j += kThreads) {
+        const int w = cv_shift >= 0 ? j >> cv_shift : j / CV;
+        const int q = j - w * CV;
+        f32x4 acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+        // windows (ho, wo) with 2*ho-1 <= h <= 2*ho+1
+        for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+            if (ho >= Ho) continue;
+            const int kh = h - (2 * ho - 1);
+            for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+                if (wo >= Wo) continue;
+                const uint32_t kk = kh * 3 + (w - (2 * wo - 1));
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * CV + q;
+                f32x4 g[NV];
+                PoolChunk<T>::load(dy + o * VEC, g);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const uint32_t id = idx[o * NV + k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (((id >> (8 * e)) & 0xffu) == kk) acc[k][e] += g[k][e];
+                }
+            }
+        }
+        PoolChunk<T>::store(dx + ((irow + w) * CV + q) * VEC, acc);
+    }
+}
+
+// log2(v) when v is a power of two, else -1
+int pow2_shift(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
 }
 
 // ---- global average pool + FC heads (resnet_cls.py:152-160, 214-222) ----------------------------
@@ -453,13 +590,27 @@ int io_maxpool_fwd_t(const void* x, int N, int H, int W, int C, void* out, uint3
 #define IO_MP(T_, XF_)                                                                                              \
     hipLaunchKernelGGL((maxpool_fwd_kernel<T_, XF_>), dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const T_*)x, N, H, \
                        W, C, (T_*)out, idx, xs, xh, npg, xm)
-    if (dt == IO_BF16) {
+    const int vec = dt == IO_BF16 ? 8 : 4;
+    const long rows = (long)N * ((H + 1) / 2);
+#define IO_MPR(T_, XF_)                                                                                             \
+    hipLaunchKernelGGL((maxpool_fwd_rows_kernel<T_, XF_>), dim3((unsigned)rows), dim3(kThreads), 0, st, (const T_*)x, N, H, \
+                       W, C, (T_*)out, idx, xs, xh, npg, xm, pow2_shift(C / vec))
+    if (IO_POOL_ROWS && C % vec == 0 && rows < (1L << 31)) {
+        if (dt == IO_BF16) {
+            if (xs) IO_MPR(bf16_t, true);
+            else IO_MPR(bf16_t, false);
+        } else {
+            if (xs) IO_MPR(float, true);
+            else IO_MPR(float, false);
+        }
+    } else if (dt == IO_BF16) {
         if (xs) IO_MP(bf16_t, true);
         else IO_MP(bf16_t, false);
     } else {
         if (xs) IO_MP(float, true);
         else IO_MP(float, false);
     }
+#undef IO_MPR
 #undef IO_MP
     return io_check_launch("maxpool_fwd");
 }
@@ -482,7 +633,16 @@ int io_maxpool_bwd_t(const void* dy, const uint32_t* idx, int N, int H, int W, i
     IO_REQUIRE(C % 4 == 0, IO_ERR_SHAPE, "maxpool: C=%d", C);
     const size_t total = (size_t)N * H * W * (C / 4);
     IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, (double)io_dtype_bytes(dt) * N * H * W * C * 1.3125, st);
-    if (dt == IO_BF16)
+    const int vec = dt == IO_BF16 ? 8 : 4;
+    const long rows = (long)N * H;
+    if (IO_POOL_ROWS && C % vec == 0 && rows < (1L << 31)) {
+        if (dt == IO_BF16)
+            hipLaunchKernelGGL(maxpool_bwd_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(kThreads), 0, st,
+                               (const bf16_t*)dy, idx, N, H, W, C, (bf16_t*)dx, pow2_shift(C / vec));
+        else
+            hipLaunchKernelGGL(maxpool_bwd_rows_kernel<float>, dim3((unsigned)rows), dim3(kThreads), 0, st, (const float*)dy,
+                               idx, N, H, W, C, (float*)dx, pow2_shift(C / vec));
+    } else if (dt == IO_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(kThreads), 0, st, (const bf16_t*)dy,
                            idx, N, H, W, C, (bf16_t*)dx);
     else
