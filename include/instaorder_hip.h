@@ -177,8 +177,16 @@ long io_net_activation_offset(const io_net* net, int N, int S, int which);
  * io_net_backward. */
 int io_net_forward(io_net* net, const float* params, float* running, const void* x8, int N, int S, int G,
                    int training, void* workspace, size_t workspace_bytes, float* logits, hipStream_t stream);
+/* Inference forward on H x W inputs (both multiples of 32): the eval path of io_net_forward (folded BatchNorm, running
+ * statistics) for inputs that are not square -- resnet_cls.py:199-222 is fully convolutional up to its AdaptiveAvgPool, and
+ * the reference's 'orig' inference mode (inference.py:401-407) feeds it whole images at their own aspect ratio.
+ * x8[N,H,W,8] in the net's storage type; workspace of io_net_workspace_bytes_hw(net, N, H, W) bytes. */
+size_t io_net_workspace_bytes_hw(const io_net* net, int N, int H, int W);
+int io_net_forward_eval_hw(io_net* net, const float* params, float* running, const void* x8, int N, int H, int W,
+                           void* workspace, size_t workspace_bytes, float* logits, hipStream_t stream);
 /* gradient of every parameter into grads (same layout as params; fully overwritten).  Must follow a
  * training io_net_forward with the same x8 / N / S / G / workspace. */
+
 /* The same pass cut into io_net_backward_num_stages() stages in execution order -- 0: heads + layer4, 1: layer3,
  * 2: layer2, 3: layer1 + stem -- running the stages [stage_lo, stage_hi).  The parameter gradients of a stage are final
  * when its call returns (stream order), so a data-parallel caller can start the exchange of that contiguous slice of
@@ -433,6 +441,11 @@ typedef struct io_pair_desc {
 int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
                       const io_pair_desc* desc_host, int P, int S, const double* mean3, const double* std3, float* rgb,
                       float* modal1, float* modal2, hipStream_t stream);
+/* ... onto SH x SW planes (rgb[P][3][SH][SW], modal1 / modal2 [P][SH][SW]): the 'orig' inference mode renders the whole
+ * image at its own aspect ratio, sides rounded to multiples of 32 (inference.py:401-407, 490-496, 569-575). */
+int io_pair_planes_u8_hw(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
+                         const io_pair_desc* desc_host, int P, int SH, int SW, const double* mean3, const double* std3,
+                         float* rgb, float* modal1, float* modal2, hipStream_t stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of

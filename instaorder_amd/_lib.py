@@ -80,6 +80,7 @@ SIGNATURES = {
     "io_avgpool_fc_bwd": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "io_pack_planes_nhwc8": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), _I, _I, _I, _I, _P, _P]),
     "io_pair_planes_u8": (_I, [_P, _Z, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "io_pair_planes_u8_hw": (_I, [_P, _Z, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "io_order_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P]),
     "io_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),
     "io_net_create": (_P, [_I, _I, C.POINTER(C.c_int)]),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "io_net_tensor_info": (_I, [_P, _I, C.POINTER(TensorInfo)]),
     "io_net_num_logits": (_I, [_P]),
     "io_net_workspace_bytes": (_Z, [_P, _I, _I, _I]),
+    "io_net_workspace_bytes_hw": (_Z, [_P, _I, _I, _I]),
+    "io_net_forward_eval_hw": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _P]),
     "io_net_activation_offset": (_L, [_P, _I, _I, _I]),
     "io_net_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "io_net_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),

@@ -132,13 +132,16 @@ struct Arena {
     }
 };
 
-Plan make_plan(const io_net* net, int N, int S, bool training) {
+// SW: input width when it differs from the height S (eval only: the 'orig' inference mode feeds whole images at their
+// own aspect ratio); 0 = square
+Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
     Plan p;
     Arena a;
-    const int H0 = S / 2, H1 = S / 4;
+    if (SW <= 0) SW = S;
+    const int H0 = S / 2, H1 = S / 4, W0 = SW / 2;
     const size_t f = sizeof(float);
     const size_t e = (size_t)io_dtype_bytes(net->dtype);   // activation element size
-    const size_t maxact = (size_t)N * H0 * H0 * 64 * e;   // == N*H1*H1*256*e, the largest activations
+    const size_t maxact = (size_t)N * H0 * W0 * 64 * e;   // == N*H1*W1*256*e, the largest activations
     p.wop = net->dtype == IO_BF16 ? a.take((size_t)net->param_floats * sizeof(bf16_t)) : 0;
     {
         const size_t sb = (size_t)64 * io_stem_kp(49, net->in_ch) * f;
@@ -154,7 +157,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training) {
     p.pooled = a.take((size_t)N * 2048 * f);
     {
         // per (128-row tile, channel) partials of the widest conv output + room for the level-1 merge
-        const size_t tiles_x_c = (size_t)N * H0 * H0 * 64 / kIoStatTileRows + (size_t)kMaxGroups * 2048;
+        const size_t tiles_x_c = (size_t)N * H0 * W0 * 64 / kIoStatTileRows + (size_t)kMaxGroups * 2048;
         const size_t fl = training ? tiles_x_c + tiles_x_c / 32 + (size_t)kMaxGroups * 2048 : 0;
         p.tile_mean = a.take(fl * f);
         p.tile_m2 = a.take(fl * f);
@@ -283,6 +286,7 @@ struct Ctx {
     char* ws;
     Plan plan;
     int N, S, G;
+    int SW;                 // input width (== S except for an eval forward on a non-square input)
     bool training;
     hipStream_t st;
     std::vector<long> chan_prefix;
@@ -429,8 +433,9 @@ int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, co
 }
 
 // conv + folded BatchNorm (+ residual) (+ ReLU) of an inference forward
-int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int H, const void* add, int relu) {
-    IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
+int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int H, int W, const void* add,
+                int relu) {
+    IoConvGeom g = io_geom_fwd(c.N, H, W, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     IoBwStats ep{};
     ep.bias = c.fbias(b);
     ep.relu = relu;
@@ -472,28 +477,30 @@ int run_forward_eval(Ctx& c, const void* x8, float* logits) {
                                reinterpret_cast<float*>(c.ws + p.wfold), c.buf(p.fbias));
         IO_TRY(io_check_launch("fold_bn"));
     }
-    IO_TRY(conv_folded(c, net->stem, net->bn1, x8, c.act(p.a0), c.S, nullptr, 1));
-    IO_TRY(io_maxpool_fwd_t(c.act(p.a0), c.N, H0, H0, 64, c.act(p.p0), nullptr, c.st, c.dt()));
+    const int W0 = c.SW / 2;
+    IO_TRY(conv_folded(c, net->stem, net->bn1, x8, c.act(p.a0), c.S, c.SW, nullptr, 1));
+    IO_TRY(io_maxpool_fwd_t(c.act(p.a0), c.N, H0, W0, 64, c.act(p.p0), nullptr, c.st, c.dt()));
     const void* x = c.act(p.p0);
-    int H = H1;
+    int H = H1, W = c.SW / 4;
     for (size_t i = 0; i < net->blocks.size(); ++i) {
         const Block& b = net->blocks[i];
         const BlockBufs& bb = p.blk[i];
-        const int Ho = H / b.stride;
-        IO_TRY(conv_folded(c, b.c1, b.b1, x, c.act(bb.a1), H, nullptr, 1));
-        IO_TRY(conv_folded(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.a2), H, nullptr, 1));
+        const int Ho = H / b.stride, Wo = W / b.stride;
+        IO_TRY(conv_folded(c, b.c1, b.b1, x, c.act(bb.a1), H, W, nullptr, 1));
+        IO_TRY(conv_folded(c, b.c2, b.b2, c.act(bb.a1), c.act(bb.a2), H, W, nullptr, 1));
         const void* identity = x;
         if (b.down) {
-            IO_TRY(conv_folded(c, b.cd, b.bd, x, c.act(bb.yd), H, nullptr, 0));
+            IO_TRY(conv_folded(c, b.cd, b.bd, x, c.act(bb.yd), H, W, nullptr, 0));
             identity = c.act(bb.yd);
         }
-        IO_TRY(conv_folded(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.out), Ho, identity, 1));
+        IO_TRY(conv_folded(c, b.c3, b.b3, c.act(bb.a2), c.act(bb.out), Ho, Wo, identity, 1));
         x = c.act(bb.out);
         H = Ho;
+        W = Wo;
     }
     const float* w1 = net->n_heads > 1 ? c.params + net->fcw_off[1] : nullptr;
     const float* b1 = net->n_heads > 1 ? c.params + net->fcb_off[1] : nullptr;
-    return io_avgpool_fc_fwd_t(x, c.N, H * H, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
+    return io_avgpool_fc_fwd_t(x, c.N, H * W, 2048, c.params + net->fcw_off[0], c.params + net->fcb_off[0],
                                net->head_dims[0], w1, b1, net->n_heads > 1 ? net->head_dims[1] : 0, c.buf(p.pooled),
                                logits, c.st, c.dt());
 }
@@ -1025,16 +1032,17 @@ extern "C" long io_net_activation_offset(const io_net* net, int N, int S, int wh
 }
 
 static void fill_ctx(Ctx& c, io_net* net, const float* params, float* running, float* grads, int N, int S, int G,
-                     bool training, void* ws, hipStream_t st) {
+                     bool training, void* ws, hipStream_t st, int SW = 0) {
     c.net = net;
     c.params = params;
     c.running = running;
     c.grads = grads;
     c.ws = (char*)ws;
     c.N = N; c.S = S; c.G = G;
+    c.SW = SW > 0 ? SW : S;
     c.training = training;
     c.st = st;
-    c.plan = make_plan(net, N, S, training);
+    c.plan = make_plan(net, N, S, training, c.SW);
     c.chan_prefix.assign(net->n_bn, 0);
     // BN index -> channel prefix (tables are packed in BN creation order)
     std::vector<int> Cs(net->n_bn, 0);
@@ -1058,6 +1066,28 @@ extern "C" int io_net_forward(io_net* net, const float* params, float* running, 
     IO_REQUIRE(ws_bytes >= c.plan.total, IO_ERR_WORKSPACE, "io_net_forward: workspace %zu < %zu bytes", ws_bytes,
                c.plan.total);
     return run_forward(c, x8, logits);
+}
+
+// Inference on H x W inputs (the reference's 'orig' mode: the whole image at its own aspect ratio, sides rounded to
+// multiples of 32; the network is fully convolutional up to the global average pool)
+static int check_shape_hw(int N, int H, int W) {
+    IO_REQUIRE(H >= 32 && H % 32 == 0 && W >= 32 && W % 32 == 0, IO_ERR_SHAPE,
+               "input %d x %d: both sides must be multiples of 32 (five stride-2 stages)", H, W);
+    IO_REQUIRE(N >= 1 && (double)N * H * W < 2.0e9, IO_ERR_SHAPE, "N=%d x %d x %d: more than 2^31 input pixels", N, H, W);
+    return IO_OK;
+}
+extern "C" size_t io_net_workspace_bytes_hw(const io_net* net, int N, int H, int W) {
+    if (check_shape_hw(N, H, W)) return 0;
+    return make_plan(net, N, H, false, W).total;
+}
+extern "C" int io_net_forward_eval_hw(io_net* net, const float* params, float* running, const void* x8, int N, int H,
+                                      int W, void* ws, size_t ws_bytes, float* logits, hipStream_t st) {
+    IO_TRY(check_shape_hw(N, H, W));
+    Ctx c;
+    fill_ctx(c, net, params, running, nullptr, N, H, 1, false, ws, st, W);
+    IO_REQUIRE(ws_bytes >= c.plan.total, IO_ERR_WORKSPACE, "io_net_forward_eval_hw: workspace %zu < %zu bytes", ws_bytes,
+               c.plan.total);
+    return run_forward_eval(c, x8, logits);
 }
 
 extern "C" int io_net_backward(io_net* net, const float* params, float* grads, const void* x8,

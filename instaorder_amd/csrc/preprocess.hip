@@ -87,21 +87,23 @@ __device__ __forceinline__ void cubic_coefs_f(int d, int src, int dst, int (&idx
 }
 
 __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restrict__ arena,
-                                                         const io_pair_desc* __restrict__ desc, int S,
+                                                         const io_pair_desc* __restrict__ desc, int SH, int S,
                                                          double m0, double m1, double m2, double s0, double s1, double s2,
                                                          float* __restrict__ rgb, float* __restrict__ modal1,
                                                          float* __restrict__ modal2) {
     const int p = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= S * S) return;
+    // (S = output width, SH = output height; the square outputs of the training / 'patch' / 'image' / 'resize' paths
+    // have SH == S, the 'orig' inference mode renders the whole image at its own aspect ratio)
+    if (pix >= SH * S) return;
     const io_pair_desc d = desc[p];
     const int oy = pix / S, ox = pix - oy * S;
     const int dx = d.flip ? S - 1 - ox : ox;
-    const size_t plane = (size_t)S * S;
+    const size_t plane = (size_t)SH * S;
 
     // masks: nearest sample of the zero-padded crop
     {
-        const int cx = nearest_index(dx, d.w, S), cy = nearest_index(oy, d.h, S);
+        const int cx = nearest_index(dx, d.w, S), cy = nearest_index(oy, d.h, SH);
         const int ix = d.x + cx, iy = d.y + cy;
         const bool in = (unsigned)ix < (unsigned)d.W && (unsigned)iy < (unsigned)d.H;
         const size_t o = in ? (size_t)iy * d.W + ix : 0;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
         int xi[4], yi[4];
         float xa[4], ya[4];
         cubic_coefs_f(dx, d.w, S, xi, xa);
-        cubic_coefs_f(oy, d.h, S, yi, ya);
+        cubic_coefs_f(oy, d.h, SH, yi, ya);
         double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
         for (int c = 0; c < 3; ++c) rgb[(p * 3 + c) * plane + pix] = (float)((acc[c] - mean[c]) / sd[c]);
         return;
     }
-    const Taps tx = make_taps(dx, d.w, S, d.interp), ty = make_taps(oy, d.h, S, d.interp);
+    const Taps tx = make_taps(dx, d.w, S, d.interp), ty = make_taps(oy, d.h, SH, d.interp);
     int h[4][3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -178,12 +180,22 @@ __global__ __launch_bounds__(256) void pair_planes_kernel(const uint8_t* __restr
 
 }  // namespace
 
+extern "C" int io_pair_planes_u8_hw(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
+                                    const io_pair_desc* desc_host, int P, int SH, int SW, const double* mean3,
+                                    const double* std3, float* rgb, float* modal1, float* modal2, hipStream_t st);
 extern "C" int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
                                  const io_pair_desc* desc_host, int P, int S, const double* mean3, const double* std3,
                                  float* rgb, float* modal1, float* modal2, hipStream_t st) {
-    IO_REQUIRE(P > 0 && S > 0 && arena && desc_dev && desc_host && modal1 && modal2, IO_ERR_SHAPE,
-               "pair_planes: empty batch or null pointer (P=%d, S=%d)", P, S);
-    IO_REQUIRE(P <= 65535 && (long)S * S < (1L << 31), IO_ERR_SHAPE, "pair_planes: P=%d S=%d out of range", P, S);
+    return io_pair_planes_u8_hw(arena, arena_bytes, desc_dev, desc_host, P, S, S, mean3, std3, rgb, modal1, modal2, st);
+}
+
+extern "C" int io_pair_planes_u8_hw(const uint8_t* arena, size_t arena_bytes, const io_pair_desc* desc_dev,
+                                    const io_pair_desc* desc_host, int P, int SH, int SW, const double* mean3,
+                                    const double* std3, float* rgb, float* modal1, float* modal2, hipStream_t st) {
+    const int S = SW;
+    IO_REQUIRE(P > 0 && SH > 0 && SW > 0 && arena && desc_dev && desc_host && modal1 && modal2, IO_ERR_SHAPE,
+               "pair_planes: empty batch or null pointer (P=%d, %d x %d)", P, SH, SW);
+    IO_REQUIRE(P <= 65535 && (long)SH * SW < (1L << 31), IO_ERR_SHAPE, "pair_planes: P=%d %d x %d out of range", P, SH, SW);
     IO_REQUIRE(!rgb || (mean3 && std3), IO_ERR_SHAPE, "pair_planes: rgb output needs mean / std");
     // the descriptors are validated on the host copy: every byte the kernel may touch lies inside the arena
     for (int p = 0; p < P; ++p) {
@@ -205,8 +217,8 @@ extern "C" int io_pair_planes_u8(const uint8_t* arena, size_t arena_bytes, const
             m[c] = mean3[c];
             s[c] = std3[c];
         }
-    IoProfScope prof(IO_PROF_PACK, 0.0, (double)P * S * S * (rgb ? 20.0 : 8.0), st);
-    hipLaunchKernelGGL(pair_planes_kernel, dim3(io_cdiv((long)S * S, 256), P), dim3(256), 0, st, arena, desc_dev, S,
+    IoProfScope prof(IO_PROF_PACK, 0.0, (double)P * SH * S * (rgb ? 20.0 : 8.0), st);
+    hipLaunchKernelGGL(pair_planes_kernel, dim3(io_cdiv((long)SH * S, 256), P), dim3(256), 0, st, arena, desc_dev, SH, S,
                        m[0], m[1], m[2], s[0], s[1], s[2], rgb, modal1, modal2);
     return io_check_launch("pair_planes");
 }

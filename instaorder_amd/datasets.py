@@ -69,12 +69,16 @@ def crop_plan(mode, modal_shape, bboxes, idx1, idx2, phase, base_aug, rng, rands
 
 # ---- the device renderer --------------------------------------------------------------------------------------------
 class PairRenderer(object):
-    """uint8 images + instance masks -> (rgb[P,3,S,S], modal1[P,1,S,S], modal2[P,1,S,S]) fp32 on the GPU."""
+    """uint8 images + instance masks -> (rgb[P,3,S,S], modal1[P,1,S,S], modal2[P,1,S,S]) fp32 on the GPU.
+    ``input_size`` = S, or (height, width) for outputs that are not square (the 'orig' inference mode)."""
 
     def __init__(self, input_size, mean, std, device="cuda:0"):
         if not torch.cuda.is_available():
             raise RuntimeError("instaorder_amd.datasets.PairRenderer needs a GPU (there is no CPU path)")
-        self.S = int(input_size)
+        if isinstance(input_size, (tuple, list)):
+            self.SH, self.S = int(input_size[0]), int(input_size[1])
+        else:
+            self.SH = self.S = int(input_size)
         self.device = torch.device(device)
         self.mean = (C.c_double * 3)(*[float(v) for v in mean])
         self.std = (C.c_double * 3)(*[float(v) for v in std])
@@ -98,7 +102,7 @@ class PairRenderer(object):
         P = len(items)
         if P == 0:
             raise ValueError("PairRenderer.render: empty batch")
-        S = self.S
+        S, SH = self.S, self.SH
         # arena layout: every referenced image once, every referenced mask once (16-byte aligned)
         off, cursor = {}, 0
 
@@ -137,17 +141,17 @@ class PairRenderer(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._events[slot] = ev
-        rgb = torch.empty((P, 3, S, S), device=self.device) if load_rgb else None
-        m1 = torch.empty((P, 1, S, S), device=self.device)
-        m2 = torch.empty((P, 1, S, S), device=self.device)
-        rc = _lib.lib().io_pair_planes_u8(
+        rgb = torch.empty((P, 3, SH, S), device=self.device) if load_rgb else None
+        m1 = torch.empty((P, 1, SH, S), device=self.device)
+        m2 = torch.empty((P, 1, SH, S), device=self.device)
+        rc = _lib.lib().io_pair_planes_u8_hw(
             C.c_void_p(dev.data_ptr()), C.c_size_t(nbytes), C.c_void_p(dev.data_ptr() + nbytes),
-            C.cast(desc, C.c_void_p), P, S, C.cast(self.mean, C.c_void_p), C.cast(self.std, C.c_void_p),
+            C.cast(desc, C.c_void_p), P, SH, S, C.cast(self.mean, C.c_void_p), C.cast(self.std, C.c_void_p),
             C.c_void_p(rgb.data_ptr()) if load_rgb else None, C.c_void_p(m1.data_ptr()), C.c_void_p(m2.data_ptr()),
             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        _lib.check(rc, "io_pair_planes_u8")
+        _lib.check(rc, "io_pair_planes_u8_hw")
         if rgb is None:
-            rgb = torch.zeros((P, 3, S, S), device=self.device)      # occ_order_dataset.py:231-232
+            rgb = torch.zeros((P, 3, SH, S), device=self.device)     # occ_order_dataset.py:231-232
         return rgb, m1, m2
 
 

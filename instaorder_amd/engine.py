@@ -82,6 +82,19 @@ class Net(object):
                                            int(G), int(bool(training)), _ptr(ws), ws.numel() * ws.element_size(),
                                            _ptr(logits), _stream()), "io_net_forward")
 
+    def workspace_bytes_hw(self, N, H, W):
+        n = int(self.lib.io_net_workspace_bytes_hw(self.handle, int(N), int(H), int(W)))
+        if n == 0:
+            raise RuntimeError("io_net_workspace_bytes_hw: " + _lib.last_error())
+        return n
+
+    def forward_eval_hw(self, params, running, x8, N, H, W, ws, logits):
+        """inference forward on H x W inputs (multiples of 32): the 'orig' mode of the reference's inference.py"""
+        _lib.require_gpu()
+        _lib.check(self.lib.io_net_forward_eval_hw(self.handle, _ptr(params), _ptr(running), _ptr(x8), int(N), int(H),
+                                                   int(W), _ptr(ws), ws.numel() * ws.element_size(), _ptr(logits),
+                                                   _stream()), "io_net_forward_eval_hw")
+
     def backward(self, params, grads, x8, dlogits, N, S, G, ws, stages=None):
         """stages = (lo, hi): only the backward stages [lo, hi) of io_net_backward_stages (0 = heads + layer4 .. 3 =
         layer1 + stem); None = the whole pass"""

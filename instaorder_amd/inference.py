@@ -203,7 +203,8 @@ def decision_margins(pair_logits, method):
 
 def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, return_logits=False,
                         world_size=1, rank=0, pair_planes=None):
-    """Order matrices of one image.  rgb[1,3,S,S] normalised fp32, masks[N,S,S] in {0,1}.
+    """Order matrices of one image.  rgb[1,3,S,S] normalised fp32, masks[N,S,S] in {0,1} (or [.., H, W] with both sides
+    multiples of 32: the 'orig' mode).
 
     ``pair_planes = (rgb[P,3,S,S], modal_i[P,1,S,S], modal_j[P,1,S,S])`` (one entry per pair of ``pairs``, e.g. from
     ``datasets.PairRenderer``) replaces the shared image and masks: the 'patch' pre-processing of the reference crops
@@ -216,7 +217,8 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
     n = masks.shape[0]
     pairs = upper_pairs(n) if pairs is None else list(pairs)
     P = len(pairs)
-    S = masks.shape[-1] if pair_planes is None else pair_planes[0].shape[-1]
+    SH, S = (masks.shape[-2:] if pair_planes is None else pair_planes[0].shape[-2:])      # S = width; SH != S: 'orig'
+    SH, S = int(SH), int(S)
     dev = net.flat_params.device
     if pair_planes is None:
         rgb = rgb.to(dev, torch.float32).contiguous()
@@ -231,14 +233,14 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
     K = kocc + kdep
     l1 = torch.empty((len(my), K), device=dev)
     l2 = torch.empty((len(my), K), device=dev)
-    HW = S * S
+    HW = SH * S
     was_training = net.training
     net.eval()
     with torch.no_grad():
         for c0 in range(0, len(my), max_pairs):
             chunk = my[c0:c0 + max_pairs]
             p = len(chunk)
-            x8 = torch.empty((2 * p, S, S, 8), device=dev, dtype=engine.TORCH_DTYPE[net.dtype])
+            x8 = torch.empty((2 * p, SH, S, 8), device=dev, dtype=engine.TORCH_DTYPE[net.dtype])
             if pair_planes is None:
                 ii = torch.tensor([a for a, _ in chunk], device=dev)
                 jj = torch.tensor([b for _, b in chunk], device=dev)
@@ -253,8 +255,8 @@ def infer_order_batched(model, rgb, masks, method, pairs=None, max_pairs=256, re
                     idx = torch.tensor(sel, device=dev)
                     rp, mi, mj = [t[idx].contiguous() for t in pair_planes]
                 rgbp, rs = [(rp, c * HW) for c in range(3)], 3 * HW
-            engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, rs, rs, rs], p, S, S, x8[:p])
-            engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, rs, rs, rs], p, S, S, x8[p:])
+            engine.pack_planes([(mi, 0), (mj, 0)] + rgbp, [HW, HW, rs, rs, rs], p, SH, S, x8[:p])
+            engine.pack_planes([(mj, 0), (mi, 0)] + rgbp, [HW, HW, rs, rs, rs], p, SH, S, x8[p:])
             z = net.forward_packed(x8, 1)
             l1[c0:c0 + p], l2[c0:c0 + p] = z[:p], z[p:]
     net.train(was_training)
@@ -299,12 +301,11 @@ def _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, 
     """The per-pair pre-processing of inference.py:449-482 on the device (datasets.PairRenderer): 'patch' = square
     crop around the pair (zero padded), INTER_CUBIC; 'image' = zero padding to a square, INTER_LINEAR; masks
     INTER_NEAREST; then x / 255 and the ImageNet mean / std (utils/data_utils.py:9-10, 28-34).  Returns
-    (rgb[P,3,S,S], modal_i[P,1,S,S], modal_j[P,1,S,S]).  The 'resize' / 'orig' modes go through MiDaS' float
-    ``Resize`` transform (utils/data_utils.py:37-53) and are not built."""
+    (rgb[P,3,S,S], modal_i[P,1,S,S], modal_j[P,1,S,S]).  The 'resize' / 'orig' modes share one image among all pairs
+    (resize_mode_inputs / orig_mode_inputs)."""
     from . import datasets
     if patch_or_image not in ("patch", "image"):
-        raise NotImplementedError("patch_or_image=%r: 'patch', 'image' and 'resize' are built ('orig' feeds the "
-                                  "network non-square inputs)" % (patch_or_image,))
+        raise ValueError("patch_or_image=%r: one of 'patch', 'image', 'resize', 'orig'" % (patch_or_image,))
     dev = model.net.flat_params.device
     modal = np.ascontiguousarray(inmodal.astype(np.uint8))
     image = np.ascontiguousarray(image.astype(np.uint8))
@@ -323,8 +324,9 @@ def _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, 
 
 
 def _renderer(dev, input_size):
+    """input_size: S, or (height, width) for the 'orig' mode"""
     from . import datasets
-    key = (int(input_size), str(dev))
+    key = (tuple(int(v) for v in input_size) if isinstance(input_size, (tuple, list)) else int(input_size), str(dev))
     if key not in _RENDERERS:
         _RENDERERS[key] = datasets.PairRenderer(input_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], dev)
     return _RENDERERS[key]
@@ -335,18 +337,41 @@ def resize_mode_inputs(dev, image, inmodal, input_size):
     image / 255. + ImageNet normalisation (utils/data_utils.py:37-53) and INTER_NEAREST masks, the whole image squeezed
     to input_size x input_size (a multiple of 32, so MiDaS' Resize keeps it).  One image shared by all pairs:
     returns (rgb[1,3,S,S], masks[N,S,S]) on the device."""
-    from . import datasets
     if input_size % 32:
         raise ValueError("'resize' mode: input_size must be a multiple of 32 (midas/transforms.py:96-105)")
+    return _whole_image_inputs(dev, image, inmodal, input_size)
+
+
+def _whole_image_inputs(dev, image, inmodal, size):
+    from . import datasets
     modal = np.ascontiguousarray(inmodal.astype(np.uint8))
     image = np.ascontiguousarray(image.astype(np.uint8))
     n, hh, ww = modal.shape
     box = (0, 0, ww, hh)
-    r = _renderer(dev, input_size)
+    r = _renderer(dev, size)
     rgb, _, _ = r.render([image], [modal], [(0, 0, 0, box, datasets.INTER_CUBIC_F64, False)])
     _, m, _ = r.render([image], [modal], [(0, i, i, box, datasets.INTER_CUBIC_F64, False) for i in range(n)],
                        load_rgb=False)
     return rgb, m[:, 0]
+
+
+def get_closest_int_multiple_of(orig_num, multiplier):
+    """utils/data_utils.py:13-17 (a remainder of exactly half the multiplier rounds UP)"""
+    if orig_num % multiplier >= multiplier // 2:
+        return orig_num + multiplier - (orig_num % multiplier)
+    return orig_num - (orig_num % multiplier)
+
+
+def orig_mode_inputs(dev, image, inmodal):
+    """The 'orig' pre-processing (inference.py:401-407, 490-496, 569-575): the whole image at its own aspect ratio, both
+    sides rounded to the closest multiple of 32 -- ``transform_resize(image, ww, hh)`` (INTER_CUBIC on image / 255. in
+    float64, ImageNet normalisation; MiDaS' Resize keeps a size that is already a multiple of 32) and INTER_NEAREST masks.
+    Returns (rgb[1,3,hh,ww], masks[N,hh,ww]) on the device."""
+    _, hh, ww = inmodal.shape
+    hh, ww = get_closest_int_multiple_of(int(hh), 32), get_closest_int_multiple_of(int(ww), 32)
+    if hh < 32 or ww < 32:
+        raise ValueError("'orig' mode: the image rounds to %d x %d; the network needs at least 32 x 32" % (hh, ww))
+    return _whole_image_inputs(dev, image, inmodal, (hh, ww))
 
 
 def _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, input_size):
@@ -355,8 +380,10 @@ def _infer_sup(model, image, inmodal, bboxes, pairs, method, patch_or_image, inp
     if not pair_list:
         z = np.zeros((n, n), dtype=np.int64)
         return {"occ_order": z, "depth_order": z.copy()}
-    if patch_or_image == "resize":
-        rgb, masks = resize_mode_inputs(model.net.flat_params.device, image, inmodal, input_size)
+    if patch_or_image in ("resize", "orig"):
+        dev = model.net.flat_params.device
+        rgb, masks = (resize_mode_inputs(dev, image, inmodal, input_size) if patch_or_image == "resize"
+                      else orig_mode_inputs(dev, image, inmodal))
         return infer_order_batched(model, rgb, masks, method, pairs=pair_list)
     planes = _preprocess_pairs(model, image, inmodal, bboxes, pair_list, patch_or_image, input_size)
     return infer_order_batched(model, None, torch.from_numpy(np.asarray(inmodal)), method, pairs=pair_list,
@@ -467,13 +494,15 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
         dev = next(model.parameters()).device
         if patch_or_image == "resize":
             rgb, masks = resize_mode_inputs(dev, image, inmodal, input_size)
+        elif patch_or_image == "orig":
+            rgb, masks = orig_mode_inputs(dev, image, inmodal)
         elif patch_or_image == "image" and image.shape[0] == image.shape[1] == input_size:
             from .synthetic import image_mode_inputs
             rgb, masks = image_mode_inputs(image, inmodal, input_size)
             rgb, masks = torch.from_numpy(rgb).to(dev), torch.from_numpy(masks)
         else:
-            raise NotImplementedError("midas_pretrained: patch_or_image='resize', or 'image' on square images of the "
-                                      "network size")
+            raise NotImplementedError("midas_pretrained: patch_or_image='resize' / 'orig', or 'image' on square images of "
+                                      "the network size")
         with torch.no_grad():
             disp = model(rgb.to(dev)).squeeze().float()
         clipped = torch.clip(disp, torch.quantile(disp, 0.05), torch.quantile(disp, 0.95))
@@ -497,12 +526,16 @@ def infer_order_sup_depth(model, image, inmodal, bboxes, pairs, method, patch_or
         dev = next(model.model.parameters()).device
         rgb, masks = resize_mode_inputs(dev, image, inmodal, input_size)
         rgb, masks = rgb.cpu().numpy(), masks.cpu().numpy()
+    elif patch_or_image == "orig":              # the whole image at its own aspect ratio (inference.py:569-575)
+        dev = next(model.model.parameters()).device
+        rgb, masks = orig_mode_inputs(dev, image, inmodal)
+        rgb, masks = rgb.cpu().numpy(), masks.cpu().numpy()
     elif patch_or_image == "image" and image.shape[0] == image.shape[1] == input_size:
         from .synthetic import image_mode_inputs
         rgb, masks = image_mode_inputs(image, inmodal, input_size)
     else:
-        raise NotImplementedError("InstaDepthNet inference: patch_or_image='resize', or 'image' on square images of the "
-                                  "network size (per-pair crops would run the MiDaS encoder once per pair)")
+        raise NotImplementedError("InstaDepthNet inference: patch_or_image='resize' / 'orig', or 'image' on square images "
+                                  "of the network size (per-pair crops would run the MiDaS encoder once per pair)")
     res = infer_depthnet_batched(model, torch.from_numpy(rgb), torch.from_numpy(masks), pairs=plist)
     if disp_select_method == "":
         return res["depth_order"], None

@@ -215,6 +215,19 @@ class ResNet(nn.Module):
             self.bump_batches_tracked(G)
         return logits, ws
 
+    def _run_forward_eval_hw(self, x8, N, H, W):
+        dev = self._flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("instaorder_amd: the network runs only on an MI355X (module is on %s); "
+                               "there is no CPU fallback" % dev)
+        nbytes = self.plan.workspace_bytes_hw(N, H, W)
+        if self._eval_ws is None or self._eval_ws.numel() < nbytes:
+            self._eval_ws = None
+            self._eval_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        logits = torch.empty((N, self.plan.num_logits), dtype=torch.float32, device=dev)
+        self.plan.forward_eval_hw(self._flat, self._running, x8, N, H, W, self._eval_ws, logits)
+        return logits
+
     def _run_backward(self, x8, dlogits, N, S, G, ws, stages=None):
         self.plan.backward(self._flat, self._flat_grad, x8, dlogits, N, S, G, ws, stages)
 
@@ -236,11 +249,15 @@ class ResNet(nn.Module):
         normalised in ``groups`` independent BN groups (2 = both mask orders of a pair batch) and the
         result carries autograd history when gradients are enabled."""
         N, S = x8.shape[0], x8.shape[1]
-        if x8.shape[2] != S:
-            raise ValueError("square inputs only, got %s" % (tuple(x8.shape),))
         if x8.dtype != engine.TORCH_DTYPE[self.dtype] or not x8.is_contiguous():
             raise ValueError("packed input must be contiguous %s (the net's storage type), got %s"
                              % (self.dtype, x8.dtype))
+        if x8.shape[2] != S:
+            # H x W inputs: inference only (the 'orig' mode of inference.py:401-407 feeds whole images at their own
+            # aspect ratio; resnet_cls.py:152 pools adaptively, so the network takes them)
+            if self.training:
+                raise ValueError("training takes square inputs only, got %s" % (tuple(x8.shape),))
+            return self._run_forward_eval_hw(x8, N, int(x8.shape[1]), int(x8.shape[2]))
         if self.training:
             if torch.is_grad_enabled():
                 params = [p for _, p in self._param_list]

@@ -128,8 +128,38 @@ def test_batches_feed_a_training_step_and_patch_inference():
         torch.from_numpy(np.stack([po.resize(mm, (S, S), po.INTER_NEAREST) for mm in sc["modal"]]).astype(np.float32)),
         "InstaOrderNet_o")["occ_order"]
     assert np.array_equal(got, want)
-    with pytest.raises(NotImplementedError):
-        inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "orig", S)
+    # 'orig' (inference.py:401-407, 490-496): the whole image at its own aspect ratio, sides rounded to the closest
+    # multiples of 32 -- an H x W network input.  Device transform == the oracle's transform_resize / nearest masks bit
+    # for bit; the orders == the batched driver on the oracle's planes; the network itself on the non-square input
+    # against the CPU oracle (resnet_cls.py:199-222 with its AdaptiveAvgPool) on the same weights.
+    from oracle import resnet_oracle as orc
+    sc = rd.scenes[3]                                           # 131 x 102 -> 128 x 96
+    H, W = sc["image"].shape[:2]
+    hh, ww = inference.get_closest_int_multiple_of(H, 32), inference.get_closest_int_multiple_of(W, 32)
+    assert hh != ww and (hh, ww) != (H, W), "the scene should give a non-square network input"
+    rgb, masks = inference.orig_mode_inputs("cuda:0", sc["image"], sc["modal"])
+    assert tuple(rgb.shape) == (1, 3, hh, ww) and tuple(masks.shape) == (sc["modal"].shape[0], hh, ww)
+    want_rgb = po.transform_resize(sc["image"], ww, hh)
+    want_m = np.stack([po.resize(mm, (ww, hh), po.INTER_NEAREST) for mm in sc["modal"]]).astype(np.float32)
+    assert np.array_equal(rgb[0].cpu().numpy(), want_rgb)
+    assert np.array_equal(masks.cpu().numpy(), want_m)
+    got = inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "orig", S)
+    res = inference.infer_order_batched(m, torch.from_numpy(want_rgb)[None], torch.from_numpy(want_m), "InstaOrderNet_o",
+                                        return_logits=True)
+    assert np.array_equal(got, res["occ_order"])
+    state = orc.state_from_numpy({k[len("module."):]: v.detach().cpu().numpy() for k, v in m.model.state_dict().items()})
+    pairs = inference.upper_pairs(sc["modal"].shape[0])
+    mi = torch.from_numpy(want_m[[a for a, _ in pairs]])[:, None]
+    mj = torch.from_numpy(want_m[[b for _, b in pairs]])[:, None]
+    img = torch.from_numpy(want_rgb)[None].expand(len(pairs), -1, -1, -1)
+    with torch.no_grad():
+        z1 = orc.resnet_forward(state, torch.cat([mi, mj, img], 1), False)
+        z2 = orc.resnet_forward(state, torch.cat([mj, mi, img], 1), False)
+    ref = torch.cat([z1, z2], 1).numpy()
+    err = np.abs(res["pair_logits"] - ref).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < 1e-3, err
+    with pytest.raises(ValueError):
+        inference.infer_order_sup_occ(m, sc["image"], sc["modal"], sc["bboxes"], "all", "InstaOrderNet_o", "whole", S)
 
 
 def test_descriptor_validation():

@@ -230,6 +230,40 @@ def test_round3_entry_points_reject_bad_arguments():
     bad(L().io_disp_order_count(P(a), P(a), P(b), P(b), P(lab), P(lab), 2, 2, 8, 0, 1.0, P(t[0]), P(t[1]), ST()))
 
 
+def test_rectangular_inference_entries_reject_bad_shapes():
+    """io_net_forward_eval_hw / io_net_workspace_bytes_hw / io_pair_planes_u8_hw: sides that are not multiples of 32, a
+    short workspace, empty outputs; training on a non-square batch is refused by the module."""
+    import instaorder_amd as ia
+    from instaorder_amd import engine
+    net = engine.Net(5, 2)
+    assert L().io_net_workspace_bytes_hw(net.handle, 2, 96, 70) == 0
+    assert L().io_net_workspace_bytes_hw(net.handle, 2, 0, 64) == 0
+    nb = net.workspace_bytes_hw(2, 96, 64)
+    assert nb > 0
+    params = torch.zeros(net.param_floats, device=DEV)
+    running = torch.ones(net.running_floats, device=DEV)
+    x8 = torch.zeros(2, 96, 64, 8, device=DEV)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    logits = torch.empty(2, 2, device=DEV)
+
+    def bad(rc):
+        assert rc != 0 and _lib.last_error()
+
+    bad(L().io_net_forward_eval_hw(net.handle, P(params), P(running), P(x8), 2, 96, 70, P(ws), nb, P(logits), ST()))
+    bad(L().io_net_forward_eval_hw(net.handle, P(params), P(running), P(x8), 2, 96, 64, P(ws), nb // 2, P(logits), ST()))
+    assert L().io_net_forward_eval_hw(net.handle, P(params), P(running), P(x8), 2, 96, 64, P(ws), nb, P(logits), ST()) == 0
+    torch.cuda.synchronize()
+    bad(L().io_pair_planes_u8_hw(P(x8), 16, P(x8), P(x8), 1, 0, 64, None, None, None, P(logits), P(logits), ST()))
+    cfg = dict(algo="InstaOrderNet_o", lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=2), use_rgb=True)
+    m = ia.InstaOrderNet_o(cfg, dist_model=False)
+    m.switch_to("train")
+    with pytest.raises(ValueError):
+        m.net.forward_packed(torch.zeros(2, 96, 64, 8, device=DEV), 1)
+    m.switch_to("eval")
+    assert tuple(m.net.forward_packed(torch.zeros(2, 96, 64, 8, device=DEV), 1).shape) == (2, 2)
+
+
 def test_staged_backward_rejects_bad_stage_ranges():
     import instaorder_amd as ia
     from instaorder_amd import engine

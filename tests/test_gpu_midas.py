@@ -175,6 +175,21 @@ def test_batched_depthnet_inference_equals_per_pair_calls():
     masks3 = np.stack([po.resize(mm, (64, 64), po.INTER_NEAREST) for mm in sc["modal"]]).astype(np.float32)
     want3 = inference.infer_depthnet_batched(m, torch.from_numpy(rgb3), torch.from_numpy(masks3))["depth_order"]
     assert (order3 == want3).all()
+    # 'orig' (inference.py:569-575): the whole image at its own aspect ratio, sides rounded to multiples of 32 -- here
+    # 130 x 70 -> 128 x 64, an H x W input to the MiDaS encoder / decoder and the order branches; the batched driver
+    # against the per-pair two-call loop on the same oracle-transformed planes
+    sc4 = synthetic.make_images(11, 1, 3, 64)[0]
+    img4 = np.ascontiguousarray(np.pad(sc4["image"], ((0, 66), (0, 6), (0, 0)), mode="edge"))
+    mod4 = np.ascontiguousarray(np.pad(sc4["modal"], ((0, 0), (0, 66), (0, 6))))
+    order4, _ = inference.infer_order_sup_depth(m, img4, mod4, None, "all", algo, "orig", 64, "")
+    rgb4 = po.transform_resize(img4, 64, 128)[None]
+    masks4 = np.stack([po.resize(mm, (64, 128), po.INTER_NEAREST) for mm in mod4]).astype(np.float32)
+    assert rgb4.shape == (1, 3, 128, 64)
+    res4 = inference.infer_depthnet_batched(m, torch.from_numpy(rgb4), torch.from_numpy(masks4))
+    assert (order4 == res4["depth_order"]).all() and res4["disp"].shape == (128, 64)
+    for (i, j) in res4["pairs"]:
+        d, _, _, _, _ = inference.net_forward_InstaDepthNet(m, torch.from_numpy(rgb4), masks4[i], masks4[j])
+        assert (res4["depth_order"][i, j], res4["depth_order"][j, i]) == {0: (1, 0), 1: (0, 1), 2: (2, 2)}[d]
 
 
 def test_checkpoint_roundtrip_with_momentum(tmp_path):

@@ -277,6 +277,16 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert "tensors 163 convs 53 bns 53 logits 5 param_floats" in out, out
 
 
+def test_orig_mode_rounding_rule():
+    """utils/data_utils.py:13-17 get_closest_int_multiple_of: a remainder of at least half the multiplier rounds up (so
+    exactly half rounds UP), anything below rounds down; multiples stay."""
+    from instaorder_amd import inference
+    f = inference.get_closest_int_multiple_of
+    assert [f(v, 32) for v in (32, 47, 48, 49, 63, 64, 79, 80, 131, 102, 15, 16)] == \
+        [32, 32, 64, 64, 64, 64, 64, 96, 128, 96, 0, 32]
+    assert f(10, 4) == 12 and f(9, 4) == 8 and f(7, 3) == 9 and f(8, 3) == 9 and f(6, 3) == 6     # (3 // 2 == 1)
+
+
 def test_bordering_and_pair_selection():
     """inference.py:691-696 / :446-447: neighbour test = one cross dilation of the FIRST mask; checked against
     scipy's binary_dilation with the same structuring element."""
