@@ -756,10 +756,16 @@ TESTER_SCENARIOS = [   # (name, trainval_dataset, order_method, patch_or_image, 
     ("occ_net_image", "SupOcclusionOrderDataset", "InstaOrderNet_o", "image", "InstaOrderNet_o"),
     ("od_net_resize", "SupDepthOccOrderDataset", "InstaOrderNet_od", "resize", "InstaOrderNet_od"),
 ]
+# the 'orig' mode (inference.py:401-407, 490-496): whole images at their own aspect ratio -- the scenes of the reader round
+# to 128 x 128 (twice), 96 x 128 and 128 x 160 network inputs
+TESTER_SCENARIOS_ORIG = [
+    ("occ_net_orig", "SupOcclusionOrderDataset", "InstaOrderNet_o", "orig", "InstaOrderNet_o"),
+    ("od_net_orig", "SupDepthOccOrderDataset", "InstaOrderNet_od", "orig", "InstaOrderNet_od"),
+]
 TESTER_S, TESTER_SEED, TESTER_READER_SEED, TESTER_WARM = 64, 31, 91, 6
 
 
-def case_tester(tag):
+def case_tester(tag, TESTER_SCENARIOS=TESTER_SCENARIOS):
     """The reference's own tools/test.py Tester loops (eval_occ_order / eval_depth_order / eval_occ_depth_order) over
     synthetic scenes: heuristics and the supervised nets in 'patch' / 'image' / 'resize' mode (cv2.resize = the oracle's
     restatement, cv2.dilate = scipy's binary_dilation).  Recorded: every predicted order matrix, the pair logits
@@ -918,6 +924,7 @@ CASES = {
     "od_S256_B4_k": lambda: case_train("InstaOrderNet_od", 256, 4, 26, 1, "od_S256_B4_k", "kaiming"),
     "od_S384_B2_k": lambda: case_train("InstaOrderNet_od", 384, 2, 27, 1, "od_S384_B2_k", "kaiming"),
     "tester": lambda: case_tester("tester"),
+    "tester_orig": lambda: case_tester("tester_orig", TESTER_SCENARIOS_ORIG),
     "heuristics": lambda: case_heuristics("heuristics"),
     "dataset_items": lambda: case_dataset_items("dataset_items"),
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),

@@ -227,15 +227,16 @@ def test_training_harness_with_resume(tmp_path):
         os.path.exists(os.path.join(str(tmp_path), "ckpt_iter_10.pth.tar"))
 
 
-@pytest.mark.parametrize("k", [4, 5, 6])
-def test_evaluate_equals_reference_tester_with_networks(k):
+@pytest.mark.parametrize("gold,k", [("tester", 4), ("tester", 5), ("tester", 6), ("tester_orig", 0), ("tester_orig", 1)])
+def test_evaluate_equals_reference_tester_with_networks(gold, k):
     """instaorder_amd.evaluate (device pre-processing + batched drivers + metrics) against the reference's tools/test.py
     Tester run on the same weights and scenes (tests/golden/tester.npz): 'patch' / 'image' (InstaOrderNet_o) and
-    'resize' (InstaOrderNet_od).  Decisions must agree wherever the reference's own margin is above the fp32 noise;
-    when they all agree the aggregated metrics must be equal."""
+    'resize' (InstaOrderNet_od); tester_orig.npz: the 'orig' mode (H x W network inputs: 128 x 128, 96 x 128, 128 x 160)
+    for both nets.  Decisions must agree wherever the reference's own margin is above the fp32 noise; when they all
+    agree the aggregated metrics must be equal."""
     import instaorder_amd as ia
     from instaorder_amd import evaluate, inference
-    z = load_golden("tester")
+    z = load_golden(gold)
     cfg = json.loads(str(z["data_cfg_json"]))
     name, kind, method, mode, algo = str(z["scenarios"][k]).split("|")
     S, seed, rseed, warm = [int(v) for v in z["meta"]]
