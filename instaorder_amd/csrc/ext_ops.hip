@@ -120,16 +120,26 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const T_* __re
         const T_* dp = dy + ((size_t)n * OH * OW * C4 + q) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int oh0 = max(0, 2 * h - 3), oh1 = min(OH - 1, 2 * h + 4);
-        const int ow0 = max(0, 2 * w - 3), ow1 = min(OW - 1, 2 * w + 4);
+        // the column weights do not depend on the row: 8 stencil evaluations per element, not 64 (same products, same
+        // order of accumulation)
+        float wws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ow = 2 * w - 3 + k;
+            wws[k] = 0.f;
+            if ((unsigned)ow < (unsigned)OW) {
+                const Lerp lw = lerp_of(ow, W, align);
+                wws[k] = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
+            }
+        }
         for (int oh = oh0; oh <= oh1; ++oh) {
             const Lerp lh = lerp_of(oh, H, align);
             const float wh = (lh.i0 == h ? lh.w0 : 0.f) + (lh.i1 == h ? lh.w1 : 0.f);
             if (wh == 0.f) continue;
-            for (int ow = ow0; ow <= ow1; ++ow) {
-                const Lerp lw = lerp_of(ow, W, align);
-                const float ww = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
-                if (ww == 0.f) continue;
-                acc += (wh * ww) * io_ldv(dp + ((size_t)oh * OW + ow) * C4 * 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (wws[k] == 0.f) continue;
+                acc += (wh * wws[k]) * io_ldv(dp + ((size_t)oh * OW + (2 * w - 3 + k)) * C4 * 4);
             }
         }
         io_stv(dx + i * 4, acc);
@@ -528,15 +538,17 @@ __device__ __forceinline__ void mm_merge(MinMaxIdx& a, const MinMaxIdx& b) {
     a.sum += b.sum;
 }
 
-// one block per sample: min / max (+ the element torch's chained min(2).min(3) selects), sum.  stats[b][8] =
-// {mn, mx, sum, key_min, key_max, -, -, -} (keys as float bit patterns of ints)
-__global__ __launch_bounds__(kThreads) void smooth_stats_kernel(const float* __restrict__ disp, int H, int W,
+constexpr int kStatThreads = 1024;
+// one block of 1024 threads per sample (16 samples of 147 k pixels: the block size is the parallelism): min / max (+ the
+// element torch's chained min(2).min(3) selects), sum.  stats[b][8] = {mn, mx, sum, key_min, key_max, -, -, -} (keys as
+// float bit patterns of ints)
+__global__ __launch_bounds__(kStatThreads) void smooth_stats_kernel(const float* __restrict__ disp, int H, int W,
                                                                float* __restrict__ stats) {
-    __shared__ MinMaxIdx sh[kThreads];
+    __shared__ MinMaxIdx sh[kStatThreads];
     const int b = blockIdx.x, N = H * W;
     const float* d = disp + (size_t)b * N;
     MinMaxIdx a{INFINITY, -INFINITY, 0.f, 0x7fffffff, 0x7fffffff};
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = threadIdx.x; i < N; i += kStatThreads) {
         const int h = i / W, w = i - h * W;
         const float v = d[i];
         MinMaxIdx e{v, v, v, w * H + h, w * H + h};
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(kThreads) void smooth_stats_kernel(const float* __r
     }
     sh[threadIdx.x] = a;
     __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
+    for (int off = kStatThreads / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             MinMaxIdx t = sh[threadIdx.x];
             mm_merge(t, sh[threadIdx.x + off]);
@@ -780,7 +792,7 @@ extern "C" int io_smooth_loss_fwd(const float* disp, const float* img, int B, in
     float* stats = workspace;
     float* part = workspace + (size_t)B * 8;
     const float cx = 1.f / ((float)B * H * (W - 1)), cy = 1.f / ((float)B * (H - 1) * W);
-    hipLaunchKernelGGL(smooth_stats_kernel, dim3(B), dim3(kThreads), 0, st, disp, H, W, stats);
+    hipLaunchKernelGGL(smooth_stats_kernel, dim3(B), dim3(kStatThreads), 0, st, disp, H, W, stats);
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nblk, B), dim3(kThreads), 0, st, disp, img, H, W, stats, cx, cy, g, part);
     hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(kThreads), 0, st, part, B, nblk, cx, cy, out_scale, stats, loss);
     return io_check_launch("smooth_loss_fwd");
