@@ -11,6 +11,10 @@
 // All tensors NHWC fp32.
 #include "io_common.h"
 
+#ifndef IO_HEAD_ROWS
+#define IO_HEAD_ROWS 1
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -261,6 +265,115 @@ __global__ __launch_bounds__(kThreads) void head1_bwd_kernel(const float* __rest
     }
 }
 
+// Row forms of the two kernels above for rows that are whole 16-byte chunks (pitch = NQ chunks of VEC = 4 fp32 / 8 bf16
+// channels): one thread per row, 16-byte loads / stores, the filter in registers, and -- backward -- the C sums of
+// dz * x in registers, reduced once per block (wave shuffles, then LDS across the four waves).  The column-lane form
+// above moves 2..4 bytes per lane.
+template <typename T_> struct HeadChunk;
+template <> struct HeadChunk<float> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+        v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct HeadChunk<bf16_t> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __builtin_bit_cast(float, w[k] << 16);
+            v[2 * k + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        uint4 r;
+        r.x = io_f2bf2(v[0], v[1]); r.y = io_f2bf2(v[2], v[3]); r.z = io_f2bf2(v[4], v[5]); r.w = io_f2bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = r;
+    }
+};
+
+template <typename T_, int NQ>
+__global__ __launch_bounds__(kThreads) void head1_fwd_rows_kernel(const T_* __restrict__ x, int M, int C,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 int relu, float* __restrict__ out) {
+    constexpr int VEC = HeadChunk<T_>::VEC, P = NQ * VEC;
+    float wr[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) wr[c] = c < C ? w[c] : 0.f;
+    const float b0 = b ? b[0] : 0.f;
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < (size_t)M; m += (size_t)gridDim.x * blockDim.x) {
+        const T_* xp = x + m * P;
+        float s = b0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float v[VEC];
+            HeadChunk<T_>::load(xp + q * VEC, v);
+            // (the element order and the grouping by four of head1_fwd_kernel: the same sums)
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4)
+                if (q * VEC + e < C)                   // (the padding channels are not read into the sum)
+                    s += v[e] * wr[q * VEC + e] + v[e + 1] * wr[q * VEC + e + 1] + v[e + 2] * wr[q * VEC + e + 2] +
+                         v[e + 3] * wr[q * VEC + e + 3];
+        }
+        out[m] = (relu && s < 0.f) ? 0.f : s;
+    }
+}
+
+template <typename T_, int NQ>
+__global__ __launch_bounds__(kThreads) void head1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                                 const T_* __restrict__ x, int M, int C,
+                                                                 const float* __restrict__ w, int relu, int rpb,
+                                                                 T_* __restrict__ dx, float* __restrict__ partial) {
+    constexpr int VEC = HeadChunk<T_>::VEC, P = NQ * VEC;
+    __shared__ float red[kThreads / 64][P + 1];
+    float wr[P], acc[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        wr[c] = c < C ? w[c] : 0.f;
+        acc[c] = 0.f;
+    }
+    float sb = 0.f;
+    const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, M);
+    for (int r = r0 + threadIdx.x; r < r1; r += kThreads) {
+        float dz = dy[r];
+        if (relu && !(out[r] > 0.f)) dz = 0.f;
+        sb += dz;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float v[VEC], o[VEC];
+            HeadChunk<T_>::load(x + (size_t)r * P + q * VEC, v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                acc[q * VEC + e] += dz * v[e];
+                o[e] = dz * wr[q * VEC + e];           // (zero in the padding channels: wr is)
+            }
+            HeadChunk<T_>::store(dx + (size_t)r * P + q * VEC, o);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c <= P; ++c) {
+        float v = c < P ? acc[c < P ? c : 0] : sb;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= C) {
+        const int c = (int)threadIdx.x < C ? (int)threadIdx.x : P;     // entry C of the partial row = the sum of dz
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) t += red[k][c];
+        partial[(size_t)blockIdx.x * (C + 1) + threadIdx.x] = t;
+    }
+}
+
 int rows_per_block(int M, int* nb) {
     int want = 1024;
     int rpb = (M + want - 1) / want;
@@ -497,8 +610,16 @@ extern "C" int io_head1_fwd(const void* x, int M, int pitch, int C, const float*
     IO_REQUIRE(C % 4 == 0 && C <= 64 && pitch % 4 == 0 && pitch >= C && pitch <= 64 && M > 0, IO_ERR_SHAPE,
                "head1: C=%d pitch=%d (C <= pitch <= 64, multiples of 4)", C, pitch);
     IoProfScope prof(IO_PROF_POOL_HEAD, 2.0 * M * C, (double)M * (io_dtype_bytes(dt) * pitch + 4.0), st);
-    IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_fwd_kernel<T_>, dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, st,
-                                       (const T_*)x, M, pitch, C, w, b, relu, out));
+    const int nq = pitch * io_dtype_bytes(dt) / 16;        // whole 16-byte chunks per row: the row form
+#define IO_H1F(NQ_)                                                                                                  \
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL((head1_fwd_rows_kernel<T_, NQ_>), dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, \
+                                       st, (const T_*)x, M, C, w, b, relu, out))
+    if (IO_HEAD_ROWS && pitch * io_dtype_bytes(dt) % 16 == 0 && nq == 4) IO_H1F(4);
+    else if (IO_HEAD_ROWS && pitch * io_dtype_bytes(dt) % 16 == 0 && nq == 8) IO_H1F(8);
+    else
+        IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_fwd_kernel<T_>, dim3(ew_blocks((size_t)M)), dim3(kThreads), 0, st,
+                                           (const T_*)x, M, pitch, C, w, b, relu, out));
+#undef IO_H1F
     return io_check_launch("head1_fwd");
 }
 
@@ -513,8 +634,16 @@ extern "C" int io_head1_bwd(const float* dy, const float* out, const void* x, in
     IO_REQUIRE(partial_floats >= (size_t)nb * (C + 1), IO_ERR_WORKSPACE, "head1_bwd: workspace %zu < %zu floats",
                partial_floats, (size_t)nb * (C + 1));
     IoProfScope prof(IO_PROF_POOL_HEAD, 4.0 * M * C, (double)M * (2.0 * io_dtype_bytes(dt) * pitch + 8.0), st);
-    IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_bwd_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, dy, out, (const T_*)x, M,
-                                       pitch, C, w, relu, rpb, (T_*)dx, partial));
+    const int nq = pitch * io_dtype_bytes(dt) / 16;
+#define IO_H1B(NQ_)                                                                                                  \
+    IO_BY_DTYPE(dt, hipLaunchKernelGGL((head1_bwd_rows_kernel<T_, NQ_>), dim3(nb), dim3(kThreads), 0, st, dy, out,   \
+                                       (const T_*)x, M, C, w, relu, rpb, (T_*)dx, partial))
+    if (IO_HEAD_ROWS && pitch * io_dtype_bytes(dt) % 16 == 0 && nq == 4) IO_H1B(4);
+    else if (IO_HEAD_ROWS && pitch * io_dtype_bytes(dt) % 16 == 0 && nq == 8) IO_H1B(8);
+    else
+        IO_BY_DTYPE(dt, hipLaunchKernelGGL(head1_bwd_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, dy, out, (const T_*)x, M,
+                                           pitch, C, w, relu, rpb, (T_*)dx, partial));
+#undef IO_H1B
     // the per-block sums are [nb][C+1]: column sums give dw[0..C) and db
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial, nb, C + 1, C, dw);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, st, partial + C, nb, C + 1, 1, db);
