@@ -374,6 +374,36 @@ __global__ __launch_bounds__(kThreads) void head1_bwd_rows_kernel(const float* _
     }
 }
 
+// column sums with 16-byte chunks per lane: thread = (chunk q = tid % (C / VEC), row lane tid / (C / VEC)); the element
+// form (colsum_partial_kernel) moves 2..4 bytes per lane
+template <typename T_>
+__global__ __launch_bounds__(kThreads) void colsum_partial_rows_kernel(const T_* __restrict__ x, int M, int C, int rpb,
+                                                                      float* __restrict__ partial) {
+    constexpr int VEC = HeadChunk<T_>::VEC;
+    __shared__ float red[kThreads][VEC + 1];
+    const int CV = C / VEC, TY = kThreads / CV, q = threadIdx.x % CV, ty = threadIdx.x / CV;
+    const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, M);
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    for (int r = r0 + ty; r < r1; r += TY) {
+        float v[VEC];
+        HeadChunk<T_>::load(x + (size_t)r * C + q * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (ty == 0) {
+        for (int k = 1; k < TY; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += red[k * CV + q][e];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) partial[(size_t)blockIdx.x * C + q * VEC + e] = s[e];
+    }
+}
+
 int rows_per_block(int M, int* nb) {
     int want = 1024;
     int rpb = (M + want - 1) / want;
@@ -598,8 +628,13 @@ extern "C" int io_colsum(const void* x, int M, int C, float* out, float* partial
     IO_REQUIRE(partial_floats >= (size_t)nb * C, IO_ERR_WORKSPACE, "colsum: workspace %zu < %zu floats", partial_floats,
                (size_t)nb * C);
     IoProfScope prof(IO_PROF_BN_BWD, 0.0, (double)io_dtype_bytes(dt) * M * C, st);
-    IO_BY_DTYPE(dt, hipLaunchKernelGGL(colsum_partial_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, (const T_*)x, M, C, rpb,
-                                       partial));
+    const int vec = 16 / io_dtype_bytes(dt);
+    if (IO_HEAD_ROWS && C % vec == 0 && kThreads % (C / vec) == 0)
+        IO_BY_DTYPE(dt, hipLaunchKernelGGL(colsum_partial_rows_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, (const T_*)x, M,
+                                           C, rpb, partial));
+    else
+        IO_BY_DTYPE(dt, hipLaunchKernelGGL(colsum_partial_kernel<T_>, dim3(nb), dim3(kThreads), 0, st, (const T_*)x, M, C,
+                                           rpb, partial));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial, nb, C, C, out);
     return io_check_launch("colsum");
 }
