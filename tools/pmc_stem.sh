@@ -8,7 +8,7 @@ i=0
 for CNT in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmc_${TAG}_$i
-  rocprofv3 --pmc $CNT -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- python3 $R/tools/one_stem.py > /tmp/pmc_${TAG}_$i.log 2>&1
+  rocprofv3 --pmc $CNT -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- python3 $R/tools/one_stem.py ${STEM_ARGS:-512 256 10 fwd} > /tmp/pmc_${TAG}_$i.log 2>&1
   f=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | head -1)
   python3 - "$f" "${KERNEL:-stem_rows_kernel}" <<'PY' >> $R/gpurun_out/pmc_$TAG.txt
 import csv, sys, collections
