@@ -191,7 +191,12 @@ int io_net_forward_eval_hw(io_net* net, const float* params, float* running, con
  * 2: layer2, 3: layer1 + stem -- running the stages [stage_lo, stage_hi).  The parameter gradients of a stage are final
  * when its call returns (stream order), so a data-parallel caller can start the exchange of that contiguous slice of
  * `grads` (utils/distributed_utils.py:27-31 average_gradients) while the next stage computes.  Calling every stage once, in order,
- * with the same arguments IS io_net_backward: nothing is carried between the calls but `workspace`. */
+ * with the same arguments IS io_net_backward: nothing is carried between the calls but `workspace`.
+ * CONTRACT: the stages of one pass must be enqueued IN ORDER (0, 1, 2, 3; a call may cover several consecutive ones) on
+ * ONE workspace, after the training io_net_forward they belong to and with nothing else writing that workspace in
+ * between: a later stage reads what the earlier ones left there (the transposed filters made by stage 0, the gradient
+ * of the stage's input, BatchNorm tile partials).  The library cannot check this -- the state lives in device memory and
+ * no entry point synchronises -- so a call with stage_lo > 0 on a fresh or reused workspace returns IO_OK and garbage. */
 int io_net_backward_num_stages(const io_net* net);
 int io_net_backward_stages(io_net* net, const float* params, float* grads, const void* x8, const float* dlogits, int N,
                            int S, int G, void* workspace, size_t workspace_bytes, int stage_lo, int stage_hi,

@@ -91,90 +91,3 @@ class FixModule(torch.nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
-
-
-# ---- harness helpers (utils/common_utils.py:66-127): used by trainer.py / tools/test.py around the hot path -----------------
-def create_logger(name, log_file, level=None):
-    """File + stream logger with the '[time] message' format (utils/common_utils.py:66-77)."""
-    import logging
-    lg = logging.getLogger(name)
-    fmt = logging.Formatter("[%(asctime)s] %(message)s")
-    for h in (logging.FileHandler(log_file), logging.StreamHandler()):
-        h.setFormatter(fmt)
-        lg.addHandler(h)
-    lg.setLevel(logging.INFO if level is None else level)
-    return lg
-
-
-class AverageMeter(object):
-    """Running (length = 0) or windowed (last ``length`` values) mean with ``.val`` / ``.avg``
-    (utils/common_utils.py:80-109)."""
-
-    def __init__(self, length=0):
-        self.length = length
-        self.reset()
-
-    def reset(self):
-        if self.length > 0:
-            self.history = []
-        else:
-            self.count = 0
-            self.sum = 0.0
-        self.val = 0.0
-        self.avg = 0.0
-
-    def update(self, val):
-        if self.length > 0:
-            self.history.append(val)
-            if len(self.history) > self.length:
-                del self.history[0]
-            self.val = self.history[-1]
-            self.avg = sum(self.history) / float(len(self.history))
-        else:
-            self.val = val
-            self.sum += val
-            self.count += 1
-            self.avg = self.sum / self.count
-
-
-def accuracy(output, target, topk=(1,)):
-    """precision@k in percent for logits [B,K] and class ids [B] (utils/common_utils.py:112-126)."""
-    maxk = max(topk)
-    pred = output.topk(maxk, 1, True, True)[1].t()
-    correct = pred.eq(target.view(1, -1).expand_as(pred))
-    return [correct[:k].reshape(-1).float().sum(0, keepdim=True) * (100.0 / target.size(0)) for k in topk]
-
-
-def disp_to_depth(disp, min_depth, max_depth):
-    """utils/common_utils.py:9-14: sigmoid disparity -> (scaled disparity, depth) between the two depth bounds."""
-    min_disp, max_disp = 1 / max_depth, 1 / min_depth
-    scaled_disp = min_disp + (max_disp - min_disp) * disp
-    return scaled_disp, 1 / scaled_disp
-
-
-class UnNormalize(object):
-    """Inverse of the ImageNet normalisation, in place on a [C,H,W] tensor (utils/common_utils.py:17-32)."""
-
-    def __init__(self):
-        self.mean = [0.485, 0.456, 0.406]
-        self.std = [0.229, 0.224, 0.225]
-
-    def __call__(self, tensor):
-        for t, m, s in zip(tensor, self.mean, self.std):
-            t.mul_(s).add_(m)
-        return tensor
-
-
-def load_weights(path, model):
-    """utils/common_utils.py:152-166: a bare state_dict file into ``model`` (strict=False), with the reference's
-    warnings for keys the file lacks."""
-    import os
-    if not os.path.isfile(path):
-        raise Exception("File not exist: {}".format(path))
-    print("=> loading checkpoint '{}'".format(path))
-    weights = torch.load(path, map_location="cpu")
-    model.load_state_dict(weights, strict=False)
-    missing = set(model.state_dict().keys()) - set(weights.keys())
-    for k in missing:
-        if "num_batches_tracked" not in k:
-            print("caution: missing keys from checkpoint {}: {}".format(path, k))

@@ -1954,12 +1954,11 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 #define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_, LIN_, XB_)                               \
     do {                                                                                                     \
         const size_t ldsz = (size_t)NBUF_ * (128 + BN_) * (BN_ == 64 ? 32 : 36) * sizeof(float);             \
-        static bool attr_done = false;                                                                       \
-        if (!attr_done) {                                                                                    \
+        static std::atomic<unsigned long long> attr_done{0};                                                                       \
+        if (io_first_on_device(attr_done)) {                                                                                    \
             (void)hipFuncSetAttribute(                                                                       \
                 (const void*)conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_, XB_>,    \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                      \
-            attr_done = true;                                                                                \
         }                                                                                                    \
         hipLaunchKernelGGL((conv_nt_kernel<TI_, TO_, BN_, STEM_, 4, NBUF_, MINB_, BWE_, XF_, LIN_, XB_>),    \
                            grid, block, ldsz, st, g, (const TI_*)in, (const TI_*)wgt, (TO_*)out,             \
@@ -2084,12 +2083,11 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #define IO_LAUNCH_WGT_(BMO_, BNC_, W4_, NBUF_, MINB_)                                                           \
     do {                                                                                                        \
         const size_t lds = (size_t)NBUF_ * (BMO_ + BNC_) * 36 * sizeof(float);                                  \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
+        static std::atomic<unsigned long long> attr_done{0};                                                                          \
+        if (io_first_on_device(attr_done)) {                                                                                       \
             (void)hipFuncSetAttribute(                                                                          \
                 (const void*)conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, W4_, NBUF_, MINB_>,           \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                          \
-            attr_done = true;                                                                                   \
         }                                                                                                       \
         hipLaunchKernelGGL((conv_wgrad_kernel<float, float, BMO_, BNC_, 0, true, W4_, NBUF_, MINB_>), grid,     \
                            block, lds, st, g, (const float*)in, (const float*)dy, dst, p.ntile_c, p.tiles,      \
@@ -2129,11 +2127,10 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #define IO_LAUNCH_WGB_(BMO_, BNC_, STEM_, W8_, NBUF_, MINB_)                                                     \
     do {                                                                                                         \
         const size_t lds = (size_t)NBUF_ * (BMO_ + BNC_) * 36 * sizeof(float);                                   \
-        static bool attr_done = false;                                                                           \
-        if (!attr_done) {                                                                                        \
+        static std::atomic<unsigned long long> attr_done{0};                                                                           \
+        if (io_first_on_device(attr_done)) {                                                                                        \
             (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, W8_, NBUF_, MINB_>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-            attr_done = true;                                                                                    \
         }                                                                                                        \
         hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMO_, BNC_, STEM_, W8_, NBUF_, MINB_>), grid1, block, lds,    \
                            st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles, kps64,          \
@@ -2152,11 +2149,10 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
 #define IO_LAUNCH_WGTR(BMO_, BNC_, STEM_)                                                                               \
     do {                                                                                                         \
         const size_t lds = (size_t)2 * (BMO_ + BNC_) * IO_TR_BKM * 2;                                            \
-        static bool attr_done = false;                                                                           \
-        if (!attr_done) {                                                                                        \
+        static std::atomic<unsigned long long> attr_done{0};                                                                           \
+        if (io_first_on_device(attr_done)) {                                                                                        \
             (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-            attr_done = true;                                                                                    \
         }                                                                                                        \
         hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>), grid1, block,  \
                            lds, st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles,            \

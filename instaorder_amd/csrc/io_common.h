@@ -20,6 +20,20 @@ int io_check_launch(const char* what);
 
 static inline int io_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Per-device one-time set-up of a launcher (the dynamic-LDS opt-in of a kernel, the CU count): `mask` holds one bit per
+// device id; returns true the first time it is asked on the CURRENT device (a process may launch on several devices; two
+// threads racing here both do the idempotent set-up).  *dev_out: the current device id.
+#include <atomic>
+static inline bool io_first_on_device(std::atomic<unsigned long long>& mask, int* dev_out = nullptr) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (dev_out) *dev_out = d;
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short bf16_t;          // bfloat16 storage (activations / activation gradients in bf16 mode)

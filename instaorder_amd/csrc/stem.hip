@@ -407,15 +407,17 @@ int io_launch_stem_rows(const IoConvGeom& g, const float* x8, const float* wp, f
                         const float* bias, int relu, hipStream_t st) {
     IO_REQUIRE(io_stem_rows_ok(g), IO_ERR_SHAPE, "stem_rows: not the 7x7 stride-2 stem on whole 128-pixel output rows");
     const int ntiles = g.N * g.Ho * (g.Wo / 128);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
+    static std::atomic<unsigned long long> seen{0};
+    static int ncu_of[64];
+    int dev = 0;
+    if (io_first_on_device(seen, &dev)) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
+        int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+        ncu_of[dev & 63] = n > 0 ? n : 256;
         (void)hipFuncSetAttribute((const void*)stem_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         (void)hipFuncSetAttribute((const void*)stem_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
     }
+    const int ncu = ncu_of[dev & 63] > 0 ? ncu_of[dev & 63] : 256;
     const int blocks = ntiles < ncu ? ntiles : ncu;
     const int per_block = (ntiles + blocks - 1) / blocks;
     const dim3 grid((unsigned)((ntiles + per_block - 1) / per_block));
@@ -438,15 +440,17 @@ int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float*
                               size_t partial_bytes, hipStream_t st, const IoStemXb* xb) {
     IO_REQUIRE(io_stem_rows_ok(g), IO_ERR_SHAPE, "stem_wgrad_rows: not the 7x7 stride-2 stem on whole 128-pixel output rows");
     const int ntiles = g.N * g.Ho * (g.Wo / 128);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
+    static std::atomic<unsigned long long> seen{0};
+    static int ncu_of[64];
+    int dev = 0;
+    if (io_first_on_device(seen, &dev)) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0 || ncu > io_stem_wgrad_rows_max_blocks()) ncu = io_stem_wgrad_rows_max_blocks();
+        int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+        ncu_of[dev & 63] = (n <= 0 || n > io_stem_wgrad_rows_max_blocks()) ? io_stem_wgrad_rows_max_blocks() : n;
         (void)hipFuncSetAttribute((const void*)stem_wgrad_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
         (void)hipFuncSetAttribute((const void*)stem_wgrad_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
     }
+    const int ncu = ncu_of[dev & 63] > 0 ? ncu_of[dev & 63] : io_stem_wgrad_rows_max_blocks();
     const int blocks = ntiles < ncu ? ntiles : ncu;
     const int per_block = (ntiles + blocks - 1) / blocks;
     const int grid = (ntiles + per_block - 1) / per_block;

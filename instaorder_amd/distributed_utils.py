@@ -218,46 +218,6 @@ def dist_init(launcher, backend="nccl", **kwargs):
     return dist_init_(launcher, backend, kwargs.get("dist_url"))
 
 
-def _comm_device():
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-
-
-def gather_tensors(input_array):
-    """All-gather of numpy arrays whose shapes differ per rank (distributed_utils.py:89-111): shapes first, then the
-    flattened data padded to the largest count; returns the list of per-rank arrays (float32, like the reference's
-    ``torch.Tensor`` round trip)."""
-    world_size = dist.get_world_size()
-    dev = _comm_device()
-    input_array = np.asarray(input_array)
-    shape_t = torch.tensor(list(input_array.shape), dtype=torch.int64, device=dev)
-    ndim = torch.tensor([input_array.ndim], dtype=torch.int64, device=dev)
-    dist.all_reduce(ndim, op=dist.ReduceOp.MAX)
-    if int(ndim.item()) != input_array.ndim:
-        raise ValueError("gather_tensors: ranks disagree on the number of dimensions")
-    all_shape = [torch.zeros_like(shape_t) for _ in range(world_size)]
-    dist.all_gather(all_shape, shape_t)
-    all_shape = [[int(v) for v in s.cpu().tolist()] for s in all_shape]
-    all_count = [int(np.prod(s)) for s in all_shape]
-    max_count = max(all_count)
-    padded = torch.zeros(max_count, dtype=torch.float32, device=dev)
-    padded[:input_array.size] = torch.from_numpy(np.ascontiguousarray(input_array, dtype=np.float32).reshape(-1)).to(dev)
-    outs = [torch.zeros_like(padded) for _ in range(world_size)]
-    dist.all_gather(outs, padded)
-    return [o.cpu().numpy()[:all_count[i]].reshape(all_shape[i]) for i, o in enumerate(outs)]
-
-
-def gather_tensors_batch(input_array, part_size=10):
-    """distributed_utils.py:114-130: ``gather_tensors`` in slices of ``part_size`` rows, re-joined per rank."""
-    n = input_array.shape[0]
-    part_num = (n + part_size - 1) // part_size
-    parts = []
-    for i in range(part_num):
-        part = input_array[i * part_size:min((i + 1) * part_size, n), ...]
-        assert part.shape[0] > 0, "rank: {}, length of part features should > 0".format(dist.get_rank())
-        parts.append(gather_tensors(part))
-    return [np.concatenate([parts[i][j] for i in range(part_num)], axis=0) for j in range(len(parts[0]))]
-
-
 class GivenIterationSampler(DistributedGivenIterationSampler):
     """The single-process form (distributed_utils.py:163-200): the same tiled, seed-0-shuffled index stream."""
 

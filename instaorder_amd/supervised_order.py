@@ -143,6 +143,10 @@ class _OrderBase(SingleStageModel):
             logits, losses = (t.clone() for t in self._dp_out)
             return logits, losses
         if graphs_ok and self._seen_key == key:
+            # Only the CAPTURE sits in the try-block.  Once a collective of this step has been launched there is no falling
+            # back to another path: re-running the forward would advance the BatchNorm running statistics twice and post
+            # more all-reduces than the peer ranks do.
+            graphs = None
             try:
                 torch.cuda.synchronize()
                 g0 = torch.cuda.CUDAGraph()
@@ -156,16 +160,18 @@ class _OrderBase(SingleStageModel):
                     with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode="thread_local"):
                         net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(s, s + 1))
                     graphs.append(g)
+            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager (nothing has run yet)
+                graphs = None
+                self._use_graph = False
+                self._dp_graphs = None
+                print("instaorder_amd: per-stage hipGraph capture disabled (%s)" % ex)
+            if graphs is not None:
                 self._dp_graphs, self._dp_key, self._dp_out, self._dp_keep = graphs, key, (logits, losses), (ws, dlogits)
                 for s, g in enumerate(graphs):
                     g.replay()
                     bk.launch(s)
                 bk.finish()
                 return logits.clone(), losses.clone()
-            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
-                self._use_graph = False
-                self._dp_graphs = None
-                print("instaorder_amd: per-stage hipGraph capture disabled (%s)" % ex)
         logits, ws = net._run_forward(self._x8, N, S, 2, True)
         losses, dlogits = self._loss(logits, True, True)
         for s in range(ns):
@@ -231,7 +237,9 @@ def _check_labels(t, lo, hi, what, is_overlap=None):
     looked at: with ``is_overlap`` given, those whose flag is 0 or 1 -- the reference keeps -1 for overlapped pairs under
     ``remove_depth_overlap`` (datasets/reader.py:363-380) and its boolean masks drop them (supervised_order.py:62-73)."""
     if t is not None and torch.is_tensor(t) and not t.is_cuda and t.numel():
-        if is_overlap is not None and torch.is_tensor(is_overlap) and not is_overlap.is_cuda:
+        if is_overlap is not None and torch.is_tensor(is_overlap):
+            if is_overlap.is_cuda:        # labels on the host, flags already on the device: bring the flags over
+                is_overlap = is_overlap.cpu()
             live = (is_overlap.reshape(-1) == 0) | (is_overlap.reshape(-1) == 1)
             t = t.reshape(-1)[live]
             if not t.numel():

@@ -309,30 +309,6 @@ def test_bordering_and_pair_selection():
         inference.select_pairs(m, "some")
 
 
-def test_heuristic_baselines_and_gt_order_match_reference():
-    """inference.py:272-347, 719-754 (area / y-axis baselines, infer_gt_order, eval_order) against matrices produced by
-    the reference's own functions (tests/golden/heuristics.npz)."""
-    from instaorder_amd import inference
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heuristics.npz"))
-    rd = synthetic.SyntheticReader(88, n_images=4, n_inst=6, empty_every=0)
-    for k, sc in enumerate(rd.scenes):
-        m = sc["modal"]
-        got = {"occ_area_s": inference.infer_occ_order_area(m, "smaller"),
-               "occ_area_l": inference.infer_occ_order_area(m, "larger"),
-               "occ_y_lo": inference.infer_occ_order_yaxis(m, "lower"),
-               "occ_y_hi": inference.infer_occ_order_yaxis(m, "higher"),
-               "dep_area_s": inference.infer_depth_order_area(m, "smaller"),
-               "dep_area_l": inference.infer_depth_order_area(m, "larger"),
-               "dep_y_lo": inference.infer_depth_order_yaxis(m, "lower"),
-               "dep_y_hi": inference.infer_depth_order_yaxis(m, "higher"),
-               "gt": inference.infer_gt_order(m, z["amodal_%d" % k])}
-        for name, v in got.items():
-            assert np.array_equal(v, z["%s_%d" % (name, k)]), (name, k)
-        ev = inference.eval_order(got["occ_area_s"], got["gt"])
-        assert np.allclose(np.asarray(ev[:4], np.float64), z["eval_%d" % k])
-        assert np.array_equal(ev[4], z["eval_err_%d" % k])
-
-
 def _tester_golden():
     import json
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tester.npz"))
@@ -351,8 +327,9 @@ def test_evaluate_heuristics_equal_reference_tester(k):
     assert algo == "None"
     S, seed, rseed, warm = [int(v) for v in z["meta"]]
     rd = synthetic.SyntheticReader(rseed, n_images=4, n_inst=5, empty_every=0)
-    res = evaluate.evaluate(None, rd, rd.load_image, dict(cfg, trainval_dataset=kind, patch_or_image=mode), method,
-                            return_orders=True)
+    from helpers import baseline_rule          # the reference's area / y-axis baselines: test-side ordering rules
+    res = evaluate.evaluate(None, rd, rd.load_image, dict(cfg, trainval_dataset=kind, patch_or_image=mode),
+                            baseline_rule(kind, method), return_orders=True)
     for i in range(4):
         occ, dep = res["orders"][i]
         assert np.array_equal(occ if dep is None else dep, z["%s_pred_%d" % (name, i)])
@@ -363,28 +340,6 @@ def test_evaluate_heuristics_equal_reference_tester(k):
         for key in evaluate.WHDR_KEYS:
             ovl, eq = key.split("_")
             assert abs(res["WHDR_" + key] - float(z["%s_log_val_%s.WHDR_%s" % (name, ovl, eq)])) < 1e-9
-
-
-def test_harness_helpers(tmp_path):
-    """AverageMeter (running / windowed), accuracy@k and create_logger of utils/common_utils.py:66-126."""
-    from instaorder_amd import common_utils as cu
-    m = cu.AverageMeter()
-    for v in (1.0, 2.0, 6.0):
-        m.update(v)
-    assert m.val == 6.0 and m.avg == 3.0 and m.count == 3
-    w = cu.AverageMeter(2)
-    for v in (1.0, 2.0, 6.0):
-        w.update(v)
-    assert w.val == 6.0 and w.avg == 4.0 and w.history == [2.0, 6.0]
-    out = torch.tensor([[0.1, 0.7, 0.2], [0.6, 0.3, 0.1], [0.2, 0.3, 0.5], [0.5, 0.4, 0.1]])
-    tgt = torch.tensor([1, 1, 2, 2])
-    a1, a2 = cu.accuracy(out, tgt, topk=(1, 2))
-    assert float(a1) == 50.0 and float(a2) == 75.0
-    lg = cu.create_logger("io_test_logger", str(tmp_path / "log.txt"))
-    lg.info("hello")
-    for h in lg.handlers:
-        h.flush()
-    assert "hello" in open(str(tmp_path / "log.txt")).read()
 
 
 def test_ordernet_decisions_and_f1_corners_match_reference_golden():
