@@ -368,6 +368,11 @@ typedef struct io_dgrad_fused {
     const float *ep_mean, *ep_rstd, *ep_scale, *ep_shift;
     void* ep_act_out;
     float *ep_p1, *ep_p2;
+    /* optional: io_conv2d_wino_scratch_floats(Cin, Cout) floats of device scratch -- a 3x3 pad-1 fp32 data gradient without
+     * add / relu_mask / xb_* on whole 128-row tiles with even W then runs in the Winograd F(2, 3) row form (2/3 of the
+     * MFMAs; results differ from the direct form at rounding level) */
+    float* wino_scratch;
+    size_t wino_scratch_floats;
 } io_dgrad_fused;
 int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout, int R,
                              int S, int pad, int G, const io_dgrad_fused* f, int dtype, hipStream_t stream);
@@ -378,6 +383,17 @@ int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx, int N, in
  * io_conv2d_fwd_bnstats produce for the first BatchNorm (the expression is io_bn_apply's; in_mean may be NULL = 0).  workspace != NULL: also the training statistics of y, exactly as
  * io_conv2d_fwd_bnstats_dt (gamma .. shift then describe the BatchNorm AFTER this convolution); workspace == NULL: they
  * are ignored.  Output rows per group must be a multiple of 128; Cin a multiple of 32 (fp32) / 64 (bf16). */
+/* Winograd F(2, 3) row form of the 3x3 stride-1 pad-1 fp32 convolution (resnet_cls.py:23-26 conv3x3): the arguments of
+ * io_conv2d_fwd_xf_dt (in_scale / in_shift NULL: no input transform; workspace NULL: no statistics) + device scratch of
+ * io_conv2d_wino_scratch_floats(Cin, Cout) floats for the transformed filters.  A pair of horizontally adjacent outputs
+ * costs 4 products per filter row instead of 6; the result differs from the direct form at fp32 rounding level only.
+ * Needs even W and N*H*W/G a multiple of 128 (other shapes silently run the direct kernel). */
+size_t io_conv2d_wino_scratch_floats(int Cin, int Cout);
+int io_conv2d_fwd_wino(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int G,
+                       const float* in_mean, const float* in_scale, const float* in_shift, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                       float* rstd, float* scale, float* shift, float* workspace, size_t workspace_floats,
+                       float* wino_scratch, size_t wino_floats, hipStream_t stream);
 int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                         int stride, int pad, int G, const float* in_mean, const float* in_scale, const float* in_shift,
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,

@@ -44,7 +44,8 @@ class PairDesc(C.Structure):
 class DgradFused(C.Structure):
     """io_dgrad_fused of include/instaorder_hip.h (device pointers as integers, None = NULL)"""
     _fields_ = [(n, C.c_void_p) for n in ("xb_y", "xb_coef", "xb_dy_out", "add", "relu_mask", "ep_y", "ep_mean", "ep_rstd",
-                                          "ep_scale", "ep_shift", "ep_act_out", "ep_p1", "ep_p2")]
+                                          "ep_scale", "ep_shift", "ep_act_out", "ep_p1", "ep_p2", "wino_scratch")] + \
+               [("wino_scratch_floats", C.c_size_t)]
 
 
 class ProfEntry(C.Structure):
@@ -151,6 +152,9 @@ SIGNATURES = {
     "io_maxpool_fwd_xf_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P]),
     "io_conv2d_fwd_xf_dt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P,
                                  _P, _P, _P, _P, _Z, _I, _P]),
+    "io_conv2d_wino_scratch_floats": (_Z, [_I, _I]),
+    "io_conv2d_fwd_wino": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z,
+                                _P, _Z, _P]),
     "io_maxpool_fwd_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "io_maxpool_bwd_dt": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "io_avgpool_fc_fwd_dt": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P]),

@@ -193,7 +193,8 @@ std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[IO_PROF_NCLASS] = {"conv_nt_kernel<128,false>", "conv_nt_kernel<64,false>",
     "conv_nt_kernel<64,true>", "conv_wgrad_kernel", "conv_wgrad_kernel<64,64,true>", "bn_stats_finalize",
-    "bn_apply", "bn_bwd", "pool_head", "filter_transpose", "pack_planes", "order_loss", "sgd_momentum"};
+    "bn_apply", "bn_bwd", "pool_head", "filter_transpose", "pack_planes", "order_loss", "sgd_momentum",
+    "conv_nt_kernel<wino>"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -543,8 +544,14 @@ extern "C" int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx
         bw.xb_y = f->xb_y; bw.xb_a = f->xb_coef; bw.xb_b = f->xb_coef + gs; bw.xb_c = f->xb_coef + 2 * gs;
         bw.xb_out = f->xb_dy_out; bw.xb_Mg = M / G;
     }
-    return io_run_dgrad(dy, wt, dx, f->add, f->relu_mask, N, H, W, Cin, Cout, R, S, 1, pad, st, grouped ? &bw : nullptr,
-                        dtype);
+    if (f->wino_scratch) {
+        IO_REQUIRE(f->wino_scratch_floats >= io_conv2d_wino_scratch_floats(Cin, Cout), IO_ERR_WORKSPACE,
+                   "conv2d_dgrad_fused: wino_scratch %zu < %zu floats", f->wino_scratch_floats,
+                   io_conv2d_wino_scratch_floats(Cin, Cout));
+        bw.wino_u = f->wino_scratch;
+    }
+    return io_run_dgrad(dy, wt, dx, f->add, f->relu_mask, N, H, W, Cin, Cout, R, S, 1, pad, st,
+                        (grouped || f->wino_scratch) ? &bw : nullptr, dtype);
 }
 
 /* Forward convolution whose INPUT goes through the BatchNorm + ReLU of the layer that produced it, applied while the
@@ -553,13 +560,49 @@ extern "C" int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx
  * zero padding applied AFTER the transform, as nn.Conv2d pads relu(bn(x)) (resnet_cls.py:99-111: bn -> relu -> next
  * conv).  in_scale / in_shift: [G][Cin]; group g = the samples [g N/G, (g+1) N/G).  With workspace != NULL the training
  * statistics of y are produced as by io_conv2d_fwd_bnstats_dt (same G). */
+extern "C" size_t io_conv2d_wino_scratch_floats(int Cin, int Cout) { return (size_t)12 * Cin * Cout; }
+
+static int conv2d_fwd_xf_impl(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
+                              int S, int stride, int pad, int G, const float* in_mean, const float* in_scale,
+                              const float* in_shift, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              float* workspace, size_t workspace_floats, int dtype, hipStream_t st, float* wino_scratch,
+                              size_t wino_floats);
+
 extern "C" int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
                                    int S, int stride, int pad, int G, const float* in_mean, const float* in_scale,
                                    const float* in_shift, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
                                    float* workspace, size_t workspace_floats, int dtype, hipStream_t st) {
-    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_xf: unknown dtype %d", dtype);
     IO_REQUIRE(in_scale && in_shift, IO_ERR_SHAPE, "conv2d_fwd_xf: in_scale / in_shift are required");
+    return conv2d_fwd_xf_impl(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, G, in_mean, in_scale, in_shift, gamma, beta,
+                              running_mean, running_var, momentum, eps, mean, rstd, scale, shift, workspace,
+                              workspace_floats, dtype, st, nullptr, 0);
+}
+
+/* The 3x3 stride-1 pad-1 fp32 convolution of io_conv2d_fwd_xf_dt (in_scale NULL: no input transform) in the Winograd
+ * F(2, 3) row form; wino_scratch: io_conv2d_wino_scratch_floats(Cin, Cout) floats of device scratch for the transformed
+ * filters.  Shapes the form does not cover (odd W, rows not in whole 128-row tiles) run the direct kernel. */
+extern "C" int io_conv2d_fwd_wino(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int G,
+                                  const float* in_mean, const float* in_scale, const float* in_shift, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* mean, float* rstd, float* scale, float* shift, float* workspace,
+                                  size_t workspace_floats, float* wino_scratch, size_t wino_floats, hipStream_t st) {
+    IO_REQUIRE(wino_scratch && wino_floats >= io_conv2d_wino_scratch_floats(Cin, Cout), IO_ERR_WORKSPACE,
+               "conv2d_fwd_wino: wino_scratch %zu < %zu floats", wino_floats, io_conv2d_wino_scratch_floats(Cin, Cout));
+    return conv2d_fwd_xf_impl(x, w, y, N, H, W, Cin, Cout, 3, 3, 1, 1, G, in_mean, in_scale, in_shift, gamma, beta,
+                              running_mean, running_var, momentum, eps, mean, rstd, scale, shift, workspace,
+                              workspace_floats, IO_F32, st, wino_scratch, wino_floats);
+}
+
+static int conv2d_fwd_xf_impl(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
+                              int S, int stride, int pad, int G, const float* in_mean, const float* in_scale,
+                              const float* in_shift, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              float* workspace, size_t workspace_floats, int dtype, hipStream_t st, float* wino_scratch,
+                              size_t wino_floats) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_xf: unknown dtype %d", dtype);
+    IO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), IO_ERR_SHAPE, "conv2d_fwd_xf: in_scale / in_shift come as a pair");
     IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad);
     const int M = N * g.Ho * g.Wo;
     IO_REQUIRE(G >= 1 && N % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
@@ -569,6 +612,7 @@ extern "C" int io_conv2d_fwd_xf_dt(const void* x, const void* w, void* y, int N,
     ep.in_scale = in_scale;
     ep.in_shift = in_shift;
     ep.in_Mg = M / G;
+    ep.wino_u = wino_scratch;
     if (!workspace) return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, 0, st, nullptr, nullptr, &ep, dtype, dtype);
     const size_t need = io_conv2d_bnstats_workspace_floats(N, H, W, Cout, R, S, stride, pad, G);
     IO_REQUIRE(workspace_floats >= need, IO_ERR_WORKSPACE, "conv2d_fwd_xf: workspace %zu < %zu floats", workspace_floats,

@@ -167,8 +167,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // validity, k offsets and output row steps ride in the scalar offset of the buffer instructions.  The generic path spends
 // ~800 VALU + ~500 SALU instructions per wave and tile on addressing; with a bf16 tile of K <= 512 worth only 16..128
 // MFMAs the SIMDs were instruction-issue bound on exactly these layers (measured: 69 % issue utilisation, 19 % MFMA).
+// WINO (fp32, BN = 64, 3x3 stride-1 same-size convolutions / data gradients on whole 128-pixel tiles, Wo even): the
+// convolution along the image ROW in Winograd's minimal form F(2, 3).  A pair of horizontally adjacent output pixels
+// (w, w + 1), w even, needs per filter row 4 products per (input channel, output channel) instead of 6: with d0..d3 the
+// inputs at columns w - 1 .. w + 2 of that row and g0..g2 the filter row,
+//     V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)        U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)
+//     m_f = sum over filter rows and input channels of V_f * U_f            (f = 0..3: FOUR independent GEMMs)
+//     y(w) = m0 + m1 + m2        y(w + 1) = m1 - m2 - m3
+// so the 3x3 layer runs 2/3 of the MFMAs of the direct form.  The block tile is the same 128 output pixels (= 64 pairs) x
+// 64 output channels; a wave owns 32 pairs x 32 channels x the FOUR frequencies -- four 32x32 accumulators, the same 64
+// registers as the direct kernel's 2 x 2 tile -- and because the four accumulators of a lane hold the SAME (pair, channel)
+// entries, the output transform is plain register arithmetic.  U is prepared by wino_filter_kernel (layout
+// [filter row][f][Co][Ci]); V is formed between the global loads and the LDS stores of the A operand (after the optional
+// input transform XF), i.e. the LDS image holds 4 x 64 rows of V and 4 x 64 rows of U per k-tile, and a k-tile is one
+// filter row x 32 input channels: K = 3 Ci per frequency.  Everything behind the accumulators -- statistics, the fused
+// BatchNorm-backward epilogue, side outputs -- is the direct kernel's code on (even pixel, odd pixel) tiles.
 template <typename TA, typename TO, int BN, int STEM, int NW, int NBUF = 2, int MINB = 1, bool BWE = false,
-          bool XF = false, bool LIN = false, int XB = 0>
+          bool XF = false, bool LIN = false, int XB = 0, bool WINO = false>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, const TA* __restrict__ in,
                                                          const TA* __restrict__ wgt, TO* __restrict__ out,
                                                          const TO* __restrict__ add,
@@ -189,7 +204,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     constexpr bool XK = STEM == 2;          // exact-K stem
     static_assert(!XK || ES == 4, "the exact-K stem is an fp32 path");
     constexpr int WN = NW / 2;              // waves along N (2 along M)
-    constexpr int TI = 2, TJ = BN / (32 * WN);
+    static_assert(!WINO || (ES == 4 && OS == 4 && BN == 64 && NW == 4 && STEM == 0 && NBUF == 1 && !LIN && XB == 0),
+                  "WINO: fp32, 64-wide tiles, single LDS buffer, plain / XF / BWE forms");
+    constexpr int TI = WINO ? 4 : 2, TJ = BN / (32 * WN);   // WINO: the 4 frequencies of 32 pairs
+    constexpr int ETI = 2;                  // row blocks of a wave's OUTPUT tile (WINO: even / odd pixels of its 32 pairs)
+    constexpr int AROWS = WINO ? 2 * BM : BM, BROWS = WINO ? 4 * BN : BN;   // LDS rows per operand tile
     constexpr int AR = (BM * 8) / NT;       // A rows loaded per thread (8 float4 per row)
     constexpr int BR = (BN * 8) / NT;       // weight rows loaded per thread
     constexpr int RS = NT / 8;              // row step between a thread's rows
@@ -197,8 +216,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // the row-wise bf16 epilogues turn 32 x (BN / WN) fp32 values per wave through the operand LDS
     static_assert(NBUF * (BM + BN) * LDT >= NW * 32 * (BN / WN + 4), "operand LDS too small for the row epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                       // [2][BM][LDT]
-    float* sB = smem + NBUF * BM * LDT;     // [NBUF][BN][LDT]
+    float* sA = smem;                       // [2][AROWS][LDT]
+    float* sB = smem + NBUF * AROWS * LDT;  // [NBUF][BROWS][LDT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     const int cbase = g.gw ? n0 : 0;             // first input channel of the k range
     const int nkc = STEM ? 1 : kw / BK;
     const int kp = XK ? stem_kp(g.wT, g.cr) : 0;
-    const int nk = XK ? kp / 32 : STEM ? (g.wT + TPT - 1) / TPT : g.Th * g.Tw * nkc;
+    const int nk = XK ? kp / 32 : STEM ? (g.wT + TPT - 1) / TPT : (WINO ? g.Th : g.Th * g.Tw) * nkc;
 
     // Addressing: every operand row gets ONE 32-bit byte offset per tile (rowv / wv); a k-tile adds a
     // wave-uniform tap/channel offset to it.  Invalid rows / padding taps get kInvalidOff and the buffer
@@ -244,6 +263,29 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             wi0[j] = wo * g.is;
             rowv[j] = (unsigned)((((n - n_lo) * g.Hi + hi0[j]) * g.Wi + wi0[j]) * g.Ci + (STEM ? 0 : kq * VE)) * (unsigned)ES;
         }
+    }
+    // WINO: a thread stages AI = 2 (pair, 16-byte channel chunk) items of the A operand -- pairs lr and lr + 32 of the tile --
+    // from the 4 pixels w - 1 .. w + 2 of the pair's row, and 8 rows (f, channel) of U
+    constexpr int AI = 2, WBR = 8;
+    unsigned wrow[AI];
+    int whi[AI];
+    bool wl[AI], wr[AI];
+    unsigned wvb[WBR];
+    f32x4 wa[WINO ? AI : 1][4], wb[WINO ? WBR : 1];
+    if constexpr (WINO) {
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            const int m = m0 + 2 * (lr + 32 * j);                      // whole tiles: always < M
+            const int n = fdiv(m, g.fd_howo), rem = m - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+            whi[j] = ho;
+            wl[j] = wo > 0;
+            wr[j] = wo + 2 < g.Wi;
+            wrow[j] = (unsigned)((((n - n_lo) * g.Hi + ho) * g.Wi + wo) * g.Ci + kq * 4) * 4u;
+        }
+#pragma unroll
+        for (int j = 0; j < WBR; ++j)     // LDS row lr + 32 j = (f = j >> 1, channel lr + 32 (j & 1)); U is [th][f][Co][Ci]
+            wvb[j] = (unsigned)(((j >> 1) * g.Co + n0 + lr + 32 * (j & 1)) * g.Ci + kq * 4) * 4u;
     }
     unsigned wv[BR];
 #pragma unroll
@@ -341,6 +383,32 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv[j], koff, 0));
             return;
         }
+        if constexpr (WINO) {
+            const int dh = g.dh0 + g.dhs * th;
+            // (unsigned wrap-around: "- 1 pixel" on an offset that stays inside the descriptor whenever it is used)
+            const unsigned aoff = (unsigned)(((dh * g.Wi - 1) * g.Ci + cc * BK) * 4);
+            const unsigned woff = (unsigned)((th * 4 * g.Co * g.Ci + cc * BK) * 4);
+            if constexpr (XF) {
+                const unsigned coff = (unsigned)(cc * BK + kq * VE) * 4u;
+                xm[0] = bld4(rs_xm, coff);
+                xs[0] = bld4(rs_xs, coff);
+                xh[0] = bld4(rs_xh, coff);
+            }
+            xok = 0;
+#pragma unroll
+            for (int j = 0; j < AI; ++j) {
+                const bool rowok = (unsigned)(whi[j] + dh) < (unsigned)g.Hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = rowok & (i == 0 ? wl[j] : i == 3 ? wr[j] : true);
+                    xok |= ok ? (1u << (j * 4 + i)) : 0u;
+                    wa[j][i] = bld4(rs_in, ok ? wrow[j] + aoff + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WBR; ++j) wb[j] = bld4(rs_w, wvb[j] + woff);
+            return;
+        }
         int dh, dw;
         unsigned aoff, woff;     // wave-uniform for the regular path
         bool tapok = true;
@@ -396,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             const int c1 = cc + 1;
             const bool wrapc = c1 == nkc;
             const int t1 = tw + (wrapc ? 1 : 0);
-            const bool wrapt = t1 == g.Tw;
+            const bool wrapt = t1 == (WINO ? 1 : g.Tw);
             cc = really ? (wrapc ? 0 : c1) : cc;
             tw = really ? (wrapt ? 0 : t1) : tw;
             th = really ? th + (wrapt ? 1 : 0) : th;
@@ -406,6 +474,29 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // XB: the operand transform of the tile in (ra, ry) + its side output.  Its own step so that the loop can run it under
     // the MFMAs of the previous tile instead of inside the barrier-to-barrier section of store_tile (IO_XB_PIPE).
     auto xform_tile = [&]() {
+        if constexpr (WINO) {
+#pragma unroll
+            for (int j = 0; j < AI; ++j) {
+                if constexpr (XF) {
+                    // relu(bn(x)) of the 4 pixels first (bn_apply_kernel's expression; padding stays zero)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ok = (xok >> (j * 4 + i)) & 1u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = fmaxf(__builtin_fmaf(wa[j][i][e] - xm[0][e], xs[0][e], xh[0][e]), 0.f);
+                            wa[j][i][e] = ok ? v : 0.f;
+                        }
+                    }
+                }
+                const f32x4 d0 = wa[j][0], d1 = wa[j][1], d2 = wa[j][2], d3 = wa[j][3];
+                wa[j][0] = d0 - d2;
+                wa[j][1] = d1 + d2;
+                wa[j][2] = d2 - d1;
+                wa[j][3] = d1 - d3;
+            }
+            return;
+        }
         if constexpr (XF) {
             // relu((x - mean) * scale + shift) on the staged chunk (bn_apply_kernel's expression); rows that are padding (or past M) stay zero -- the transform of
             // the zeros the buffer unit returned would be relu(shift)
@@ -496,6 +587,18 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         }
     };
     auto store_tile = [&](int buf, bool xdone = false) {
+        if constexpr (WINO) {
+            if (!xdone) xform_tile();
+            float* a = sA + lr * LDT + wchunk * 4;      // rows f * 64 + pair (pairs lr, lr + 32: the same swizzle bits)
+            float* b = sB + lr * LDT + wchunk * 4;      // rows lr + 32 j
+#pragma unroll
+            for (int j = 0; j < AI; ++j)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) st4(a + (f * 64 + 32 * j) * LDT, wa[j][f]);
+#pragma unroll
+            for (int j = 0; j < WBR; ++j) st4(b + 32 * j * LDT, wb[j]);
+            return;
+        }
         float* a = sA + buf * BM * LDT + lr * LDT + wchunk * 4;
         float* b = sB + buf * BN * LDT + lr * LDT + wchunk * 4;
         if constexpr (XT) {
@@ -523,10 +626,19 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     // 3 and 4 of tile k -- whose operands are already in registers -- with the first fragments of
     // tile k+1 fetched right behind the barrier, under that last group.
     const int rsw = SWZ ? (lane >> 1) & 7 : 0;                 // all fragment rows of a lane are = lane mod 32
-    const int a_off = (wm * 64 + (lane & 31)) * LDT + (SWZ ? 0 : (lane >> 5) * 4);
+    const int a_off = (wm * (WINO ? 32 : 64) + (lane & 31)) * LDT + (SWZ ? 0 : (lane >> 5) * 4);
     const int b_off = (wn * (BN / WN) + (lane & 31)) * LDT + (SWZ ? 0 : (lane >> 5) * 4);
-    auto read_frags = [&](int buf, int kk, f32x4 (&a)[TI], f32x4 (&b)[TJ]) {
+    constexpr int FB = WINO ? 4 : TJ;       // B fragments per read (WINO: one per frequency)
+    auto read_frags = [&](int buf, int kk, f32x4 (&a)[TI], f32x4 (&b)[FB]) {
         const int koff = SWZ ? ((((lane >> 5) + kk * 2) ^ rsw) * 4) : kk * 8;
+        if constexpr (WINO) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                a[f] = ld4(sA + a_off + koff + f * 64 * LDT);
+                b[f] = ld4(sB + b_off + koff + f * 64 * LDT);
+            }
+            return;
+        }
         const float* al = sA + buf * BM * LDT + a_off + koff;
         const float* bl = sB + buf * BN * LDT + b_off + koff;
 #pragma unroll
@@ -535,8 +647,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         for (int j = 0; j < TJ; ++j) b[j] = ld4(bl + j * 32 * LDT);
     };
     // one fragment read (16 B per lane and tile) feeds 4 fp32 MFMAs (k = 2 each) or 1 bf16 MFMA (k = 16)
-    auto mma16 = [&](const f32x4 (&a)[TI], const f32x4 (&b)[TJ]) {
-        if constexpr (ES == 4) {
+    auto mma16 = [&](const f32x4 (&a)[TI], const f32x4 (&b)[FB]) {
+        if constexpr (WINO) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f][tt], b[f][tt], acc[f][0], 0, 0, 0);
+        } else if constexpr (ES == 4) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -555,7 +673,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         }
     };
 
-    f32x4 fa[TI], fb[TJ];
+    f32x4 fa[TI], fb[FB];
     if (nk > 0) {
         load_tile(0);
         store_tile(0);
@@ -572,20 +690,20 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         advance(true);
         // (fp32 only: in bf16 the transform is VALU-bound whatever its place and the longer live ranges spill --
         // profiles/r03_xb_microbench_bf16.txt; the bf16 step does not use the operand forms)
-        constexpr bool PIPE = ES == 4 && ((XB != 0 && IO_XB_PIPE) || (XF && IO_XF_PIPE));
+        constexpr bool PIPE = ES == 4 && ((XB != 0 && IO_XB_PIPE) || (XF && IO_XF_PIPE) || WINO);
         if constexpr (!PIPE) load_tile(kt + 1);
 #if IO_EARLY_LOADS
         __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
 #endif
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
-            f32x4 na[TI], nb[TJ];
+            f32x4 na[TI], nb[FB];
             read_frags(buf, kk + 1, na, nb);
             mma16(fa, fb);
 #pragma unroll
             for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+            for (int j = 0; j < FB; ++j) fb[j] = nb[j];
             if constexpr (PIPE) {
                 // operand forms: the fetches of tile kt+1 go out behind the first MFMA group, and the transform of what
                 // they bring runs under the third -- not between the barriers, where all four waves of the block wait
@@ -600,30 +718,42 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
         store_tile(nbuf, PIPE);
         __syncthreads();
-        f32x4 na[TI], nb[TJ];
+        f32x4 na[TI], nb[FB];
         read_frags(nbuf, 0, na, nb);           // first fragments of tile kt+1
         __builtin_amdgcn_sched_barrier(0);
         mma16(fa, fb);                         // group 4 of tile kt, operands already in registers
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+        for (int j = 0; j < FB; ++j) fb[j] = nb[j];
     }
     if (nk > 0) {
         const int buf = NBUF == 2 ? (nk - 1) & 1 : 0;
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
-            f32x4 na[TI], nb[TJ];
+            f32x4 na[TI], nb[FB];
             read_frags(buf, kk + 1, na, nb);
             mma16(fa, fb);
 #pragma unroll
             for (int i = 0; i < TI; ++i) fa[i] = na[i];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
+            for (int j = 0; j < FB; ++j) fb[j] = nb[j];
         }
         mma16(fa, fb);
     }
 
+    // WINO: the output transform -- y(even pixel) = m0 + m1 + m2, y(odd pixel) = m1 - m2 - m3 -- in place: from here on
+    // acc[0] / acc[1] are the wave's OUTPUT tiles (32 even / 32 odd pixels x 32 channels).  Row of element r of tile i inside
+    // the wave's 64 rows: direct i * 32 + q, WINO 2 q + i, with q = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    if constexpr (WINO) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m1 = acc[1][0][r], m2 = acc[2][0][r];
+            acc[0][0][r] = acc[0][0][r] + m1 + m2;
+            acc[1][0][r] = m1 - m2 - acc[3][0][r];
+        }
+    }
+    constexpr int RQ = WINO ? 2 : 1, RI = WINO ? 1 : 32;      // row = RI * i + RQ * q
     // Fused BatchNorm statistics (forward convs in training mode): per (row tile, channel) the mean of the
     // tile's valid rows and the sum of squared deviations from it -- two in-register passes over the
     // accumulators, combined across the two row-waves through LDS.  Merged later with Chan's update.
@@ -638,10 +768,10 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             for (int j = 0; j < TJ; ++j) {
                 float sacc = 0.f;
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < ETI; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int m = m0 + wm * 64 + RI * i + RQ * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                         const float v = acc[i][j][r];
                         const float d = pass == 0 ? v : (v - cmean[j]) * (v - cmean[j]);
                         sacc += m < M ? d : 0.f;
@@ -694,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         // layout ride in the scalar offset of the buffer instructions (no per-row offset registers, no selects).
         const unsigned colb2 = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
         const unsigned rowstep = (unsigned)g.Co * (unsigned)OS;
-        const unsigned lane_base = (unsigned)(m0 - opix_lo + wm * 64 + 4 * (lane >> 5)) * rowstep + colb2;
+        const unsigned lane_base = (unsigned)(m0 - opix_lo + wm * 64 + RQ * 4 * (lane >> 5)) * rowstep + colb2;
         const __amdgpu_buffer_rsrc_t rs_add0 = add ? rs_add : make_rsrc(out, 0);
         const __amdgpu_buffer_rsrc_t rs_mask0 = mask ? rs_mask : make_rsrc(out, 0);
         const bool nomask = mask == nullptr;
@@ -710,20 +840,20 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         float* ep = smem + wave * (32 * EPP);
         if (ROWS) __syncthreads();               // every wave is done with the operand tiles
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+        for (int i = 0; i < ETI; ++i) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const unsigned voff = lane_base + (unsigned)(i * 32) * rowstep + (unsigned)j * 32u * OS;
+                const unsigned voff = lane_base + (unsigned)(i * RI) * rowstep + (unsigned)j * 32u * OS;
                 // All three tensors are fetched unconditionally -- a per-element "load or constant" on a runtime pointer
                 // makes hipcc branch around every load and drain the queue each time; an absent `add` / `mask` has a
                 // zero-length descriptor instead, whose loads return 0 without touching memory.
                 float av[16], mv[16], yv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = ld_el_s<TO>(rs_bwy, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                for (int r = 0; r < 16; ++r) yv[r] = ld_el_s<TO>(rs_bwy, voff, (unsigned)(RQ * ((r & 3) + 8 * (r >> 2))) * rowstep);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) av[r] = ld_el_s<TO>(rs_add0, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                for (int r = 0; r < 16; ++r) av[r] = ld_el_s<TO>(rs_add0, voff, (unsigned)(RQ * ((r & 3) + 8 * (r >> 2))) * rowstep);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = ld_el_s<TO>(rs_mask0, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                for (int r = 0; r < 16; ++r) mv[r] = ld_el_s<TO>(rs_mask0, voff, (unsigned)(RQ * ((r & 3) + 8 * (r >> 2))) * rowstep);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + av[r];
@@ -733,9 +863,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     bw_s1[j] += v;
                     bw_s2[j] += v * ((yv[r] - bw_mu[j]) * bw_rs[j]);
                     if constexpr (ROWS) ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = v;
-                    else st_el_s<TO>(v, rs_out, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    else st_el_s<TO>(v, rs_out, voff, (unsigned)(RQ * ((r & 3) + 8 * (r >> 2))) * rowstep);
                     // (no a_out: a zero-length descriptor drops the store)
-                    st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+                    st_el_s<TO>(fmaxf(t, 0.f), rs_aout, voff, (unsigned)(RQ * ((r & 3) + 8 * (r >> 2))) * rowstep);
                 }
             }
             if constexpr (ROWS) {
@@ -778,7 +908,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                 __syncthreads();                 // every wave is done with the operand tiles
                 float* ep = smem + wave * (32 * EPP);
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
+                for (int i = 0; i < ETI; ++i) {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -804,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             }
         }
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+        for (int i = 0; i < ETI; ++i) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const unsigned voff = lane_base + (unsigned)(i * 32) * rowstep + (unsigned)j * 32u * OS;
@@ -840,11 +970,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     const unsigned colb = (unsigned)(n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
     constexpr unsigned JS = 32u * OS;     // byte step between a lane's column blocks
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
+    for (int i = 0; i < ETI; ++i) {
         unsigned rowb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm * 64 + RI * i + RQ * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
             const bool ok = m < M;
             int pix = ok ? m : m0;
             if (!dense) {
@@ -1787,6 +1917,32 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
 // two blocks per CU, 117.8 with 16-row k-tiles at four, against 118.3 for the register-staged kernel at three; the
 // fp32 filter gradient is bound by the matrix pipe, not by its staging, so it stays on conv_wgrad_kernel.)
 
+// Winograd F(2, 3) filter transform along the filter ROW for conv_nt_kernel<..., WINO>: w [Co][9][Ci] (the operand layout
+// of the direct kernel; for a data gradient the transposed filter) -> U [filter-row step th][f][Co][Ci] with
+// U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2), where g_j is the tap that meets the input column w + j - 1 in the
+// launch's gather geometry (forward: tap j; data gradient: tap 2 - j) and th walks the geometry's row taps in kernel order.
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co,
+                                                         int Ci, int S, int r0, int rs, int s0, int ss, int dw0,
+                                                         int dws) {
+    const int th = blockIdx.y, c4n = Ci / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Co * c4n) return;
+    const int o = idx / c4n, c = (idx - o * c4n) * 4;
+    f32x4 gq[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tw = (j - 1 - dw0) * dws;                    // dws = +-1
+        const int tap = (r0 + rs * th) * S + s0 + ss * tw;
+        gq[j] = ld4(w + ((size_t)o * (3 * S) + tap) * Ci + c);
+    }
+    const size_t plane = (size_t)Co * Ci;
+    float* dst = U + (size_t)th * 4 * plane + (size_t)o * Ci + c;
+    st4(dst, gq[0]);
+    st4(dst + plane, 0.5f * (gq[0] + gq[1] + gq[2]));
+    st4(dst + 2 * plane, 0.5f * (gq[0] - gq[1] + gq[2]));
+    st4(dst + 3 * plane, gq[2]);
+}
+
 // dst[i] = sum_z partial[z][i]: block = 32 float4 columns x 8 split lanes (8 loads in flight per lane),
 // fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
@@ -1943,6 +2099,44 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo && M % 128 == 0 &&
                      128.0 * g.Ci * es < 4.0e9 && 128.0 * g.Co * os < 4.0e9;
     IO_REQUIRE(!bws.xb_res || lin, IO_ERR_SHAPE, "conv_nt: the residual operand form needs a dense 1x1 stride-1 GEMM on whole tiles");
+    // 3x3 stride-1 same-size convolutions / data gradients in fp32 with a scratch for the transformed filters: the
+    // Winograd F(2, 3) row form (2/3 of the MFMAs).  Forms it carries: plain, input transform (XF), fused BatchNorm-backward
+    // epilogue (BWE), each with optional statistics; everything else stays on the direct kernel.
+#ifndef IO_WINO
+#define IO_WINO 1
+#endif
+    if (IO_WINO && bws.wino_u && !stem && !g.gw && dt_in == IO_F32 && dt_out == IO_F32 && g.Th == 3 && g.Tw == 3 &&
+        g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho &&
+        g.outW == g.Wo && g.Wo % 2 == 0 && M % 128 == 0 && g.Ci % 32 == 0 && !add && !mask && !bws.xb_a && !bws.bias &&
+        g.dhs * g.dhs == 1 && g.dws * g.dws == 1 && g.dw0 * (g.dw0 + 2 * g.dws) == -1 && g.rs == 1 && g.ss == 1 &&
+        !(bws.y && bws.in_scale) && 12.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
+        const double kred9 = 9.0 * g.Ci;
+        IoProfScope prof(IO_PROF_CONV_WINO, 2.0 * (double)M * g.Co * kred9,
+                         (double)os * M * g.Co * (1.0 + (bws.y ? 1.0 : 0.0)) +
+                             (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred9), st);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)io_cdiv((long)g.Co * g.Ci / 4, 256), 3), dim3(256), 0, st,
+                           (const float*)wgt, bws.wino_u, g.Co, g.Ci, g.S, g.r0, g.rs, g.s0, g.ss, g.dw0, g.dws);
+        const unsigned wu_bytes = (unsigned)(12.0 * g.Co * g.Ci * 4.0);
+        const int ntw = g.Co / 64;
+        dim3 gridw((unsigned)((M / 128) * ntw));
+        const size_t ldsz = (size_t)(256 + 256) * 32 * sizeof(float);
+#define IO_LAUNCH_WINO_(BWE_, XF_)                                                                                    \
+    do {                                                                                                             \
+        static std::atomic<unsigned long long> attr_done{0};                                                         \
+        if (io_first_on_device(attr_done))                                                                           \
+            (void)hipFuncSetAttribute(                                                                               \
+                (const void*)conv_nt_kernel<float, float, 64, 0, 4, 1, 2, BWE_, XF_, false, 0, true>,                \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);                                              \
+        hipLaunchKernelGGL((conv_nt_kernel<float, float, 64, 0, 4, 1, 2, BWE_, XF_, false, 0, true>), gridw, block,  \
+                           ldsz, st, g, (const float*)in, (const float*)bws.wino_u, (float*)out, (const float*)nullptr, \
+                           (const float*)nullptr, ntw, in_bytes, wu_bytes, out_bytes, st_mean, st_m2, bws);          \
+    } while (0)
+        if (bws.y) IO_LAUNCH_WINO_(true, false);
+        else if (bws.in_scale) IO_LAUNCH_WINO_(false, true);
+        else IO_LAUNCH_WINO_(false, false);
+#undef IO_LAUNCH_WINO_
+        return io_check_launch("conv_nt(wino)");
+    }
     // algorithmic work: real taps x real channels (the stem's 3 padding channels do not count)
     const double kred = stem ? (double)g.wT * 5.0 : (double)g.Th * g.Tw * (g.gw ? g.gw : g.Ci);
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),

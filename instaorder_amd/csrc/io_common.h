@@ -156,6 +156,11 @@ struct IoBwStats {
     // xb_res == 2: the block has a downsample branch -- operand = relu(xb_a * y3 + xb_b * yd + xb_c) with xb_y = yd (the
     // downsample convolution's output) and the two BatchNorms folded into one table set (io_bn_resid2_tables).
     int xb_res;
+    // Independent again: scratch for the Winograd form of 3x3 stride-1 same-size launches (fp32, Wo even, whole 128-row
+    // tiles, no add / mask): 12 * Co * Ci floats that the launcher fills with the transformed filters ([filter row][4][Co][Ci],
+    // wino_filter_kernel) before it starts conv_nt_kernel<..., WINO>.  Null: the direct form.  (A caller-owned buffer
+    // because no entry point of the library allocates.)
+    float* wino_u;
 };
 
 // internal launchers shared between the C ABI and the network executor
@@ -259,7 +264,7 @@ int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, cons
 enum IoProfClass {
     IO_PROF_CONV_NT128 = 0, IO_PROF_CONV_NT64, IO_PROF_CONV_STEM, IO_PROF_WGRAD, IO_PROF_WGRAD_STEM,
     IO_PROF_BN_STATS, IO_PROF_BN_APPLY, IO_PROF_BN_BWD, IO_PROF_POOL_HEAD, IO_PROF_TRANSPOSE, IO_PROF_PACK,
-    IO_PROF_LOSS, IO_PROF_SGD, IO_PROF_NCLASS
+    IO_PROF_LOSS, IO_PROF_SGD, IO_PROF_CONV_WINO, IO_PROF_NCLASS
 };
 struct IoProfScope {
     int idx;

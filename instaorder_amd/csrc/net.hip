@@ -102,6 +102,9 @@ BnL add_bn(io_net* net, const char* name, int C) {
 #ifndef IO_WT_ALL
 #define IO_WT_ALL 1      // all filter transposes of a backward pass in one launch
 #endif
+#ifndef IO_NET_WINO
+#define IO_NET_WINO 1    // 3x3 stride-1 forward convolutions and data gradients of the fp32 step in the Winograd F(2, 3) row form
+#endif
 constexpr size_t kNoBuf = ~(size_t)0;
 struct BlockBufs {
     size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets (a1 / a2 = kNoBuf: never materialised, see fuse_in)
@@ -120,6 +123,7 @@ struct Plan {
     size_t stem_wp, stem_dwp;   // fp32: exact-K stem filter / filter gradient, [64][io_stem_kp]
     size_t wt_all;              // transposed copies of all filters (kNoBuf: one transpose launch per data gradient)
     size_t wfold, fbias; // eval: filters with the BatchNorm scale folded in (storage type, parameter offsets) + biases
+    size_t wino_u;       // fp32: transformed filters of the 3x3 launch in flight (Winograd row form), 12 * 512 * 512 floats
     size_t total;
 };
 
@@ -150,6 +154,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
     }
     p.wfold = training ? 0 : a.take((size_t)net->param_floats * e);
     p.fbias = training ? 0 : a.take((size_t)net->bn_channels * f);
+    p.wino_u = net->dtype == IO_F32 ? a.take((size_t)12 * 512 * 512 * f) : kNoBuf;
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
     p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
@@ -337,6 +342,9 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         ep.in_shift = t.shift;
         ep.in_Mg = Mout / c.G;
     }
+    // 3x3 stride-1 convolutions in fp32: scratch for the Winograd row form (the launcher falls back where it does not apply)
+    const bool wino = IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32;
+    if (wino) ep.wino_u = c.buf(c.plan.wino_u);
     if (xr) {
         Tables t = c.tables(*xr);
         ep.xb_y = xr_id;
@@ -356,7 +364,7 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
     }
     return io_launch_conv_nt(g, x, w, y, nullptr, nullptr, stem, c.st,
                              stats ? c.buf(c.plan.tile_mean) : nullptr, stats ? c.buf(c.plan.tile_m2) : nullptr,
-                             (xf || xr) ? &ep : nullptr, c.dt(), c.dt());
+                             (xf || xr || wino) ? &ep : nullptr, c.dt(), c.dt());
 }
 
 // BN statistics (training) or table preparation (eval) for y[M][C]
@@ -397,6 +405,7 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 #ifndef IO_XR
 #define IO_XR 1
 #endif
+
 #ifndef IO_XB_BF16_MAXP
 #define IO_XB_BF16_MAXP 64
 #endif
@@ -719,6 +728,7 @@ int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H,
         IoBwStats bw = bw_for(c, b, y, M, true);
         bw.a_out = a_out;
         if (xb) xb_fill(c, bw, *xb, xb_y, xb_M, xb_out);
+        if (IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && c.dt() == IO_F32 && !xb) bw.wino_u = c.buf(c.plan.wino_u);
         IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
         if (!dyb) return IO_OK;
         return bn_back_tiles(c, b, dx, y, M, dyb);

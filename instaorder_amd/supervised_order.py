@@ -45,6 +45,8 @@ class _OrderBase(SingleStageModel):
         # is launch-bound (small per-GPU batches, e.g. the reference recipe's 32 pairs/GPU); IO_NO_GRAPH=1 disables
         self._use_graph = os.environ.get("IO_NO_GRAPH", "0") != "1"
         self._graph = None
+        self._graph_ws = None
+        self._dp_keep = None
         self._graph_key = None
         self._seen_key = None
         self._static = {}
@@ -172,13 +174,17 @@ class _OrderBase(SingleStageModel):
                     bk.launch(s)
                 bk.finish()
                 return logits.clone(), losses.clone()
+        lent = self._dp_keep[0] if (self._dp_graphs is not None and not net._pool.free) else None
+        if lent is not None:          # (see step(): the stage graphs own their arena; lend it to this eager step)
+            net._pool.give(lent)
         logits, ws = net._run_forward(self._x8, N, S, 2, True)
         losses, dlogits = self._loss(logits, True, True)
         for s in range(ns):
             net._run_backward(self._x8, dlogits, N, S, 2, ws, stages=(s, s + 1))
             bk.launch(s)
         bk.finish()
-        net._pool.give(ws)
+        if ws is not lent:
+            net._pool.give(ws)
         self._seen_key = key
         return logits, losses
 
@@ -220,8 +226,15 @@ class _OrderBase(SingleStageModel):
                 logits, losses, ws = self._fwd_loss_bwd(N, S)
                 net._pool.give(ws)
         else:
+            # An eager step while a captured graph exists (a profiled pass, a changed batch shape): the graph owns the
+            # workspace arena it was captured on -- lend it to this step instead of allocating a second one (55 GiB at the
+            # bench batch; nothing of the graph is in flight on this stream)
+            lent = self._graph_ws if (self._graph is not None and not net._pool.free) else None
+            if lent is not None:
+                net._pool.give(lent)
             logits, losses, ws = self._fwd_loss_bwd(N, S)
-            net._pool.give(ws)
+            if ws is not lent:
+                net._pool.give(ws)
             self._seen_key = key
         self.last_logits = logits
         if self.world_size > 1:
