@@ -194,7 +194,7 @@ std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[IO_PROF_NCLASS] = {"conv_nt_kernel<128,false>", "conv_nt_kernel<64,false>",
     "conv_nt_kernel<64,true>", "conv_wgrad_kernel", "conv_wgrad_kernel<64,64,true>", "bn_stats_finalize",
     "bn_apply", "bn_bwd", "pool_head", "filter_transpose", "pack_planes", "order_loss", "sgd_momentum",
-    "conv_nt_kernel<wino>"};
+    "conv_nt_kernel<wino>", "conv_wgrad_kernel<wino>"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e;

@@ -21,6 +21,7 @@
 // (global loads of tile k+1 fly under the 64 MFMAs of tile k), 73 KiB LDS -> 2 blocks/CU.  Operands are addressed
 // with 32-bit offsets through buffer descriptors rebased per tile, so tensors may exceed 4 GiB.
 #include <string.h>
+#include <stdlib.h>
 
 #include "io_common.h"
 
@@ -29,6 +30,12 @@ namespace {
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Pins a register value at this point of the program: the LDS read that produces it must have been ISSUED (and waited
+// for) before.  The GEMM loops prefetch the last fragment group of a k-tile and then pass a barrier behind which the
+// other waves overwrite the tile -- and hipcc sinks such ds_reads below the s_barrier (they are only used after the
+// NEXT barrier; observed in conv_wgrad_wino_kernel, where the sunk reads raced with the refill whenever two blocks shared
+// a CU).  __syncthreads() does not stop that; a value that is "modified" by an empty asm statement before it does.
+template <typename T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // bijective XCD-aware remap of a 1-D grid: blocks that run on one XCD (b % 8) get a contiguous
@@ -715,6 +722,10 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) pin(fa[i]);      // the group-3 fragments are in registers BEFORE the barrier
+#pragma unroll
+        for (int j = 0; j < FB; ++j) pin(fb[j]);
         if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
         store_tile(nbuf, PIPE);
         __syncthreads();
@@ -1371,6 +1382,13 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_kernel(IoConvGeom g
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {              // the group-3 fragments are in registers BEFORE the barrier
+#pragma unroll
+            for (int i = 0; i < TI; ++i) pin(fa[s4][i]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) pin(fb[s4][j]);
+        }
         if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
         store_tile(nbuf);
         __syncthreads();
@@ -1610,6 +1628,10 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_kernel(IoConvG
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[j] = nb[j];
         }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) pin(fa[i]);      // the group-3 fragments are in registers BEFORE the barrier
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) pin(fb[j]);
         if (NBUF == 1) __syncthreads();        // every wave has read the last fragments of tile kt
         store_tile(nbuf);
         __syncthreads();
@@ -1912,6 +1934,199 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
         }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// TN kernel, Winograd F(2, 3) row form (fp32; 3x3 stride-1 same-size convolutions, 8 | Wo, 64 | M)
+// ------------------------------------------------------------------------------------------
+// The transpose of the forward form of conv_nt_kernel<..., WINO>: for a pair of horizontally adjacent output pixels (w, w+1)
+// and one filter row r, the three taps dW[r][0..2] += (dy0 d0 + dy1 d1, dy0 d1 + dy1 d2, dy0 d2 + dy1 d3) (d0..d3 = the
+// inputs at columns w - 1 .. w + 2 of input row h + r - 1) cost 4 products instead of 6:
+//     Y = (dy0, dy0 + dy1, dy0 - dy1, -dy1)        V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+//     P_f = sum over all pairs of Y_f * V_f                       (f = 0..3: four independent GEMMs, reduction index = pair)
+//     dW[r][0] = P0 + (P1 + P2) / 2      dW[r][1] = (P1 - P2) / 2      dW[r][2] = (P1 + P2) / 2 + P3
+// A block owns (output-channel tile of 64, filter row r, input-channel tile of 64, split of the pairs); a wave owns 32 x 32
+// channels x the four frequencies -- four 32x32 accumulators whose lanes hold the same (o, c) entry, so the combination above
+// is register arithmetic in the epilogue and the block writes its three taps straight into the [Co][9][Ci] partial.
+// Staging: a k-tile is 32 pairs = 64 consecutive output pixels.  Threads 0..127 stage dY -- a thread fetches 8 consecutive
+// pixels (4 pairs) of a 4-channel chunk, forms Y and writes it transposed ([f][channel][4 pairs]: register renaming, as in the
+// TR form above) -- threads 128..255 stage the input the same way from the 10 pixels w - 1 .. w + 8 of row h + r - 1 (8 | Wo:
+// a thread's pixels lie in one image row, one row decode per k-tile).  LDS image [f][64 channels][32 pairs], 36-word pitch,
+// chunk index XORed with channel bits 4..5 (conflict-free transposed writes and fragment reads, see conv_wgrad_kernel).
+template <int MINB = 2>
+__global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_wino_kernel(IoConvGeom g, const float* __restrict__ in,
+                                                                  const float* __restrict__ dy,
+                                                                  float* __restrict__ dst, int ntile_c, int tiles,
+                                                                  int kps, size_t in_bytes, size_t dy_bytes) {
+    constexpr int BC = 64, BKP = 32, LDT = 36;          // channels per operand tile, pairs per k-tile, LDS pitch
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                   // [4 f][64 o][LDT]
+    float* sB = smem + 4 * BC * LDT;                    // [4 f][64 c][LDT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = g.Ho * g.Wo;
+    const int M = g.N * HoWo;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int per_o = 3 * ntile_c;
+    const int ot = tile / per_o, rem0 = tile - ot * per_o;
+    const int o0 = ot * BC;
+    const int fr = rem0 / ntile_c;                      // filter row of this block
+    const int c0 = (rem0 - fr * ntile_c) * BC;
+    const int dh = g.dh0 + g.dhs * fr;                  // input row offset of that filter row (forward geometry: fr - 1)
+
+    const int nkt = M / 64;
+    const int kt0 = split * kps;
+    const int kt1 = min(kt0 + kps, nkt);
+    const int mfirst = min(kt0 * 64, M - 1);
+    const int n_lo = fdiv(mfirst, g.fd_howo);
+    const int ipix_lo = n_lo * g.Hi * g.Wi;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)ipix_lo * (size_t)(g.Ci * 4), in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc_at(dy, (size_t)mfirst * (size_t)(g.Co * 4), dy_bytes);
+
+    // staging roles (wave-uniform): waves 0, 1 move dY, waves 2, 3 move the input
+    const bool role_a = wave < 2;
+    const int t7 = tid & 127;
+    const int q4 = t7 & 15, pg = t7 >> 4;               // 4-channel chunk, pair-quad (8 pixels) of the k-tile
+    f32x4 px[10];                                       // dY: 8 pixels; input: the 10 pixels w - 1 .. w + 8
+    auto load_tile = [&](int kt) {
+        const int m = kt * 64 + 8 * pg;                 // first pixel of this thread's pair-quad
+        if (role_a) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)                 // rows past M fall off the descriptor -> zeros
+                px[i] = bld4(rs_dy, (unsigned)((m + i - mfirst) * g.Co + o0 + q4 * 4) * 4u);
+            px[8] = px[9] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const bool ok0 = m < M;
+            const int mm = ok0 ? m : 0;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+            const int hi = ho + dh;
+            const bool okh = ok0 & ((unsigned)hi < (unsigned)g.Hi);
+            // (unsigned wrap-around for the pixel at w - 1: the offset is only used when that pixel exists)
+            const unsigned base = (unsigned)(((((n - n_lo) * g.Hi + hi) * g.Wi + wo - 1) * g.Ci + c0 + q4 * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const bool ok = okh & (i == 0 ? wo > 0 : i == 9 ? wo + 8 < g.Wi : true);
+                px[i] = bld4(rs_in, ok ? base + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        float* base = (role_a ? sA : sB) + (q4 * 4) * LDT + ((pg ^ ((q4 >> 2) & 3)) * 4);
+        f32x4 v[4][4];                                  // [f][pair]
+        if (role_a) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 y0 = px[2 * t], y1 = px[2 * t + 1];
+                v[0][t] = y0;
+                v[1][t] = y0 + y1;
+                v[2][t] = y0 - y1;
+                v[3][t] = -y1;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 d0 = px[2 * t], d1 = px[2 * t + 1], d2 = px[2 * t + 2], d3 = px[2 * t + 3];
+                v[0][t] = d0 - d2;
+                v[1][t] = d1 + d2;
+                v[2][t] = d2 - d1;
+                v[3][t] = d1 - d3;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {               // channel i of the chunk: its 4 pairs as one 16-byte row segment
+                const f32x4 row = {v[f][0][i], v[f][1][i], v[f][2][i], v[f][3][i]};
+                st4(base + (f * BC + i) * LDT, row);
+            }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31);
+    auto read_frags = [&](int grp, f32x4 (&a)[4], f32x4 (&b)[4]) {
+        const int chunk = grp * 2 + (lane >> 5);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            a[f] = ld4(sA + (f * BC + arow) * LDT + ((chunk ^ ((arow >> 4) & 3)) * 4));
+            b[f] = ld4(sB + (f * BC + brow) * LDT + ((chunk ^ ((brow >> 4) & 3)) * 4));
+        }
+    };
+    auto mma16 = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f][tt], b[f][tt], acc[f], 0, 0, 0);
+    };
+
+    f32x4 fa[4], fb[4];
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile();
+    }
+    __syncthreads();
+    if (kt0 < kt1) read_frags(0, fa, fb);
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            f32x4 na[4], nb[4];
+            read_frags(grp + 1, na, nb);
+            mma16(fa, fb);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { fa[f] = na[f]; fb[f] = nb[f]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                 // the group-3 fragments are in registers BEFORE the barrier
+            pin(fa[f]);
+            pin(fb[f]);
+        }
+        __syncthreads();                       // every wave has read the last fragments of tile kt
+        store_tile();
+        __syncthreads();
+        f32x4 na[4], nb[4];
+        read_frags(0, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(fa, fb);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { fa[f] = na[f]; fb[f] = nb[f]; }
+    }
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            f32x4 na[4], nb[4];
+            read_frags(grp + 1, na, nb);
+            mma16(fa, fb);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { fa[f] = na[f]; fb[f] = nb[f]; }
+        }
+        mma16(fa, fb);
+    }
+
+    // epilogue: rows = output channel, cols = input channel; the three taps of filter row fr
+    const size_t wrow = (size_t)g.wT * g.Ci;
+    float* base = dst + (size_t)split * g.Co * wrow + (size_t)(g.r0 + g.rs * fr) * g.S * g.Ci + c0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float h12 = 0.5f * (acc[1][r] + acc[2][r]);
+        float* p = base + (size_t)o * wrow;
+        p[0] = acc[0][r] + h12;
+        p[g.Ci] = 0.5f * (acc[1][r] - acc[2][r]);
+        p[2 * g.Ci] = h12 + acc[3][r];
+    }
+}
+
 // (An fp32 sibling -- LDS-DMA into a row-major [m][channels] image, ds_read_b32 fragments, no transposes at all because
 // v_mfma_f32_32x32x2_f32 takes one reduction index per lane -- was built and measured: 112.9 TF/s with 32-row k-tiles at
 // two blocks per CU, 117.8 with 16-row k-tiles at four, against 118.3 for the register-staged kernel at three; the
@@ -2017,12 +2232,41 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem, bool fp32 = true) {
     return p;
 }
 
+#ifndef IO_WGRAD_WINO
+#define IO_WGRAD_WINO 1
+#endif
+// the Winograd row form of the fp32 filter gradient: 3x3 stride-1 same-size convolutions with 8 | Wo and 64 | M
+bool wgrad_wino_ok(const IoConvGeom& g, int stem) {
+    return IO_WGRAD_WINO && !stem && !g.gw && !g.cr && g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 &&
+           g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.dh0 == -1 && g.dhs == 1 && g.dw0 == -1 && g.dws == 1 &&
+           g.rs == 1 && g.ss == 1 && g.r0 == 0 && g.s0 == 0 && g.Wo % 8 == 0 && ((long)g.N * g.Ho * g.Wo) % 64 == 0 &&
+           g.Ci % 64 == 0 && g.Co % 64 == 0;
+}
+WgradPlan plan_wgrad_wino(const IoConvGeom& g) {
+    WgradPlan p;
+    p.bmo = p.bnc = 64;
+    p.ntile_c = g.Ci / 64;
+    p.tiles = (g.Co / 64) * 3 * p.ntile_c;
+    const int nkt = (int)(((long)g.N * g.Ho * g.Wo) / 64);
+    // two blocks per CU: 512 resident -- two full rounds
+    const int want = 1024 / p.tiles, maxs = nkt / 8 > 0 ? nkt / 8 : 1;
+    p.splits = want < maxs ? want : maxs;
+    if (p.splits < 1) p.splits = 1;
+    p.kps = io_cdiv(nkt, p.splits);
+    p.splits = io_cdiv(nkt, p.kps);
+    return p;
+}
+
 }  // namespace
 
 size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     // sized for either storage type: the fp32 and the bf16 kernels split differently
     const int s0 = plan_wgrad(g, stem, true).splits, s1 = plan_wgrad(g, stem, false).splits;
-    const int splits = s0 > s1 ? s0 : s1;
+    int splits = s0 > s1 ? s0 : s1;
+    if (wgrad_wino_ok(g, stem)) {
+        const int sw = plan_wgrad_wino(g).splits;
+        if (sw > splits) splits = sw;
+    }
     size_t need = splits == 1 ? 0 : (size_t)splits * g.Co * io_filter_row(g) * sizeof(float);
     if (stem && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g)) {      // one partial per block of the row-persistent kernel
         const size_t rows = (size_t)io_stem_wgrad_rows_max_blocks() * g.Co * io_filter_row(g) * sizeof(float);
@@ -2240,6 +2484,28 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     // the fp32 exact-K stem on whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
     if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g))
         return io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, dw, partial, partial_bytes, st);
+    if (dt_in == IO_F32 && dt_dy == IO_F32 && wgrad_wino_ok(g, stem)) {
+        const WgradPlan pw = plan_wgrad_wino(g);
+        float* dstw = pw.splits == 1 ? dw : partial;
+        const size_t in_b = (size_t)4 * g.N * g.Hi * g.Wi * g.Ci, dy_b = (size_t)4 * g.N * g.Ho * g.Wo * g.Co;
+        const double rows = (double)pw.kps * 64.0 + 64.0, samples = rows / ((double)g.Ho * g.Wo) + 2.0;
+        IO_REQUIRE(rows * g.Co * 4.0 < 4.0e9 && samples * g.Hi * g.Wi * g.Ci * 4.0 < 4.0e9 && (double)g.N * g.Hi * g.Wi < 2.0e9,
+                   IO_ERR_SHAPE, "conv_wgrad(wino): one split spans more than 4 GB (32-bit offsets)");
+        const double Mdw = (double)g.N * g.Ho * g.Wo;
+        IoProfScope prof(IO_PROF_WGRAD_WINO, 2.0 * Mdw * g.Co * 9.0 * g.Ci,
+                         4.0 * (Mdw * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + 9.0 * g.Co * g.Ci), st);
+        const size_t lds = (size_t)2 * 4 * 64 * 36 * sizeof(float);
+        static std::atomic<unsigned long long> attr_done{0};
+        if (io_first_on_device(attr_done))
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+        hipLaunchKernelGGL((conv_wgrad_wino_kernel<2>), dim3((unsigned)(pw.tiles * pw.splits)), dim3(kThreads), lds, st, g,
+                           (const float*)in, (const float*)dy, dstw, pw.ntile_c, pw.tiles, pw.kps, in_b, dy_b);
+        int rcw = io_check_launch("conv_wgrad(wino)");
+        if (rcw) return rcw;
+        if (pw.splits > 1) rcw = io_splitk_reduce(partial, dw, (size_t)g.Co * io_filter_row(g) / 4, pw.splits, st);
+        return rcw;
+    }
     float* dst = p.splits == 1 ? dw : partial;
     int splits = p.splits;
     dim3 grid((unsigned)(p.tiles * p.splits)), block(kThreads);

@@ -264,7 +264,7 @@ int io_run_dgrad(const void* dy, const void* wt, void* dx, const void* add, cons
 enum IoProfClass {
     IO_PROF_CONV_NT128 = 0, IO_PROF_CONV_NT64, IO_PROF_CONV_STEM, IO_PROF_WGRAD, IO_PROF_WGRAD_STEM,
     IO_PROF_BN_STATS, IO_PROF_BN_APPLY, IO_PROF_BN_BWD, IO_PROF_POOL_HEAD, IO_PROF_TRANSPOSE, IO_PROF_PACK,
-    IO_PROF_LOSS, IO_PROF_SGD, IO_PROF_CONV_WINO, IO_PROF_NCLASS
+    IO_PROF_LOSS, IO_PROF_SGD, IO_PROF_CONV_WINO, IO_PROF_WGRAD_WINO, IO_PROF_NCLASS
 };
 struct IoProfScope {
     int idx;

@@ -165,3 +165,23 @@ def test_wino_dgrad_with_bn_backward_epilogue(case):
         del ya_d, tabs, sc
     assert relerr(outs[0][0], outs[1][0].double().cpu()) < TOL
     assert torch.equal(outs[0][1], outs[1][1])          # the side output does not depend on the product form
+
+
+@pytest.mark.parametrize("case", CASES + [(16, 32, 32, 64, 64, 1), (64, 16, 16, 128, 128, 1)])
+def test_wino_wgrad(case):
+    """Filter gradient of the 3x3 stride-1 convolution in the Winograd row form (conv_wgrad_wino_kernel: the launcher takes it
+    for fp32, 8 | W, 64 | N*H*W) against fp64 autograd; the last cases split the reduction over many blocks."""
+    N, H, W, Cin, Cout, G = case
+    g = torch.Generator().manual_seed(3 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64).float().double()
+    dy = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64).float().double()
+    w0 = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref = torch.autograd.grad(F.conv2d(x, w0, padding=1), w0, dy)[0]
+    lib = _lib.lib()
+    nb = lib.io_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, 3, 3, 1, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    dw = torch.full((Cout, 9, Cin), float("nan"), device=DEV)
+    _lib.check(lib.io_conv2d_wgrad_dt(P(nhwc(x)), P(nhwc(dy)), P(dw), N, H, W, Cin, Cout, 3, 3, 1, 1, P(ws), nb, 0, 0, ST()),
+               "wgrad")
+    got = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert relerr(got, ref) < TOL
