@@ -365,6 +365,12 @@ def main():
                            args.backend, model.net.flat_grads.numel(), len(model.net.grad_stage_slices()),
                            " / ".join("%.0f" % ((hi - lo) * 4 / 1e6) for lo, hi in model.net.grad_stage_slices()))
                        if (not depthnet and getattr(model, "_overlap_comm", False)) else
+                       "%s all-reduce (SUM) of the %d gradient floats in %d stage buckets (%s MB: %s), each launched when its "
+                       "stage of the backward pass is enqueued" % (
+                           args.backend, model.optim.flat_grads.numel(), len(model.grad_stage_slices()),
+                           " / ".join("%.0f" % ((hi - lo) * 4 / 1e6) for lo, hi in model.grad_stage_slices()),
+                           ", ".join(model.STAGE_NAMES))
+                       if (depthnet and getattr(model, "_overlap_comm", False) and hasattr(model.optim, "gather_grads")) else
                        "%s flat all-reduce, %d floats/step" % (
                            args.backend, (model.optim if depthnet else model.net).flat_grads.numel()))},
         "achieved_tflops_whole_step": pairs_per_s * flop_per_pair / 1e12,

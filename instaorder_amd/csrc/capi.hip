@@ -560,7 +560,7 @@ extern "C" int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx
  * zero padding applied AFTER the transform, as nn.Conv2d pads relu(bn(x)) (resnet_cls.py:99-111: bn -> relu -> next
  * conv).  in_scale / in_shift: [G][Cin]; group g = the samples [g N/G, (g+1) N/G).  With workspace != NULL the training
  * statistics of y are produced as by io_conv2d_fwd_bnstats_dt (same G). */
-extern "C" size_t io_conv2d_wino_scratch_floats(int Cin, int Cout) { return (size_t)12 * Cin * Cout; }
+extern "C" size_t io_conv2d_wino_scratch_floats(int Cin, int Cout) { return (size_t)18 * Cin * Cout; }   // F(4,3): 3 x 6 planes
 
 static int conv2d_fwd_xf_impl(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,
                               int S, int stride, int pad, int G, const float* in_mean, const float* in_scale,

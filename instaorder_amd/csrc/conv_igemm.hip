@@ -2132,6 +2132,324 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_wino_kernel(IoConvG
 // two blocks per CU, 117.8 with 16-row k-tiles at four, against 118.3 for the register-staged kernel at three; the
 // fp32 filter gradient is bound by the matrix pipe, not by its staging, so it stays on conv_wgrad_kernel.)
 
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, Winograd F(4, 3) row form (fp32; 3x3 stride-1 same-size convolutions / data gradients, 4 | Wo, 256 | M)
+// ------------------------------------------------------------------------------------------
+// The next member of the family of conv_nt_kernel<..., WINO> (F(2, 3): 4 products per 2 outputs and filter row): FOUR
+// horizontally adjacent outputs from the six inputs d0..d5 at columns w - 1 .. w + 4 with SIX products -- half the MFMAs
+// of the direct form.  With g0..g2 the filter row (g_j meets input column w + j - 1):
+//     V = (4 d0 - 5 d2 + d4,  -4 d1 - 4 d2 + d3 + d4,  4 d1 - 4 d2 - d3 + d4,  -2 d1 - d2 + 2 d3 + d4,
+//          2 d1 - d2 - 2 d3 + d4,  4 d1 - 5 d3 + d5)
+//     U = (g0 / 4,  -(g0 + g1 + g2) / 6,  -(g0 - g1 + g2) / 6,  (g0 + 2 g1 + 4 g2) / 24,  (g0 - 2 g1 + 4 g2) / 24,  g2)
+//     m_f = sum over filter rows and input channels of V_f * U_f        (f = 0..5: six independent GEMMs)
+//     y0 = m0 + m1 + m2 + m3 + m4     y1 = m1 - m2 + 2 (m3 - m4)     y2 = m1 + m2 + 4 (m3 + m4)     y3 = m1 - m2 + 8 (m3 - m4) + m5
+// (Lavin & Gray's matrices; in fp32 the form is about eight times the rounding error of the direct product -- 6e-7 of
+// the output scale at K = 576 -- three orders inside the 1e-3 bar.)
+// Block tile: 256 output pixels (64 quads) x 64 output channels; wave (wm, wn) owns quads [32 wm, 32 wm + 32) = the 128
+// pixels of ONE statistics tile x channels [32 wn, 32 wn + 32) x the six frequencies: six 32x32 accumulators (96
+// registers) whose lanes hold the same (quad, channel) entry, so the output transform is register arithmetic and the
+// per-128-row reductions of the epilogues (BatchNorm statistics, BatchNorm-backward sums) never leave the wave.
+// A k-tile is one filter row x 16 input channels (K = 3 Ci per frequency): LDS image 6 x 64 rows of V + 6 x 64 rows of U,
+// 64 bytes per row, chunk index XORed with row bits 2..3 (conflict-free 16-byte stores and fragment reads), 48 KB, one
+// buffer, two blocks per CU.  Fragments are prefetched one 12-MFMA group (three frequencies x 8 k) ahead.
+// XF: the A operand goes through relu(bn(x)) while it is staged (IoBwStats::in_scale, as in conv_nt_kernel).
+// BWE: the fused BatchNorm-backward epilogue (IoBwStats::y ...: ReLU mask recomputed from y, per-tile sums, activation side
+// output).  Both need whole 256-row tiles per BatchNorm group.
+template <bool BWE, bool XF>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const float* __restrict__ in,
+                                                        const float* __restrict__ U, float* __restrict__ out, int ntn,
+                                                        size_t in_bytes, unsigned u_bytes, size_t out_bytes,
+                                                        float* __restrict__ st_mean, float* __restrict__ st_m2,
+                                                        IoBwStats bw) {
+    constexpr int BM = 256, BN = 64, BK = 16, LDT = 16, NF = 6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                       // [6 f][64 quads][16]
+    float* sB = smem + NF * 64 * LDT;       // [6 f][64 channels][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / ntn;
+    const int m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+    const int HoWo = g.Ho * g.Wo;
+    const int nkc = g.Ci / BK, nk = 3 * nkc;
+    const int n_lo = fdiv(m0, g.fd_howo);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)n_lo * (size_t)(g.Hi * g.Wi) * (size_t)(g.Ci * 4), in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(U, u_bytes);
+
+    // staging: thread = (row sr = tid >> 2, 16-byte chunk sc = tid & 3): quad sr of the A operand (6 pixels) and the six
+    // rows (f, channel sr) of U
+    const int sr = tid >> 2, sc = tid & 3;
+    unsigned arow, urow;
+    int aho;
+    bool aleft, aright;
+    {
+        const int m = m0 + 4 * sr;                                      // whole tiles: always < M
+        const int n = fdiv(m, g.fd_howo), rem = m - n * HoWo;
+        const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+        aho = ho;
+        aleft = wo > 0;
+        aright = wo + 4 < g.Wi;
+        arow = (unsigned)((((n - n_lo) * g.Hi + ho) * g.Wi + wo) * g.Ci + sc * 4) * 4u;
+        urow = (unsigned)((n0 + sr) * g.Ci + sc * 4) * 4u;
+    }
+    const unsigned uplane = (unsigned)(g.Co * g.Ci) * 4u;               // bytes per (filter row, f) plane of U
+    const int xgrp = XF ? m0 / bw.in_Mg : 0;
+    const __amdgpu_buffer_rsrc_t rs_xs = make_rsrc(XF ? (const void*)(bw.in_scale + (size_t)xgrp * g.Ci) : (const void*)U,
+                                                   XF ? (unsigned)g.Ci * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_xh = make_rsrc(XF ? (const void*)(bw.in_shift + (size_t)xgrp * g.Ci) : (const void*)U,
+                                                   XF ? (unsigned)g.Ci * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_xm = make_rsrc((XF && bw.in_mean) ? (const void*)(bw.in_mean + (size_t)xgrp * g.Ci)
+                                                                      : (const void*)U,
+                                                   (XF && bw.in_mean) ? (unsigned)g.Ci * 4u : 0u);
+    f32x4 pa[6], pu[6], xm, xs, xh;
+    unsigned xok = 0;
+    int th = 0, cc = 0;
+    auto load_tile = [&]() {                 // the k-tile (th, cc)
+        const int dh = g.dh0 + g.dhs * th;
+        const unsigned aoff = (unsigned)(((dh * g.Wi - 1) * g.Ci + cc * BK) * 4);      // (wraps; used only where the pixel exists)
+        const unsigned uoff = (unsigned)(th * NF) * uplane + (unsigned)(cc * BK) * 4u;
+        if constexpr (XF) {
+            const unsigned coff = (unsigned)(cc * BK + sc * 4) * 4u;
+            xm = bld4(rs_xm, coff);
+            xs = bld4(rs_xs, coff);
+            xh = bld4(rs_xh, coff);
+        }
+        const bool rowok = (unsigned)(aho + dh) < (unsigned)g.Hi;
+        xok = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = rowok & (i == 0 ? aleft : i == 5 ? aright : true);
+            xok |= ok ? (1u << i) : 0u;
+            pa[i] = bld4(rs_in, ok ? arow + aoff + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) pu[f] = bld4(rs_u, urow + uoff + (unsigned)f * uplane);
+    };
+    auto advance = [&]() {
+        const int c1 = cc + 1;
+        const bool wrap = c1 == nkc;
+        cc = wrap ? 0 : c1;
+        th += wrap ? 1 : 0;
+    };
+    auto xform_tile = [&]() {
+        if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool ok = (xok >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(__builtin_fmaf(pa[i][e] - xm[e], xs[e], xh[e]), 0.f);     // bn_apply's expression
+                    pa[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+        const f32x4 d0 = pa[0], d1 = pa[1], d2 = pa[2], d3 = pa[3], d4 = pa[4], d5 = pa[5];
+        const f32x4 e42 = d4 - 4.f * d2, e31 = d3 - 4.f * d1, f42 = d4 - d2, f31 = d3 - d1;
+        pa[0] = 4.f * d0 - 5.f * d2 + d4;
+        pa[1] = e42 + e31;
+        pa[2] = e42 - e31;
+        pa[3] = f42 + 2.f * f31;
+        pa[4] = f42 - 2.f * f31;
+        pa[5] = 4.f * d1 - 5.f * d3 + d5;
+    };
+    const int swz = sc ^ ((sr >> 2) & 3);
+    auto store_tile = [&]() {
+        float* a = sA + sr * LDT + swz * 4;
+        float* b = sB + sr * LDT + swz * 4;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            st4(a + f * 64 * LDT, pa[f]);
+            st4(b + f * 64 * LDT, pu[f]);
+        }
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // fragment group gi = (kk = gi >> 1, frequencies 3 (gi & 1) .. + 2): lane reads 4 consecutive k of its row
+    const int frow = lane & 31;
+    const int a_base = (wm * 32 + frow) * LDT, b_base = (wn * 32 + frow) * LDT;
+    const int fsw = (frow >> 2) & 3;
+    auto read_frags = [&](int gi, f32x4 (&a)[3], f32x4 (&b)[3]) {
+        const int chunk = ((gi >> 1) * 2 + (lane >> 5)) ^ fsw;
+        const int f0 = (gi & 1) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[j] = ld4(sA + (f0 + j) * 64 * LDT + a_base + chunk * 4);
+            b[j] = ld4(sB + (f0 + j) * 64 * LDT + b_base + chunk * 4);
+        }
+    };
+    auto mma12 = [&](int gi, const f32x4 (&a)[3], const f32x4 (&b)[3]) {
+        const int f0 = (gi & 1) * 3;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[f0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][tt], b[j][tt], acc[f0 + j], 0, 0, 0);
+    };
+
+    f32x4 fa[3], fb[3];
+    load_tile();
+    xform_tile();
+    store_tile();
+    __syncthreads();
+    read_frags(0, fa, fb);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        advance();
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            f32x4 na[3], nb[3];
+            read_frags(gi + 1, na, nb);
+            mma12(gi, fa, fb);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+            if (gi == 0) {                       // the fetches of tile kt + 1 go out behind the first MFMA group ...
+                load_tile();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (gi == 1) xform_tile();           // ... and their transform runs under the third
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pin(fa[j]); pin(fb[j]); }      // group-3 fragments in registers BEFORE the barrier
+        __syncthreads();                         // every wave has read the last fragments of tile kt
+        store_tile();
+        __syncthreads();
+        f32x4 na[3], nb[3];
+        read_frags(0, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma12(3, fa, fb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+    }
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+        f32x4 na[3], nb[3];
+        read_frags(gi + 1, na, nb);
+        mma12(gi, fa, fb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+    }
+    mma12(3, fa, fb);
+
+    // output transform: acc[0..3] <- y0..y3 (the wave's 32 quads x 32 channels; pixel = 4 q + i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+        const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
+        const float y0 = acc[0][r] + s12 + s34, y3 = d12 + 8.f * d34 + acc[5][r];
+        acc[1][r] = d12 + 2.f * d34;
+        acc[2][r] = s12 + 4.f * s34;
+        acc[0][r] = y0;
+        acc[3][r] = y3;
+    }
+    // this wave's 128 rows are statistics tile st of the tensor; its column: co
+    const int st = 2 * mt + wm;
+    const int co = n0 + wn * 32 + (lane & 31);
+    if (st_mean) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[i][r];
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 128.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m2 += (acc[i][r] - mean) * (acc[i][r] - mean);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (lane < 32) {
+            st_mean[(size_t)st * g.Co + co] = mean;
+            st_m2[(size_t)st * g.Co + co] = m2;
+        }
+    }
+    // dense output, whole tiles: one VGPR offset per lane, the row steps in the scalar offset of the buffer instructions
+    const size_t out_base = (size_t)(m0 + wm * 128) * (size_t)(g.Co * 4);
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_at(out, out_base, out_bytes);
+    const unsigned rowstep = (unsigned)g.Co * 4u;
+    const unsigned lane_off = (unsigned)(16 * (lane >> 5)) * rowstep + (unsigned)co * 4u;      // q = .. + 4 (lane >> 5): 4 q rows
+    if constexpr (BWE) {
+        const __amdgpu_buffer_rsrc_t rs_y = make_rsrc_at(bw.y, out_base, out_bytes);
+        const __amdgpu_buffer_rsrc_t rs_ao = make_rsrc_at(bw.a_out ? bw.a_out : (void*)out, out_base,
+                                                           bw.a_out ? out_bytes : out_base);     // absent: stores dropped
+        const int gcol = ((m0 + wm * 128) / bw.Mg) * g.Co + co;
+        const float mu = bw.mean[gcol], rs = bw.rstd[gcol];
+        const float sc_ = bw.mscale ? bw.mscale[gcol] : 0.f, sh_ = bw.mscale ? bw.mshift[gcol] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float yv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                yv[r] = ld_el_s<float>(rs_y, lane_off, (unsigned)(4 * ((r & 3) + 8 * (r >> 2)) + i) * rowstep);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned so = (unsigned)(4 * ((r & 3) + 8 * (r >> 2)) + i) * rowstep;
+                const float t = __builtin_fmaf(yv[r] - mu, sc_, sh_);          // bn(y), bn_apply's fma
+                float v = acc[i][r];
+                if (bw.mscale) v = t > 0.f ? v : 0.f;
+                s1 += v;
+                s2 += v * ((yv[r] - mu) * rs);
+                st_el_s<float>(v, rs_out, lane_off, so);
+                st_el_s<float>(fmaxf(t, 0.f), rs_ao, lane_off, so);
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32) {
+            bw.p1[(size_t)st * g.Co + co] = s1;
+            bw.p2[(size_t)st * g.Co + co] = s2;
+        }
+    } else {
+        const float bias = bw.bias ? bw.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][r];
+                if (bw.bias) {
+                    v += bias;
+                    v = (bw.relu && v < 0.f) ? 0.f : v;
+                }
+                st_el_s<float>(v, rs_out, lane_off, (unsigned)(4 * ((r & 3) + 8 * (r >> 2)) + i) * rowstep);
+            }
+    }
+}
+
+// Filter transform of conv_wino4_kernel: w [Co][9][Ci] -> U [filter-row step th][f][Co][Ci], f = 0..5 (see the kernel);
+// tap mapping as in wino_filter_kernel.
+__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co,
+                                                          int Ci, int S, int r0, int rs, int s0, int ss, int dw0,
+                                                          int dws) {
+    const int th = blockIdx.y, c4n = Ci / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Co * c4n) return;
+    const int o = idx / c4n, c = (idx - o * c4n) * 4;
+    f32x4 gq[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tw = (j - 1 - dw0) * dws;
+        const int tap = (r0 + rs * th) * S + s0 + ss * tw;
+        gq[j] = ld4(w + ((size_t)o * (3 * S) + tap) * Ci + c);
+    }
+    const size_t plane = (size_t)Co * Ci;
+    float* dst = U + (size_t)th * 6 * plane + (size_t)o * Ci + c;
+    const f32x4 s02 = gq[0] + gq[2], q02 = gq[0] + 4.f * gq[2];
+    st4(dst, 0.25f * gq[0]);
+    st4(dst + plane, (-1.0f / 6.0f) * (s02 + gq[1]));
+    st4(dst + 2 * plane, (-1.0f / 6.0f) * (s02 - gq[1]));
+    st4(dst + 3 * plane, (1.0f / 24.0f) * (q02 + 2.f * gq[1]));
+    st4(dst + 4 * plane, (1.0f / 24.0f) * (q02 - 2.f * gq[1]));
+    st4(dst + 5 * plane, gq[2]);
+}
+
 // Winograd F(2, 3) filter transform along the filter ROW for conv_nt_kernel<..., WINO>: w [Co][9][Ci] (the operand layout
 // of the direct kernel; for a data gradient the transposed filter) -> U [filter-row step th][f][Co][Ci] with
 // U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2), where g_j is the tap that meets the input column w + j - 1 in the
@@ -2344,20 +2662,44 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                      128.0 * g.Ci * es < 4.0e9 && 128.0 * g.Co * os < 4.0e9;
     IO_REQUIRE(!bws.xb_res || lin, IO_ERR_SHAPE, "conv_nt: the residual operand form needs a dense 1x1 stride-1 GEMM on whole tiles");
     // 3x3 stride-1 same-size convolutions / data gradients in fp32 with a scratch for the transformed filters: the
-    // Winograd F(2, 3) row form (2/3 of the MFMAs).  Forms it carries: plain, input transform (XF), fused BatchNorm-backward
-    // epilogue (BWE), each with optional statistics; everything else stays on the direct kernel.
+    // Winograd F(2, 3) row form (2/3 of the MFMAs).  Forms it carries: plain (incl. the inference epilogue bias + ReLU), input
+    // transform (XF), fused BatchNorm-backward epilogue (BWE), each with optional statistics; everything else stays on the
+    // direct kernel.
 #ifndef IO_WINO
 #define IO_WINO 1
 #endif
     if (IO_WINO && bws.wino_u && !stem && !g.gw && dt_in == IO_F32 && dt_out == IO_F32 && g.Th == 3 && g.Tw == 3 &&
         g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho &&
-        g.outW == g.Wo && g.Wo % 2 == 0 && M % 128 == 0 && g.Ci % 32 == 0 && !add && !mask && !bws.xb_a && !bws.bias &&
+        g.outW == g.Wo && g.Wo % 2 == 0 && M % 128 == 0 && g.Ci % 32 == 0 && !add && !mask && !bws.xb_a &&
         g.dhs * g.dhs == 1 && g.dws * g.dws == 1 && g.dw0 * (g.dw0 + 2 * g.dws) == -1 && g.rs == 1 && g.ss == 1 &&
         !(bws.y && bws.in_scale) && 12.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
         const double kred9 = 9.0 * g.Ci;
         IoProfScope prof(IO_PROF_CONV_WINO, 2.0 * (double)M * g.Co * kred9,
                          (double)os * M * g.Co * (1.0 + (bws.y ? 1.0 : 0.0)) +
                              (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred9), st);
+#ifndef IO_WINO4
+#define IO_WINO4 1
+#endif
+        // F(4, 3): 4 | Wo, whole 256-row tiles (per BatchNorm group where tables are indexed by group)
+        if (IO_WINO4 && g.Wo % 4 == 0 && M % 256 == 0 && g.Ci % 16 == 0 && (!bws.y || bws.Mg % 256 == 0) &&
+            (!bws.in_scale || bws.in_Mg % 256 == 0) && 18.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
+            hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)io_cdiv((long)g.Co * g.Ci / 4, 256), 3), dim3(256), 0, st,
+                               (const float*)wgt, bws.wino_u, g.Co, g.Ci, g.S, g.r0, g.rs, g.s0, g.ss, g.dw0, g.dws);
+            const unsigned u_bytes = (unsigned)(18.0 * g.Co * g.Ci * 4.0);
+            const int ntw = g.Co / 64;
+            dim3 grid4((unsigned)((M / 256) * ntw));
+            const size_t lds4 = (size_t)2 * 6 * 64 * 16 * sizeof(float);
+            if (bws.y)
+                hipLaunchKernelGGL((conv_wino4_kernel<true, false>), grid4, block, lds4, st, g, (const float*)in,
+                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
+            else if (bws.in_scale)
+                hipLaunchKernelGGL((conv_wino4_kernel<false, true>), grid4, block, lds4, st, g, (const float*)in,
+                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
+            else
+                hipLaunchKernelGGL((conv_wino4_kernel<false, false>), grid4, block, lds4, st, g, (const float*)in,
+                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
+            return io_check_launch("conv_nt(wino4)");
+        }
         hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)io_cdiv((long)g.Co * g.Ci / 4, 256), 3), dim3(256), 0, st,
                            (const float*)wgt, bws.wino_u, g.Co, g.Ci, g.S, g.r0, g.rs, g.s0, g.ss, g.dw0, g.dws);
         const unsigned wu_bytes = (unsigned)(12.0 * g.Co * g.Ci * 4.0);

@@ -157,7 +157,7 @@ struct IoBwStats {
     // downsample convolution's output) and the two BatchNorms folded into one table set (io_bn_resid2_tables).
     int xb_res;
     // Independent again: scratch for the Winograd form of 3x3 stride-1 same-size launches (fp32, Wo even, whole 128-row
-    // tiles, no add / mask): 12 * Co * Ci floats that the launcher fills with the transformed filters ([filter row][4][Co][Ci],
+    // tiles, no add / mask): 18 * Co * Ci floats that the launcher fills with the transformed filters ([filter row][4 | 6][Co][Ci],
     // wino_filter_kernel) before it starts conv_nt_kernel<..., WINO>.  Null: the direct form.  (A caller-owned buffer
     // because no entry point of the library allocates.)
     float* wino_u;

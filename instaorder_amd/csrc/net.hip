@@ -123,7 +123,7 @@ struct Plan {
     size_t stem_wp, stem_dwp;   // fp32: exact-K stem filter / filter gradient, [64][io_stem_kp]
     size_t wt_all;              // transposed copies of all filters (kNoBuf: one transpose launch per data gradient)
     size_t wfold, fbias; // eval: filters with the BatchNorm scale folded in (storage type, parameter offsets) + biases
-    size_t wino_u;       // fp32: transformed filters of the 3x3 launch in flight (Winograd row form), 12 * 512 * 512 floats
+    size_t wino_u;       // fp32: transformed filters of the 3x3 launch in flight (Winograd row form), 18 * 512 * 512 floats
     size_t total;
 };
 
@@ -154,7 +154,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
     }
     p.wfold = training ? 0 : a.take((size_t)net->param_floats * e);
     p.fbias = training ? 0 : a.take((size_t)net->bn_channels * f);
-    p.wino_u = net->dtype == IO_F32 ? a.take((size_t)12 * 512 * 512 * f) : kNoBuf;
+    p.wino_u = net->dtype == IO_F32 ? a.take((size_t)18 * 512 * 512 * f) : kNoBuf;
     p.tables = a.take((size_t)4 * kMaxGroups * net->bn_channels * f);
     p.bn_partial_floats = (size_t)3 * 1100 * 2048;
     p.bn_partial = a.take(p.bn_partial_floats * f);
@@ -448,6 +448,8 @@ int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void*
     IoBwStats ep{};
     ep.bias = c.fbias(b);
     ep.relu = relu;
+    if (IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32 && !add)
+        ep.wino_u = c.buf(c.plan.wino_u);      // (square or H x W inputs alike; odd widths fall back in the launcher)
     const void* w = c.wfold(L.w_off);
     if (stem_exact(c, L)) {
         g.cr = L.cin;

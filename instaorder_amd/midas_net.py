@@ -244,6 +244,10 @@ class _InstaDepthBase(nn.Module):
             parameters = parameters["model"]
         self.load_state_dict(parameters, strict=False)
 
+    @staticmethod
+    def _cut(t):
+        return t.detach().requires_grad_(True)
+
     def _act_dtype(self):
         return torch.bfloat16 if self.dtype == "bf16" else torch.float32
 
@@ -261,10 +265,24 @@ class _InstaDepthBase(nn.Module):
             raise RuntimeError("instaorder_amd: input must be on the GPU; there is no CPU fallback")
         p, s = self.pretrained, self.scratch
         x8 = ops.nhwc_from_nchw(img.float(), pad_to=8, dtype=self._act_dtype())
-        l1 = p.run_layer1(x8)
-        l2 = p.layer2(l1)
-        l3 = p.layer3(l2)
-        l4 = p.layer4(l3)
+        # The encoder's stage outputs are where a data-parallel step cuts its backward pass into stages (supervised_order.
+        # _DepthBase._staged_steps: heads + order branches + decoder, then encoder layer4, layer3, layer2 + layer1).  With
+        # `_stage_cut` every consumer of a stage output -- the next encoder stage, the decoder, the order branches -- reads a
+        # detached alias of it (same storage, its own autograd leaf), so each stage is an autograd graph of its own and the
+        # gradient a boundary collects is handed to the stage below by the caller; without it this is the plain graph.
+        staged = getattr(self, "_stage_cut", False) and torch.is_grad_enabled()
+        cut = self._cut if staged else (lambda t: t)
+        r1 = p.run_layer1(x8)
+        l1 = cut(r1)
+        r2 = p.layer2(l1)
+        l2 = cut(r2)
+        r3 = p.layer3(l2)
+        l3 = cut(r3)
+        r4 = p.layer4(l3)
+        l4 = cut(r4)
+        # (stage output, what its consumers read) -- only for the staged caller, which drops it again: a reference held here
+        # would keep the step's autograd graph alive into the next step
+        self._feats = ((r1, l1), (r2, l2), (r3, l3), (r4, l4)) if staged else None
         path4 = s.refinenet4(s.layer4_rn(l4))
         path3 = s.refinenet3(path4, s.layer3_rn(l3))
         path2 = s.refinenet2(path3, s.layer2_rn(l2))

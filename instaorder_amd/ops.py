@@ -67,7 +67,9 @@ class WeightPlan(object):
         self.optim, self.dtype = optim, dtype
         self.entries = {}
         rows, n_op, n_g = [], 0, 0
-        for w, Cip, Cop, _ in recs:
+        # rows in the order of the flat parameter buffer: a contiguous slice of that buffer (one stage of a staged,
+        # data-parallel backward pass) is then a contiguous range of rows (unpack_grads(lo, hi))
+        for w, Cip, Cop, _ in sorted((r for r in recs if id(r[0]) in spans), key=lambda r: spans[id(r[0])]):
             if id(w) not in spans or w.dim() != 4:
                 continue
             Co, Ci, R, S = w.shape
@@ -78,6 +80,7 @@ class WeightPlan(object):
             n_op += sz * (2 if need_t else 1)
             n_g += sz
         self.n = len(rows)
+        self._row_off = [d.src for _, d in rows]
         self.ops = torch.zeros(max(n_op, 1), device=dev, dtype=dtype)
         self.gk = torch.zeros(max(n_g, 1), device=dev, dtype=torch.float32)
         tab = (_WeightDesc * max(self.n, 1))(*[d for _, d in rows])
@@ -101,10 +104,18 @@ class WeightPlan(object):
             _lib.check(_L().io_weights_prepare(_p(self.table), self.n, _p(self.optim.flat_params), _p(self.ops),
                                                1 if self.dtype == torch.bfloat16 else 0, _st()), "io_weights_prepare")
 
-    def unpack_grads(self):
-        """after optim.gather_grads(): the planned filters' gradients into their OIHW places in the flat buffer"""
-        if self.n:
-            _lib.check(_L().io_weights_unpack_grads(_p(self.table), self.n, _p(self.gk), _p(self.optim.flat_grads), _st()),
+    def unpack_grads(self, lo=None, hi=None):
+        """after optim.gather_grads(): the planned filters' gradients into their OIHW places in the flat buffer; with
+        (lo, hi) only those of the filters that live in [lo, hi) of the flat buffer (rows are in flat order)"""
+        if not self.n:
+            return
+        r0, r1 = 0, self.n
+        if lo is not None:
+            r0 = next((i for i, o in enumerate(self._row_off) if o >= lo), self.n)
+            r1 = next((i for i, o in enumerate(self._row_off) if o >= hi), self.n)
+        if r1 > r0:
+            tab = C.c_void_p(self.table.data_ptr() + r0 * C.sizeof(_WeightDesc))
+            _lib.check(_L().io_weights_unpack_grads(tab, r1 - r0, _p(self.gk), _p(self.optim.flat_grads), _st()),
                        "io_weights_unpack_grads")
 
 

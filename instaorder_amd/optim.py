@@ -126,6 +126,33 @@ class FlatSGD(torch.optim.Optimizer):
                 torch._foreach_copy_(dst, src)
         return self.flat_grads
 
+    def gather_stage(self, idx, grads, skip=None, attach=False):
+        """The gradients of the parameters ``idx`` (indices into the flat layout, one stage of a staged backward pass) ->
+        their slices of the flat gradient buffer; ``grads``: what torch.autograd.grad returned for them (None = no
+        gradient: zeros, unless the parameter is in ``skip`` -- ops.WeightPlan fills those).  attach: ``p.grad`` = the view."""
+        with torch.no_grad():
+            dst, src = [], []
+            for i, g in zip(idx, grads):
+                p = self._params[i]
+                off, k = self._spans[i]
+                view = self.flat_grads[off:off + k].view(p.shape)
+                if g is None:
+                    if skip is None or id(p) not in skip:
+                        view.zero_()
+                else:
+                    dst.append(view)
+                    src.append(g)
+                if attach:
+                    p.grad = view
+            if dst:
+                torch._foreach_copy_(dst, src)
+
+    def offset_of(self, param):
+        for p, (off, _) in zip(self._params, self._spans):
+            if p is param:
+                return off
+        raise KeyError("parameter is not in the flat buffer")
+
     @torch.no_grad()
     def step(self, closure=None, gathered=False):
         g = self.param_groups[0]

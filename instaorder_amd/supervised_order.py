@@ -379,6 +379,13 @@ class _DepthBase(SingleStageModel):
         self._seen_key = None
         self._static = {}
         self._wplan = None          # ops.WeightPlan, built from a recording of the first training step (False: none)
+        # world_size > 1: the backward pass in four stages, the all-reduce of each stage's slice of the flat gradient
+        # buffer launched as soon as the stage is enqueued (IO_COMM_OVERLAP=0: one flat all-reduce after the backward)
+        self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
+        self._stages = None
+        self._buckets = None
+        self._dp_graphs = None
+        self._dp_key = None
 
     # inputs ----------------------------------------------------------------------------------------------------------
     def _keep(self, name, t):
@@ -510,6 +517,178 @@ class _DepthBase(SingleStageModel):
         logs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in logs.items()}
         return logs, (loss.detach() if torch.is_tensor(loss) else loss)
 
+    # ---- data-parallel step: staged backward + bucketed gradient exchange ----------------------------------------------
+    STAGE_NAMES = ("heads+order branches+decoder", "encoder layer4", "encoder layer3", "encoder layer2+layer1")
+
+    def grad_stage_slices(self):
+        """[lo, hi) of the flat gradient buffer (optim.FlatSGD) that each backward stage finalises, in execution order.
+        The parameters lie in creation order -- encoder layer1..layer4, decoder (scratch), order branches, heads -- and
+        the backward pass walks them back to front, so a stage is one contiguous slice: everything behind the encoder
+        (the order branches hang off l1..l3, the decoder off l1..l4), then encoder layer4, layer3, layer2 + layer1."""
+        return [sl for sl, _ in self._stage_plan()]
+
+    @property
+    def flat_grads(self):
+        return self.optim.flat_grads
+
+    def _stage_plan(self):
+        if self._stages is None:
+            opt = self.optim
+            names = {id(p): n for n, p in self.net.named_parameters()}
+            offs = [off for off, _ in opt._spans]
+            total = opt.flat_grads.numel()
+
+            def first(prefix_ok):
+                for i, p in enumerate(opt._params):
+                    if prefix_ok(names[id(p)]):
+                        return i
+                raise RuntimeError("staged backward: parameter group not found")
+            self._i2 = first(lambda n: n.startswith("pretrained.layer2."))
+            i3 = first(lambda n: n.startswith("pretrained.layer3."))
+            i4 = first(lambda n: n.startswith("pretrained.layer4."))
+            it = first(lambda n: not n.startswith("pretrained."))
+            if not (0 < i3 < i4 < it) or any(not names[id(p)].startswith("pretrained.") for p in opt._params[:it]) \
+                    or any(names[id(p)].startswith("pretrained.") for p in opt._params[it:]):
+                raise RuntimeError("staged backward: the flat buffer is not in encoder / decoder / branches order")
+            n = len(opt._params)
+            bounds = [(it, n), (i4, it), (i3, i4), (0, i3)]
+            self._stages = [((offs[a], offs[b] if b < n else total), list(range(a, b))) for a, b in bounds]
+        return self._stages
+
+    def _staged_steps(self, plan):
+        """Generator: forward (both mask orders) + the loss terms, then the backward pass stage by stage; yields the stage
+        index each time that stage's slice of the flat gradient buffer is final (gathered, planned filters unpacked).
+        The cut points are the encoder's stage outputs l1..l4 (midas_net._encode_decode): torch.autograd.grad from the
+        losses to (parameters behind the encoder, l1..l4), then layer4 from dl4 to (its parameters, l3), and so on -- the
+        gradients a boundary collects from several consumers are summed exactly as one backward() call would.  The
+        result lands in ``self._staged_out``."""
+        opt = self.optim
+        stages = self._stage_plan()
+        P = [[opt._params[i] for i in idx] for _, idx in stages]
+        skip = plan.entries if plan is not None else None
+        self.net._stage_cut = True            # every consumer of an encoder stage output reads a detached alias of it
+        try:
+            outs = self._run(True)
+        finally:
+            self.net._stage_cut = False
+        logs, loss, heads, loss_smooth = self._losses(outs, True)
+        roots, grads = [h for h, _ in heads], [g for _, g in heads]
+        if torch.is_tensor(loss_smooth) and loss_smooth.requires_grad:
+            roots.append(loss_smooth)
+            grads.append(torch.ones_like(loss_smooth))
+        raw = [r for r, _ in self.net._feats]                # l1..l4 as the encoder stages produced them
+        cuts = [c for _, c in self.net._feats]               # ... and the leaves their consumers read
+        # (nothing may keep this step's autograd graph alive into the next one: its AccumulateGrad nodes carry the stream
+        # they were created on, and a node of an eager step re-used under a later stream capture breaks the capture)
+        self.net._feats = None
+        self._staged_out = ({k: (v.detach() if torch.is_tensor(v) else v) for k, v in logs.items()},
+                            loss.detach() if torch.is_tensor(loss) else loss)
+
+        def finish(si, idx, got):
+            opt.gather_stage(idx, got, skip=skip, attach=True)
+            if plan is not None and idx:
+                lo = opt._spans[idx[0]][0]
+                hi = opt._spans[idx[-1]][0] + opt._spans[idx[-1]][1]
+                plan.unpack_grads(lo, hi)
+
+        def add(a, b):
+            return b if a is None else (a if b is None else a + b)
+
+        def stage(si, out, g_out, idx, below):
+            """backward of one encoder stage: d(out) -> its parameters `idx` (+ the gradient of the leaf `below` it reads)"""
+            params = [opt._params[i] for i in idx]
+            if g_out is None:                                # no loss reaches this stage: zero gradients
+                finish(si, idx, [None] * len(idx))
+                return None
+            res = torch.autograd.grad([out], params + ([below] if below is not None else []), [g_out], allow_unused=True)
+            finish(si, idx, res[:len(idx)])
+            return res[-1] if below is not None else None
+
+        # stage 0: heads, order branches, decoder -> their parameters and d(l1..l4) at the cuts
+        res = torch.autograd.grad(roots, P[0] + cuts, grads, allow_unused=True)
+        finish(0, stages[0][1], res[:len(P[0])])
+        g1, g2, g3, g4 = res[len(P[0]):]
+        yield 0
+        g3 = add(g3, stage(1, raw[3], g4, stages[1][1], cuts[2]))       # encoder layer4
+        yield 1
+        g2 = add(g2, stage(2, raw[2], g3, stages[2][1], cuts[1]))       # encoder layer3
+        yield 2
+        idx3 = stages[3][1]
+        i2 = idx3.index(self._i2)
+        g1 = add(g1, stage(3, raw[1], g2, idx3[i2:], cuts[0]))          # encoder layer2 ...
+        stage(3, raw[0], g1, idx3[:i2], None)                           # ... and layer1 (incl. the stem)
+        yield 3
+
+    def _step_overlapped(self):
+        """world_size > 1 (FlatSGD): the step of supervised_order.py:198-209 with the gradient exchange
+        (utils/distributed_utils.py:27-31) cut into the four stage buckets of grad_stage_slices() and overlapped with the
+        rest of the backward pass -- the 610 MB of InstaDepthNet_od's gradients are on the wire while the encoder's
+        backward (most of the pass) still runs.  Second step of a shape: one hipGraph PER STAGE, replayed afterwards with
+        the collectives launched in between (as the ResNet nets do); identical kernels and order, bit-identical results."""
+        from . import ops
+        if self._buckets is None:
+            self._buckets = distributed_utils.GradientBuckets(self)
+        bk = self._buckets
+        key = (tuple(self.rgb.shape), self.rgb.data_ptr(), self.PAIR_MODE, self.optim.flat_params.data_ptr())
+        graphs_ok = self._use_graph and not engine.prof_active()
+        if graphs_ok and self._dp_graphs is not None and self._dp_key == key:
+            for si, g in enumerate(self._dp_graphs):
+                g.replay()
+                bk.launch(si)
+            bk.finish()
+            logs, loss = self._dp_out
+            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logs.items()}, loss.clone()
+        plan = self._wplan if (self._wplan and self.PAIR_MODE and self._wplan.dtype == self.net._act_dtype()) else None
+        recording = self._wplan is None and self.PAIR_MODE and hasattr(self.optim, "_spans")
+        capture = graphs_ok and self._seen_key == key and not recording
+        graphs = None
+        if capture:
+            # only the capture sits in the try-block: no collective has been launched yet, so falling back is safe
+            try:
+                torch.cuda.synchronize()
+                ops.WeightPlan.active = plan
+                gen = self._staged_steps(plan)
+                graphs = []
+                for si in range(bk.num_stages):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None, capture_error_mode="thread_local"):
+                        if si == 0 and plan is not None:
+                            plan.prepare()
+                        assert next(gen) == si
+                    graphs.append(g)
+                gen.close()
+            except Exception as ex:   # noqa: BLE001 -- capture unsupported here: stay eager
+                graphs = None
+                self._use_graph = False
+                print("instaorder_amd: per-stage hipGraph capture of the MiDaS step disabled (%s)" % ex)
+            finally:
+                ops.WeightPlan.active = None
+        if graphs is not None:
+            self._dp_graphs, self._dp_key, self._dp_out = graphs, key, self._staged_out
+            for si, g in enumerate(graphs):
+                g.replay()
+                bk.launch(si)
+            bk.finish()
+            logs, loss = self._dp_out
+            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logs.items()}, loss.clone()
+        # eager (first step of a shape, profiling, graphs disabled)
+        if recording:
+            ops.WeightPlan.start_recording()
+        if plan is not None:
+            plan.prepare()
+        ops.WeightPlan.active = plan
+        try:
+            for si in self._staged_steps(plan):
+                bk.launch(si)
+        finally:
+            ops.WeightPlan.active = None
+            recs = ops.WeightPlan.stop_recording() if recording else None
+        bk.finish()
+        if recording:
+            self._wplan = ops.WeightPlan(self.optim, recs, self.net._act_dtype()) if recs else False
+        self._seen_key = key
+        return self._staged_out
+
     def step(self):
         if not self.model.training:
             raise RuntimeError("step() needs switch_to('train')")
@@ -521,6 +700,10 @@ class _DepthBase(SingleStageModel):
             self.optim.step()
             from . import ops
             ops.WEIGHTS_EPOCH[0] += 1
+            return logs, {"loss": loss}
+        if self.world_size > 1 and self._overlap_comm and self.PAIR_MODE:     # (the literal two-call mode keeps the flat exchange)
+            logs, loss = self._step_overlapped()
+            self.optim.step(gathered=True)
             return logs, {"loss": loss}
         key = (tuple(self.rgb.shape), self.rgb.data_ptr(), self.PAIR_MODE, self.optim.flat_params.data_ptr())
         if self._use_graph and self._graph is not None and self._graph_key == key and not engine.prof_active():
