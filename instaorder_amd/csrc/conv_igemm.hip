@@ -2127,6 +2127,207 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_wino_kernel(IoConvG
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN kernel, Winograd F(4, 3) row form (fp32; 3x3 stride-1 same-size convolutions, 16 | Wo, 64 | M)
+// ------------------------------------------------------------------------------------------
+// The transpose of conv_wino4_kernel, as conv_wgrad_wino_kernel is of the F(2, 3) form: four horizontally adjacent output
+// pixels and one filter row give the three taps dW[r][s] += sum_i dy_i d_(i+s) (d0..d5 = inputs at columns w - 1 .. w + 4 of
+// input row h + r - 1) with SIX products instead of twelve:
+//     Y = (dy0,  dy0 + dy1 + dy2 + dy3,  dy0 - dy1 + dy2 - dy3,  dy0 + 2 dy1 + 4 dy2 + 8 dy3,  dy0 - 2 dy1 + 4 dy2 - 8 dy3,  dy3)
+//     V = as in conv_wino4_kernel          P_f = sum over all quads of Y_f * V_f       (six GEMMs, reduction index = quad)
+//     dW[r][0] = P0 / 4 - (P1 + P2) / 6 + (P3 + P4) / 24      dW[r][1] = (P2 - P1) / 6 + (P3 - P4) / 12
+//     dW[r][2] = -(P1 + P2) / 6 + (P3 + P4) / 6 + P5
+// Block = (64 output channels, filter row, 64 input channels, split of the quads); wave = 32 x 32 channels x six frequencies
+// (96 accumulator registers), combination in registers in the epilogue.  k-tile = 16 quads = 64 consecutive output pixels;
+// LDS image [f][64 channels][16 quads] per operand (48 KB, the layout and swizzle of conv_wino4_kernel).  Staging: threads
+// 0..127 take dY, 128..255 the input; a thread owns TWO channels (8-byte loads) and 4 quads: 16 (18) pixels of one image row.
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_wino4_kernel(IoConvGeom g, const float* __restrict__ in,
+                                                                const float* __restrict__ dy,
+                                                                float* __restrict__ dst, int ntile_c, int tiles,
+                                                                int kps, size_t in_bytes, size_t dy_bytes) {
+    constexpr int BC = 64, LDT = 16, NF = 6;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                   // [6 f][64 o][16 quads]
+    float* sB = smem + NF * BC * LDT;                   // [6 f][64 c][16 quads]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = g.Ho * g.Wo;
+    const int M = g.N * HoWo;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int per_o = 3 * ntile_c;
+    const int ot = tile / per_o, rem0 = tile - ot * per_o;
+    const int o0 = ot * BC;
+    const int fr = rem0 / ntile_c;
+    const int c0 = (rem0 - fr * ntile_c) * BC;
+    const int dh = g.dh0 + g.dhs * fr;
+
+    const int nkt = M / 64;
+    const int kt0 = split * kps;
+    const int kt1 = min(kt0 + kps, nkt);
+    const int mfirst = min(kt0 * 64, M - 1);
+    const int n_lo = fdiv(mfirst, g.fd_howo);
+    const int ipix_lo = n_lo * g.Hi * g.Wi;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_at(in, (size_t)ipix_lo * (size_t)(g.Ci * 4), in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc_at(dy, (size_t)mfirst * (size_t)(g.Co * 4), dy_bytes);
+
+    const bool role_a = wave < 2;
+    const int t7 = tid & 127;
+    const int cp = t7 >> 2, qg = t7 & 3;                // channel pair, quad group (16 pixels) of the k-tile
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto ld2 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x2 {
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    };
+    f32x2 px[18];
+    auto load_tile = [&](int kt) {
+        const int m = kt * 64 + 16 * qg;
+        if (role_a) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                px[i] = ld2(rs_dy, (unsigned)((m + i - mfirst) * g.Co + o0 + cp * 2) * 4u);
+            px[16] = px[17] = f32x2{0.f, 0.f};
+        } else {
+            const bool ok0 = m < M;
+            const int mm = ok0 ? m : 0;
+            const int n = fdiv(mm, g.fd_howo), rem = mm - n * HoWo;
+            const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
+            const int hi = ho + dh;
+            const bool okh = ok0 & ((unsigned)hi < (unsigned)g.Hi);
+            const unsigned base = (unsigned)(((((n - n_lo) * g.Hi + hi) * g.Wi + wo - 1) * g.Ci + c0 + cp * 2) * 4);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const bool ok = okh & (i == 0 ? wo > 0 : i == 17 ? wo + 16 < g.Wi : true);
+                px[i] = ld2(rs_in, ok ? base + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        f32x2 v[NF][4];                                 // [f][quad]
+        if (role_a) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x2 y0 = px[4 * t], y1 = px[4 * t + 1], y2 = px[4 * t + 2], y3 = px[4 * t + 3];
+                const f32x2 e = y0 + y2, o = y1 + y3, e4 = y0 + 4.f * y2, o4 = y1 + 4.f * y3;
+                v[0][t] = y0;
+                v[1][t] = e + o;
+                v[2][t] = e - o;
+                v[3][t] = e4 + 2.f * o4;
+                v[4][t] = e4 - 2.f * o4;
+                v[5][t] = y3;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x2 d0 = px[4 * t], d1 = px[4 * t + 1], d2 = px[4 * t + 2], d3 = px[4 * t + 3], d4 = px[4 * t + 4],
+                            d5 = px[4 * t + 5];
+                const f32x2 e42 = d4 - 4.f * d2, e31 = d3 - 4.f * d1, f42 = d4 - d2, f31 = d3 - d1;
+                v[0][t] = 4.f * d0 - 5.f * d2 + d4;
+                v[1][t] = e42 + e31;
+                v[2][t] = e42 - e31;
+                v[3][t] = f42 + 2.f * f31;
+                v[4][t] = f42 - 2.f * f31;
+                v[5][t] = 4.f * d1 - 5.f * d3 + d5;
+            }
+        }
+        float* base = role_a ? sA : sB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = cp * 2 + j;
+            float* p = base + row * LDT + ((qg ^ ((row >> 2) & 3)) * 4);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const f32x4 q = {v[f][0][j], v[f][1][j], v[f][2][j], v[f][3][j]};
+                st4(p + f * BC * LDT, q);
+            }
+        }
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int frow = lane & 31;
+    const int a_base = (wm * 32 + frow) * LDT, b_base = (wn * 32 + frow) * LDT;
+    const int fsw = (frow >> 2) & 3;
+    auto read_frags = [&](int gi, f32x4 (&a)[3], f32x4 (&b)[3]) {
+        const int chunk = ((gi >> 1) * 2 + (lane >> 5)) ^ fsw;
+        const int f0 = (gi & 1) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[j] = ld4(sA + (f0 + j) * BC * LDT + a_base + chunk * 4);
+            b[j] = ld4(sB + (f0 + j) * BC * LDT + b_base + chunk * 4);
+        }
+    };
+    auto mma12 = [&](int gi, const f32x4 (&a)[3], const f32x4 (&b)[3]) {
+        const int f0 = (gi & 1) * 3;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[f0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][tt], b[j][tt], acc[f0 + j], 0, 0, 0);
+    };
+
+    f32x4 fa[3], fb[3];
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile();
+    }
+    __syncthreads();
+    if (kt0 < kt1) read_frags(0, fa, fb);
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            f32x4 na[3], nb[3];
+            read_frags(gi + 1, na, nb);
+            mma12(gi, fa, fb);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pin(fa[j]); pin(fb[j]); }      // group-3 fragments in registers BEFORE the barrier
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        f32x4 na[3], nb[3];
+        read_frags(0, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma12(3, fa, fb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+    }
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            f32x4 na[3], nb[3];
+            read_frags(gi + 1, na, nb);
+            mma12(gi, fa, fb);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+        }
+        mma12(3, fa, fb);
+    }
+
+    const size_t wrow = (size_t)g.wT * g.Ci;
+    float* base = dst + (size_t)split * g.Co * wrow + (size_t)(g.r0 + g.rs * fr) * g.S * g.Ci + c0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float s12 = acc[1][r] + acc[2][r], s34 = acc[3][r] + acc[4][r];
+        float* p = base + (size_t)o * wrow;
+        p[0] = 0.25f * acc[0][r] - (1.0f / 6.0f) * s12 + (1.0f / 24.0f) * s34;
+        p[g.Ci] = (1.0f / 6.0f) * (acc[2][r] - acc[1][r]) + (1.0f / 12.0f) * (acc[3][r] - acc[4][r]);
+        p[2 * g.Ci] = (1.0f / 6.0f) * (s34 - s12) + acc[5][r];
+    }
+}
+
 // (An fp32 sibling -- LDS-DMA into a row-major [m][channels] image, ds_read_b32 fragments, no transposes at all because
 // v_mfma_f32_32x32x2_f32 takes one reduction index per lane -- was built and measured: 112.9 TF/s with 32-row k-tiles at
 // two blocks per CU, 117.8 with 16-row k-tiles at four, against 118.3 for the register-staged kernel at three; the
@@ -2836,6 +3037,14 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         const double Mdw = (double)g.N * g.Ho * g.Wo;
         IoProfScope prof(IO_PROF_WGRAD_WINO, 2.0 * Mdw * g.Co * 9.0 * g.Ci,
                          4.0 * (Mdw * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + 9.0 * g.Co * g.Ci), st);
+#ifndef IO_WGRAD_WINO4
+#define IO_WGRAD_WINO4 1
+#endif
+        if (IO_WGRAD_WINO4 && g.Wo % 16 == 0) {          // F(4, 3): a staging thread's 16 pixels lie in one image row
+            hipLaunchKernelGGL(conv_wgrad_wino4_kernel, dim3((unsigned)(pw.tiles * pw.splits)), dim3(kThreads),
+                               (size_t)2 * 6 * 64 * 16 * sizeof(float), st, g, (const float*)in, (const float*)dy, dstw,
+                               pw.ntile_c, pw.tiles, pw.kps, in_b, dy_b);
+        } else {
         const size_t lds = (size_t)2 * 4 * 64 * 36 * sizeof(float);
         static std::atomic<unsigned long long> attr_done{0};
         if (io_first_on_device(attr_done))
@@ -2843,6 +3052,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                                       (int)lds);
         hipLaunchKernelGGL((conv_wgrad_wino_kernel<2>), dim3((unsigned)(pw.tiles * pw.splits)), dim3(kThreads), lds, st, g,
                            (const float*)in, (const float*)dy, dstw, pw.ntile_c, pw.tiles, pw.kps, in_b, dy_b);
+        }
         int rcw = io_check_launch("conv_wgrad(wino)");
         if (rcw) return rcw;
         if (pw.splits > 1) rcw = io_splitk_reduce(partial, dw, (size_t)g.Co * io_filter_row(g) / 4, pw.splits, st);
