@@ -470,13 +470,15 @@ int io_pair_planes_u8_hw(const uint8_t* arena, size_t arena_bytes, const io_pair
 
 /* ---- measurement aid (bench.py): HIP-event timing of every launch, per kernel class, on the launch
  * stream.  Process-global; io_prof_end synchronises on the recorded events and returns the number of
- * classes written.  flops / bytes are the ALGORITHMIC figures of the timed launches. */
+ * classes written.  flops / bytes are the ALGORITHMIC figures of the timed launches (the direct convolution's count). */
 typedef struct io_prof_entry {
     char name[48];
     long launches;
     double total_ms;
     double flops;
     double bytes;
+    double flops_executed;   /* what the matrix pipes actually multiplied: = flops for the direct kernels, 1/2 (F(4,3)) or 2/3
+                              * (F(2,3)) of it for the Winograd row forms of the 3x3 stride-1 convolutions */
 } io_prof_entry;
 int io_prof_begin(void);
 /* share_events != 0 (what io_prof_begin uses): a launch group's start event is the previous group's end event -- half the

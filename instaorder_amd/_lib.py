@@ -50,7 +50,7 @@ class DgradFused(C.Structure):
 
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("total_ms", C.c_double),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("flops_executed", C.c_double)]
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t

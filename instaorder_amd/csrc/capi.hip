@@ -185,7 +185,7 @@ namespace {
 // e0 of a scope that directly follows a closed scope on the same stream IS that scope's e1 (own0 = false): one event
 // record per launch group instead of two -- every record is a barrier packet the GPU has to chew through, ~1 us each,
 // 1600 of them per step.  A class's time then runs from the end of the previous profiled launch to the end of its own.
-struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; bool own0, closed; hipStream_t st; };
+struct ProfRec { int cls; double flops, bytes, fexec; hipEvent_t e0, e1; bool own0, closed; hipStream_t st; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 bool g_prof_share = true;       // consecutive scopes share one event (see IoProfScope); off when foreign launches interleave
@@ -203,12 +203,12 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-IoProfScope::IoProfScope(int cls, double flops, double bytes, hipStream_t stream) : idx(-1), st(stream) {
+IoProfScope::IoProfScope(int cls, double flops, double bytes, hipStream_t stream, double flops_exec) : idx(-1), st(stream) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on) return;
     ProfRec r;
-    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.cls = cls; r.flops = flops; r.bytes = bytes; r.fexec = flops_exec < 0.0 ? flops : flops_exec;
     r.st = st; r.closed = false;
     if (g_prof_share && !g_prof_recs.empty() && g_prof_recs.back().closed && g_prof_recs.back().st == st) {
         r.e0 = g_prof_recs.back().e1;
@@ -266,6 +266,7 @@ extern "C" int io_prof_launches(io_prof_entry* out, int max_entries) {
         e.total_ms = ms;
         e.flops = r.flops;
         e.bytes = r.bytes;
+        e.flops_executed = r.fexec;
     }
     return n;
 }
@@ -283,6 +284,7 @@ extern "C" int io_prof_end(io_prof_entry* out, int max_entries) {
             acc[r.cls].total_ms += ms;
             acc[r.cls].flops += r.flops;
             acc[r.cls].bytes += r.bytes;
+            acc[r.cls].flops_executed += r.fexec;
         }
         if (r.own0) g_prof_pool.push_back(r.e0);
         g_prof_pool.push_back(r.e1);

@@ -2754,6 +2754,10 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem, bool fp32 = true) {
 #ifndef IO_WGRAD_WINO
 #define IO_WGRAD_WINO 1
 #endif
+#ifndef IO_WGRAD_WINO4
+#define IO_WGRAD_WINO4 1
+#endif
+#define IO_WGRAD_WINO4_ON IO_WGRAD_WINO4
 // the Winograd row form of the fp32 filter gradient: 3x3 stride-1 same-size convolutions with 8 | Wo and 64 | M
 bool wgrad_wino_ok(const IoConvGeom& g, int stem) {
     return IO_WGRAD_WINO && !stem && !g.gw && !g.cr && g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 &&
@@ -2875,15 +2879,18 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
         g.dhs * g.dhs == 1 && g.dws * g.dws == 1 && g.dw0 * (g.dw0 + 2 * g.dws) == -1 && g.rs == 1 && g.ss == 1 &&
         !(bws.y && bws.in_scale) && 12.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
         const double kred9 = 9.0 * g.Ci;
-        IoProfScope prof(IO_PROF_CONV_WINO, 2.0 * (double)M * g.Co * kred9,
-                         (double)os * M * g.Co * (1.0 + (bws.y ? 1.0 : 0.0)) +
-                             (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred9), st);
 #ifndef IO_WINO4
 #define IO_WINO4 1
 #endif
         // F(4, 3): 4 | Wo, whole 256-row tiles (per BatchNorm group where tables are indexed by group)
-        if (IO_WINO4 && g.Wo % 4 == 0 && M % 256 == 0 && g.Ci % 16 == 0 && (!bws.y || bws.Mg % 256 == 0) &&
-            (!bws.in_scale || bws.in_Mg % 256 == 0) && 18.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
+        const bool wino4 = IO_WINO4 && g.Wo % 4 == 0 && M % 256 == 0 && g.Ci % 16 == 0 && (!bws.y || bws.Mg % 256 == 0) &&
+                           (!bws.in_scale || bws.in_Mg % 256 == 0) && 18.0 * g.Co * g.Ci * 4.0 < 4.0e9;
+        const double fl9 = 2.0 * (double)M * g.Co * kred9;
+        IoProfScope prof(IO_PROF_CONV_WINO, fl9,
+                         (double)os * M * g.Co * (1.0 + (bws.y ? 1.0 : 0.0)) +
+                             (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred9), st,
+                         wino4 ? fl9 * 0.5 : fl9 * (2.0 / 3.0));
+        if (wino4) {
             hipLaunchKernelGGL(wino4_filter_kernel, dim3((unsigned)io_cdiv((long)g.Co * g.Ci / 4, 256), 3), dim3(256), 0, st,
                                (const float*)wgt, bws.wino_u, g.Co, g.Ci, g.S, g.r0, g.rs, g.s0, g.ss, g.dw0, g.dws);
             const unsigned u_bytes = (unsigned)(18.0 * g.Co * g.Ci * 4.0);
@@ -3036,11 +3043,9 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                    IO_ERR_SHAPE, "conv_wgrad(wino): one split spans more than 4 GB (32-bit offsets)");
         const double Mdw = (double)g.N * g.Ho * g.Wo;
         IoProfScope prof(IO_PROF_WGRAD_WINO, 2.0 * Mdw * g.Co * 9.0 * g.Ci,
-                         4.0 * (Mdw * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + 9.0 * g.Co * g.Ci), st);
-#ifndef IO_WGRAD_WINO4
-#define IO_WGRAD_WINO4 1
-#endif
-        if (IO_WGRAD_WINO4 && g.Wo % 16 == 0) {          // F(4, 3): a staging thread's 16 pixels lie in one image row
+                         4.0 * (Mdw * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + 9.0 * g.Co * g.Ci), st,
+                         2.0 * Mdw * g.Co * 9.0 * g.Ci * ((IO_WGRAD_WINO4_ON && g.Wo % 16 == 0) ? 0.5 : 2.0 / 3.0));
+        if (IO_WGRAD_WINO4_ON && g.Wo % 16 == 0) {          // F(4, 3): a staging thread's 16 pixels lie in one image row
             hipLaunchKernelGGL(conv_wgrad_wino4_kernel, dim3((unsigned)(pw.tiles * pw.splits)), dim3(kThreads),
                                (size_t)2 * 6 * 64 * 16 * sizeof(float), st, g, (const float*)in, (const float*)dy, dstw,
                                pw.ntile_c, pw.tiles, pw.kps, in_b, dy_b);

@@ -269,6 +269,7 @@ enum IoProfClass {
 struct IoProfScope {
     int idx;
     hipStream_t st;
-    IoProfScope(int cls, double flops, double bytes, hipStream_t stream);
+    // flops_exec < 0: the launch executes its algorithmic flops
+    IoProfScope(int cls, double flops, double bytes, hipStream_t stream, double flops_exec = -1.0);
     ~IoProfScope();
 };

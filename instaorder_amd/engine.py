@@ -204,10 +204,12 @@ def prof_launches(max_entries=8192):
 
 
 def prof_end():
-    """Stop and return {class name: dict(launches, total_ms, flops, bytes)} (synchronises)."""
+    """Stop and return {class name: dict(launches, total_ms, flops, bytes, flops_executed)} (synchronises); flops = the
+    algorithmic count of the direct convolution, flops_executed = what the matrix pipes multiplied (Winograd forms: less)."""
     global _prof_on
     _prof_on = False
     arr = (_lib.ProfEntry * 32)()
     n = _lib.lib().io_prof_end(arr, 32)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
-                                       flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)}
+                                       flops=float(arr[i].flops), bytes=float(arr[i].bytes),
+                                       flops_executed=float(arr[i].flops_executed)) for i in range(n)}

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One forward convolution shape, launched REPS times (for rocprofv3 --pmc / --kernel-trace on a single kernel).
-usage: python tools/one_conv.py N H Cin Cout k stride pad fp32|bf16 [reps] [fwd|wgrad]"""
+usage: python tools/one_conv.py N H Cin Cout k stride pad fp32|bf16 [reps] [fwd|wgrad|wino]
+(wino: the 3x3 stride-1 forward through io_conv2d_fwd_wino -- the Winograd row form)"""
 import ctypes as C
 import os
 import sys
@@ -28,6 +29,12 @@ if MODE == "wgrad":
     nb = L.io_conv2d_wgrad_workspace_bytes(N, H, H, Cin, Cout, k, k, st, pad)
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
     run = lambda: L.io_conv2d_wgrad_dt(P(x), P(dy), P(dw), N, H, H, Cin, Cout, k, k, st, pad, P(ws), nb, DT, DT, S())
+elif MODE == "wino":
+    nsc = L.io_conv2d_wino_scratch_floats(Cin, Cout)
+    sc = torch.empty(nsc, device="cuda")
+    Z = C.c_void_p(0)
+    run = lambda: L.io_conv2d_fwd_wino(P(x), P(w), P(y), N, H, H, Cin, Cout, 1, Z, Z, Z, Z, Z, Z, Z, 0.1, 1e-5, Z, Z, Z, Z, Z, 0,
+                                       P(sc), nsc, S())
 else:
     run = lambda: L.io_conv2d_fwd_dt(P(x), P(w), P(y), N, H, H, Cin, Cout, k, k, st, pad, DT, DT, S())
 for _ in range(3):
