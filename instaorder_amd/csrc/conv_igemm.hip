@@ -2357,6 +2357,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_wino4_kernel(IoConvGeo
 // XF: the A operand goes through relu(bn(x)) while it is staged (IoBwStats::in_scale, as in conv_nt_kernel).
 // BWE: the fused BatchNorm-backward epilogue (IoBwStats::y ...: ReLU mask recomputed from y, per-tile sums, activation side
 // output).  Both need whole 256-row tiles per BatchNorm group.
+#ifndef IO_W4_ABLATE
+#define IO_W4_ABLATE 0       // timing-only ablations of conv_wino4_kernel (WRONG results): 1 no transforms, 2 no LDS refill, 3 no global loads
+#endif
 template <bool BWE, bool XF>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const float* __restrict__ in,
                                                         const float* __restrict__ U, float* __restrict__ out, int ntn,
@@ -2407,7 +2410,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     f32x4 pa[6], pu[6], xm, xs, xh;
     unsigned xok = 0;
     int th = 0, cc = 0;
+    bool first_load = true;
     auto load_tile = [&]() {                 // the k-tile (th, cc)
+        if (IO_W4_ABLATE == 3 && !first_load) return;
+        first_load = false;
         const int dh = g.dh0 + g.dhs * th;
         const unsigned aoff = (unsigned)(((dh * g.Wi - 1) * g.Ci + cc * BK) * 4);      // (wraps; used only where the pixel exists)
         const unsigned uoff = (unsigned)(th * NF) * uplane + (unsigned)(cc * BK) * 4u;
@@ -2435,6 +2441,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         th += wrap ? 1 : 0;
     };
     auto xform_tile = [&]() {
+        if (IO_W4_ABLATE == 1) return;
         if constexpr (XF) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -2456,9 +2463,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         pa[5] = 4.f * d1 - 5.f * d3 + d5;
     };
     const int swz = sc ^ ((sr >> 2) & 3);
+    bool first_store = true;
     auto store_tile = [&]() {
         float* a = sA + sr * LDT + swz * 4;
         float* b = sB + sr * LDT + swz * 4;
+        if (IO_W4_ABLATE == 2 && !first_store) return;
+        first_store = false;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             st4(a + f * 64 * LDT, pa[f]);
@@ -2519,6 +2529,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) { pin(fa[j]); pin(fb[j]); }      // group-3 fragments in registers BEFORE the barrier
         __syncthreads();                         // every wave has read the last fragments of tile kt
+#ifndef IO_W4_ORDER
+#define IO_W4_ORDER 0
+#endif
+#if IO_W4_ORDER == 1
+        mma12(3, fa, fb);                        // the last group runs under the LDS refill
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile();
+        __syncthreads();
+        read_frags(0, fa, fb);
+#else
         store_tile();
         __syncthreads();
         f32x4 na[3], nb[3];
@@ -2527,6 +2547,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         mma12(3, fa, fb);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+#endif
     }
 #pragma unroll
     for (int gi = 0; gi < 3; ++gi) {
