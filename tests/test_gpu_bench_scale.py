@@ -6,7 +6,8 @@ test_gpu_ops.py stop at M = 32 k rows; at the bench batch layer 1 has M = 2.1 M 
 768 / 2304 split-K slices in the filter gradient, the two-block build for 769..1024-tile grids, the XCD remap over many
 rounds, BatchNorm tile partials over 16 k tiles, descriptors rebased per tile on multi-GB tensors.  So each distinct
 convolution shape of ResNet-50 at N = 512, S = 256 is run here through the C ABI in the very configuration the executor
-(csrc/net.hip) launches it in -- forward with the operand transform + statistics epilogue, data gradient with the fused
+(csrc/net.hip) launches it in -- forward with the operand transform + statistics epilogue (the fp32 3x3 stride-1 layers
+in the Winograd F(4,3) row form: forward, data gradient and filter gradient), data gradient with the fused
 BatchNorm-backward epilogue (and, in fp32, the backward operand transform + side output), filter gradient at its real
 split count -- in fp32 and bf16, and checked against fp64:
 
@@ -233,7 +234,14 @@ def test_forward_launch_at_bench_size(shape, dtype):
     nws = lib.io_conv2d_bnstats_workspace_floats(N, H, H, Cout, k, k, s, pad, G)
     ws = torch.empty(nws, device=DEV)
     y = torch.full((N, Ho, Ho, Cout), float("nan"), device=DEV, dtype=td)
-    if xf is not None:
+    wino = role == "c2" and not bf           # fp32 3x3 stride-1: the executor launches the Winograd F(4,3) row form
+    if wino:
+        nsc = lib.io_conv2d_wino_scratch_floats(Cin, Cout)
+        sc = torch.empty(nsc, device=DEV)
+        _lib.check(lib.io_conv2d_fwd_wino(P(x), P(w), P(y), N, H, H, Cin, Cout, G, P(xf[0]), P(xf[1]), P(xf[2]), P(gamma),
+                                          P(beta), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift), P(ws), nws,
+                                          P(sc), nsc, ST()), "fwd_wino")
+    elif xf is not None:
         _lib.check(lib.io_conv2d_fwd_xf_dt(P(x), P(w), P(y), N, H, H, Cin, Cout, k, k, s, pad, G, P(xf[0]), P(xf[1]), P(xf[2]),
                                            P(gamma), P(beta), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(scale), P(shift),
                                            P(ws), nws, int(bf), ST()), "fwd_xf")
@@ -244,7 +252,7 @@ def test_forward_launch_at_bench_size(shape, dtype):
     m, o = sample(g, M), sample(g, Cout)
     ref = ref_forward(x, w, H, Cin, k, s, m, o, xf, bf)
     got = y.view(M, Cout)[m, o]
-    assert relerr(got, ref) < tol(bf), name
+    assert relerr(got, ref) < (4e-5 if wino else tol(bf)), name          # (the Winograd form re-associates: twice the direct bar)
     # statistics of the output from the epilogue's 128-row tile partials, against fp64 over the kernel's own y
     Mg = M // G
     yv = y.view(G, Mg, Cout)
@@ -366,6 +374,12 @@ def test_data_gradient_launch_at_bench_size(shape, dtype):
         if not bf:                               # fp32 never stored relu(bn(y)): the epilogue rebuilds it
             aout = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=td)
             opt.ep_act_out = aout.data_ptr()
+    wino = role == "c2" and not bf           # fp32 3x3 stride-1: the executor hands the launch its Winograd scratch
+    if wino:
+        nsc = lib.io_conv2d_wino_scratch_floats(Cout, Cin)
+        sc = torch.empty(nsc, device=DEV)
+        opt.wino_scratch, opt.wino_scratch_floats = sc.data_ptr(), nsc
+        keep.append(sc)
     _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dz_in), P(wt), P(dx), N, H, H, Cin, Cout, k, k, pad, G, C.byref(opt), int(bf),
                                             ST()), "dgrad_fused")
     ref = ref_dgrad(src, wt, H, Cin, Cout, k, 1, m, c)
@@ -382,7 +396,7 @@ def test_data_gradient_launch_at_bench_size(shape, dtype):
             assert relerr(aout.view(Mi, Cin)[m, c], torch.relu(t)) < 2e-5, name
     got = host(dx.view(Mi, Cin)[m, c])
     assert int(sure.sum()) > NS // 2
-    assert relerr(got * sure, ref * sure) < tol(bf), name
+    assert relerr(got * sure, ref * sure) < (4e-5 if wino else tol(bf)), name
     if xb:      # the side output: dy itself, at sampled entries, and nothing left unwritten
         mo, co = sample(g, Mo), sample(g, Cout)
         want = src(mo, decode(mo, Ho)[0])[torch.arange(NS), co.cpu()]
