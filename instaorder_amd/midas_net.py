@@ -19,7 +19,10 @@ import torch.nn as nn
 
 from . import common_utils, ops
 
+import os
+
 __all__ = ["InstaDepthNet_od", "InstaDepthNet_d"]
+MULTI_STREAM = os.environ.get("IO_DEPTH_STREAMS", "1") != "0"      # IO_DEPTH_STREAMS=0: everything on one stream
 
 
 class Conv2d(nn.Module):
@@ -258,7 +261,7 @@ class _InstaDepthBase(nn.Module):
         f4 = net.layer4(ops.add(f3, l3))
         return ops.avgpool_fc(f4, fc.weight, fc.bias)
 
-    def _encode_decode(self, img):
+    def _encode(self, img):
         if img.dim() != 4 or img.shape[1] != 3:
             raise ValueError("expected img [B,3,H,W], got %s" % (tuple(img.shape),))
         if not img.is_cuda:
@@ -283,6 +286,10 @@ class _InstaDepthBase(nn.Module):
         # (stage output, what its consumers read) -- only for the staged caller, which drops it again: a reference held here
         # would keep the step's autograd graph alive into the next step
         self._feats = ((r1, l1), (r2, l2), (r3, l3), (r4, l4)) if staged else None
+        return l1, l2, l3, l4
+
+    def _decode(self, l1, l2, l3, l4):
+        s = self.scratch
         path4 = s.refinenet4(s.layer4_rn(l4))
         path3 = s.refinenet3(path4, s.layer3_rn(l3))
         path2 = s.refinenet2(path3, s.layer2_rn(l2))
@@ -291,8 +298,39 @@ class _InstaDepthBase(nn.Module):
         y = oc[0](path1)
         y = oc[1](y)
         y = oc[2](y, relu=True)                         # 32 real + 32 zero channels
-        disp = ops.head1(y, oc[4].weight, oc[4].bias, self.non_negative)
-        return disp, (l1, l2, l3)
+        return ops.head1(y, oc[4].weight, oc[4].bias, self.non_negative)
+
+    def _encode_decode(self, img):
+        l1, l2, l3, l4 = self._encode(img)
+        return self._decode(l1, l2, l3, l4), (l1, l2, l3)
+
+    # The decoder and the order branches all hang off the encoder's stage outputs and do not depend on one another; at the
+    # 16-pair batch of BASELINE configs[4] their launches (24 x 24 and 12 x 12 maps: 36-150 tiles) fill a fraction of the 256
+    # CUs.  IO_DEPTH_STREAMS=1: the branches run on side streams next to the decoder (fork after the encoder, join before
+    # the losses); autograd runs each backward node on its forward stream, so the backward pass overlaps the same way, and
+    # a hipGraph capture records the fork / join as parallel branches of the graph.  Same kernels, same arithmetic.
+    _side = None
+
+    def _side_streams(self, n):
+        if _InstaDepthBase._side is None or len(_InstaDepthBase._side) < n:
+            _InstaDepthBase._side = [torch.cuda.Stream() for _ in range(n)]
+        return _InstaDepthBase._side[:n]
+
+    def _fork_join(self, jobs, main_job):
+        """jobs: callables for the side streams; main_job runs on the current stream.  Returns ([side results], main result)."""
+        main = torch.cuda.current_stream()
+        sides = self._side_streams(len(jobs))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        out = []
+        for st, job in zip(sides, jobs):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                out.append(job())
+        res = main_job()
+        for st in sides:
+            main.wait_stream(st)
+        return out, res
 
 
 def _pair_inputs(mask1, mask2, feats, dtype):
@@ -329,6 +367,23 @@ class InstaDepthNet_od(_InstaDepthBase):
         call (mask1, mask2), rows [B,2B) = call (mask2, mask1).  Same values, gradients and running statistics as the
         two separate calls."""
         with _Counters():
+            if MULTI_STREAM and img.is_cuda:
+                with _BnMode(repeat=2):
+                    e1, e2, e3, e4 = self._encode(img)
+                x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, (e1, e2, e3), self._act_dtype())
+
+                def branch(net, fc):
+                    def run():
+                        with _BnMode(groups=2):
+                            return self._order_branch(net, fc, x8m, l1, l2, l3)
+                    return run
+
+                def decode():
+                    with _BnMode(repeat=2):
+                        return self._decode(e1, e2, e3, e4)
+                (depth_order, occ_order), disp = self._fork_join([branch(self.do_net, self.depth_fc),
+                                                                  branch(self.oo_net, self.occ_fc)], decode)
+                return disp, depth_order, occ_order
             with _BnMode(repeat=2):
                 disp, feats = self._encode_decode(img)
             x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())

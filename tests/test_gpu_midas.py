@@ -440,3 +440,32 @@ def test_weight_plan_equals_per_call_relayout():
             assert m._wplan and m._wplan.n > 150, m._wplan and m._wplan.n
         res.append((m.optim.flat_params.clone(), m.optim._buf.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_multi_stream_pair_forward_equals_single_stream(tmp_path):
+    """midas_net.forward_pair runs the two order branches on side streams next to the decoder (fork after the encoder, join
+    before the losses; the backward overlaps the same way, inside the captured hipGraph too).  Same kernels: the first-step
+    gradients of everything BEHIND the fork -- encoder layer4, decoder, both branches, heads -- must be bit-identical to
+    the single-stream form (IO_DEPTH_STREAMS=0); the encoder layers below collect l1..l3's gradient from three consumers in
+    a different order of summation (1e-6 of the gradient); and the multi-stream form is itself bit-reproducible."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    outs = {}
+    for tag, env in (("multi_a", {}), ("multi_b", {}), ("single", {"IO_DEPTH_STREAMS": "0"})):
+        f = str(tmp_path / (tag + ".npy"))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "depth_streams_check.py"), f, "3", "64", "2", "fp32"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[tag] = (np.load(f), np.load(f.replace(".npy", "_g1.npy")))
+    assert np.array_equal(outs["multi_a"][0], outs["multi_b"][0]) and np.array_equal(outs["multi_a"][1], outs["multi_b"][1])
+    gm, gs = outs["multi_a"][1].astype(np.float64), outs["single"][1].astype(np.float64)
+    assert np.sqrt(((gm - gs) ** 2).sum()) <= 1e-5 * np.sqrt((gs ** 2).sum())
+    import instaorder_amd as ia
+    torch.manual_seed(1234)
+    cfg = dict(algo="InstaDepthNet_od", lr=1e-4, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True,
+               **WEIGHTS)
+    m = ia.InstaDepthNet_od(cfg, dist_model=False)
+    lo = m.grad_stage_slices()[1][0]                 # first float of encoder layer4: everything from here on is behind the fork
+    assert np.array_equal(outs["multi_a"][1][lo:], outs["single"][1][lo:])
+    assert np.abs(gs[lo:]).sum() > 0
