@@ -18,4 +18,6 @@ rm -rf /tmp/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d /tmp/pmc_mfma -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /tmp/pmc_mfma.log 2>&1
 python3 $R/tools/pmc_summary.py /tmp/pmc_mfma 'conv_nt_kernel<float, float, 128, 0,' > $R/gpurun_out/mfma_busy_nt.txt
 python3 $R/tools/pmc_summary.py /tmp/pmc_mfma 'conv_wgrad_kernel<float, float, 128, 128' > $R/gpurun_out/mfma_busy_wgrad.txt
-cat $R/gpurun_out/mfma_busy_nt.txt $R/gpurun_out/mfma_busy_wgrad.txt
+python3 $R/tools/pmc_summary.py /tmp/pmc_mfma 'conv_wino4_kernel' > $R/gpurun_out/mfma_busy_wino4.txt
+python3 $R/tools/pmc_summary.py /tmp/pmc_mfma 'conv_wgrad_wino4_kernel' > $R/gpurun_out/mfma_busy_wgradwino4.txt
+cat $R/gpurun_out/mfma_busy_nt.txt $R/gpurun_out/mfma_busy_wgrad.txt $R/gpurun_out/mfma_busy_wino4.txt $R/gpurun_out/mfma_busy_wgradwino4.txt

@@ -72,6 +72,11 @@ for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv"
             f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                                                   r["MinNs"], r["MaxNs"]))
 
+for d in ("fp32", "bf16"):
+    src = os.path.join(G, "per_launch_%s.txt" % d)
+    if os.path.exists(src) and os.path.getsize(src) > 1000:
+        open(os.path.join(P, "%s_per_launch_%s.txt" % (rnd, d)), "w").write(open(src).read())
+
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     p = os.path.join(G, "traffic_%s.txt" % c)
@@ -96,7 +101,7 @@ if len(vals) == 2:
     }, open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
 # matrix-pipe occupancy (tools/collect_traffic.sh, second part)
 mf = {}
-for tag in ("nt", "wgrad"):
+for tag in ("nt", "wgrad", "wino4", "wgradwino4"):
     p = os.path.join(G, "mfma_busy_%s.txt" % tag)
     if os.path.exists(p):
         txt = open(p).read()
@@ -114,6 +119,55 @@ for tag in ("nt", "wgrad"):
 if mf:
     json.dump({"_comment": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE ... over `bench.py --steps 2 "
                            "--warmup 1` (fp32 headline configuration), counters only; sums over every launch of the family.  "
-                           "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (64 per v_mfma_f32_32x32x2_f32).",
+                           "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (64 per v_mfma_f32_32x32x2_f32).  nt / wgrad: the direct "
+                           "128-wide kernels; wino4 / wgradwino4: the Winograd F(4,3) forward + data gradient / filter gradient.",
                "commit": COMMIT, "csrc_sha": CSRC, **mf}, open(os.path.join(P, rnd + "_pmc_mfma_busy.json"), "w"), indent=1)
+# bf16 counters (tools/collect_traffic_bf16.sh): HBM traffic + matrix-pipe occupancy of the two dominant bf16 kernels
+def _fam_blocks(path):
+    """{family: {counter: (n, mean, sum)}} of a tools/pmc_summary.py output with several families"""
+    out, cur = {}, None
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line.strip()
+            out.setdefault(cur, {})
+        elif cur:
+            for m in re.finditer(r"(\w+): n=(\d+) mean=([0-9.e+]+) sum=([0-9.e+]+)", line):
+                out[cur][m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+    return out
+
+
+bf = {}
+fz, wz, mb = (_fam_blocks(os.path.join(G, n)) for n in ("bf16_traffic_FETCH_SIZE.txt", "bf16_traffic_WRITE_SIZE.txt",
+                                                         "bf16_mfma_busy.txt"))
+for fam in fz:
+    e = {}
+    if "FETCH_SIZE" in fz.get(fam, {}) and "WRITE_SIZE" in wz.get(fam, {}):
+        f_, w_ = fz[fam]["FETCH_SIZE"], wz[fam]["WRITE_SIZE"]
+        e.update(launches_profiled=f_[0], fetch_size_kib_mean=f_[1], write_size_kib_mean=w_[1],
+                 bytes_per_launch_corrected=(2 * f_[1] + w_[1]) * 1024)
+    c = mb.get(fam, {})
+    if "VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        busy, gui, cu = c["VALU_MFMA_BUSY_CYCLES"][2], c["GRBM_GUI_ACTIVE"][2], c.get("BUSY_CU_CYCLES", (0, 0, 0))[2]
+        e.update(mfma_busy_fraction_of_all_simd_cycles=busy / (gui / 8.0 * 1024.0),
+                 mfma_busy_fraction_of_busy_cu_cycles=busy / (4.0 * cu) if cu else None,
+                 wave_cycles_wait_any_frac=c["WAIT_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_ANY" in c else None,
+                 wave_cycles_wait_inst_any_frac=c["WAIT_INST_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_INST_ANY" in c else None)
+    if e:
+        bf[fam] = e
+bfb = os.path.join(G, "bench_n1_bf16.json")
+if bf and os.path.exists(bfb):
+    b = last_json(bfb)
+    kc = b.get("kernel_classes", {}).get("conv_nt_kernel<128,false>")
+    for fam, e in bf.items():
+        if fam.startswith("conv_nt_kernel") and kc and "bytes_per_launch_corrected" in e:
+            alg = kc["gbs"] * 1e9 * (kc["ms_per_step"] * 1e-3) / (kc["launches"] / b["profiled"]["steps"])
+            e["algorithmic_bytes_per_launch"] = alg
+            e["traffic_ratio"] = e["bytes_per_launch_corrected"] / alg
+    json.dump({"_comment": "bf16 headline configuration (bench.py --dtype bf16 --steps 2 --warmup 1), rocprofv3 --pmc, counters only, "
+                           "separate passes (tools/collect_traffic_bf16.sh).  FETCH_SIZE / WRITE_SIZE in KiB; bytes = (2*FETCH_SIZE + "
+                           "WRITE_SIZE)*1024 (gfx950 correction, MI355X_MICROARCH.md).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; "
+                           "busy fraction = sum / (sum GRBM_GUI_ACTIVE / 8 * 1024).",
+               "commit": COMMIT, "csrc_sha": CSRC, "kernels": bf}, open(os.path.join(P, rnd + "_pmc_bf16.json"), "w"), indent=1)
 print("profiles refreshed:", sorted(os.listdir(P)))

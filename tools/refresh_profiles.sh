@@ -14,8 +14,9 @@ mkdir -p $O
 cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_n1_bf16.json 2>> $O/bench_n1.err
-python3 bench.py --no-prof --no-cpu-baseline > $O/bench_n1_graph.json 2>> $O/bench_n1.err
-python3 bench.py --no-prof --no-cpu-baseline --dtype bf16 > $O/bench_n1_bf16_graph.json 2>> $O/bench_n1.err
+# (the timed region of every line is the unprofiled hipGraph replay since round 4: no separate "graph" lines)
+python3 tools/per_launch.py fp32 256 > $O/per_launch_fp32.txt 2>> $O/bench_n1.err
+python3 tools/per_launch.py bf16 256 > $O/per_launch_bf16.txt 2>> $O/bench_n1.err
 for m in fwd infer; do for d in fp32 bf16; do
   python3 bench.py --mode $m --dtype $d --steps 10 --warmup 3 --no-cpu-baseline 2>> $O/bench_n1.err | tail -1 > $O/bench_${m}_${d}.json
 done; done
@@ -25,6 +26,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats_raw.csv
 cd $R
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1
+bash tools/collect_traffic_bf16.sh > $O/traffic_bf16.log 2>&1
 # secondary workloads (BASELINE configs[2], [3], [4]); the MiDaS-based net without the per-launch event profiler too
 python3 bench.py --algo InstaOrderNet_od --dtype bf16 --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench_n1.err
 # the reference's own _od input_size (InstaOrderNet_od/config.yaml:35), SURVEY 8(d) secondary row
