@@ -412,6 +412,20 @@ class InstaDepthNet_d(_InstaDepthBase):
     def forward_pair(self, img, mask1, mask2):
         """See InstaDepthNet_od.forward_pair."""
         with _Counters():
+            if MULTI_STREAM and img.is_cuda:          # the order branch on a side stream next to the decoder (see _fork_join)
+                with _BnMode(repeat=2):
+                    e1, e2, e3, e4 = self._encode(img)
+                x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, (e1, e2, e3), self._act_dtype())
+
+                def branch():
+                    with _BnMode(groups=2):
+                        return self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+
+                def decode():
+                    with _BnMode(repeat=2):
+                        return self._decode(e1, e2, e3, e4)
+                (depth_order,), disp = self._fork_join([branch], decode)
+                return disp, depth_order, None
             with _BnMode(repeat=2):
                 disp, feats = self._encode_decode(img)
             x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, feats, self._act_dtype())
