@@ -62,7 +62,7 @@ for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv"
     rows = list(csv.DictReader(open(raw)))
     with open(os.path.join(P, rnd + outname), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- " + cmd + "  "
-                "(1x MI355X, 7 steps incl. warm-up; commit " + COMMIT + ")\n# kernel names shortened (namespaces / argument lists dropped); "
+                "(1x MI355X; 13 steps of the step kernels: 2 warm-up + 5 timed (hipGraph replay) + 1 + 5 of the profiled pass; commit " + COMMIT + ")\n# kernel names shortened (namespaces / argument lists dropped); "
                 "durations in ns\nName,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             n = r["Name"]
