@@ -2360,16 +2360,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_wino4_kernel(IoConvGeo
 #ifndef IO_W4_ABLATE
 #define IO_W4_ABLATE 0       // timing-only ablations of conv_wino4_kernel (WRONG results): 1 no transforms, 2 no LDS refill, 3 no global loads
 #endif
-template <bool BWE, bool XF>
+// HALO (a tile = whole image rows of ONE sample: 256 % Wo == 0, 256 | Ho Wo, Wo <= 64): the three filter rows of a tile read
+// the input rows h - 1, h, h + 1 of its R = 256 / Wo output rows, i.e. R + 2 distinct input rows -- so the k loop runs
+// channel chunk OUTER, filter row INNER, the V image of all R + 2 rows ((R + 2) Wo / 4 <= 96 quad rows per frequency) is
+// staged ONCE per channel chunk and the MFMAs of filter row r read it at an offset of (1 + dh) Wo / 4 quad rows; only U is
+// restaged per filter row.  The operand transforms (relu(bn(x)) + V: the largest part of the staging cost, see the ablations
+// in profiles/r04_pmc_wino4_vs_direct.txt) and the A loads drop by 3 R / (R + 2) = 2 .. 2.7x.
+template <bool BWE, bool XF, bool HALO = false>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const float* __restrict__ in,
                                                         const float* __restrict__ U, float* __restrict__ out, int ntn,
                                                         size_t in_bytes, unsigned u_bytes, size_t out_bytes,
                                                         float* __restrict__ st_mean, float* __restrict__ st_m2,
                                                         IoBwStats bw) {
     constexpr int BM = 256, BN = 64, BK = 16, LDT = 16, NF = 6;
+    constexpr int AQ = HALO ? 96 : 64;      // quad rows of the A image per frequency
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                       // [6 f][64 quads][16]
-    float* sB = smem + NF * 64 * LDT;       // [6 f][64 channels][16]
+    float* sA = smem;                       // [6 f][AQ quad rows][16]
+    float* sB = smem + NF * AQ * LDT;       // [6 f][64 channels][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -2388,7 +2395,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     unsigned arow, urow;
     int aho;
     bool aleft, aright;
-    {
+    // HALO: NI = 2 items per thread -- halo quad rows sr and 64 + sr (the second exists for sr < 2 Q); item validity is per
+    // input row, independent of the filter row
+    constexpr int NI = HALO ? 2 : 1;
+    const int Q = g.Wo >> 2;                                            // quads per image row
+    unsigned hrow[NI];
+    bool hvalid[NI], hleft[NI], hright[NI];
+    const bool has2 = HALO && sr < 2 * Q;
+    const bool wave_has2 = HALO && wave * 8 < Q;                        // wave-uniform: some lane of this wave has a second item
+    if constexpr (HALO) {
+        const int rem0 = m0 - n_lo * HoWo;
+        const int h0 = fdiv(rem0, g.fd_wo);                             // first output row of the tile (tiles hold whole rows)
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int hq = sr + 64 * it;
+            const int hr = hq / Q, cq = hq - hr * Q;
+            const int hi = h0 - 1 + hr, wo = 4 * cq;
+            hvalid[it] = (it == 0 || has2) && (unsigned)hi < (unsigned)g.Hi;
+            hleft[it] = wo > 0;
+            hright[it] = wo + 4 < g.Wi;
+            hrow[it] = (unsigned)(((hi * g.Wi + wo) * g.Ci + sc * 4) * 4);       // (wraps for hi = -1: used only when valid)
+        }
+        aho = 0; aleft = aright = false; arow = 0;
+        urow = (unsigned)((n0 + sr) * g.Ci + sc * 4) * 4u;
+    } else {
         const int m = m0 + 4 * sr;                                      // whole tiles: always < M
         const int n = fdiv(m, g.fd_howo), rem = m - n * HoWo;
         const int ho = fdiv(rem, g.fd_wo), wo = rem - ho * g.Wo;
@@ -2408,15 +2438,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
                                                                       : (const void*)U,
                                                    (XF && bw.in_mean) ? (unsigned)g.Ci * 4u : 0u);
     f32x4 pa[6], pu[6], xm, xs, xh;
-    unsigned xok = 0;
+    f32x4 pa2[HALO ? 6 : 1];                 // HALO: the second item
+    unsigned xok = 0, xok2 = 0;
     int th = 0, cc = 0;
     bool first_load = true;
     auto load_tile = [&]() {                 // the k-tile (th, cc)
         if (IO_W4_ABLATE == 3 && !first_load) return;
         first_load = false;
+        const unsigned uoff = (unsigned)(th * NF) * uplane + (unsigned)(cc * BK) * 4u;
+        if constexpr (HALO) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) pu[f] = bld4(rs_u, urow + uoff + (unsigned)f * uplane);
+            if (th != 0) return;             // the V image of this channel chunk is already in LDS
+            if constexpr (XF) {
+                const unsigned coff = (unsigned)(cc * BK + sc * 4) * 4u;
+                xm = bld4(rs_xm, coff);
+                xs = bld4(rs_xs, coff);
+                xh = bld4(rs_xh, coff);
+            }
+            const unsigned aoff = (unsigned)((cc * BK - g.Ci) * 4);          // channel chunk, one pixel to the left
+            xok = xok2 = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool ok = hvalid[0] & (i == 0 ? hleft[0] : i == 5 ? hright[0] : true);
+                xok |= ok ? (1u << i) : 0u;
+                pa[i] = bld4(rs_in, ok ? hrow[0] + aoff + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+            }
+            if (wave_has2) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const bool ok = hvalid[NI - 1] & (i == 0 ? hleft[NI - 1] : i == 5 ? hright[NI - 1] : true);
+                    xok2 |= ok ? (1u << i) : 0u;
+                    pa2[i] = bld4(rs_in, ok ? hrow[NI - 1] + aoff + (unsigned)(i * g.Ci * 4) : kInvalidOff);
+                }
+            }
+            return;
+        }
         const int dh = g.dh0 + g.dhs * th;
         const unsigned aoff = (unsigned)(((dh * g.Wi - 1) * g.Ci + cc * BK) * 4);      // (wraps; used only where the pixel exists)
-        const unsigned uoff = (unsigned)(th * NF) * uplane + (unsigned)(cc * BK) * 4u;
         if constexpr (XF) {
             const unsigned coff = (unsigned)(cc * BK + sc * 4) * 4u;
             xm = bld4(rs_xm, coff);
@@ -2435,32 +2494,48 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         for (int f = 0; f < NF; ++f) pu[f] = bld4(rs_u, urow + uoff + (unsigned)f * uplane);
     };
     auto advance = [&]() {
+        if constexpr (HALO) {                // channel chunk outer, filter row inner
+            const bool wrap = th == 2;
+            th = wrap ? 0 : th + 1;
+            cc += wrap ? 1 : 0;
+            return;
+        }
         const int c1 = cc + 1;
         const bool wrap = c1 == nkc;
         cc = wrap ? 0 : c1;
         th += wrap ? 1 : 0;
     };
-    auto xform_tile = [&]() {
-        if (IO_W4_ABLATE == 1) return;
+    auto xform_item = [&](f32x4 (&p)[6], unsigned okbits) {
         if constexpr (XF) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const bool ok = (xok >> i) & 1u;
+                const bool ok = (okbits >> i) & 1u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = fmaxf(__builtin_fmaf(pa[i][e] - xm[e], xs[e], xh[e]), 0.f);     // bn_apply's expression
-                    pa[i][e] = ok ? v : 0.f;
+                    const float v = fmaxf(__builtin_fmaf(p[i][e] - xm[e], xs[e], xh[e]), 0.f);     // bn_apply's expression
+                    p[i][e] = ok ? v : 0.f;
                 }
             }
         }
-        const f32x4 d0 = pa[0], d1 = pa[1], d2 = pa[2], d3 = pa[3], d4 = pa[4], d5 = pa[5];
+        const f32x4 d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4], d5 = p[5];
         const f32x4 e42 = d4 - 4.f * d2, e31 = d3 - 4.f * d1, f42 = d4 - d2, f31 = d3 - d1;
-        pa[0] = 4.f * d0 - 5.f * d2 + d4;
-        pa[1] = e42 + e31;
-        pa[2] = e42 - e31;
-        pa[3] = f42 + 2.f * f31;
-        pa[4] = f42 - 2.f * f31;
-        pa[5] = 4.f * d1 - 5.f * d3 + d5;
+        p[0] = 4.f * d0 - 5.f * d2 + d4;
+        p[1] = e42 + e31;
+        p[2] = e42 - e31;
+        p[3] = f42 + 2.f * f31;
+        p[4] = f42 - 2.f * f31;
+        p[5] = 4.f * d1 - 5.f * d3 + d5;
+    };
+    // (th, cc) here = the tile that was LOADED last: HALO transforms / stores the V image only at the start of a channel chunk
+    auto xform_tile = [&]() {
+        if (IO_W4_ABLATE == 1) return;
+        if constexpr (HALO) {
+            if (th != 0) return;
+            xform_item(pa, xok);
+            if (wave_has2) xform_item(pa2, xok2);
+            return;
+        }
+        xform_item(pa, xok);
     };
     const int swz = sc ^ ((sr >> 2) & 3);
     bool first_store = true;
@@ -2469,6 +2544,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         float* b = sB + sr * LDT + swz * 4;
         if (IO_W4_ABLATE == 2 && !first_store) return;
         first_store = false;
+        if constexpr (HALO) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) st4(b + f * 64 * LDT, pu[f]);
+            if (th != 0) return;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) st4(a + f * AQ * LDT, pa[f]);
+            if (has2) {                      // quad row 64 + sr: the same swizzle bits (64 is a multiple of 16)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) st4(a + (f * AQ + 64) * LDT, pa2[f]);
+            }
+            return;
+        }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             st4(a + f * 64 * LDT, pa[f]);
@@ -2484,14 +2571,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
 
     // fragment group gi = (kk = gi >> 1, frequencies 3 (gi & 1) .. + 2): lane reads 4 consecutive k of its row
     const int frow = lane & 31;
-    const int a_base = (wm * 32 + frow) * LDT, b_base = (wn * 32 + frow) * LDT;
+    const int b_base = (wn * 32 + frow) * LDT;
     const int fsw = (frow >> 2) & 3;
+    // HALO: the A rows of the tile being multiplied start (1 + dh) Q quad rows into the halo image (hoff, set per k-tile)
+    int arow_cur = wm * 32 + frow;
+    auto set_hoff = [&](int thc) {
+        if constexpr (HALO) arow_cur = wm * 32 + frow + (1 + g.dh0 + g.dhs * thc) * Q;
+    };
     auto read_frags = [&](int gi, f32x4 (&a)[3], f32x4 (&b)[3]) {
-        const int chunk = ((gi >> 1) * 2 + (lane >> 5)) ^ fsw;
+        const int cl = (gi >> 1) * 2 + (lane >> 5);
+        const int chunk = cl ^ fsw;
+        const int chunk_a = HALO ? (cl ^ ((arow_cur >> 2) & 3)) : chunk;
         const int f0 = (gi & 1) * 3;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            a[j] = ld4(sA + (f0 + j) * 64 * LDT + a_base + chunk * 4);
+            a[j] = ld4(sA + ((f0 + j) * AQ + arow_cur) * LDT + chunk_a * 4);
             b[j] = ld4(sB + (f0 + j) * 64 * LDT + b_base + chunk * 4);
         }
     };
@@ -2509,6 +2603,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     xform_tile();
     store_tile();
     __syncthreads();
+    int thc = 0;                             // HALO: filter row of the tile being multiplied
+    set_hoff(0);
     read_frags(0, fa, fb);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         advance();
@@ -2529,25 +2625,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) { pin(fa[j]); pin(fb[j]); }      // group-3 fragments in registers BEFORE the barrier
         __syncthreads();                         // every wave has read the last fragments of tile kt
-#ifndef IO_W4_ORDER
-#define IO_W4_ORDER 0
-#endif
-#if IO_W4_ORDER == 1
-        mma12(3, fa, fb);                        // the last group runs under the LDS refill
-        __builtin_amdgcn_sched_barrier(0);
         store_tile();
         __syncthreads();
-        read_frags(0, fa, fb);
-#else
-        store_tile();
-        __syncthreads();
+        thc = thc == 2 ? 0 : thc + 1;
+        set_hoff(thc);                           // (the fragments read next belong to tile kt + 1)
         f32x4 na[3], nb[3];
         read_frags(0, na, nb);
         __builtin_amdgcn_sched_barrier(0);
         mma12(3, fa, fb);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
-#endif
     }
 #pragma unroll
     for (int gi = 0; gi < 3; ++gi) {
@@ -2917,16 +3004,25 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
             const unsigned u_bytes = (unsigned)(18.0 * g.Co * g.Ci * 4.0);
             const int ntw = g.Co / 64;
             dim3 grid4((unsigned)((M / 256) * ntw));
-            const size_t lds4 = (size_t)2 * 6 * 64 * 16 * sizeof(float);
-            if (bws.y)
-                hipLaunchKernelGGL((conv_wino4_kernel<true, false>), grid4, block, lds4, st, g, (const float*)in,
-                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
-            else if (bws.in_scale)
-                hipLaunchKernelGGL((conv_wino4_kernel<false, true>), grid4, block, lds4, st, g, (const float*)in,
-                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
-            else
-                hipLaunchKernelGGL((conv_wino4_kernel<false, false>), grid4, block, lds4, st, g, (const float*)in,
-                                   (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws);
+#ifndef IO_W4_HALO
+#define IO_W4_HALO 1
+#endif
+            // tiles of whole image rows of one sample: the V image is staged once per channel chunk for all three filter rows
+            const bool halo = IO_W4_HALO && g.Wo <= 64 && 256 % g.Wo == 0 && ((long)g.Ho * g.Wo) % 256 == 0;
+            const size_t lds4 = (size_t)6 * ((halo ? 96 : 64) + 64) * 16 * sizeof(float);
+#define IO_LAUNCH_W4_(BWE_, XF_, HALO_)                                                                                 \
+    hipLaunchKernelGGL((conv_wino4_kernel<BWE_, XF_, HALO_>), grid4, block, lds4, st, g, (const float*)in,              \
+                       (const float*)bws.wino_u, (float*)out, ntw, in_bytes, u_bytes, out_bytes, st_mean, st_m2, bws)
+            if (halo) {
+                if (bws.y) IO_LAUNCH_W4_(true, false, true);
+                else if (bws.in_scale) IO_LAUNCH_W4_(false, true, true);
+                else IO_LAUNCH_W4_(false, false, true);
+            } else {
+                if (bws.y) IO_LAUNCH_W4_(true, false, false);
+                else if (bws.in_scale) IO_LAUNCH_W4_(false, true, false);
+                else IO_LAUNCH_W4_(false, false, false);
+            }
+#undef IO_LAUNCH_W4_
             return io_check_launch("conv_nt(wino4)");
         }
         hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)io_cdiv((long)g.Co * g.Ci / 4, 256), 3), dim3(256), 0, st,
