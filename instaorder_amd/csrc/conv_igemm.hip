@@ -2360,7 +2360,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_wino4_kernel(IoConvGeo
 #ifndef IO_W4_ABLATE
 #define IO_W4_ABLATE 0       // timing-only ablations of conv_wino4_kernel (WRONG results): 1 no transforms, 2 no LDS refill, 3 no global loads
 #endif
-// HALO (a tile = whole image rows of ONE sample: 256 % Wo == 0, 256 | Ho Wo, Wo <= 64): the three filter rows of a tile read
+// HALO (a tile = whole image rows: 256 % Wo == 0, Wo <= 64, and either 256 | Ho Wo -- rows of ONE sample -- or whole small
+// samples whose halo images fit 96 quad rows): the three filter rows of a tile read
 // the input rows h - 1, h, h + 1 of its R = 256 / Wo output rows, i.e. R + 2 distinct input rows -- so the k loop runs
 // channel chunk OUTER, filter row INNER, the V image of all R + 2 rows ((R + 2) Wo / 4 <= 96 quad rows per frequency) is
 // staged ONCE per channel chunk and the MFMAs of filter row r read it at an offset of (1 + dh) Wo / 4 quad rows; only U is
@@ -2399,22 +2400,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     // input row, independent of the filter row
     constexpr int NI = HALO ? 2 : 1;
     const int Q = g.Wo >> 2;                                            // quads per image row
+    // the tile holds whole image rows: RS rows of each of its ns samples (ns = 1: R rows of one sample; ns > 1: whole samples);
+    // a sample's block of the halo image has RS + 2 rows = HB quad rows
+    const int ns = HALO ? (HoWo >= BM ? 1 : BM / HoWo) : 1;
+    const int RS = HALO ? (64 / Q) / ns : 1;
+    const int HB = (RS + 2) * Q, hq_n = ns * HB;
     unsigned hrow[NI];
     bool hvalid[NI], hleft[NI], hright[NI];
-    const bool has2 = HALO && sr < 2 * Q;
-    const bool wave_has2 = HALO && wave * 8 < Q;                        // wave-uniform: some lane of this wave has a second item
+    const bool has2 = HALO && 64 + sr < hq_n;
+    const bool wave_has2 = HALO && 64 + wave * 16 < hq_n;               // wave-uniform: some lane of this wave has a second item
     if constexpr (HALO) {
         const int rem0 = m0 - n_lo * HoWo;
-        const int h0 = fdiv(rem0, g.fd_wo);                             // first output row of the tile (tiles hold whole rows)
+        const int h0 = ns > 1 ? 0 : fdiv(rem0, g.fd_wo);                // first output row of the tile inside its sample
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int hq = sr + 64 * it;
-            const int hr = hq / Q, cq = hq - hr * Q;
+            const int sm = hq / HB, hl = hq - sm * HB;
+            const int hr = hl / Q, cq = hl - hr * Q;
             const int hi = h0 - 1 + hr, wo = 4 * cq;
             hvalid[it] = (it == 0 || has2) && (unsigned)hi < (unsigned)g.Hi;
             hleft[it] = wo > 0;
             hright[it] = wo + 4 < g.Wi;
-            hrow[it] = (unsigned)(((hi * g.Wi + wo) * g.Ci + sc * 4) * 4);       // (wraps for hi = -1: used only when valid)
+            // (wraps for hi = -1: used only when valid)
+            hrow[it] = (unsigned)((((sm * g.Hi + hi) * g.Wi + wo) * g.Ci + sc * 4) * 4);
         }
         aho = 0; aleft = aright = false; arow = 0;
         urow = (unsigned)((n0 + sr) * g.Ci + sc * 4) * 4u;
@@ -2575,8 +2583,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     const int fsw = (frow >> 2) & 3;
     // HALO: the A rows of the tile being multiplied start (1 + dh) Q quad rows into the halo image (hoff, set per k-tile)
     int arow_cur = wm * 32 + frow;
+    const int arow_lane = HALO ? (wm * 32 + frow) + ((wm * 32 + frow) / (RS * Q)) * 2 * Q : 0;    // + the halo rows of earlier samples
     auto set_hoff = [&](int thc) {
-        if constexpr (HALO) arow_cur = wm * 32 + frow + (1 + g.dh0 + g.dhs * thc) * Q;
+        if constexpr (HALO) arow_cur = arow_lane + (1 + g.dh0 + g.dhs * thc) * Q;
     };
     auto read_frags = [&](int gi, f32x4 (&a)[3], f32x4 (&b)[3]) {
         const int cl = (gi >> 1) * 2 + (lane >> 5);
@@ -3008,7 +3017,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
 #define IO_W4_HALO 1
 #endif
             // tiles of whole image rows of one sample: the V image is staged once per channel chunk for all three filter rows
-            const bool halo = IO_W4_HALO && g.Wo <= 64 && 256 % g.Wo == 0 && ((long)g.Ho * g.Wo) % 256 == 0;
+            const long hw = (long)g.Ho * g.Wo;
+            const bool halo = IO_W4_HALO && g.Wo <= 64 && 256 % g.Wo == 0 &&
+                              (hw % 256 == 0 || (256 % hw == 0 && (256 / hw) * (g.Ho + 2) * (g.Wo / 4) <= 96));
             const size_t lds4 = (size_t)6 * ((halo ? 96 : 64) + 64) * 16 * sizeof(float);
 #define IO_LAUNCH_W4_(BWE_, XF_, HALO_)                                                                                 \
     hipLaunchKernelGGL((conv_wino4_kernel<BWE_, XF_, HALO_>), grid4, block, lds4, st, g, (const float*)in,              \
