@@ -26,9 +26,7 @@ def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_n1_bf16.json", "bench_n1_bf16.json"),
-                 ("bench_n1_graph.json", "bench_n1_hipgraph.json"),
-                 ("bench_n1_bf16_graph.json", "bench_n1_bf16_hipgraph.json")):
+for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_n1_bf16.json", "bench_n1_bf16.json")):
     if os.path.exists(os.path.join(G, src)):
         json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (rnd, dst)), "w"), indent=1)
 
