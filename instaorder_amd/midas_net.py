@@ -316,10 +316,17 @@ class _InstaDepthBase(nn.Module):
             _InstaDepthBase._side = [torch.cuda.Stream() for _ in range(n)]
         return _InstaDepthBase._side[:n]
 
-    def _fork_join(self, jobs, main_job):
-        """jobs: callables for the side streams; main_job runs on the current stream.  Returns ([side results], main result)."""
+    def _fork_join(self, jobs, main_job, shared=()):
+        """jobs: callables for the side streams; main_job runs on the current stream.  Returns ([side results], main result).
+        ``shared``: tensors made on the current stream that the side jobs read.  The caching allocator hands a freed block
+        back to the stream it was allocated on at once, and the backward nodes of a side job may still be waiting in their
+        queue when the last reference to such a tensor goes (the packed masks: released by the last stem's node, while the
+        encoder's backward is already allocating on the main stream) -- record_stream makes the block wait for them."""
         main = torch.cuda.current_stream()
         sides = self._side_streams(len(jobs))
+        for t in shared:
+            for st in sides:
+                t.record_stream(st)
         ev = torch.cuda.Event()
         ev.record(main)
         out = []
@@ -330,7 +337,23 @@ class _InstaDepthBase(nn.Module):
         res = main_job()
         for st in sides:
             main.wait_stream(st)
+        self._forked = len(sides)
         return out, res
+
+    _forked = 0
+
+    def join_side_streams(self):
+        """After the backward pass of a forked forward: the current stream waits for the side streams.  Autograd runs
+        each backward node on its forward stream and orders a node's OUTPUTS before their consumers, but the last node of
+        a branch (its stem convolution: the masks need no gradient) has none when ops.WeightPlan is active -- its filter
+        gradient goes into the plan's buffer as a side effect -- so nothing in the tape orders that kernel before what the
+        caller enqueues next (WeightPlan.unpack_grads, the optimiser).  Legal under hipGraph capture: the side streams
+        joined this capture at the fork."""
+        if self._forked:
+            main = torch.cuda.current_stream()
+            for st in (_InstaDepthBase._side or [])[:self._forked]:
+                main.wait_stream(st)
+            self._forked = 0
 
 
 def _pair_inputs(mask1, mask2, feats, dtype):
@@ -382,7 +405,8 @@ class InstaDepthNet_od(_InstaDepthBase):
                     with _BnMode(repeat=2):
                         return self._decode(e1, e2, e3, e4)
                 (depth_order, occ_order), disp = self._fork_join([branch(self.do_net, self.depth_fc),
-                                                                  branch(self.oo_net, self.occ_fc)], decode)
+                                                                  branch(self.oo_net, self.occ_fc)], decode,
+                                                                 shared=(x8m, l1, l2, l3))
                 return disp, depth_order, occ_order
             with _BnMode(repeat=2):
                 disp, feats = self._encode_decode(img)
@@ -424,7 +448,7 @@ class InstaDepthNet_d(_InstaDepthBase):
                 def decode():
                     with _BnMode(repeat=2):
                         return self._decode(e1, e2, e3, e4)
-                (depth_order,), disp = self._fork_join([branch], decode)
+                (depth_order,), disp = self._fork_join([branch], decode, shared=(x8m, l1, l2, l3))
                 return disp, depth_order, None
             with _BnMode(repeat=2):
                 disp, feats = self._encode_decode(img)

@@ -505,6 +505,7 @@ class _DepthBase(SingleStageModel):
                 roots.append(loss_smooth)
                 grads.append(torch.ones_like(loss_smooth))
             torch.autograd.backward(roots, grads)
+            self.net.join_side_streams()
         finally:
             ops.WeightPlan.active = None
             recs = ops.WeightPlan.stop_recording() if recording else None
@@ -606,6 +607,7 @@ class _DepthBase(SingleStageModel):
 
         # stage 0: heads, order branches, decoder -> their parameters and d(l1..l4) at the cuts
         res = torch.autograd.grad(roots, P[0] + cuts, grads, allow_unused=True)
+        self.net.join_side_streams()          # (the branches' last filter-gradient launches: see midas_net.join_side_streams)
         finish(0, stages[0][1], res[:len(P[0])])
         g1, g2, g3, g4 = res[len(P[0]):]
         yield 0

@@ -432,14 +432,22 @@ def test_weight_plan_equals_per_call_relayout():
         if not planned:
             m._wplan = False
         m.switch_to("train")
+        steps = []
         for it in range(3):
             t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(seed + 700 + it, B, S).items()}
             feed(m, algo, t)
             m.step()
+            steps.append(m.optim.flat_grads.clone())
         if planned:
             assert m._wplan and m._wplan.n > 150, m._wplan and m._wplan.n
-        res.append((m.optim.flat_params.clone(), m.optim._buf.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        res.append(steps + [m.optim.flat_params.clone(), m.optim._buf.clone()])
+        names = [(n, off, k) for (n, _), (off, k) in zip(m.model.named_parameters(), m.optim._spans)]
+    for what, a, b in zip(("gradients of step 1", "gradients of step 2", "gradients of step 3", "parameters", "momentum"),
+                          res[0], res[1]):
+        d = (a - b).abs()
+        bad = [(n, int((d[off:off + k] > 0).sum()), k, float(d[off:off + k].max()), float(a[off:off + k].abs().max()))
+               for n, off, k in names if bool((d[off:off + k] > 0).any())]
+        assert not bad, (what, len(bad), bad[:8])
 
 
 def test_multi_stream_pair_forward_equals_single_stream(tmp_path):
