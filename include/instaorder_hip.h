@@ -293,10 +293,12 @@ int io_smooth_loss_bwd(const float* g, const float* workspace, const float* grad
  * depth_order1 in {0, 1}, over the 3x3-cross erosions (scipy.ndimage.binary_erosion, border 0) e1, e2 of the two masks:
  * #{d[e1] <= max d[e2]} + #{min d[e1] <= d[e2]} on disp1 (with >= when depth_order1 != le_order) and the opposite
  * comparison on disp2; pairs whose eroded masks are empty are skipped.  out[0] = out_scale * total / (H * W);
- * per_sample: B floats of scratch. */
+ * workspace: io_disp_order_workspace_floats(B, H, W) floats of scratch (per-block extrema and counts: a sample is spread
+ * over several blocks, three launches). */
+size_t io_disp_order_workspace_floats(int B, int H, int W);
 int io_disp_order_count(const float* disp1, const float* disp2, const float* modal1, const float* modal2,
                         const long* depth_order1, const long* is_overlap, int B, int H, int W, int le_order,
-                        float out_scale, float* out, float* per_sample, hipStream_t stream);
+                        float out_scale, float* out, float* workspace, size_t workspace_floats, hipStream_t stream);
 /* io_conv2d_fwd_bnstats for either storage type and for the grouped window form (gw = 64; w = wc of io_gconv_pack,
  * Cin == Cout); gw = 0 is the dense convolution */
 int io_conv2d_fwd_bnstats_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,

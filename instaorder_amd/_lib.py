@@ -139,7 +139,8 @@ SIGNATURES = {
     "io_smooth_loss_workspace_floats": (_Z, [_I, _I, _I]),
     "io_smooth_loss_fwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "io_smooth_loss_bwd": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P]),
-    "io_disp_order_count": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "io_disp_order_workspace_floats": (_Z, [_I, _I, _I]),
+    "io_disp_order_count": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _Z, _P]),
     "io_bn_tile_partial_floats": (_Z, [_I, _I, _I]),
     "io_bn_bwd_coefs_dt": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "io_bn_bwd_coefs_from_tile_partials": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

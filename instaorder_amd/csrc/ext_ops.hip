@@ -461,45 +461,60 @@ struct IoWeightDesc {
 // (runs of 32 * T floats) and both writes ([o][t][c]: c fastest, [c][t][o]: o fastest) are contiguous; the first,
 // element-per-thread version wrote the transpose 2 bytes at a time with a stride of Cout' and took 2.3 ms per call for
 // the 105 M parameters of the MiDaS tree (3.4 % of its training step).
-template <typename T>
-__global__ __launch_bounds__(256) void weights_prepare_kernel(const IoWeightDesc* __restrict__ tab,
-                                                             const float* __restrict__ params, T* __restrict__ ops) {
-    constexpr int TO = 32, TC = 32, TT = 9, PITCH = TC * TT + 1;
-    __shared__ float s[TO * PITCH];
-    const IoWeightDesc d = tab[blockIdx.y];
-    const int nto = (d.Cop + TO - 1) / TO, ntc = (d.Cip + TC - 1) / TC, ntt = (d.T + TT - 1) / TT;
-    const int ntiles = nto * ntc * ntt;
-    const int tid = threadIdx.x;
+// Round 4: the tile body is instantiated for the two tap counts that carry the parameters (T = 1: 64 x 64 channel tiles,
+// 128-byte bf16 runs on both writes; T = 9) so that every index split is by a compile-time constant -- the generic body
+// spends ~40 integer instructions per element on divisions by run-time tile extents (0.84 ms per step for 105 M parameters).
+template <typename T, int NTC>      // NTC: taps per tile at compile time (0: run-time, tiles of up to 9 taps)
+__device__ __forceinline__ void weights_tile(const IoWeightDesc& d, const float* __restrict__ params, T* __restrict__ ops,
+                                             float* s, int tile, int ntc, int ntt, int tid) {
+    constexpr int TO = NTC == 1 ? 64 : 32, TC = NTC == 1 ? 64 : 32, TT = NTC ? NTC : 9, PITCH = TC * TT + 1;
     auto put = [&](long idx, float v) {
         if constexpr (sizeof(T) == 2) ops[idx] = io_f2bf(v);
         else ops[idx] = v;
     };
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tt = tile % ntt, r = tile / ntt;
-        const int o0 = (r / ntc) * TO, c0 = (r % ntc) * TC, t0 = tt * TT;
-        const int nt = min(TT, d.T - t0), row = TC * nt, n = TO * row;
-        __syncthreads();                                   // the previous tile has been written out
-        for (int e = tid; e < n; e += 256) {               // read: (c, t) fastest = contiguous in the master when nt == T
-            const int ol = e / row, rest = e - ol * row;
-            const int cl = rest / nt, tl = rest - cl * nt;
+    const int tt = tile % ntt, r = tile / ntt;
+    const int o0 = (r / ntc) * TO, c0 = (r % ntc) * TC, t0 = tt * TT;
+    const int nt = NTC ? NTC : min(TT, d.T - t0), row = TC * nt, n = TO * row;
+    __syncthreads();                                   // the previous tile has been written out
+    for (int e = tid; e < n; e += 256) {               // read: (c, t) fastest = contiguous in the master when nt == T
+        const int ol = e / row, rest = e - ol * row;
+        const int cl = rest / nt, tl = rest - cl * nt;
+        const int o = o0 + ol, c = c0 + cl;
+        s[ol * PITCH + rest] = (o < d.Co && c < d.Ci) ? params[d.src + ((long)o * d.Ci + c) * d.T + t0 + tl] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {               // operand [o][t][c]
+        const int ol = e / row, rest = e - ol * row;
+        const int tl = rest / TC, cl = rest - tl * TC;
+        const int o = o0 + ol, c = c0 + cl;
+        if (o < d.Cop && c < d.Cip) put(d.dst_op + ((long)o * d.T + t0 + tl) * d.Cip + c, s[ol * PITCH + cl * nt + tl]);
+    }
+    if (d.dst_t >= 0) {
+        for (int e = tid; e < n; e += 256) {           // transpose [c][t][o]
+            const int cl = e / (nt * TO), rest = e - cl * (nt * TO);
+            const int tl = rest / TO, ol = rest - tl * TO;
             const int o = o0 + ol, c = c0 + cl;
-            s[ol * PITCH + rest] = (o < d.Co && c < d.Ci) ? params[d.src + ((long)o * d.Ci + c) * d.T + t0 + tl] : 0.f;
+            if (o < d.Cop && c < d.Cip) put(d.dst_t + ((long)c * d.T + t0 + tl) * d.Cop + o, s[ol * PITCH + cl * nt + tl]);
         }
-        __syncthreads();
-        for (int e = tid; e < n; e += 256) {               // operand [o][t][c]
-            const int ol = e / row, rest = e - ol * row;
-            const int tl = rest / TC, cl = rest - tl * TC;
-            const int o = o0 + ol, c = c0 + cl;
-            if (o < d.Cop && c < d.Cip) put(d.dst_op + ((long)o * d.T + t0 + tl) * d.Cip + c, s[ol * PITCH + cl * nt + tl]);
-        }
-        if (d.dst_t >= 0) {
-            for (int e = tid; e < n; e += 256) {           // transpose [c][t][o]
-                const int cl = e / (nt * TO), rest = e - cl * (nt * TO);
-                const int tl = rest / TO, ol = rest - tl * TO;
-                const int o = o0 + ol, c = c0 + cl;
-                if (o < d.Cop && c < d.Cip) put(d.dst_t + ((long)c * d.T + t0 + tl) * d.Cop + o, s[ol * PITCH + cl * nt + tl]);
-            }
-        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weights_prepare_kernel(const IoWeightDesc* __restrict__ tab,
+                                                             const float* __restrict__ params, T* __restrict__ ops) {
+    __shared__ float s[64 * 65 > 32 * (32 * 9 + 1) ? 64 * 65 : 32 * (32 * 9 + 1)];
+    const IoWeightDesc d = tab[blockIdx.y];
+    const int tid = threadIdx.x;
+    if (d.T == 1) {
+        const int nto = (d.Cop + 63) / 64, ntc = (d.Cip + 63) / 64;
+        for (int tile = blockIdx.x; tile < nto * ntc; tile += gridDim.x) weights_tile<T, 1>(d, params, ops, s, tile, ntc, 1, tid);
+    } else if (d.T == 9) {
+        const int nto = (d.Cop + 31) / 32, ntc = (d.Cip + 31) / 32;
+        for (int tile = blockIdx.x; tile < nto * ntc; tile += gridDim.x) weights_tile<T, 9>(d, params, ops, s, tile, ntc, 1, tid);
+    } else {
+        const int nto = (d.Cop + 31) / 32, ntc = (d.Cip + 31) / 32, ntt = (d.T + 8) / 9;
+        for (int tile = blockIdx.x; tile < nto * ntc * ntt; tile += gridDim.x)
+            weights_tile<T, 0>(d, params, ops, s, tile, ntc, ntt, tid);
     }
 }
 
@@ -854,20 +869,40 @@ __device__ __forceinline__ bool eroded(const float* m, int H, int W, int h, int 
     return m[i] != 0.f && m[i - 1] != 0.f && m[i + 1] != 0.f && m[i - W] != 0.f && m[i + W] != 0.f;
 }
 
-constexpr int kDispThreads = 1024;
-// one block of 1024 threads per sample (a pair batch is 8..64 samples of 147 k pixels: the block size IS the parallelism).  pass 0: max over eroded mask 2 / min over eroded mask 1 of both disparity maps; pass 1: the four
-// counts of each map; out[b] = the sample's contribution (0 when the pair is skipped)
-__global__ __launch_bounds__(kDispThreads) void disp_order_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
-                                                             const float* __restrict__ m1, const float* __restrict__ m2,
-                                                             const long* __restrict__ order, const long* __restrict__ ovl,
-                                                             int H, int W, int le_order, float* __restrict__ out) {
-    __shared__ float shf[4][kDispThreads];
-    __shared__ int shi[4][kDispThreads];
-    const int b = blockIdx.x, N = H * W;
+// The batch is 8..64 samples of up to 147 k pixels, so a sample is spread over DB = disp_blocks(N) blocks and the two
+// data-dependent phases are two launches: pass 0 leaves each block's (max over eroded mask 2, min over eroded mask 1) of
+// both disparity maps, pass 1 folds a sample's DB partials (fixed order: exact for max / min) and leaves each block's four
+// counts per map, the finalize launch turns the integer counts into the batch's scalar.  (One 1024-thread block per
+// sample, the first form, took 0.5 ms of the 48 ms InstaDepthNet_od step: 16 of 256 CUs walking 147 k pixels twice.)
+constexpr int kDispThreads = 256, kDispMaxBlocks = 64;
+int disp_blocks(int N) {
+    int b = (N + kDispThreads * 8 - 1) / (kDispThreads * 8);
+    return b < 1 ? 1 : (b > kDispMaxBlocks ? kDispMaxBlocks : b);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ext[b][blk][6]: max2 of map 1 / 2, min1 of map 1 / 2, any eroded pixel in mask 1 / 2 (as floats)
+__global__ __launch_bounds__(kDispThreads) void disp_order_ext_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                                 const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                 int H, int W, float* __restrict__ ext) {
+    __shared__ float sh[kDispThreads / 64][6];
+    const int b = blockIdx.y, N = H * W;
     const float *p1 = d1 + (size_t)b * N, *p2 = d2 + (size_t)b * N, *q1 = m1 + (size_t)b * N, *q2 = m2 + (size_t)b * N;
     float mx2[2] = {-INFINITY, -INFINITY}, mn1[2] = {INFINITY, INFINITY};
     int any1 = 0, any2 = 0;
-    for (int i = threadIdx.x; i < N; i += kDispThreads) {
+    for (int i = blockIdx.x * kDispThreads + threadIdx.x; i < N; i += gridDim.x * kDispThreads) {
         const int h = i / W, w = i - h * W;
         const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
         const float v[2] = {p1[i], p2[i]};
@@ -877,56 +912,85 @@ __global__ __launch_bounds__(kDispThreads) void disp_order_kernel(const float* _
         }
         any1 |= e1; any2 |= e2;
     }
-    shf[0][threadIdx.x] = mx2[0]; shf[1][threadIdx.x] = mx2[1]; shf[2][threadIdx.x] = mn1[0]; shf[3][threadIdx.x] = mn1[1];
-    shi[0][threadIdx.x] = any1; shi[1][threadIdx.x] = any2;
+    const float r[6] = {wave_max(mx2[0]), wave_max(mx2[1]), wave_min(mn1[0]), wave_min(mn1[1]),
+                        wave_max((float)any1), wave_max((float)any2)};
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int t = 0; t < 6; ++t) sh[wave][t] = r[t];
     __syncthreads();
-    for (int off = kDispThreads / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            shf[0][threadIdx.x] = fmaxf(shf[0][threadIdx.x], shf[0][threadIdx.x + off]);
-            shf[1][threadIdx.x] = fmaxf(shf[1][threadIdx.x], shf[1][threadIdx.x + off]);
-            shf[2][threadIdx.x] = fminf(shf[2][threadIdx.x], shf[2][threadIdx.x + off]);
-            shf[3][threadIdx.x] = fminf(shf[3][threadIdx.x], shf[3][threadIdx.x + off]);
-            shi[0][threadIdx.x] |= shi[0][threadIdx.x + off];
-            shi[1][threadIdx.x] |= shi[1][threadIdx.x + off];
-        }
-        __syncthreads();
+    if (threadIdx.x < 6) {
+        const int t = threadIdx.x;
+        float v = sh[0][t];
+        for (int k = 1; k < kDispThreads / 64; ++k) v = (t == 2 || t == 3) ? fminf(v, sh[k][t]) : fmaxf(v, sh[k][t]);
+        ext[((size_t)b * gridDim.x + blockIdx.x) * 6 + t] = v;
     }
-    const float MX[2] = {shf[0][0], shf[1][0]}, MN[2] = {shf[2][0], shf[3][0]};
-    const bool have = shi[0][0] && shi[1][0];
+}
+
+// cnt[b][blk][4]: le / ge counts of map 1, le / ge counts of map 2 (zeros when the pair is skipped)
+__global__ __launch_bounds__(kDispThreads) void disp_order_cnt_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                                 const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                 const long* __restrict__ order, const long* __restrict__ ovl,
+                                                                 int H, int W, const float* __restrict__ ext,
+                                                                 int* __restrict__ cnt) {
+    __shared__ float shx[6];
+    __shared__ int shc[kDispThreads / 64][4];
+    const int b = blockIdx.y, N = H * W, DB = gridDim.x;
+    if (threadIdx.x < 64) {          // one wave folds the sample's DB <= 64 partials
+        float r[6];
+        for (int t = 0; t < 6; ++t) {
+            const bool mn = t == 2 || t == 3;
+            float v = (int)threadIdx.x < DB ? ext[((size_t)b * DB + threadIdx.x) * 6 + t] : (mn ? INFINITY : -INFINITY);
+            r[t] = mn ? wave_min(v) : wave_max(v);
+        }
+        if (threadIdx.x == 0)
+            for (int t = 0; t < 6; ++t) shx[t] = r[t];
+    }
     __syncthreads();
+    const float MX[2] = {shx[0], shx[1]}, MN[2] = {shx[2], shx[3]};
+    const bool have = shx[4] > 0.f && shx[5] > 0.f;
     const long od = order[b];
     // (the reference's .max() / .min() of an empty selection would raise; such pairs are skipped)
     const bool use = ovl[b] == 0 && (od == 0 || od == 1) && have;
-    int le[2] = {0, 0}, ge[2] = {0, 0};
-    if (use)
-        for (int i = threadIdx.x; i < N; i += kDispThreads) {
+    int c[4] = {0, 0, 0, 0};
+    if (use) {
+        const float *p1 = d1 + (size_t)b * N, *p2 = d2 + (size_t)b * N, *q1 = m1 + (size_t)b * N, *q2 = m2 + (size_t)b * N;
+        for (int i = blockIdx.x * kDispThreads + threadIdx.x; i < N; i += DB * kDispThreads) {
             const int h = i / W, w = i - h * W;
             const bool e1 = eroded(q1, H, W, h, w), e2 = eroded(q2, H, W, h, w);
             const float v[2] = {p1[i], p2[i]};
             for (int t = 0; t < 2; ++t) {
-                le[t] += (e1 && v[t] <= MX[t]) + (e2 && MN[t] <= v[t]);
-                ge[t] += (e1 && v[t] >= MX[t]) + (e2 && MN[t] >= v[t]);
+                c[2 * t] += (e1 && v[t] <= MX[t]) + (e2 && MN[t] <= v[t]);
+                c[2 * t + 1] += (e1 && v[t] >= MX[t]) + (e2 && MN[t] >= v[t]);
             }
         }
-    shi[0][threadIdx.x] = le[0]; shi[1][threadIdx.x] = ge[0]; shi[2][threadIdx.x] = le[1]; shi[3][threadIdx.x] = ge[1];
-    __syncthreads();
-    for (int off = kDispThreads / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int t = 0; t < 4; ++t) shi[t][threadIdx.x] += shi[t][threadIdx.x + off];
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        // disp1 uses `<=` when depth_order1 == le_order and `>=` otherwise; disp2 the other way round
-        const bool le1 = od == le_order;
-        out[b] = use ? (float)((le1 ? shi[0][0] : shi[1][0]) + (le1 ? shi[3][0] : shi[2][0])) : 0.f;
+    const int wave = threadIdx.x >> 6;
+    for (int t = 0; t < 4; ++t) {
+        const int v = wave_sum(c[t]);
+        if ((threadIdx.x & 63) == 0) shc[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        int v = 0;
+        for (int k = 0; k < kDispThreads / 64; ++k) v += shc[k][threadIdx.x];
+        cnt[((size_t)b * DB + blockIdx.x) * 4 + threadIdx.x] = v;
     }
 }
 
-__global__ __launch_bounds__(kThreads) void sum_scale_kernel(const float* __restrict__ v, int n, float scale,
-                                                            float* __restrict__ out) {
+// out = scale * sum over samples of (the two counts the pair's depth order selects)
+__global__ __launch_bounds__(kThreads) void disp_order_finalize_kernel(const int* __restrict__ cnt, const long* __restrict__ order,
+                                                                      int B, int DB, int le_order, float scale,
+                                                                      float* __restrict__ out) {
     __shared__ double red[kThreads];
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += kThreads) a += v[i];
+    for (int b = threadIdx.x; b < B; b += kThreads) {
+        int c[4] = {0, 0, 0, 0};
+        for (int k = 0; k < DB; ++k)
+            for (int t = 0; t < 4; ++t) c[t] += cnt[((size_t)b * DB + k) * 4 + t];
+        // disp1 uses `<=` when depth_order1 == le_order and `>=` otherwise; disp2 the other way round
+        const bool le1 = order[b] == le_order;
+        a += (double)(float)((le1 ? c[0] : c[1]) + (le1 ? c[3] : c[2]));
+    }
     red[threadIdx.x] = a;
     __syncthreads();
     for (int off = kThreads / 2; off > 0; off >>= 1) {
@@ -970,12 +1034,24 @@ extern "C" int io_smooth_loss_bwd(const float* g, const float* workspace, const 
     return io_check_launch("smooth_loss_bwd");
 }
 
+extern "C" size_t io_disp_order_workspace_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * disp_blocks(H * W) * 10;
+}
+
 extern "C" int io_disp_order_count(const float* disp1, const float* disp2, const float* modal1, const float* modal2,
                                    const long* depth_order1, const long* is_overlap, int B, int H, int W, int le_order,
-                                   float out_scale, float* out, float* per_sample, hipStream_t st) {
-    IO_REQUIRE(B > 0 && H > 2 && W > 2, IO_ERR_SHAPE, "disp_order_count: B=%d H=%d W=%d", B, H, W);
-    hipLaunchKernelGGL(disp_order_kernel, dim3(B), dim3(kDispThreads), 0, st, disp1, disp2, modal1, modal2, depth_order1,
-                       is_overlap, H, W, le_order, per_sample);
-    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(kThreads), 0, st, per_sample, B, out_scale / ((float)H * (float)W), out);
+                                   float out_scale, float* out, float* workspace, size_t workspace_floats, hipStream_t st) {
+    IO_REQUIRE(B > 0 && H > 2 && W > 2 && (double)H * W < 2.0e9, IO_ERR_SHAPE, "disp_order_count: B=%d H=%d W=%d", B, H, W);
+    IO_REQUIRE(workspace && workspace_floats >= io_disp_order_workspace_floats(B, H, W), IO_ERR_WORKSPACE,
+               "disp_order_count: workspace too small");
+    const int DB = disp_blocks(H * W);
+    float* ext = workspace;
+    int* cnt = reinterpret_cast<int*>(workspace + (size_t)B * DB * 6);
+    hipLaunchKernelGGL(disp_order_ext_kernel, dim3(DB, B), dim3(kDispThreads), 0, st, disp1, disp2, modal1, modal2, H, W, ext);
+    hipLaunchKernelGGL(disp_order_cnt_kernel, dim3(DB, B), dim3(kDispThreads), 0, st, disp1, disp2, modal1, modal2,
+                       depth_order1, is_overlap, H, W, ext, cnt);
+    hipLaunchKernelGGL(disp_order_finalize_kernel, dim3(1), dim3(kThreads), 0, st, cnt, depth_order1, B, DB, le_order,
+                       out_scale / ((float)H * (float)W), out);
     return io_check_launch("disp_order_count");
 }

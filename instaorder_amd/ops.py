@@ -764,14 +764,15 @@ def smooth_loss(disp, img, times=1):
 
 
 def disp_order_count(disp1, disp2, modal1, modal2, depth_order1, is_overlap, le_order=0, scale=1.0):
-    """supervised_order.py:152-173 for the whole batch in two launches (io_disp_order_count): erosion, masked max / min,
+    """supervised_order.py:152-173 for the whole batch in three launches (io_disp_order_count): erosion, masked max / min,
     comparisons and counts on the device, no host round trip; returns a 0-dim tensor = scale * total / (H * W)."""
     B, _, H, W_ = disp1.shape
     dev = disp1.device
     out = torch.empty((), device=dev, dtype=torch.float32)
-    per = torch.empty(B, device=dev, dtype=torch.float32)
+    nws = int(_L().io_disp_order_workspace_floats(B, H, W_))
+    ws = torch.empty(max(nws, 1), device=dev, dtype=torch.float32)
     f = lambda t: t.detach().float().contiguous()       # noqa: E731
     _lib.check(_L().io_disp_order_count(_p(f(disp1)), _p(f(disp2)), _p(f(modal1)), _p(f(modal2)),
                                         _p(depth_order1.long().contiguous()), _p(is_overlap.long().contiguous()), B, H, W_,
-                                        int(le_order), float(scale), _p(out), _p(per), _st()), "io_disp_order_count")
+                                        int(le_order), float(scale), _p(out), _p(ws), nws, _st()), "io_disp_order_count")
     return out

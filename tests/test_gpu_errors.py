@@ -227,7 +227,8 @@ def test_round3_entry_points_reject_bad_arguments():
     bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 1, 8, 1.0, P(t[0]), P(c), P(d), 1 << 18, ST()))          # one row: no y edges
     bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 8, 8, 1.0, P(t[0]), P(c), P(d), 1, ST()))                # workspace
     lab = torch.zeros(4, dtype=torch.long, device=DEV)
-    bad(L().io_disp_order_count(P(a), P(a), P(b), P(b), P(lab), P(lab), 2, 2, 8, 0, 1.0, P(t[0]), P(t[1]), ST()))
+    bad(L().io_disp_order_count(P(a), P(a), P(b), P(b), P(lab), P(lab), 2, 2, 8, 0, 1.0, P(t[0]), P(d), 1 << 18, ST()))   # H = 2
+    bad(L().io_disp_order_count(P(a), P(a), P(b), P(b), P(lab), P(lab), 2, 8, 8, 0, 1.0, P(t[0]), P(d), 1, ST()))         # workspace
 
 
 def test_rectangular_inference_entries_reject_bad_shapes():

@@ -201,7 +201,7 @@ def test_smooth_loss_value_and_gradient(B, H, W):
             assert abs(a - r) < 2e-4 * float(gref.abs().max()) + 1e-3 * abs(r), (b, idx, a, r)
 
 
-@pytest.mark.parametrize("B,H,W", [(6, 32, 48), (4, 64, 64)])
+@pytest.mark.parametrize("B,H,W", [(6, 32, 48), (4, 64, 64), (3, 160, 208), (2, 384, 384)])   # 1, 2, 17, 64 blocks per sample
 def test_disp_order_count(B, H, W):
     """ops.disp_order_count (io_disp_order_count) == the oracle's restatement of supervised_order.py:152-173 with
     scipy.ndimage.binary_erosion: every (is_overlap, depth_order) combination, an empty erosion (pair skipped), two

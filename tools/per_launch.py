@@ -2,7 +2,7 @@
 """Per-launch roofline table of ONE training step of the headline configuration (InstaOrderNet_o, 256 pairs, 256x256,
 fp32 | bf16): every launch group with its HIP-event time, algorithmic FLOPs / bytes, the time its roofs would allow
 (MFMA at the practical ceiling, HBM at the streaming ceiling) and what it loses against them -- sorted by loss.
-usage: python tools/per_launch.py [fp32|bf16] [pairs] > profiles/rNN_per_launch_<dtype>.txt"""
+usage: python tools/per_launch.py [fp32|bf16] [pairs] [full] > profiles/rNN_per_launch_<dtype>.txt"""
 import os
 import sys
 
@@ -43,6 +43,10 @@ print("# %4s %-30s %8s %8s %8s %8s %8s  bound" % ("seq", "class", "ms", "ideal",
 for lost, i, name, ms, fl, by, ideal in sorted(rows, reverse=True)[:70]:
     print("  %4d %-30s %8.3f %8.3f %8.3f %8.1f %8.2f  %s" % (i, name, ms, ideal, lost, fl / ms / 1e9, by / ms / 1e9,
                                                           "mfma" if fl / MFMA > by / HBM else "hbm"))
+if len(sys.argv) > 3 and sys.argv[3] == "full":      # every launch group in execution order, with its work
+    print("# full sequence: seq class ms ideal GFLOP MB")
+    for lost, i, name, ms, fl, by, ideal in sorted(rows, key=lambda r: r[1]):
+        print("S %4d %-30s %8.3f %8.3f %9.2f %9.1f" % (i, name, ms, ideal, fl / 1e9, by / 1e6))
 agg = {}
 for lost, i, name, ms, fl, by, ideal in rows:
     a = agg.setdefault(name, [0.0, 0.0, 0])
