@@ -87,66 +87,104 @@ __device__ __forceinline__ Lerp lerp_of(int dst, int H, int align) {
     return l;
 }
 
-template <typename T_>
+// V channels per thread: 16 bytes of either storage type where the channel count allows (fp32: 4, bf16: 8; else 4).  The grid
+// is (chunks of one output / input image row, image rows): the row decode and the row's interpolation weights are block
+// uniform, a thread divides once by the chunks per pixel.  (The first form -- 8 bytes per lane in bf16, three 64-bit
+// divisions per element -- ran the 384 x 384 x 128 map of the MiDaS output head at 2.0 TB/s.)
+template <typename T_, int V> struct UpVec {
+    f32x4 v[V / 4];
+};
+template <typename T_, int V> __device__ __forceinline__ UpVec<T_, V> up_ld(const T_* p) {
+    UpVec<T_, V> r;
+    if constexpr (V == 4) {
+        r.v[0] = io_ldv(p);
+    } else {
+        static_assert(sizeof(T_) == 2 && V == 8, "8 channels per thread: bf16");
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        r.v[0][0] = __builtin_bit_cast(float, q.x << 16); r.v[0][1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+        r.v[0][2] = __builtin_bit_cast(float, q.y << 16); r.v[0][3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+        r.v[1][0] = __builtin_bit_cast(float, q.z << 16); r.v[1][1] = __builtin_bit_cast(float, q.z & 0xffff0000u);
+        r.v[1][2] = __builtin_bit_cast(float, q.w << 16); r.v[1][3] = __builtin_bit_cast(float, q.w & 0xffff0000u);
+    }
+    return r;
+}
+template <typename T_, int V> __device__ __forceinline__ void up_st(T_* p, const UpVec<T_, V>& r) {
+    if constexpr (V == 4) {
+        io_stv(p, r.v[0]);
+    } else {
+        uint4 q;
+        q.x = io_f2bf2(r.v[0][0], r.v[0][1]); q.y = io_f2bf2(r.v[0][2], r.v[0][3]);
+        q.z = io_f2bf2(r.v[1][0], r.v[1][1]); q.w = io_f2bf2(r.v[1][2], r.v[1][3]);
+        *reinterpret_cast<uint4*>(p) = q;
+    }
+}
+
+template <typename T_, int V>
 __global__ __launch_bounds__(kThreads) void upsample2x_fwd_kernel(const T_* __restrict__ x, int N, int H, int W,
-                                                                 int C4, int align, T_* __restrict__ out) {
-    const int OH = 2 * H, OW = 2 * W;
-    const size_t total = (size_t)N * OH * OW * C4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % C4);
-        size_t t = i / C4;
-        const int ow = (int)(t % OW);
-        t /= OW;
-        const int oh = (int)(t % OH);
-        const int n = (int)(t / OH);
-        const Lerp lh = lerp_of(oh, H, align), lw = lerp_of(ow, W, align);
-        const T_* xp = x + ((size_t)n * H * W * C4 + q) * 4;
-        const f32x4 a = io_ldv(xp + ((size_t)lh.i0 * W + lw.i0) * C4 * 4), b = io_ldv(xp + ((size_t)lh.i0 * W + lw.i1) * C4 * 4);
-        const f32x4 c = io_ldv(xp + ((size_t)lh.i1 * W + lw.i0) * C4 * 4), d = io_ldv(xp + ((size_t)lh.i1 * W + lw.i1) * C4 * 4);
-        // same association as PyTorch's CPU kernel: h0lambda*(w0lambda*a + w1lambda*b) + h1lambda*(...)
-        io_stv(out + i * 4, lh.w0 * (lw.w0 * a + lw.w1 * b) + lh.w1 * (lw.w0 * c + lw.w1 * d));
+                                                                 int CV, int align, T_* __restrict__ out) {
+    const int OH = 2 * H, OW = 2 * W, rowlen = OW * CV;
+    for (int row = blockIdx.y; row < N * OH; row += gridDim.y) {
+        const int n = row / OH, oh = row - n * OH;
+        const Lerp lh = lerp_of(oh, H, align);
+        const T_* x0 = x + ((size_t)n * H + lh.i0) * W * CV * V;
+        const T_* x1 = x + ((size_t)n * H + lh.i1) * W * CV * V;
+        T_* o = out + (size_t)row * rowlen * V;
+        for (int j = blockIdx.x * kThreads + threadIdx.x; j < rowlen; j += gridDim.x * kThreads) {
+            const int ow = j / CV, q = j - ow * CV;
+            const Lerp lw = lerp_of(ow, W, align);
+            const UpVec<T_, V> a = up_ld<T_, V>(x0 + ((size_t)lw.i0 * CV + q) * V), b = up_ld<T_, V>(x0 + ((size_t)lw.i1 * CV + q) * V);
+            const UpVec<T_, V> c = up_ld<T_, V>(x1 + ((size_t)lw.i0 * CV + q) * V), d = up_ld<T_, V>(x1 + ((size_t)lw.i1 * CV + q) * V);
+            UpVec<T_, V> r;
+            // same association as PyTorch's CPU kernel: h0lambda*(w0lambda*a + w1lambda*b) + h1lambda*(...)
+#pragma unroll
+            for (int k = 0; k < V / 4; ++k)
+                r.v[k] = lh.w0 * (lw.w0 * a.v[k] + lw.w1 * b.v[k]) + lh.w1 * (lw.w0 * c.v[k] + lw.w1 * d.v[k]);
+            up_st<T_, V>(o + (size_t)j * V, r);
+        }
     }
 }
 
 // exact adjoint in gather form: input pixel (h, w) collects from every output pixel whose stencil touches it
-template <typename T_>
+template <typename T_, int V>
 __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const T_* __restrict__ dy, int N, int H, int W,
-                                                                 int C4, int align, T_* __restrict__ dx) {
-    const int OH = 2 * H, OW = 2 * W;
-    const size_t total = (size_t)N * H * W * C4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % C4);
-        size_t t = i / C4;
-        const int w = (int)(t % W);
-        t /= W;
-        const int h = (int)(t % H);
-        const int n = (int)(t / H);
-        const T_* dp = dy + ((size_t)n * OH * OW * C4 + q) * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                                                                 int CV, int align, T_* __restrict__ dx) {
+    const int OH = 2 * H, OW = 2 * W, rowlen = W * CV;
+    for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+        const int n = row / H, h = row - n * H;
+        const T_* dp = dy + (size_t)n * OH * OW * CV * V;
         const int oh0 = max(0, 2 * h - 3), oh1 = min(OH - 1, 2 * h + 4);
-        // the column weights do not depend on the row: 8 stencil evaluations per element, not 64 (same products, same
-        // order of accumulation)
-        float wws[8];
+        T_* o = dx + (size_t)row * rowlen * V;
+        for (int j = blockIdx.x * kThreads + threadIdx.x; j < rowlen; j += gridDim.x * kThreads) {
+            const int w = j / CV, q = j - w * CV;
+            UpVec<T_, V> acc;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ow = 2 * w - 3 + k;
-            wws[k] = 0.f;
-            if ((unsigned)ow < (unsigned)OW) {
-                const Lerp lw = lerp_of(ow, W, align);
-                wws[k] = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
-            }
-        }
-        for (int oh = oh0; oh <= oh1; ++oh) {
-            const Lerp lh = lerp_of(oh, H, align);
-            const float wh = (lh.i0 == h ? lh.w0 : 0.f) + (lh.i1 == h ? lh.w1 : 0.f);
-            if (wh == 0.f) continue;
+            for (int k = 0; k < V / 4; ++k) acc.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the column weights do not depend on the row: 8 stencil evaluations per element, not 64 (same products, same
+            // order of accumulation)
+            float wws[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (wws[k] == 0.f) continue;
-                acc += (wh * wws[k]) * io_ldv(dp + ((size_t)oh * OW + (2 * w - 3 + k)) * C4 * 4);
+                const int ow = 2 * w - 3 + k;
+                wws[k] = 0.f;
+                if ((unsigned)ow < (unsigned)OW) {
+                    const Lerp lw = lerp_of(ow, W, align);
+                    wws[k] = (lw.i0 == w ? lw.w0 : 0.f) + (lw.i1 == w ? lw.w1 : 0.f);
+                }
             }
+            for (int oh = oh0; oh <= oh1; ++oh) {
+                const Lerp lh = lerp_of(oh, H, align);
+                const float wh = (lh.i0 == h ? lh.w0 : 0.f) + (lh.i1 == h ? lh.w1 : 0.f);
+                if (wh == 0.f) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (wws[k] == 0.f) continue;
+                    const UpVec<T_, V> g = up_ld<T_, V>(dp + (((size_t)oh * OW + (2 * w - 3 + k)) * CV + q) * V);
+#pragma unroll
+                    for (int e = 0; e < V / 4; ++e) acc.v[e] += (wh * wws[k]) * g.v[e];
+                }
+            }
+            up_st<T_, V>(o + (size_t)j * V, acc);
         }
-        io_stv(dx + i * 4, acc);
     }
 }
 
@@ -577,27 +615,48 @@ extern "C" int io_gconv2d_wgrad(const void* x, const void* dy, float* dwc, int N
                                 dt);
 }
 
+// grid of the row-decomposed upsample kernels: x over the chunks of one image row, y over the image rows
+static dim3 up_grid(long rowlen, long rows) {
+    long gx = (rowlen + kThreads - 1) / kThreads;
+    return dim3((unsigned)(gx < 1 ? 1 : (gx > 64 ? 64 : gx)), (unsigned)(rows > 65535 ? 65535 : rows));
+}
+#define IO_UPSAMPLE_LAUNCH(K_, ROWLEN_, ROWS_, ...)                                                                    \
+    do {                                                                                                              \
+        if (dt == IO_BF16 && C % 8 == 0)                                                                              \
+            hipLaunchKernelGGL((K_<bf16_t, 8>), up_grid((long)(ROWLEN_) * (C / 8), ROWS_), dim3(kThreads), 0, st,     \
+                               (const bf16_t*)src, N, H, W, C / 8, align_corners, (bf16_t*)dst);                      \
+        else if (dt == IO_BF16)                                                                                       \
+            hipLaunchKernelGGL((K_<bf16_t, 4>), up_grid((long)(ROWLEN_) * (C / 4), ROWS_), dim3(kThreads), 0, st,     \
+                               (const bf16_t*)src, N, H, W, C / 4, align_corners, (bf16_t*)dst);                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((K_<float, 4>), up_grid((long)(ROWLEN_) * (C / 4), ROWS_), dim3(kThreads), 0, st,      \
+                               (const float*)src, N, H, W, C / 4, align_corners, (float*)dst);                        \
+    } while (0)
+
 extern "C" int io_upsample2x_bilinear_fwd(const void* x, int N, int H, int W, int C, int align_corners, void* out,
                                           int dt, hipStream_t st) {
     IO_DT_REQUIRE(dt);
-    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
-    const size_t total = (size_t)N * 4 * H * W * (C / 4);
+    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && (double)N * H * 2 < 2.0e9 && (double)W * 2 * C < 2.0e9, IO_ERR_SHAPE,
+               "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
     IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 5.0 * io_dtype_bytes(dt) * N * H * W * C, st);
-    IO_BY_DTYPE(dt, hipLaunchKernelGGL(upsample2x_fwd_kernel<T_>, dim3(ew_blocks(total)), dim3(kThreads), 0, st,
-                                       (const T_*)x, N, H, W, C / 4, align_corners, (T_*)out));
+    const void* src = x;
+    void* dst = out;
+    IO_UPSAMPLE_LAUNCH(upsample2x_fwd_kernel, 2 * W, (long)N * 2 * H);
     return io_check_launch("upsample2x_fwd");
 }
 
 extern "C" int io_upsample2x_bilinear_bwd(const void* dy, int N, int H, int W, int C, int align_corners, void* dx,
                                           int dt, hipStream_t st) {
     IO_DT_REQUIRE(dt);
-    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, IO_ERR_SHAPE, "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
-    const size_t total = (size_t)N * H * W * (C / 4);
+    IO_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && (double)N * H * 2 < 2.0e9 && (double)W * 2 * C < 2.0e9, IO_ERR_SHAPE,
+               "upsample2x: N=%d H=%d W=%d C=%d", N, H, W, C);
     IoProfScope prof(IO_PROF_POOL_HEAD, 0.0, 5.0 * io_dtype_bytes(dt) * N * H * W * C, st);
-    IO_BY_DTYPE(dt, hipLaunchKernelGGL(upsample2x_bwd_kernel<T_>, dim3(ew_blocks(total)), dim3(kThreads), 0, st,
-                                       (const T_*)dy, N, H, W, C / 4, align_corners, (T_*)dx));
+    const void* src = dy;
+    void* dst = dx;
+    IO_UPSAMPLE_LAUNCH(upsample2x_bwd_kernel, W, (long)N * H);
     return io_check_launch("upsample2x_bwd");
 }
+#undef IO_UPSAMPLE_LAUNCH
 
 extern "C" int io_bias_act(const void* x, const float* bias, int M, int C, int relu, void* out, int dt, hipStream_t st) {
     IO_DT_REQUIRE(dt);

@@ -152,16 +152,17 @@ def test_grouped_conv_and_decoder_ops_bf16():
     _lib.check(L().io_gconv_unpack_grad(P(dwc), C, cg, 9, P(dw), ST()), "unpack")
     assert relerr(dw.view(C, cg, 3, 3), gw) < 2e-5
     # bilinear x2, bias + ReLU, column sums on bf16 tensors
-    xs = _bf(torch.randn(2, 64, 5, 7, generator=g)).requires_grad_(True)
-    up = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=True)
-    dup = _bf(torch.randn(up.shape, generator=g))
-    gxs, = torch.autograd.grad(up, [xs], dup)
-    out = torch.empty(2, 10, 14, 64, device=DEV, dtype=torch.bfloat16)
-    _lib.check(L().io_upsample2x_bilinear_fwd(P(bdev(xs.detach().permute(0, 2, 3, 1))), 2, 5, 7, 64, 1, P(out), 1, ST()), "up")
-    assert relerr(out.float().permute(0, 3, 1, 2), up.detach()) < 6e-3
-    dxs = torch.empty(2, 5, 7, 64, device=DEV, dtype=torch.bfloat16)
-    _lib.check(L().io_upsample2x_bilinear_bwd(P(bdev(dup.permute(0, 2, 3, 1))), 2, 5, 7, 64, 1, P(dxs), 1, ST()), "up bwd")
-    assert relerr(dxs.float().permute(0, 3, 1, 2), gxs) < 6e-3
+    for Cu, al in ((64, 1), (12, 0), (40, 1)):      # 16-byte lanes (8 | C) and the 8-byte form (C = 12)
+        xs = _bf(torch.randn(2, Cu, 5, 7, generator=g)).requires_grad_(True)
+        up = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=bool(al))
+        dup = _bf(torch.randn(up.shape, generator=g))
+        gxs, = torch.autograd.grad(up, [xs], dup)
+        out = torch.empty(2, 10, 14, Cu, device=DEV, dtype=torch.bfloat16)
+        _lib.check(L().io_upsample2x_bilinear_fwd(P(bdev(xs.detach().permute(0, 2, 3, 1))), 2, 5, 7, Cu, al, P(out), 1, ST()), "up")
+        assert relerr(out.float().permute(0, 3, 1, 2), up.detach()) < 6e-3
+        dxs = torch.empty(2, 5, 7, Cu, device=DEV, dtype=torch.bfloat16)
+        _lib.check(L().io_upsample2x_bilinear_bwd(P(bdev(dup.permute(0, 2, 3, 1))), 2, 5, 7, Cu, al, P(dxs), 1, ST()), "up bwd")
+        assert relerr(dxs.float().permute(0, 3, 1, 2), gxs) < 6e-3
     M, Cc = 2000, 128
     v, b = _bf(torch.randn(M, Cc, generator=g)), torch.randn(Cc, generator=g).double()
     o = torch.empty(M, Cc, device=DEV, dtype=torch.bfloat16)
