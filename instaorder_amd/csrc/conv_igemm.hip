@@ -3064,7 +3064,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     IoProfScope prof(stem ? IO_PROF_CONV_STEM : (bn == 128 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64),
                      2.0 * (double)M * g.Co * kred,
                      (double)os * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
-                         (double)es * ((double)g.N * g.Hi * g.Wi * g.Ci * ((bw && bw->xb_a) ? (bw->xb_out ? 3.0 : 2.0) : 1.0) +
+                         // (a lattice class of a strided data gradient that no tap reaches reads nothing: it only writes zeros)
+                         (double)es * ((kred > 0.0 ? (double)g.N * g.Hi * g.Wi * g.Ci : 0.0) *
+                                           ((bw && bw->xb_a) ? (bw->xb_out ? 3.0 : 2.0) : 1.0) +
                                        (double)g.Co * kred),
                      st);
 #define IO_LAUNCH_NT_(TI_, TO_, BN_, STEM_, NBUF_, MINB_, BWE_, XF_, LIN_, XB_)                               \
