@@ -58,10 +58,9 @@ def _gather_rows(rows, n_total, world_size):
 
 def evaluate(model, data_reader, load_image, data_cfg, order_method, pairs="all", zd=0, disp_select_method="",
              gt_ordering="ann", world_size=1, rank=0, return_orders=False):
-    """Dispatch of ``Tester.run`` on ``data_cfg['trainval_dataset']``.  ``order_method``: one of the network methods of
-    tools/test.py, or a callable ``(modal_masks, dataset_name) -> order matrix`` (any model-free ordering rule: the
-    reference's area / y-axis baselines are out of this package's scope and live with the tests, which drive the
-    protocol of this function through them on the CPU).  Returns a dict with 'recall', 'precision', 'f1'
+    """Dispatch of ``Tester.run`` on ``data_cfg['trainval_dataset']``.  ``order_method``: one of the method strings of
+    tools/test.py -- the network methods, or the annotation-free baselines 'area' / 'yaxis' (tools/test.py:306-318,
+    421-433) -- or a callable ``(modal_masks, dataset_name) -> order matrix`` (any other model-free rule).  Returns a dict with 'recall', 'precision', 'f1'
     (occlusion datasets) and / or 'WHDR_<ovl>_<eq>' (depth datasets), plus 'num_test_images'; with ``return_orders``
     also 'orders' = {image index: (occlusion matrix | None, depth matrix | None)} of this rank's images."""
     kind = data_cfg["trainval_dataset"]
@@ -79,7 +78,7 @@ def evaluate(model, data_reader, load_image, data_cfg, order_method, pairs="all"
         modal, category, bboxes, amodal_gt, image_fn = data_reader.get_image_instances(i, with_gt=True)
         if kind != "SupDepthOccOrderDataset" and data_cfg.get("use_category", False):
             modal = modal * category[:, None, None]
-        image = None if callable(order_method) else np.asarray(load_image(image_fn))
+        image = None if (callable(order_method) or order_method in ("area", "yaxis")) else np.asarray(load_image(image_fn))
         boxes = expand_bbox(bboxes, data_cfg["enlarge_box"])
         gt_occ = gt_dep = None
         if want_occ:
@@ -105,6 +104,11 @@ def evaluate(model, data_reader, load_image, data_cfg, order_method, pairs="all"
         elif want_dep:
             if callable(order_method):      # a device-free ordering rule: (modal masks, dataset name) -> matrix
                 pred_dep = order_method(modal, dataset)
+            elif order_method == "area":    # tools/test.py:306-312: 'larger' for every dataset
+                pred_dep = infer.infer_depth_order_area(modal, closer="larger")
+            elif order_method == "yaxis":   # :314-318
+                pred_dep = infer.infer_depth_order_yaxis(modal, closer="lower" if dataset in ("COCOA", "InstaOrder")
+                                                         else "higher")
             elif order_method in ("InstaOrderNet_d", "InstaDepthNet_d", "midas_pretrained"):
                 pred_dep, _ = infer.infer_order_sup_depth(model, image, modal, boxes, pairs, order_method, mode, size,
                                                           disp_select_method)
@@ -113,6 +117,11 @@ def evaluate(model, data_reader, load_image, data_cfg, order_method, pairs="all"
         else:
             if callable(order_method):
                 pred_occ = order_method(modal, dataset)
+            elif order_method == "area":    # tools/test.py:421-427
+                pred_occ = infer.infer_occ_order_area(modal, occluder="larger")
+            elif order_method == "yaxis":   # :429-433
+                pred_occ = infer.infer_occ_order_yaxis(modal, occluder="lower" if dataset in ("COCOA", "InstaOrder")
+                                                       else "higher")
             elif order_method in ("InstaOrderNet_o", "OrderNet"):
                 pred_occ = infer.infer_order_sup_occ(model, image, modal, boxes, pairs, order_method, mode, size)
             else:

@@ -39,7 +39,49 @@ def bordering(a, b):
     return bool(np.any(d & (np.asarray(b) != 0)))
 
 
-# ---- ground-truth derivation (host; inference.py:719-739) ----------------------------------------------------------
+# ---- annotation-free baselines and ground-truth derivation (host; inference.py:272-347, 719-754) -------------------
+def _centre_y(mask):
+    return np.where(np.asarray(mask) == 1)[0].mean()
+
+
+def _pairwise(inmodal, need_border, key, direction):
+    """Shared double loop of the four heuristics: for i < j (optionally only bordering pairs) order the pair by
+    ``key`` (strict <; ties go to (j, i) as in the reference) and mark [a, b] = 1 with (a, b) per ``direction``."""
+    n = inmodal.shape[0]
+    order = np.zeros((n, n), dtype=np.int64)
+    keys = [key(m) for m in inmodal]
+    for i in range(n):
+        for j in range(i + 1, n):
+            if need_border and not bordering(inmodal[i], inmodal[j]):
+                continue
+            lo, hi = (i, j) if keys[i] < keys[j] else (j, i)          # lo: smaller area / smaller y (higher up)
+            a, b = (lo, hi) if direction else (hi, lo)
+            order[a, b] = 1
+    return order
+
+
+def infer_occ_order_area(inmodal, occluder="smaller"):
+    """inference.py:272-289: among bordering pairs the smaller (or larger) mask occludes."""
+    return _pairwise(inmodal, True, lambda m: m.sum(), occluder == "smaller")
+
+
+def infer_occ_order_yaxis(inmodal, occluder="lower"):
+    """inference.py:292-307.  Reference naming quirk kept: its ``lower`` is the mask with the SMALLER mean row index
+    (higher up in the image), and occluder='lower' marks that one as the occluder."""
+    return _pairwise(inmodal, True, _centre_y, occluder == "lower")
+
+
+def infer_depth_order_area(inmodal, closer="smaller"):
+    """inference.py:310-328: every pair; the smaller (or larger) mask is closer."""
+    return _pairwise(inmodal, False, lambda m: m.sum(), closer == "smaller")
+
+
+def infer_depth_order_yaxis(inmodal, closer="lower"):
+    """inference.py:331-346: every pair; closer='lower' marks the mask with the LARGER mean row index (lower in the
+    image) as closer -- here the reference's variable names are the right way round."""
+    return _pairwise(inmodal, False, _centre_y, closer != "lower")
+
+
 def infer_gt_order(inmodal, amodal):
     """inference.py:719-739 (KINS / COCOA ground truth): for bordering pairs, i occludes j when i's visible mask covers
     at least as much of j's amodal mask as the other way round (and the overlap is not empty)."""
@@ -58,6 +100,19 @@ def infer_gt_order(inmodal, amodal):
             else:
                 gt[j, i] = 1
     return gt
+
+
+def eval_order(order_matrix, gt_order_matrix):
+    """inference.py:742-754: (correct pairs, pairs, correct occluded pairs, occluded pairs, error table)."""
+    n = order_matrix.shape[0]
+    same = order_matrix == gt_order_matrix
+    allpair_true = (same.sum() - n) / 2
+    allpair = (n * n - n) / 2
+    occpair_true = (same & (gt_order_matrix != 0)).sum() / 2
+    occpair = (gt_order_matrix != 0).sum() / 2
+    err = np.where(~same)
+    show_err = np.concatenate([np.array(err).T + 1, gt_order_matrix[err][:, None], order_matrix[err][:, None]], axis=1)
+    return allpair_true, allpair, occpair_true, occpair, show_err
 
 
 def select_pairs(inmodal, pairs):

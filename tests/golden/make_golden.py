@@ -714,6 +714,57 @@ def case_dataset_items(tag):
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
 
 
+def case_heuristics(tag):
+    """inference.py's annotation-free baselines, infer_gt_order and eval_order on synthetic scenes; cv2.dilate (absent)
+    is scipy's binary_dilation with the same cross."""
+    from scipy import ndimage
+    cv2 = sys.modules["cv2"]
+    cv2.dilate = lambda a, k, iterations=1: ndimage.binary_dilation(a.astype(bool), structure=k.astype(bool),
+                                                                     iterations=iterations).astype(np.uint8)
+    import inference as ref_inf
+    rd = synthetic.SyntheticReader(88, n_images=4, n_inst=6, empty_every=0)
+    out = {}
+    for k, sc in enumerate(rd.scenes):
+        m = sc["modal"]
+        rng = np.random.RandomState(k)
+        amodal = np.stack([ndimage.binary_dilation(x.astype(bool), iterations=int(rng.randint(1, 6))).astype(np.uint8)
+                           for x in m])
+        out["amodal_%d" % k] = amodal
+        out["occ_area_s_%d" % k] = ref_inf.infer_occ_order_area(m, "smaller")
+        out["occ_area_l_%d" % k] = ref_inf.infer_occ_order_area(m, "larger")
+        out["occ_y_lo_%d" % k] = ref_inf.infer_occ_order_yaxis(m, "lower")
+        out["occ_y_hi_%d" % k] = ref_inf.infer_occ_order_yaxis(m, "higher")
+        out["dep_area_s_%d" % k] = ref_inf.infer_depth_order_area(m, "smaller")
+        out["dep_area_l_%d" % k] = ref_inf.infer_depth_order_area(m, "larger")
+        out["dep_y_lo_%d" % k] = ref_inf.infer_depth_order_yaxis(m, "lower")
+        out["dep_y_hi_%d" % k] = ref_inf.infer_depth_order_yaxis(m, "higher")
+        gt = ref_inf.infer_gt_order(m, amodal)
+        out["gt_%d" % k] = gt
+        ev = ref_inf.eval_order(out["occ_area_s_%d" % k], gt)
+        out["eval_%d" % k] = np.asarray(ev[:4], np.float64)
+        out["eval_err_%d" % k] = ev[4]
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, "scenes", len(rd.scenes), "gt ones", [int(out["gt_%d" % k].sum()) for k in range(len(rd.scenes))])
+
+
+TESTER_SCENARIOS = [   # (name, trainval_dataset, order_method, patch_or_image, algo or None)
+    ("occ_area", "SupOcclusionOrderDataset", "area", "patch", None),
+    ("occ_yaxis", "SupOcclusionOrderDataset", "yaxis", "patch", None),
+    ("dep_area", "SupDepthOrderDataset", "area", "resize", None),
+    ("dep_yaxis", "SupDepthOrderDataset", "yaxis", "resize", None),
+    ("occ_net_patch", "SupOcclusionOrderDataset", "InstaOrderNet_o", "patch", "InstaOrderNet_o"),
+    ("occ_net_image", "SupOcclusionOrderDataset", "InstaOrderNet_o", "image", "InstaOrderNet_o"),
+    ("od_net_resize", "SupDepthOccOrderDataset", "InstaOrderNet_od", "resize", "InstaOrderNet_od"),
+]
+# the 'orig' mode (inference.py:401-407, 490-496): whole images at their own aspect ratio -- the scenes of the reader round
+# to 128 x 128 (twice), 96 x 128 and 128 x 160 network inputs
+TESTER_SCENARIOS_ORIG = [
+    ("occ_net_orig", "SupOcclusionOrderDataset", "InstaOrderNet_o", "orig", "InstaOrderNet_o"),
+    ("od_net_orig", "SupDepthOccOrderDataset", "InstaOrderNet_od", "orig", "InstaOrderNet_od"),
+]
+TESTER_S, TESTER_SEED, TESTER_READER_SEED, TESTER_WARM = 64, 31, 91, 6
+
+
 def case_tester(tag, TESTER_SCENARIOS=TESTER_SCENARIOS):
     """The reference's own tools/test.py Tester loops (eval_occ_order / eval_depth_order / eval_occ_depth_order) over
     synthetic scenes: heuristics and the supervised nets in 'patch' / 'image' / 'resize' mode (cv2.resize = the oracle's
@@ -874,6 +925,7 @@ CASES = {
     "od_S384_B2_k": lambda: case_train("InstaOrderNet_od", 384, 2, 27, 1, "od_S384_B2_k", "kaiming"),
     "tester": lambda: case_tester("tester"),
     "tester_orig": lambda: case_tester("tester_orig", TESTER_SCENARIOS_ORIG),
+    "heuristics": lambda: case_heuristics("heuristics"),
     "dataset_items": lambda: case_dataset_items("dataset_items"),
     "o_S64_B4": lambda: case_train("InstaOrderNet_o", 64, 4, 11, 3, "o_S64_B4"),
     "od_S64_B6": lambda: case_train("InstaOrderNet_od", 64, 6, 12, 3, "od_S64_B6"),

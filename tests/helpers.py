@@ -173,49 +173,12 @@ def check_backward_golden(g, grads, label, factor=3.0, floor=5e-3):
 from instaorder_amd import inference as _inference  # noqa: E402
 
 
-# ---- the reference's annotation-free baselines (inference.py:272-347; SURVEY.md section 2 marks them out of the hot-path scope):
-# test-only ordering rules that drive instaorder_amd.evaluate's protocol on the CPU (tests/golden/tester.npz holds the
-# reference Tester's results for them)
-def _centre_y(mask):
-    return np.where(np.asarray(mask) == 1)[0].mean()
-
-
-def _pairwise(inmodal, need_border, key, first_wins_smaller, direction):
-    """Shared double loop of the four heuristics: for i < j (optionally only bordering pairs) order the pair by
-    ``key`` (strict <; ties go to (j, i) as in the reference) and mark [a, b] = 1 with (a, b) per ``direction``."""
-    n = inmodal.shape[0]
-    order = np.zeros((n, n), dtype=np.int64)
-    keys = [key(m) for m in inmodal]
-    for i in range(n):
-        for j in range(i + 1, n):
-            if need_border and not _inference.bordering(inmodal[i], inmodal[j]):
-                continue
-            lo, hi = (i, j) if keys[i] < keys[j] else (j, i)          # lo: smaller area / smaller y (higher up)
-            a, b = (lo, hi) if direction else (hi, lo)
-            order[a, b] = 1
-    return order
-
-
-def infer_occ_order_area(inmodal, occluder="smaller"):
-    """inference.py:272-289: among bordering pairs the smaller (or larger) mask occludes."""
-    return _pairwise(inmodal, True, lambda m: m.sum(), None, occluder == "smaller")
-
-
-def infer_occ_order_yaxis(inmodal, occluder="lower"):
-    """inference.py:292-307.  Reference naming quirk kept: its ``lower`` is the mask with the SMALLER mean row index
-    (higher up in the image), and occluder='lower' marks that one as the occluder."""
-    return _pairwise(inmodal, True, _centre_y, None, occluder == "lower")
-
-
-def infer_depth_order_area(inmodal, closer="smaller"):
-    """inference.py:310-328: every pair; the smaller (or larger) mask is closer."""
-    return _pairwise(inmodal, False, lambda m: m.sum(), None, closer == "smaller")
-
-
-def infer_depth_order_yaxis(inmodal, closer="lower"):
-    """inference.py:331-346: every pair; closer='lower' marks the mask with the LARGER mean row index (lower in the
-    image) as closer -- here the reference's variable names are the right way round."""
-    return _pairwise(inmodal, False, _centre_y, None, closer != "lower")
+# ---- the Tester's model-free methods in the CALLABLE form of evaluate.evaluate (the string form 'area' / 'yaxis' is
+# dispatched inside the package; both are held to tests/golden/tester.npz)
+infer_occ_order_area = _inference.infer_occ_order_area
+infer_occ_order_yaxis = _inference.infer_occ_order_yaxis
+infer_depth_order_area = _inference.infer_depth_order_area
+infer_depth_order_yaxis = _inference.infer_depth_order_yaxis
 
 
 def baseline_rule(kind, method):

@@ -309,6 +309,30 @@ def test_bordering_and_pair_selection():
         inference.select_pairs(m, "some")
 
 
+def test_heuristic_baselines_and_gt_order_match_reference():
+    """inference.py:272-347, 719-754 (area / y-axis baselines, infer_gt_order, eval_order) against matrices produced by
+    the reference's own functions (tests/golden/heuristics.npz)."""
+    from instaorder_amd import inference
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "heuristics.npz"))
+    rd = synthetic.SyntheticReader(88, n_images=4, n_inst=6, empty_every=0)
+    for k, sc in enumerate(rd.scenes):
+        m = sc["modal"]
+        got = {"occ_area_s": inference.infer_occ_order_area(m, "smaller"),
+               "occ_area_l": inference.infer_occ_order_area(m, "larger"),
+               "occ_y_lo": inference.infer_occ_order_yaxis(m, "lower"),
+               "occ_y_hi": inference.infer_occ_order_yaxis(m, "higher"),
+               "dep_area_s": inference.infer_depth_order_area(m, "smaller"),
+               "dep_area_l": inference.infer_depth_order_area(m, "larger"),
+               "dep_y_lo": inference.infer_depth_order_yaxis(m, "lower"),
+               "dep_y_hi": inference.infer_depth_order_yaxis(m, "higher"),
+               "gt": inference.infer_gt_order(m, z["amodal_%d" % k])}
+        for name, v in got.items():
+            assert np.array_equal(v, z["%s_%d" % (name, k)]), (name, k)
+        ev = inference.eval_order(got["occ_area_s"], got["gt"])
+        assert np.allclose(np.asarray(ev[:4], np.float64), z["eval_%d" % k])
+        assert np.array_equal(ev[4], z["eval_err_%d" % k])
+
+
 def _tester_golden():
     import json
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tester.npz"))
@@ -317,8 +341,9 @@ def _tester_golden():
     return z, cfg, rows
 
 
+@pytest.mark.parametrize("form", ["string", "callable"])
 @pytest.mark.parametrize("k", range(4))
-def test_evaluate_heuristics_equal_reference_tester(k):
+def test_evaluate_heuristics_equal_reference_tester(k, form):
     """instaorder_amd.evaluate against the reference's own tools/test.py Tester loops (tests/golden/tester.npz) for the
     model-free methods: per-image matrices and the aggregated P / R / F1 / WHDR means."""
     from instaorder_amd import evaluate
@@ -327,9 +352,9 @@ def test_evaluate_heuristics_equal_reference_tester(k):
     assert algo == "None"
     S, seed, rseed, warm = [int(v) for v in z["meta"]]
     rd = synthetic.SyntheticReader(rseed, n_images=4, n_inst=5, empty_every=0)
-    from helpers import baseline_rule          # the reference's area / y-axis baselines: test-side ordering rules
+    from helpers import baseline_rule          # the same baselines handed over as a callable ordering rule
     res = evaluate.evaluate(None, rd, rd.load_image, dict(cfg, trainval_dataset=kind, patch_or_image=mode),
-                            baseline_rule(kind, method), return_orders=True)
+                            method if form == "string" else baseline_rule(kind, method), return_orders=True)
     for i in range(4):
         occ, dep = res["orders"][i]
         assert np.array_equal(occ if dep is None else dep, z["%s_pred_%d" % (name, i)])
