@@ -41,6 +41,13 @@ int io_abi_version(void);
 const char* io_last_error_string(void);
 /* number of visible HIP devices whose arch is gfx950; <= 0 means the library cannot run */
 int io_device_count(void);
+/* Product form of the fp32 3x3 stride-1 convolutions / data gradients / filter gradients: 1 (default) = Winograd's minimal
+ * row forms F(4,3) / F(2,3) where the shape allows (half / two thirds of the matrix products, re-associated sums), 0 = the
+ * direct implicit GEMM everywhere -- the arithmetic of the reference's nn.Conv2d up to summation order (resnet_cls.py:23-26).
+ * Process-wide, read by every later launch; the initial value comes from the environment variable IO_WINOGRAD (unset = 1).
+ * Workspace sizes do not depend on it.  Returns the previous value. */
+int io_set_winograd(int on);
+int io_get_winograd(void);
 
 /* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
  * nn.Conv2d(bias=False) forward as used by conv1x1 / conv3x3 / the 7x7 stem

@@ -1,6 +1,7 @@
 // C ABI glue: error plumbing, device probe, convolution entry points (geometry builders).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "io_common.h"
@@ -24,6 +25,24 @@ int io_check_launch(const char* what) {
 }
 
 extern "C" int io_abi_version(void) { return 1; }
+
+// Winograd row forms on / off (header: io_set_winograd).  -1 = not read from the environment yet.
+static std::atomic<int> g_wino{-1};
+bool io_wino_on() {
+    int v = g_wino.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("IO_WINOGRAD");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_wino.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int io_get_winograd(void) { return io_wino_on() ? 1 : 0; }
+extern "C" int io_set_winograd(int on) {
+    const int prev = io_wino_on() ? 1 : 0;
+    g_wino.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
 extern "C" const char* io_last_error_string(void) { return g_err; }
 
 extern "C" int io_device_count(void) {
@@ -482,7 +501,7 @@ extern "C" int io_stem_wgrad_exact_bn(const float* x8, const float* da, const fl
     IO_REQUIRE(real_channels >= 1 && real_channels <= 8 && packed && coef, IO_ERR_SHAPE,
                "stem_wgrad_exact_bn: real_channels=%d (1..8)", real_channels);
     IoConvGeom g = stem_geom_exact(N, H, W, real_channels);
-    IO_REQUIRE(IO_STEM_ROWS && io_stem_rows_ok(g) && G >= 1 && N % G == 0, IO_ERR_SHAPE,
+    IO_REQUIRE(io_stem_rows_ok(g) && G >= 1 && N % G == 0, IO_ERR_SHAPE,
                "stem_wgrad_exact_bn: needs 5 real channels, 256 | H, W and G | N (else: io_bn_bwd + io_stem_wgrad_exact)");
     const int M = N * g.Ho * g.Wo;
     int rc = io_bn_bwd_coefs_t(da, y, M, 64, G, gamma, mean, rstd, dgamma, dbeta, coef, bn_partial, bn_partial_floats, st, IO_F32,

@@ -63,29 +63,10 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 // column of the accumulator layout and nt sends its 64-byte half lines to memory unmerged (write-only probe: 3.3 TB/s
 // nt vs 5.5-6.0 plain for 2-byte stores; no such gap for 4-byte stores or whole lines); in the network the two builds are
 // indistinguishable (the BatchNorm pass that follows pays back what the convolution gains).  nt is kept; the bf16
-// epilogues that matter store whole rows through LDS instead (IO_EP_ROWS).  (sc0 / sc1 bits: no gain / -15 %.)
-#ifndef IO_ST_AUX
-#define IO_ST_AUX 2
-#endif
-#ifndef IO_TR_BKM
-#define IO_TR_BKM 64       // rows (output pixels) per k-tile of the LDS-DMA filter-gradient kernel ...
-#define IO_TR_MINB 2       // ... and the blocks per CU asked of the register allocator
-#endif
-#ifndef IO_EP_ROWS
-#define IO_EP_ROWS 1       // bf16 epilogues of the dense 1x1 GEMMs store whole rows through LDS (0: one column per lane)
-#endif
-#ifndef IO_EARLY_LOADS
-#define IO_EARLY_LOADS 0
-#endif
-#ifndef IO_XF_PIPE
-#define IO_XF_PIPE 1       // the same for the forward input transform (fp32): NT class -0.3 ms per step, same-box
-#endif
-#ifndef IO_XB_PIPE
-#define IO_XB_PIPE 1
-#endif
-#ifndef IO_WGRAD_TR
-#define IO_WGRAD_TR 1      // bf16 filter gradients through LDS-DMA + transpose reads where the shape allows (0: staged kernel)
-#endif
+// epilogues that matter store whole rows through LDS instead.  (sc0 / sc1 bits: no gain / -15 %.)
+constexpr int kStAux = 2;       // aux bits of the epilogue stores: nt
+constexpr int kTrBkm = 64;      // rows (output pixels) per k-tile of the LDS-DMA filter-gradient kernel ...
+constexpr int kTrMinB = 2;      // ... and the blocks per CU asked of the register allocator
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -122,10 +103,10 @@ template <> __device__ __forceinline__ float ld_el<bf16_t>(__amdgpu_buffer_rsrc_
 }
 template <typename T> __device__ __forceinline__ void st_el(float v, __amdgpu_buffer_rsrc_t r, unsigned off);
 template <> __device__ __forceinline__ void st_el<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, IO_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, kStAux);
 }
 template <> __device__ __forceinline__ void st_el<bf16_t>(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, 0, IO_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, 0, kStAux);
 }
 // the same with a wave-uniform (SGPR) offset added on top of the per-lane one.  NOTE: the scalar offset takes no part in
 // the bounds check of the descriptor -- only for accesses known to be in range.
@@ -138,10 +119,10 @@ template <> __device__ __forceinline__ float ld_el_s<bf16_t>(__amdgpu_buffer_rsr
 }
 template <typename T> __device__ __forceinline__ void st_el_s(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff);
 template <> __device__ __forceinline__ void st_el_s<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, soff, IO_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, soff, kStAux);
 }
 template <> __device__ __forceinline__ void st_el_s<bf16_t>(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, soff, IO_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b16(io_f2bf(v), r, off, soff, kStAux);
 }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -479,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
     };
     const int wchunk = SWZ ? (kq ^ ((lr >> 1) & 7)) : kq;      // (the row step RS = 32 leaves bits 1..3 alone)
     // XB: the operand transform of the tile in (ra, ry) + its side output.  Its own step so that the loop can run it under
-    // the MFMAs of the previous tile instead of inside the barrier-to-barrier section of store_tile (IO_XB_PIPE).
+    // the MFMAs of the previous tile instead of inside the barrier-to-barrier section of store_tile.
     auto xform_tile = [&]() {
         if constexpr (WINO) {
 #pragma unroll
@@ -697,11 +678,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         advance(true);
         // (fp32 only: in bf16 the transform is VALU-bound whatever its place and the longer live ranges spill --
         // profiles/r03_xb_microbench_bf16.txt; the bf16 step does not use the operand forms)
-        constexpr bool PIPE = ES == 4 && ((XB != 0 && IO_XB_PIPE) || (XF && IO_XF_PIPE) || WINO);
+        constexpr bool PIPE = ES == 4 && (XB != 0 || XF || WINO);
         if constexpr (!PIPE) load_tile(kt + 1);
-#if IO_EARLY_LOADS
-        __builtin_amdgcn_sched_barrier(0);     // the fetches of tile kt+1 are ISSUED here, ahead of the MFMAs of tile kt
-#endif
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             f32x4 na[TI], nb[FB];
@@ -846,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                                                             bw.a_out ? out_bytes : out_base);
         // bf16, 128-wide tiles: dz leaves through the wave's LDS slice as whole rows (see the plain 1x1 epilogue below for
         // the why); the optional activation side output keeps its column stores
-        constexpr bool ROWS = OS == 2 && BN == 128 && IO_EP_ROWS;
+        constexpr bool ROWS = OS == 2 && BN == 128;
         constexpr int WC = BN / WN, EPP = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NI = 32 / RPI;
         float* ep = smem + wave * (32 * EPP);
         if (ROWS) __syncthreads();               // every wave is done with the operand tiles
@@ -888,7 +866,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                     const u32x2_ pk = {io_f2bf2(q[0], q[1]), io_f2bf2(q[2], q[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(
                         pk, rs_out, (unsigned)((m0 - opix_lo + wm * 64 + i * 32 + row) * g.Co + n0 + wn * WC + cc) * 2u, 0,
-                        IO_ST_AUX);
+                        kStAux);
                 }
             }
         }
@@ -903,7 +881,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
         // layout in the scalar offset (as in the fused BatchNorm-backward epilogue above)
         const unsigned rowstep = (unsigned)g.Co * (unsigned)OS;
         const unsigned lane_base = (unsigned)((wm * 64 + 4 * (lane >> 5)) * g.Co + n0 + wn * (BN / WN) + (lane & 31)) * (unsigned)OS;
-        if constexpr (OS == 2 && BN == 128 && IO_EP_ROWS) {
+        if constexpr (OS == 2 && BN == 128) {
             // bf16 output without residual / mask: the accumulator layout gives a lane ONE column, i.e. 2-byte stores
             // that reach memory as 64-byte half lines -- 3.3 TB/s with the non-temporal bit against 5.6+ for whole
             // lines (profiles/r02_store_and_shortk_probes.txt), and the p -> 4p layers write four times what they read.
@@ -938,7 +916,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_nt_kernel(IoConvGeom g, co
                         typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
                         const u32x2_ pk = {io_f2bf2(q[0], q[1]), io_f2bf2(q[2], q[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(
-                            pk, rs_out, (unsigned)((wm * 64 + i * 32 + row) * g.Co + n0 + wn * WC + cc) * 2u, 0, IO_ST_AUX);
+                            pk, rs_out, (unsigned)((wm * 64 + i * 32 + row) * g.Co + n0 + wn * WC + cc) * 2u, 0, kStAux);
                     }
                 }
                 return;
@@ -2357,9 +2335,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_wino4_kernel(IoConvGeo
 // XF: the A operand goes through relu(bn(x)) while it is staged (IoBwStats::in_scale, as in conv_nt_kernel).
 // BWE: the fused BatchNorm-backward epilogue (IoBwStats::y ...: ReLU mask recomputed from y, per-tile sums, activation side
 // output).  Both need whole 256-row tiles per BatchNorm group.
-#ifndef IO_W4_ABLATE
-#define IO_W4_ABLATE 0       // timing-only ablations of conv_wino4_kernel (WRONG results): 1 no transforms, 2 no LDS refill, 3 no global loads
-#endif
 // HALO (a tile = whole image rows: 256 % Wo == 0, Wo <= 64, and either 256 | Ho Wo -- rows of ONE sample -- or whole small
 // samples whose halo images fit 96 quad rows): the three filter rows of a tile read
 // the input rows h - 1, h, h + 1 of its R = 256 / Wo output rows, i.e. R + 2 distinct input rows -- so the k loop runs
@@ -2449,10 +2424,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     f32x4 pa2[HALO ? 6 : 1];                 // HALO: the second item
     unsigned xok = 0, xok2 = 0;
     int th = 0, cc = 0;
-    bool first_load = true;
     auto load_tile = [&]() {                 // the k-tile (th, cc)
-        if (IO_W4_ABLATE == 3 && !first_load) return;
-        first_load = false;
         const unsigned uoff = (unsigned)(th * NF) * uplane + (unsigned)(cc * BK) * 4u;
         if constexpr (HALO) {
 #pragma unroll
@@ -2536,7 +2508,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
     };
     // (th, cc) here = the tile that was LOADED last: HALO transforms / stores the V image only at the start of a channel chunk
     auto xform_tile = [&]() {
-        if (IO_W4_ABLATE == 1) return;
         if constexpr (HALO) {
             if (th != 0) return;
             xform_item(pa, xok);
@@ -2546,12 +2517,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(IoConvGeom g, const 
         xform_item(pa, xok);
     };
     const int swz = sc ^ ((sr >> 2) & 3);
-    bool first_store = true;
     auto store_tile = [&]() {
         float* a = sA + sr * LDT + swz * 4;
         float* b = sB + sr * LDT + swz * 4;
-        if (IO_W4_ABLATE == 2 && !first_store) return;
-        first_store = false;
         if constexpr (HALO) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) st4(b + f * 64 * LDT, pu[f]);
@@ -2868,20 +2836,14 @@ WgradPlan plan_wgrad(const IoConvGeom& g, int stem, bool fp32 = true) {
     return p;
 }
 
-#ifndef IO_WGRAD_WINO
-#define IO_WGRAD_WINO 1
-#endif
-#ifndef IO_WGRAD_WINO4
-#define IO_WGRAD_WINO4 1
-#endif
-#define IO_WGRAD_WINO4_ON IO_WGRAD_WINO4
 // the Winograd row form of the fp32 filter gradient: 3x3 stride-1 same-size convolutions with 8 | Wo and 64 | M
-bool wgrad_wino_ok(const IoConvGeom& g, int stem) {
-    return IO_WGRAD_WINO && !stem && !g.gw && !g.cr && g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 &&
+bool wgrad_wino_shape_ok(const IoConvGeom& g, int stem) {
+    return !stem && !g.gw && !g.cr && g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 &&
            g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.dh0 == -1 && g.dhs == 1 && g.dw0 == -1 && g.dws == 1 &&
            g.rs == 1 && g.ss == 1 && g.r0 == 0 && g.s0 == 0 && g.Wo % 8 == 0 && ((long)g.N * g.Ho * g.Wo) % 64 == 0 &&
            g.Ci % 64 == 0 && g.Co % 64 == 0;
 }
+bool wgrad_wino_ok(const IoConvGeom& g, int stem) { return io_wino_on() && wgrad_wino_shape_ok(g, stem); }
 WgradPlan plan_wgrad_wino(const IoConvGeom& g) {
     WgradPlan p;
     p.bmo = p.bnc = 64;
@@ -2903,12 +2865,12 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     // sized for either storage type: the fp32 and the bf16 kernels split differently
     const int s0 = plan_wgrad(g, stem, true).splits, s1 = plan_wgrad(g, stem, false).splits;
     int splits = s0 > s1 ? s0 : s1;
-    if (wgrad_wino_ok(g, stem)) {
+    if (wgrad_wino_shape_ok(g, stem)) {          // (by shape alone: the size must not depend on the run-time switch)
         const int sw = plan_wgrad_wino(g).splits;
         if (sw > splits) splits = sw;
     }
     size_t need = splits == 1 ? 0 : (size_t)splits * g.Co * io_filter_row(g) * sizeof(float);
-    if (stem && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g)) {      // one partial per block of the row-persistent kernel
+    if (stem && g.cr && io_stem_rows_ok(g)) {      // one partial per block of the row-persistent kernel
         const size_t rows = (size_t)io_stem_wgrad_rows_max_blocks() * g.Co * io_filter_row(g) * sizeof(float);
         if (rows > need) need = rows;
     }
@@ -2987,20 +2949,14 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     // Winograd F(2, 3) row form (2/3 of the MFMAs).  Forms it carries: plain (incl. the inference epilogue bias + ReLU), input
     // transform (XF), fused BatchNorm-backward epilogue (BWE), each with optional statistics; everything else stays on the
     // direct kernel.
-#ifndef IO_WINO
-#define IO_WINO 1
-#endif
-    if (IO_WINO && bws.wino_u && !stem && !g.gw && dt_in == IO_F32 && dt_out == IO_F32 && g.Th == 3 && g.Tw == 3 &&
+    if (io_wino_on() && bws.wino_u && !stem && !g.gw && dt_in == IO_F32 && dt_out == IO_F32 && g.Th == 3 && g.Tw == 3 &&
         g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.outH == g.Ho &&
         g.outW == g.Wo && g.Wo % 2 == 0 && M % 128 == 0 && g.Ci % 32 == 0 && !add && !mask && !bws.xb_a &&
         g.dhs * g.dhs == 1 && g.dws * g.dws == 1 && g.dw0 * (g.dw0 + 2 * g.dws) == -1 && g.rs == 1 && g.ss == 1 &&
         !(bws.y && bws.in_scale) && 12.0 * g.Co * g.Ci * 4.0 < 4.0e9) {
         const double kred9 = 9.0 * g.Ci;
-#ifndef IO_WINO4
-#define IO_WINO4 1
-#endif
         // F(4, 3): 4 | Wo, whole 256-row tiles (per BatchNorm group where tables are indexed by group)
-        const bool wino4 = IO_WINO4 && g.Wo % 4 == 0 && M % 256 == 0 && g.Ci % 16 == 0 && (!bws.y || bws.Mg % 256 == 0) &&
+        const bool wino4 = g.Wo % 4 == 0 && M % 256 == 0 && g.Ci % 16 == 0 && (!bws.y || bws.Mg % 256 == 0) &&
                            (!bws.in_scale || bws.in_Mg % 256 == 0) && 18.0 * g.Co * g.Ci * 4.0 < 4.0e9;
         const double fl9 = 2.0 * (double)M * g.Co * kred9;
         IoProfScope prof(IO_PROF_CONV_WINO, fl9,
@@ -3013,12 +2969,9 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
             const unsigned u_bytes = (unsigned)(18.0 * g.Co * g.Ci * 4.0);
             const int ntw = g.Co / 64;
             dim3 grid4((unsigned)((M / 256) * ntw));
-#ifndef IO_W4_HALO
-#define IO_W4_HALO 1
-#endif
             // tiles of whole image rows of one sample: the V image is staged once per channel chunk for all three filter rows
             const long hw = (long)g.Ho * g.Wo;
-            const bool halo = IO_W4_HALO && g.Wo <= 64 && 256 % g.Wo == 0 &&
+            const bool halo = g.Wo <= 64 && 256 % g.Wo == 0 &&
                               (hw % 256 == 0 || (256 % hw == 0 && (256 / hw) * (g.Ho + 2) * (g.Wo / 4) <= 96));
             const size_t lds4 = (size_t)6 * ((halo ? 96 : 64) + 64) * 16 * sizeof(float);
 #define IO_LAUNCH_W4_(BWE_, XF_, HALO_)                                                                                 \
@@ -3113,7 +3066,7 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
             IO_LAUNCH_NT(bf16_t, bf16_t, 64, 1, 1, 4);
         } else if (dt_out == IO_BF16) {
             IO_LAUNCH_NT(float, bf16_t, 64, 1, 2, 1);
-        } else if (g.cr && IO_STEM_ROWS && io_stem_rows_ok(g) && !add && !mask && !bws.y && !bws.in_scale) {
+        } else if (g.cr && io_stem_rows_ok(g) && !add && !mask && !bws.y && !bws.in_scale) {
             // whole 128-pixel output rows: the row-persistent kernel of stem.hip (filter resident in LDS, A fragments read
             // straight out of a compact input patch)
             return io_launch_stem_rows(g, (const float*)in, (const float*)wgt, (float*)out, st_mean, st_m2, bws.bias,
@@ -3162,7 +3115,7 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     IO_REQUIRE(partial_bytes >= need && (need == 0 || partial), IO_ERR_WORKSPACE,
                "conv_wgrad: workspace %zu < %zu bytes", partial_bytes, need);
     // the fp32 exact-K stem on whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
-    if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && IO_STEM_ROWS && io_stem_rows_ok(g))
+    if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && io_stem_rows_ok(g))
         return io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, dw, partial, partial_bytes, st);
     if (dt_in == IO_F32 && dt_dy == IO_F32 && wgrad_wino_ok(g, stem)) {
         const WgradPlan pw = plan_wgrad_wino(g);
@@ -3174,8 +3127,8 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         const double Mdw = (double)g.N * g.Ho * g.Wo;
         IoProfScope prof(IO_PROF_WGRAD_WINO, 2.0 * Mdw * g.Co * 9.0 * g.Ci,
                          4.0 * (Mdw * g.Co + (double)g.N * g.Hi * g.Wi * g.Ci + 9.0 * g.Co * g.Ci), st,
-                         2.0 * Mdw * g.Co * 9.0 * g.Ci * ((IO_WGRAD_WINO4_ON && g.Wo % 16 == 0) ? 0.5 : 2.0 / 3.0));
-        if (IO_WGRAD_WINO4_ON && g.Wo % 16 == 0) {          // F(4, 3): a staging thread's 16 pixels lie in one image row
+                         2.0 * Mdw * g.Co * 9.0 * g.Ci * (g.Wo % 16 == 0 ? 0.5 : 2.0 / 3.0));
+        if (g.Wo % 16 == 0) {          // F(4, 3): a staging thread's 16 pixels lie in one image row
             hipLaunchKernelGGL(conv_wgrad_wino4_kernel, dim3((unsigned)(pw.tiles * pw.splits)), dim3(kThreads),
                                (size_t)2 * 6 * 64 * 16 * sizeof(float), st, g, (const float*)in, (const float*)dy, dstw,
                                pw.ntile_c, pw.tiles, pw.kps, in_b, dy_b);
@@ -3291,19 +3244,19 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     } while (0)
         // LDS-DMA + transpose-read form where its shape conditions hold (see the kernel)
         const int rb_rows = 512 / p.bnc;
-        const bool trk = IO_WGRAD_TR && !(stem && g.cr) && (long)Md % 64 == 0 && (g.Ho * g.Wo) % 64 == 0 &&
+        const bool trk = !(stem && g.cr) && (long)Md % 64 == 0 && (g.Ho * g.Wo) % 64 == 0 &&
                          g.Wo % rb_rows == 0;
 #define IO_LAUNCH_WGTR(BMO_, BNC_, STEM_)                                                                               \
     do {                                                                                                         \
-        const size_t lds = (size_t)2 * (BMO_ + BNC_) * IO_TR_BKM * 2;                                            \
+        const size_t lds = (size_t)2 * (BMO_ + BNC_) * kTrBkm * 2;                                            \
         static std::atomic<unsigned long long> attr_done{0};                                                                           \
         if (io_first_on_device(attr_done)) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>, \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         }                                                                                                        \
-        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, IO_TR_MINB, IO_TR_BKM>), grid1, block,  \
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm>), grid1, block,  \
                            lds, st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles,            \
-                           kps64 * (64 / IO_TR_BKM), in_bytes, dy_bytes);                                        \
+                           kps64 * (64 / kTrBkm), in_bytes, dy_bytes);                                        \
     } while (0)
         if (trk && stem) IO_LAUNCH_WGTR(64, 64, true);
         else if (trk && p.bmo == 128 && p.bnc == 128) IO_LAUNCH_WGTR(128, 128, false);

@@ -163,6 +163,9 @@ struct IoBwStats {
     float* wino_u;
 };
 
+// run-time switch of the Winograd row forms (io_set_winograd / IO_WINOGRAD, capi.hip)
+bool io_wino_on();
+
 // internal launchers shared between the C ABI and the network executor
 // dt_in: storage of `in` and `wgt`; dt_out: storage of out / add / mask / bw.y
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
@@ -226,9 +229,6 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem);
 IoConvGeom io_geom_fwd(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 // stem.hip: the exact-K stem forward on whole 128-pixel output rows (row-persistent; statistics partials in the tile
 // format of io_launch_conv_nt, or the inference epilogue relu(acc + bias))
-#ifndef IO_STEM_ROWS
-#define IO_STEM_ROWS 1
-#endif
 bool io_stem_rows_ok(const IoConvGeom& g);
 int io_launch_stem_rows(const IoConvGeom& g, const float* x8, const float* wp, float* out, float* st_mean, float* st_m2,
                         const float* bias, int relu, hipStream_t st);

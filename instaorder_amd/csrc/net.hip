@@ -99,12 +99,6 @@ BnL add_bn(io_net* net, const char* name, int C) {
 }
 
 // ---- workspace plan ---------------------------------------------------------------------------
-#ifndef IO_WT_ALL
-#define IO_WT_ALL 1      // all filter transposes of a backward pass in one launch
-#endif
-#ifndef IO_NET_WINO
-#define IO_NET_WINO 1    // 3x3 stride-1 forward convolutions and data gradients of the fp32 step in the Winograd F(2, 3) row form
-#endif
 constexpr size_t kNoBuf = ~(size_t)0;
 struct BlockBufs {
     size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets (a1 / a2 = kNoBuf: never materialised, see fuse_in)
@@ -222,7 +216,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
         p.wt = a.take(wtmax);
         // every filter's transpose (the B operand of its data gradient) at the filter's own offset: one launch per
         // backward pass instead of one per layer
-        p.wt_all = IO_WT_ALL ? a.take((size_t)net->param_floats * e) : kNoBuf;
+        p.wt_all = a.take((size_t)net->param_floats * e);
     } else {
         // eval: rotating buffers (block input / a1 / a2 / y / yd / output)
         const size_t r0 = a.take(maxact), r1 = a.take(maxact), r2 = a.take(maxact), r3 = a.take(maxact),
@@ -343,7 +337,7 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         ep.in_Mg = Mout / c.G;
     }
     // 3x3 stride-1 convolutions in fp32: scratch for the Winograd row form (the launcher falls back where it does not apply)
-    const bool wino = IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32;
+    const bool wino = c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32;
     if (wino) ep.wino_u = c.buf(c.plan.wino_u);
     if (xr) {
         Tables t = c.tables(*xr);
@@ -402,24 +396,17 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 // stages its operand (conv_fwd's xr) instead of by a pass of its own?  fp32 (there the transform hides under the MFMAs),
 // whole 128-row tiles per group; the caller also needs an identity that is a plain tensor (no downsample branch) and a
 // next block.  Like the backward form: a 12 B / element pass becomes 8 B / element inside a GEMM.
-#ifndef IO_XR
-#define IO_XR 1
-#endif
-
 #ifndef IO_XB_BF16_MAXP
 #define IO_XB_BF16_MAXP 64
 #endif
 #ifndef IO_XB_BF16_L1
 #define IO_XB_BF16_L1 1   // bf16: the operand forms on the layer-1 (64-plane) blocks only
 #endif
-#ifndef IO_XR2
-#define IO_XR2 1      // ... also the outputs of the four blocks with a downsample branch (two BatchNorms folded into one table set)
-#endif
 // bf16: only for the 64-plane blocks of layer 1 -- the form is VALU-bound next to bf16 MFMAs, but those launches are so
 // HBM-bound that dropping the pass still wins (as for the backward form, run_backward)
 bool xr_ok(const Ctx& c, int Mout, int planes) {
     const bool dt_ok = c.net->dtype == IO_F32 || (IO_XB_BF16_L1 && planes <= IO_XB_BF16_MAXP);
-    return IO_XR && c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
+    return c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
 bool fuse_in(const Ctx& c, int Mout) {
@@ -448,7 +435,7 @@ int conv_folded(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void*
     IoBwStats ep{};
     ep.bias = c.fbias(b);
     ep.relu = relu;
-    if (IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32 && !add)
+    if (c.plan.wino_u != kNoBuf && L.k == 3 && L.stride == 1 && c.dt() == IO_F32 && !add)
         ep.wino_u = c.buf(c.plan.wino_u);      // (square or H x W inputs alike; odd widths fall back in the launcher)
     const void* w = c.wfold(L.w_off);
     if (stem_exact(c, L)) {
@@ -571,7 +558,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         }
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
-            if (IO_XR2 && i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
+            if (i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
                 // relu(bn3(y3) + bnd(yd)) = relu(a * y3 + b * yd + c): one table set, then as below
                 Tables t3 = c.tables(b.b3), td = c.tables(b.bd);
                 IO_TRY(io_bn_resid2_tables(t3.mean, t3.scale, t3.shift, td.mean, td.scale, td.shift, c.G, b.b3.C,
@@ -653,22 +640,10 @@ bool tiles_ok(const Ctx& c, int M) { return M % c.G == 0 && (M / c.G) % kIoStatT
 // Does the BatchNorm backward of a layer with M rows leave its apply pass to the data-gradient kernel that consumes dy
 // (IoBwStats::xb_a: dy = a * dz + b * y + c evaluated on the staged operand, written out once for the filter gradient)?
 // fp32 only: there the transform hides under the MFMAs (as the forward one does); whole 128-row tiles per group.
-#ifndef IO_XB
-#define IO_XB 1
-#endif
-#ifndef IO_STEM_XB
-#define IO_STEM_XB 1     // bn1 (stem) backward in the staging of the stem's filter gradient (stem.hip)
-#endif
-#ifndef IO_XB1S
-#define IO_XB1S 1       // ... and bn1's of the three blocks whose conv2 is strided
-#endif
-#ifndef IO_XBD
-#define IO_XBD 1        // ... and the downsample BatchNorm's into the downsample convolution's data gradient
-#endif
-#ifndef IO_XB_C2
-#define IO_XB_C2 0      // ... also into conv2's 3x3 data gradient (measured: a loss, see run_backward)
-#endif
-bool xb_ok(const Ctx& c, int M) { return IO_XB && c.net->dtype == IO_F32 && tiles_ok(c, M); }
+// Applied: bn3 -> conv3's, bn1 -> conv1's (also of the three blocks whose conv2 is strided), the downsample BatchNorm's -> the
+// downsample convolution's data gradient, the stem's bn1 in the staging of the stem's filter gradient (stem.hip).  NOT bn2 ->
+// conv2's 3x3 data gradient (measured: a loss, see run_backward).
+bool xb_ok(const Ctx& c, int M) { return c.net->dtype == IO_F32 && tiles_ok(c, M); }
 
 IoBwStats bw_for(const Ctx& c, const BnL& b, const void* y, int M, bool mask_from_y) {
     Tables t = c.tables(b);
@@ -730,7 +705,7 @@ int dgrad_then_bn(const Ctx& c, const ConvL& L, const void* dy, void* dx, int H,
         IoBwStats bw = bw_for(c, b, y, M, true);
         bw.a_out = a_out;
         if (xb) xb_fill(c, bw, *xb, xb_y, xb_M, xb_out);
-        if (IO_NET_WINO && c.plan.wino_u != kNoBuf && L.k == 3 && c.dt() == IO_F32 && !xb) bw.wino_u = c.buf(c.plan.wino_u);
+        if (c.plan.wino_u != kNoBuf && L.k == 3 && c.dt() == IO_F32 && !xb) bw.wino_u = c.buf(c.plan.wino_u);
         IO_TRY(conv_dgrad(c, L, dy, dx, nullptr, nullptr, H, &bw));
         if (!dyb) return IO_OK;
         return bn_back_tiles(c, b, dx, y, M, dyb);
@@ -813,19 +788,18 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // Measured per shape at the bench batch (tools/xb_bench.py, profiles/r03_xb_microbench_fp32.txt): the 1x1 data
         // gradients pay +0.00..0.17 ms for the doubled operand load (+0.54 on the HBM-bound 256 -> 64 layer) and save an
         // apply pass of 0.04..1.29 ms -- a gain on every conv3 and conv1; a 3x3 data gradient stages every chunk nine
-        // times (once per tap), pays +0.21..0.61 ms and saves 0.04..0.32: bn2 keeps its apply pass (IO_XB_C2).
+        // times (once per tap), pays +0.21..0.61 ms and saves 0.04..0.32: bn2 keeps its apply pass.
         // (bf16: the transform is VALU-bound next to bf16 MFMAs and loses everywhere except on layer 1's 256 -> 64 data
         // gradient, which is so HBM-bound that the saved pass still wins: -0.33 ms per launch, r03_xb_microbench_bf16.txt)
         const bool x3 = xb_ok(c, Mout) ||                        // bn3 -> conv3's data gradient
                         (IO_XB_BF16_L1 && c.net->dtype == IO_BF16 && b.planes <= IO_XB_BF16_MAXP && tiles_ok(c, Mout));
         const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
-        const bool x2 = IO_XB_C2 && x3 && b.stride == 1;         // bn2 -> conv2's (a strided one runs as parity classes)
         // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
         const bool x1d = b.stride == 1 && xb_ok(c, Min) && tiles_ok(c, Mout);
         // a strided conv2 runs its data gradient as parity classes, which carry no BatchNorm epilogue: there the mask comes
         // from the stored activation a1 (kept for exactly these blocks) in that launch's epilogue, bn1's sums from a
         // reduction pass over (dz1, y1), and the apply pass again rides in conv1's operand load
-        const bool x1s = IO_XB1S && b.stride != 1 && xb_ok(c, Min) && bb.a1 != kNoBuf;
+        const bool x1s = b.stride != 1 && xb_ok(c, Min) && bb.a1 != kNoBuf;
         const bool x1 = x1d || x1s;
         if (x3)
             IO_TRY(bn_back_coefs(c, b.b3, Gd, c.act(bb.y3), Mout, have_tiles));
@@ -839,19 +813,17 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // the filter gradient that needs it runs right after (instead of right before) that launch.
         void* As = f3 ? c.act(p.aside) : nullptr;
         if (!f3 && !x3) IO_TRY(conv_wgrad(c, b.c3, c.act(bb.a2), Ga, Ho));
-        // conv3: (dy3 | dz3 + y3) -> Gb = dz2 (+ bn2's partials); without x2 also Gc = dy2
-        IO_TRY(dgrad_then_bn(c, b.c3, x3 ? Gd : Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, x2 ? nullptr : Gc, f3 ? As : nullptr,
+        // conv3: (dy3 | dz3 + y3) -> Gb = dz2 (+ bn2's partials), Gc = dy2
+        IO_TRY(dgrad_then_bn(c, b.c3, x3 ? Gd : Ga, Gb, Ho, b.b2, c.act(bb.y2), Mout, Gc, f3 ? As : nullptr,
                              x3 ? &b.b3 : nullptr, c.act(bb.y3), Mout, Ga));
         if (f3 || x3) IO_TRY(conv_wgrad(c, b.c3, f3 ? As : c.act(bb.a2), Ga, Ho));
-        if (x2) IO_TRY(bn_back_coefs(c, b.b2, Gb, c.act(bb.y2), Mout, true));
-        if (!f2 && !x2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
+        if (!f2) IO_TRY(conv_wgrad(c, b.c2, c.act(bb.a1), Gc, H));
         // conv2: (dy2 | dz2 + y2) -> Ga = dz1 (+ bn1's partials); without x1 also Gb = dy1
         if (x1s)
             IO_TRY(conv_dgrad(c, b.c2, Gc, Ga, nullptr, c.act(bb.a1), H));
         else
-            IO_TRY(dgrad_then_bn(c, b.c2, x2 ? Gb : Gc, Ga, H, b.b1, c.act(bb.y1), Min, x1 ? nullptr : Gb,
-                                 f2 ? As : nullptr, x2 ? &b.b2 : nullptr, c.act(bb.y2), Mout, Gc));
-        if (f2 || x2) IO_TRY(conv_wgrad(c, b.c2, f2 ? As : c.act(bb.a1), Gc, H));
+            IO_TRY(dgrad_then_bn(c, b.c2, Gc, Ga, H, b.b1, c.act(bb.y1), Min, x1 ? nullptr : Gb, f2 ? As : nullptr));
+        if (f2) IO_TRY(conv_wgrad(c, b.c2, As, Gc, H));
         if (!x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));
         // d(x_in) = dgrad(conv1) + identity path, masked by the ReLU of x_in (= previous block's output).
         // Without a downsample branch this launch completes d(x_in), so it can also carry the reductions of
@@ -861,7 +833,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // does not reach are written as zeros -- so that conv1's dense stride-1 data gradient is again the launch
         // that completes d(x_in) and can carry the previous block's bn3 reductions there too.
         const void* partial = Gd;          // what conv1's data gradient accumulates onto: the identity path ...
-        if (b.down && IO_XBD && x3) {
+        if (b.down && x3) {
             // the downsample BatchNorm the same way: reductions over (dz, yd) -> tables, dy evaluated on the operand of the
             // (strided) 1x1 data gradient -- only the lattice class that has a tap stages anything -- and written to Gc for
             // the filter gradient.  (Gc: dy2 has been consumed by conv2's data and filter gradients; Ga may hold dz1.)
@@ -899,7 +871,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
     {
         IoConvGeom g = io_geom_fwd(c.N, c.S, c.S, 8, 64, 7, 7, 2, 3);
         g.cr = net->stem.cin;
-        if (IO_STEM_XB && IO_STEM_ROWS && stem_exact(c, net->stem) && io_stem_rows_ok(g) && c.N % c.G == 0) {
+        if (stem_exact(c, net->stem) && io_stem_rows_ok(g) && c.N % c.G == 0) {
             const BnL& b = net->bn1;
             Tables t = c.tables(b);
             IO_TRY(io_bn_bwd_coefs_t(Ge, c.act(p.y0), c.N * H0 * H0, b.C, c.G, c.params + b.g_off, t.mean, t.rstd,

@@ -183,6 +183,17 @@ def sgd_momentum(params, grads, buf, lr, momentum, weight_decay):
 _prof_on = False
 
 
+def set_winograd(on):
+    """Product form of the fp32 3x3 stride-1 layers: True = Winograd row forms where the shape allows (default; env
+    IO_WINOGRAD=0 starts a process with them off), False = the direct implicit GEMM everywhere.  Returns the previous
+    setting.  A captured hipGraph keeps the form it was captured with."""
+    return bool(_lib.lib().io_set_winograd(1 if on else 0))
+
+
+def get_winograd():
+    return bool(_lib.lib().io_get_winograd())
+
+
 def prof_active():
     return _prof_on
 

@@ -53,6 +53,9 @@ class _OrderBase(SingleStageModel):
         # world_size > 1: the gradient all-reduce in stage buckets under the backward pass (IO_COMM_OVERLAP=0: one flat
         # all-reduce after it, the round-1/2 behaviour)
         self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
+        # IO_COMM_OVERLAP=force: the staged path on ONE rank too (an initialised process group of size 1) -- the per-stage
+        # hipGraphs with the backend's asynchronous all-reduce in between, exercised where a second GPU is not to be had
+        self._force_overlap = os.environ.get("IO_COMM_OVERLAP", "1") == "force"
         self._buckets = None
         self._dp_graphs = None          # world_size > 1: one hipGraph per backward stage (the collectives sit between them)
         self._dp_key = None
@@ -195,7 +198,7 @@ class _OrderBase(SingleStageModel):
         N = 2 * self.B
         S = self._x8.shape[1]
         key = (N, S, self._x8.data_ptr(), net.flat_params.data_ptr())
-        if self.world_size > 1 and self._overlap_comm:
+        if (self.world_size > 1 or self._force_overlap) and self._overlap_comm:
             logits, losses = self._step_overlapped(N, S)
             self.last_logits = logits
             net.attach_grads()
@@ -382,6 +385,7 @@ class _DepthBase(SingleStageModel):
         # world_size > 1: the backward pass in four stages, the all-reduce of each stage's slice of the flat gradient
         # buffer launched as soon as the stage is enqueued (IO_COMM_OVERLAP=0: one flat all-reduce after the backward)
         self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
+        self._force_overlap = os.environ.get("IO_COMM_OVERLAP", "1") == "force"     # (as in _OrderBase: one-rank staging)
         self._stages = None
         self._buckets = None
         self._dp_graphs = None
@@ -703,7 +707,7 @@ class _DepthBase(SingleStageModel):
             from . import ops
             ops.WEIGHTS_EPOCH[0] += 1
             return logs, {"loss": loss}
-        if self.world_size > 1 and self._overlap_comm and self.PAIR_MODE:     # (the literal two-call mode keeps the flat exchange)
+        if (self.world_size > 1 or self._force_overlap) and self._overlap_comm and self.PAIR_MODE:     # (the literal two-call mode keeps the flat exchange)
             logs, loss = self._step_overlapped()
             self.optim.step(gathered=True)
             return logs, {"loss": loss}

@@ -99,6 +99,18 @@ def main():
         np.save(os.path.join(out_dir, "paramsD_rank%d.npy" % rank), m.optim.flat_params.cpu().numpy())
         rm = torch.cat([b.reshape(-1) for k, b in m.model.named_buffers() if k.endswith("running_mean")])
         np.save(os.path.join(out_dir, "rmD_rank%d.npy" % rank), rm.cpu().numpy())
+        # E..G: the VALUES of replayed steps, free of the chaos of a randomly initialised net (a 1e-8 perturbation of the
+        # weights moves these tiny-batch BatchNorm gradients by 1e-3): rank 0's initial state again on every rank, lr = 0,
+        # a fresh shard per step -- the caller compares the last step's all-reduced gradient across exchange forms
+        from instaorder_amd import ops
+        m.optim.param_groups[0]["lr"] = 0.0
+        m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd0.items()}, strict=True)
+        ops.WEIGHTS_EPOCH[0] += 1
+        for j in range(3):
+            feed({k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(seed + 300 + 10 * j + rank, B, S).items()})
+            m.step()
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "gradsG_rank%d.npy" % rank), m.optim.flat_grads.cpu().numpy())
         res.update(ok=True, losses=losses, staged_graphs=bool(getattr(m, "_dp_graphs", None)),
                    overlap=bool(m._overlap_comm))
     except Exception:   # noqa: BLE001

@@ -90,3 +90,71 @@ def test_transform_resize_matches_reference_chain():
     flat = np.full((30, 50, 3), 77, np.uint8)              # constant image: cubic weights sum to one (within 1 ulp of fp32)
     out = po.resize_cubic_f64(flat / 255., (64, 32))
     assert np.abs(out - 77 / 255.).max() < 1e-6
+
+
+# ---- a second, independent source for the resize layer (the row stays "parity unpinned": cv2 itself is absent) ------------
+def _torch_resize(img, dsize, mode, dtype):
+    """torch.nn.functional.interpolate of an HxWxC image to (width, height) = dsize -- PyTorch's own implementation of the
+    same published sampling geometry (half-pixel centres: src = (dst + 0.5) * scale - 0.5, border taps clamped, Keys
+    A = -0.75 for bicubic; 'nearest' = floor(dst * scale))."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.from_numpy(np.ascontiguousarray(img)).to(dtype).permute(2, 0, 1)[None]
+    kw = {} if mode == "nearest" else dict(align_corners=False, antialias=False)
+    y = F.interpolate(x, size=(int(dsize[1]), int(dsize[0])), mode=mode, **kw)
+    return y[0].permute(1, 2, 0).numpy()
+
+
+SIZES = [((40, 52), (64, 64)), ((97, 61), (64, 64)), ((256, 256), (64, 64)), ((33, 47), (256, 256)),
+         ((300, 180), (256, 256)), ((480, 640), (384, 384)), ((64, 64), (96, 128))]
+
+
+@pytest.mark.parametrize("src,dst", SIZES)
+def test_resize_against_torch_interpolate(src, dst):
+    """utils/data_utils.py:104-124 / datasets/occ_order_dataset.py:138-180 resize crops with cv2.resize; cv2 is not in this
+    image, so the oracle's restatement of OpenCV's arithmetic is bounded here by a second implementation of the same
+    geometry that IS available: the 8-bit fixed-point paths stay within +-1 LSB of the float result (11-bit coefficients,
+    two roundings), the float64 cubic agrees to float32 coefficient precision, nearest picks the same source pixels."""
+    import torch
+    rng = np.random.RandomState(src[0] * 131 + dst[0])
+    img = rng.randint(0, 256, (src[0], src[1], 3)).astype(np.uint8)
+    # a smooth component too, so that not every pixel is an extremum
+    yy, xx = np.mgrid[0:src[0], 0:src[1]]
+    img[:, :, 1] = (127 + 120 * np.sin(yy / 7.0) * np.cos(xx / 5.0)).astype(np.uint8)
+    dsize = (dst[1], dst[0])
+    near = po.resize(img, dsize, po.INTER_NEAREST)
+    assert np.array_equal(near, _torch_resize(img, dsize, "nearest", torch.float32).astype(np.uint8))
+    lin = po.resize(img, dsize, po.INTER_LINEAR).astype(np.float64)
+    ref = _torch_resize(img, dsize, "bilinear", torch.float64)
+    assert np.abs(lin - ref).max() <= 1.0 + 1e-9, np.abs(lin - ref).max()
+    assert np.abs(lin - ref).mean() < 0.35           # (rounding to 8 bits alone: 0.25)
+    cub = po.resize(img, dsize, po.INTER_CUBIC).astype(np.float64)
+    refc = np.clip(_torch_resize(img, dsize, "bicubic", torch.float64), 0, 255)
+    assert np.abs(cub - refc).max() <= 1.0 + 1e-9, np.abs(cub - refc).max()
+    assert np.abs(cub - refc).mean() < 0.35
+    f64 = po.resize_cubic_f64(img.astype(np.float64) / 255.0, dsize)
+    reff = _torch_resize(img.astype(np.float64) / 255.0, dsize, "bicubic", torch.float64)
+    # OpenCV evaluates the source coordinate and the Keys coefficients in float32 (restated so), PyTorch in double: a
+    # coordinate near 640 carries 3e-5 of rounding, hence the bound (0.03 of an 8-bit step on [0, 1] data)
+    assert np.abs(f64 - reff).max() < 1e-4, np.abs(f64 - reff).max()
+
+
+def test_dataset_item_crops_within_one_lsb_of_float_resize():
+    """The same bound on what the pipeline really resizes: the crops of the dataset-item fixtures' scenes (patch mode,
+    random boxes with padding) at the fixtures' input size."""
+    import torch
+    rd = synthetic.SyntheticReader(77, n_images=3, n_inst=4, max_side=160, min_side=96, empty_every=0)
+    rng = np.random.RandomState(3)
+    worst = 0.0
+    for k in range(3):
+        image = np.asarray(rd.load_image("scene%d" % k))
+        H, W = image.shape[:2]
+        for _ in range(6):
+            w, h = int(rng.randint(20, W)), int(rng.randint(20, H))
+            x, y = int(rng.randint(-w // 3, W - w // 2)), int(rng.randint(-h // 3, H - h // 2))
+            crop = po.crop_padding(image, (x, y, w, h))
+            for it, mode in ((po.INTER_LINEAR, "bilinear"), (po.INTER_CUBIC, "bicubic")):
+                got = po.resize(crop, (64, 64), it).astype(np.float64)
+                ref = np.clip(_torch_resize(crop, (64, 64), mode, torch.float64), 0, 255)
+                worst = max(worst, float(np.abs(got - ref).max()))
+    assert worst <= 1.0 + 1e-9, worst

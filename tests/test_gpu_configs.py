@@ -213,24 +213,63 @@ def test_two_ranks_depthnet_step(tmp_path):
     f0, f1 = np.load(b / "paramsD_rank0.npy"), np.load(b / "paramsD_rank1.npy")
     assert np.array_equal(f0, f1)
     assert not np.array_equal(np.load(a / "paramsA_rank0.npy"), np.load(a / "paramsD_rank0.npy"))
+    # the VALUES of the captured / replayed staged steps (a stale slice or a wrong unpack range would be the same on both
+    # ranks and pass every rank-against-rank check above): steps E..G of the worker -- replays from rank 0's initial state
+    # with lr = 0 -- leave the same all-reduced gradient whatever the exchange form, and the staged form run eagerly
+    # (IO_NO_GRAPH=1) launches the same kernels in the same order as the stage graphs
+    gG, fG = np.load(a / "gradsG_rank0.npy").astype(np.float64), np.load(b / "gradsG_rank0.npy").astype(np.float64)
+    assert np.array_equal(np.load(a / "gradsG_rank0.npy"), np.load(a / "gradsG_rank1.npy"))
+    assert np.sqrt(((gG - fG) ** 2).sum()) <= 1e-5 * np.sqrt((fG ** 2).sum()), "staged graph replays vs flat exchange"
+    c = tmp_path / "staged_eager"
+    res_e = _run_two_ranks(str(c), {"IO_NO_GRAPH": "1"}, worker="dp_worker_depth.py")
+    assert res_e[0]["overlap"] and not res_e[0]["staged_graphs"]
+    eG = np.load(c / "gradsG_rank0.npy").astype(np.float64)
+    assert np.sqrt(((gG - eG) ** 2).sum()) <= 1e-6 * np.sqrt((eG ** 2).sum()), "graph replay vs eager staging"
 
 
-# ---- configs[4]: InstaDepthNet_od at 384 x 384 -----------------------------------------------------------------
-W4 = dict(overlap_weight=0.1, distinct_weight=0.9, dorder_weight=1.0, smooth_weight=0.1, occ_order_weight=1.0)
-
-
-def _depthnet(dtype, S, B, seed=11):
-    import instaorder_amd as ia
-    g = np.load(os.path.join(GOLDEN, "depthnet_od_S64_B2.npz"), allow_pickle=False)
-    spec = [(str(k), tuple(int(d) for d in str(s).split(",") if d), (str(a) or None))
-            for k, s, a in zip(g["keys"], g["shapes"], g["aliases"])]
-    cfg = dict(algo="InstaDepthNet_od", lr=1e-5, weight_decay=1e-4, optim="SGD", pretrained_weight=None, use_rgb=True,
-               dtype=dtype, **W4)
-    m = ia.InstaDepthNet_od(cfg, dist_model=False)
-    sd = synthetic.make_spec_state_dict(seed, spec, prefix="module.")
-    m.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
-    batch = synthetic.make_depth_batch(seed + 100, B, S)
-    return m, sd, batch
+def test_depthnet_staged_overlap_path_on_one_nccl_rank(monkeypatch):
+    """_DepthBase._step_overlapped -- the MiDaS step's backward in four autograd stages, one hipGraph per stage, RCCL's
+    asynchronous all-reduce of each stage's slice of the flat gradient buffer between the replays -- on ONE nccl rank
+    (IO_COMM_OVERLAP=force): eager step, capture, two replays, against the flat path (no staging: one backward, one
+    graph) at the summation-order bar of the two-rank test, and bit for bit against the staged form run eagerly."""
+    import socket
+    import torch.distributed as dist
+    from instaorder_amd import distributed_utils as du
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    du.dist_init_("pytorch", backend="nccl")
+    try:
+        res = {}
+        for tag, env in (("staged", {"IO_COMM_OVERLAP": "force"}), ("flat", {"IO_COMM_OVERLAP": "0"}),
+                         ("staged_eager", {"IO_COMM_OVERLAP": "force", "IO_NO_GRAPH": "1"})):
+            for k in ("IO_COMM_OVERLAP", "IO_NO_GRAPH"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m, sd, _ = _depthnet("fp32", 64, 2)
+            # lr = 0: every step starts from the same weights, so the forms are compared on what a step COMPUTES (with an
+            # update in between, the tiny-batch BatchNorms of this random net turn a 1e-8 weight perturbation into 1e-3 of
+            # gradient: tools/depth_staged_check.py with CHECK_LR=1e-3)
+            m.optim.param_groups[0]["lr"] = 0.0
+            m.switch_to("train")
+            grads, losses = [], []
+            for i in range(5):                                   # eager, capture + replay, three more replays
+                t = {k: torch.from_numpy(v.copy()) for k, v in synthetic.make_depth_batch(500 + i, 2, 64).items()}
+                m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+                losses.append(float(m.step()[1]["loss"]))
+                torch.cuda.synchronize()
+                grads.append(m.optim.flat_grads.clone())
+            res[tag] = (losses, grads, bool(m._dp_graphs))
+        assert res["staged"][2] and not res["flat"][2] and not res["staged_eager"][2]
+        for i in range(5):
+            a, e, b = res["staged"][1][i].double(), res["staged_eager"][1][i].double(), res["flat"][1][i].double()
+            assert float((a - e).norm()) <= 1e-6 * float(e.norm()), ("graph replay vs eager staging", i)
+            assert float((a - b).norm()) <= 1e-5 * float(b.norm()), ("staged vs flat", i)
+        assert np.allclose(res["staged"][0], res["flat"][0], rtol=1e-5)
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

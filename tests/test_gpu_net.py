@@ -463,9 +463,61 @@ def test_properties_larger_batch():
     net._pool.give(ws)
 
 
+def test_generic_autograd_path_is_wired_like_the_fused_step():
+    """The STRICT wiring check between the generic autograd path (model(x) in train mode + loss.backward() through the
+    reference's own loss expression) and the fused step(): with the Winograd row forms switched off (engine.set_winograd)
+    both paths run the direct kernels, whose sums do not depend on the rows per launch -- every gradient tensor, BN betas
+    and the fc bias included, agrees to 1e-4 of its own norm.  (With the forms on the two paths take different product
+    forms per layer: the conditioning-aware bar of the test below.)"""
+    from instaorder_amd import engine
+    algo = "InstaOrderNet_od"
+    B, S = 4, 64
+    batch = synthetic.make_pair_batch(951, B, S)
+    prev = engine.set_winograd(False)
+    try:
+        m = build(algo, 54, "kaiming")
+        m.switch_to("train")
+        m.optim.param_groups[0]["lr"] = 0.0
+        set_input(m, algo, batch)
+        m.step()
+        m2 = build(algo, 54, "kaiming")
+        m2.switch_to("train")
+        t = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+        F = torch.nn.functional
+        tot = 0
+        for ma, mb, flip in ((t["modal1"], t["modal2"], False), (t["modal2"], t["modal1"], True)):
+            occ, dep = m2.model(torch.cat([ma, mb, t["rgb"]], 1))
+            y = t["occ_order"][:, [1, 0]] if flip else t["occ_order"]
+            d = t["depth_order"]
+            if flip:
+                d = torch.where(d == 2, d, 1 - d)
+            pd = torch.softmax(dep, 1)
+            ov = t["is_overlap"] == 1
+            tot = tot + F.binary_cross_entropy(torch.sigmoid(occ), y)
+            # supervised_order.py:62-73: CE on the probabilities, per overlap subset, weights 0.1 / 0.9
+            if bool(ov.any()):
+                tot = tot + 0.1 * F.cross_entropy(pd[ov], d[ov])
+            di = t["is_overlap"] == 0
+            if bool(di.any()):
+                tot = tot + 0.9 * F.cross_entropy(pd[di], d[di])
+        tot.backward()
+    finally:
+        engine.set_winograd(prev)
+    worst = (0.0, None)
+    for (tinfo, p), gv in zip(m2.net._param_list, m.net._grad_views):
+        a, b = p.grad.double().cpu().numpy(), gv.double().cpu().numpy()
+        assert np.sqrt((b * b).sum()) > 0, tinfo
+        e = np.sqrt(((a - b) ** 2).sum()) / np.sqrt((b * b).sum())
+        if e > worst[0]:
+            worst = (e, tinfo)
+    print("generic vs fused, direct kernels: worst per-tensor relative L2 %.2e" % worst[0])
+    assert worst[0] < 1e-4, worst
+
+
 def test_generic_autograd_path_matches_fused_step():
     """model(x) in train mode carries autograd history: loss.backward() through the reference's own
-    loss expression gives the same gradients as the fused step()."""
+    loss expression gives the same gradients as the fused step() -- here with the Winograd forms ON (the extra check;
+    the strict one is test_generic_autograd_path_is_wired_like_the_fused_step)."""
     algo = "InstaOrderNet_o"
     B, S = 4, 64
     batch = synthetic.make_pair_batch(950, B, S)
@@ -556,6 +608,58 @@ def test_nccl_single_rank_dp_path():
             tot = du.reduce_tensors(out["loss"])
             res.append((float(tot), m.net.flat_params.clone()))
         assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
+def _nccl_one_rank():
+    import os
+    import socket
+    from instaorder_amd import distributed_utils as du
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    du.dist_init_("pytorch", backend="nccl")
+
+
+def test_nccl_staged_overlap_path_on_one_rank(monkeypatch):
+    """The data-parallel step as N > 1 ranks run it -- forward + loss + backward stage 0 in one hipGraph, stages 1..3 in
+    one each, ProcessGroupNCCL's (= RCCL's) asynchronous all-reduce of every stage bucket launched between the replays
+    (supervised_order._step_overlapped, distributed_utils.GradientBuckets; reference: utils/distributed_utils.py:27-37,
+    main.py:35) -- driven on ONE rank (IO_COMM_OVERLAP=force): eager step, capture, two replays.  A SUM over one rank is
+    the identity, so losses and weights must equal the flat path (IO_COMM_OVERLAP=0: one graph, one all-reduce after the
+    backward) bit for bit; what this pins is RCCL's stream hand-over around per-stage graph replays, which no gloo run
+    sees.  The eager staged form (IO_NO_GRAPH=1) is held to the same."""
+    import torch.distributed as dist
+    import instaorder_amd as ia
+    algo = "InstaOrderNet_od"
+    _nccl_one_rank()
+    try:
+        batches = [synthetic.make_pair_batch(975 + i, 6, 64) for i in range(4)]
+        res = {}
+        for tag, env in (("staged", {"IO_COMM_OVERLAP": "force"}), ("flat", {"IO_COMM_OVERLAP": "0"}),
+                         ("staged_eager", {"IO_COMM_OVERLAP": "force", "IO_NO_GRAPH": "1"})):
+            for k in ("IO_COMM_OVERLAP", "IO_NO_GRAPH"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m = getattr(ia, algo)(cfg_for(algo), dist_model=True)
+            sd = synthetic.make_state_dict(72, 5, [2, 3], prefix="module.", style="kaiming")
+            m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+            m.switch_to("train")
+            losses = []
+            for b in batches:           # the wrapper keys its graphs on the input buffer: same shapes -> step 2 captures
+                set_input(m, algo, b)
+                losses.append(float(m.step()[1]["loss"]))
+            torch.cuda.synchronize()
+            res[tag] = (losses, m.net.flat_params.clone(), None, bool(m._dp_graphs), bool(m._graph))
+        assert res["staged"][3] and not res["staged"][4], "the staged run must have replayed per-stage graphs"
+        assert res["flat"][4] and not res["flat"][3]
+        assert not res["staged_eager"][3] and not res["staged_eager"][4]
+        for tag in ("staged", "staged_eager"):
+            assert res[tag][0] == res["flat"][0], (tag, res[tag][0], res["flat"][0])
+            assert torch.equal(res[tag][1], res["flat"][1]), tag
     finally:
         dist.destroy_process_group()
 

@@ -1,0 +1,340 @@
+// What does the bf16 NT GEMM of the step (C[M][N] = A[M][K] * B[N][K]^T, bf16 in / out, fp32 accumulate) reach on the layer
+// shapes of the bench batch when both operands go global -> LDS by LDS-DMA (buffer_load ... lds, no staging registers, no
+// ds_write pass) into an XOR-swizzled image, with STAGES k-tiles in flight and ONE barrier per k-tile -- against the
+// register-staged single-buffer structure the library's conv_nt_kernel has (variant "lib": 128 x 128 x 64, 4 waves of 64 x 64,
+// 3 blocks per CU)?  Tile / wave-tile / stage count are template parameters; every variant is checked against a naive kernel.
+// usage: ./bf16_dma_probe [shape-index]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+__device__ __forceinline__ u32x4 dma_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000u};
+    return r;
+}
+// 16 bytes per lane from descriptor rs at voff (per lane) + soff (uniform) to LDS byte address lds_addr + 16 * lane
+__device__ __forceinline__ void dma16(u32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the count");
+}
+
+// BM x BN x 64 block tile, WM x WN waves of (BM / WM) x (BN / WN), STAGES LDS stages of (BM + BN) rows x 128 bytes.
+// LDS image: row r of an operand tile at r * 128; its 16-byte k-chunk c sits in slot c ^ ((r >> 1) & 7) -- the 16 rows a
+// ds_read_b128 lane group touches (distinct mod 16) land in 16 distinct bank quads.  A DMA instruction fills 8 rows (1 KiB):
+// lane i fetches the chunk that belongs in slot i & 7 of row i >> 3.
+template <int BM, int BN, int WM, int WN, int STAGES, int MINB, bool EPROWS = true>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_dma(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                              bf16_t* __restrict__ C, int M, int N, int K) {
+    constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 128, CH = (BM + BN) / 8, CPW = CH / NW, CHA = BM / 8;
+    static_assert(CH % NW == 0, "chunks per wave");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / ntn, m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+    const int nk = K / 64;
+    const u32x4 rsA = dma_rsrc(A + (size_t)m0 * K, (size_t)BM * K * 2);
+    const u32x4 rsB = dma_rsrc(B + (size_t)n0 * K, (size_t)BN * K * 2);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // lane part of a fetch: in-chunk row r, slot p -> k-chunk p ^ (r >> 1) ^ (4 if the chunk index is odd)
+    const int r8 = lane >> 3, p8 = lane & 7;
+    const unsigned v_even = (unsigned)(r8 * K * 2 + ((p8 ^ (r8 >> 1)) << 4));
+    const unsigned v_odd = v_even ^ 64u;
+    auto issue = [&](int kt, int stage) {
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+        const unsigned koff = (unsigned)kt * 128u;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const int ch = wave * CPW + u;                  // wave-uniform
+            if (ch < CHA) dma16(rsA, sb + (unsigned)(ch * 1024), (ch & 1) ? v_odd : v_even, koff + (unsigned)(ch * 8 * K * 2));
+            else dma16(rsB, sb + (unsigned)(ch * 1024), ((ch - CHA) & 1) ? v_odd : v_even, koff + (unsigned)((ch - CHA) * 8 * K * 2));
+        }
+    };
+    // fragment reads: lane l reads row (l & 31) of a 32-row tile, k-chunk 2 kk + (l >> 5), i.e. slot that ^ ((l >> 1) & 7)
+    const int swz = (lane >> 1) & 7;
+    unsigned ko[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ko[kk] = (unsigned)(((2 * kk + (lane >> 5)) ^ swz) << 4);
+    const unsigned a_row = (unsigned)((wm * TM * 32 + (lane & 31)) * 128);
+    const unsigned b_row = (unsigned)(BM * 128 + (wn * TN * 32 + (lane & 31)) * 128);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed when at most the younger groups are outstanding
+        if (STAGES > 2 && kt + STAGES - 2 < nk) vm_wait<CPW*(STAGES > 2 ? STAGES - 2 : 0)>();
+        else vm_wait<0>();
+        __syncthreads();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const char* sb = smem + (kt % STAGES) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + a_row + i * 4096 + ko[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + j * 4096 + ko[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: each wave turns its tile through its own LDS slice, 32 rows at a time, out as 16-byte row pieces
+    __syncthreads();
+    constexpr int JG = TN >= 2 ? 2 : 1, WC = JG * 32, EPP = WC + 4;     // column groups of (up to) 64 go through the slice
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPP);
+    static_assert(NW * 32 * EPP * 4 <= STAGES * STAGE, "epilogue slice");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jg = 0; jg < TN / JG; ++jg) {
+#pragma unroll
+            for (int j = 0; j < JG; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][jg * JG + j][r];
+            constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = 32 / RPI;      // lanes per row, rows per instruction
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 8;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc + 4);
+                const u32x4 pk = {f2bf2(q0[0], q0[1]), f2bf2(q0[2], q0[3]), f2bf2(q1[0], q1[1]), f2bf2(q1[2], q1[3])};
+                *reinterpret_cast<u32x4*>(C + (size_t)(m0 + wm * TM * 32 + i * 32 + row) * N + n0 + wn * TN * 32 + jg * WC + cc) = pk;
+            }
+        }
+    }
+}
+
+// the library's structure (tools/bf16_depth_probe.hip, depth 1): register staging, one LDS buffer, two barriers per k-tile
+constexpr int P = 72;
+template <int MINB, int TI, int TJ>
+__global__ __launch_bounds__(256, MINB) void gemm_lib(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                      bf16_t* __restrict__ C, int M, int N, int K) {
+    constexpr int BM = 64 * TI, BN = 64 * TJ, AR = BM / 32, BR = BN / 32, BK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_);
+    bf16_t* sB = sA + BM * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / BN, tile = xcd_remap(blockIdx.x, gridDim.x), mt = tile / ntn, m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+    const int lr = tid >> 3, kq = tid & 7;
+    u32x4 ra[AR], rb[BR];
+    const int nk = K / BK;
+    auto load = [&](int kt) {
+        const int k0 = (kt < nk ? kt : 0) * BK;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) ra[j] = *reinterpret_cast<const u32x4*>(A + (size_t)(m0 + lr + 32 * j) * K + k0 + kq * 8);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const u32x4*>(B + (size_t)(n0 + lr + 32 * j) * K + k0 + kq * 8);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(sA + (lr + 32 * j) * P + kq * 8) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(sB + (lr + 32 * j) * P + kq * 8) = rb[j];
+    };
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_off = (wm * 32 * TI + (lane & 31)) * P + (lane >> 5) * 8, b_off = (wn * 32 * TJ + (lane & 31)) * P + (lane >> 5) * 8;
+    load(0);
+    store();
+    __syncthreads();
+    load(1);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sA + a_off + i * 32 * P + s * 16);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + b_off + j * 32 * P + s * 16);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        store();
+        __syncthreads();
+        load(kt + 2);
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                C[(size_t)row * N + n0 + wn * 32 * TJ + j * 32 + (lane & 31)] = (bf16_t)(f2bf2(acc[i][j][r], 0.f) & 0xffffu);
+            }
+}
+
+__global__ void fill(bf16_t* p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned s = (unsigned)i * 2654435761u + seed;
+        s ^= s >> 13; s *= 1274126177u; s ^= s >> 16;
+        const float v = (float)(s & 0xffff) / 65536.0f - 0.5f;
+        p[i] = (bf16_t)(__builtin_bit_cast(unsigned, v) >> 16);
+    }
+}
+// reference: 4096 sampled entries of C in fp32
+__global__ void ref_samples(const bf16_t* A, const bf16_t* B, int M, int N, int K, float* out, int ns) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= ns) return;
+    const unsigned h = (unsigned)s * 2654435761u;
+    const int m = (int)(h % (unsigned)M), n = (int)((h >> 7) % (unsigned)N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k)
+        acc += __builtin_bit_cast(float, (unsigned)A[(size_t)m * K + k] << 16) * __builtin_bit_cast(float, (unsigned)B[(size_t)n * K + k] << 16);
+    out[s] = acc;
+}
+__global__ void cmp_samples(const bf16_t* C, int M, int N, const float* ref, int ns, float* maxerr) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= ns) return;
+    const unsigned h = (unsigned)s * 2654435761u;
+    const int m = (int)(h % (unsigned)M), n = (int)((h >> 7) % (unsigned)N);
+    const float got = __builtin_bit_cast(float, (unsigned)C[(size_t)m * N + n] << 16);
+    const float e = fabsf(got - ref[s]) / (fabsf(ref[s]) + 0.05f);
+    atomicMax(reinterpret_cast<int*>(maxerr), __builtin_bit_cast(int, e));
+}
+
+template <typename F> double time_ms(F launch) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 8; ++i) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms / 8 < best ? ms / 8 : best;
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    // (M, N, K) of the step's GEMMs at 256 pairs (512 samples): layer 1..4 x {conv1, conv3, conv2 as a GEMM}
+    const int shapes[][3] = {{2097152, 64, 256},  {2097152, 256, 64},  {2097152, 64, 576},
+                             {524288, 128, 512},  {524288, 512, 128},  {524288, 128, 1152},
+                             {131072, 256, 1024}, {131072, 1024, 256}, {131072, 256, 2304},
+                             {32768, 512, 2048},  {32768, 2048, 512},  {32768, 512, 4608}};
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    const int NS = 4096;
+    float *dref, *derr;
+    CK(hipMalloc(&dref, NS * 4)); CK(hipMalloc(&derr, 4));
+    for (int si = 0; si < 12; ++si) {
+        if (only >= 0 && si != only) continue;
+        const int M = shapes[si][0], N = shapes[si][1], K = shapes[si][2];
+        const int NR = 3;
+        bf16_t *dA[NR], *dC[NR], *dB;
+        for (int r = 0; r < NR; ++r) {
+            CK(hipMalloc(&dA[r], (size_t)M * K * 2)); CK(hipMalloc(&dC[r], (size_t)M * N * 2));
+            hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, dA[r], (size_t)M * K, 17u);
+        }
+        CK(hipMalloc(&dB, (size_t)N * K * 2));
+        hipLaunchKernelGGL(fill, dim3(256), dim3(256), 0, 0, dB, (size_t)N * K, 99u);
+        hipLaunchKernelGGL(ref_samples, dim3(NS / 64), dim3(64), 0, 0, dA[0], dB, M, N, K, dref, NS);
+        const double flop = 2.0 * M * N * K, bytes = 2.0 * ((double)M * K + (double)M * N + (double)N * K);
+        printf("M=%7d N=%5d K=%5d  (roofs: %.3f ms at 2.4 PF/s, %.3f ms at 5.9 TB/s)\n", M, N, K, flop / 2.4e12, bytes / 5.9e9);
+        int rot = 0;
+        auto report = [&](const char* name, double ms) {
+            CK(hipMemset(derr, 0, 4));
+            hipLaunchKernelGGL(cmp_samples, dim3(NS / 64), dim3(64), 0, 0, dC[(rot - 1) % NR], M, N, dref, NS, derr);
+            float e; CK(hipMemcpy(&e, derr, 4, hipMemcpyDeviceToHost));
+            printf("   %-34s %7.3f ms %6.0f TF/s %5.2f TB/s  err %.1e %s\n", name, ms, flop / ms / 1e9, bytes / ms / 1e9, e, e < 2e-2 ? "" : "WRONG");
+        };
+#define RUN_DMA(BM_, BN_, WM_, WN_, ST_, MB_)                                                                               \
+        if (M % BM_ == 0 && N % BN_ == 0) {                                                                                  \
+            const size_t lds = (size_t)ST_ * (BM_ + BN_) * 128;                                                              \
+            auto kfn = gemm_dma<BM_, BN_, WM_, WN_, ST_, MB_>;                                                               \
+            CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            const dim3 grid((M / BM_) * (N / BN_));                                                                          \
+            for (int r = 0; r < NR; ++r) CK(hipMemsetAsync(dC[r], 0, (size_t)M * N * 2));                                    \
+            double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
+            report("dma " #BM_ "x" #BN_ " waves " #WM_ "x" #WN_ " stages " #ST_ " minb " #MB_, ms);                           \
+        }
+#define RUN_LIB(MB_, TI_, TJ_)                                                                                              \
+        if (M % (64 * TI_) == 0 && N % (64 * TJ_) == 0) {                                                                    \
+            const size_t lds = (size_t)(64 * TI_ + 64 * TJ_) * P * 2;                                                        \
+            auto kfn = gemm_lib<MB_, TI_, TJ_>;                                                                              \
+            CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            const dim3 grid((M / (64 * TI_)) * (N / (64 * TJ_)));                                                            \
+            double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(256), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
+            report("lib " #TI_ "x" #TJ_ " tiles/wave minb " #MB_, ms);                                                       \
+        }
+        RUN_LIB(3, 2, 2)
+        RUN_LIB(3, 2, 1)
+        RUN_DMA(128, 128, 2, 2, 2, 2)
+        RUN_DMA(128, 128, 2, 2, 3, 1)
+        RUN_DMA(128, 64, 2, 2, 2, 3)
+        RUN_DMA(128, 64, 2, 2, 3, 2)
+        RUN_DMA(256, 64, 4, 1, 2, 2)
+        RUN_DMA(256, 64, 4, 1, 3, 1)
+        RUN_DMA(256, 128, 2, 2, 2, 1)
+        RUN_DMA(256, 128, 2, 2, 3, 1)
+        RUN_DMA(128, 256, 2, 2, 2, 1)
+        RUN_DMA(128, 256, 2, 2, 3, 1)
+        RUN_DMA(256, 128, 4, 2, 2, 1)
+        RUN_DMA(256, 128, 4, 2, 3, 1)
+        RUN_DMA(256, 256, 2, 4, 2, 1)
+        RUN_DMA(256, 256, 4, 2, 2, 1)
+        for (int r = 0; r < NR; ++r) { CK(hipFree(dA[r])); CK(hipFree(dC[r])); }
+        CK(hipFree(dB));
+        fflush(stdout);
+    }
+    return 0;
+}
