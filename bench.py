@@ -188,6 +188,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    elif os.environ.get("IO_COMM_OVERLAP") == "force":
+        # the staged data-parallel step on ONE rank (per-stage hipGraphs + the backend's all-reduce of every stage bucket):
+        # what a rank of an N-GPU job executes, minus the wire
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=0, world_size=1)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     B, S = args.batch, args.size

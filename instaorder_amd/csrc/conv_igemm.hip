@@ -2933,7 +2933,16 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const size_t in_bytes = (size_t)es * g.N * g.Hi * g.Wi * g.Ci;
     const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
     const unsigned w_bytes = (unsigned)w_b;
-    const int bn = g.gw ? g.gw : ((g.Co % 128 == 0) ? 128 : 64);
+    // Output-channel tile: 128 wide where that leaves enough tiles to fill the chip, 64 wide otherwise -- a small per-GPU batch
+    // (the reference's own 32 pairs per GPU, or a strong-scaling rank) gives layers 3-4 only 32..128 row tiles, and 128-wide
+    // tiles then occupy a fraction of the 256 CUs with one block each (measured at 32 pairs: 43-51 TF/s on the 8 x 8 maps).
+    static int small_tiles = -1;
+    if (small_tiles < 0) {
+        const char* e = getenv("IO_NT_SMALL_TILES");        // (experiments: the largest 128-wide tile count that still goes 64 wide)
+        small_tiles = e ? atoi(e) : 0;
+    }
+    const long tiles128 = (long)io_cdiv(M, 128) * (g.Co / 128);
+    const int bn = g.gw ? g.gw : ((g.Co % 128 == 0 && tiles128 > small_tiles) ? 128 : 64);
     IO_REQUIRE(!g.gw || (g.gw == 64 && !stem && g.Ci == g.Co), IO_ERR_SHAPE,
                "conv_nt: grouped mode needs a 64-channel window and Ci == Co");
     const int ntn = g.Co / bn;

@@ -22,7 +22,6 @@ from . import common_utils, ops
 import os
 
 __all__ = ["InstaDepthNet_od", "InstaDepthNet_d"]
-MULTI_STREAM = os.environ.get("IO_DEPTH_STREAMS", "1") != "0"      # IO_DEPTH_STREAMS=0: everything on one stream
 
 
 class Conv2d(nn.Module):
@@ -228,6 +227,8 @@ class _InstaDepthBase(nn.Module):
         for i in (4, 3, 2, 1):
             setattr(self.scratch, "refinenet%d" % i, FeatureFusionBlock(features))
         self.non_negative = non_negative
+        # IO_DEPTH_STREAMS=0: everything on one stream (read per model, so a test can build both forms in one process)
+        self.multi_stream = os.environ.get("IO_DEPTH_STREAMS", "1") != "0"
         self.dtype = "fp32"       # 'bf16': activations / GEMM operands in bf16 (set by SingleStageModel from params['dtype'])
         self.scratch.output_conv = nn.Sequential(                              # midas_net.py:134-141
             Conv2d(features, 128, 3, 1, 1, bias=True),
@@ -256,9 +257,9 @@ class _InstaDepthBase(nn.Module):
 
     def _order_branch(self, net, fc, x8m, l1, l2, l3):
         f1 = net.run_layer1(x8m)
-        f2 = net.layer2(ops.add(f1, l1))
-        f3 = net.layer3(ops.add(f2, l2))
-        f4 = net.layer4(ops.add(f3, l3))
+        f2 = net.layer2(ops.add_shared(f1, l1))       # (l1..l3 feed both branches and the decoder: see ops._AddShared)
+        f3 = net.layer3(ops.add_shared(f2, l2))
+        f4 = net.layer4(ops.add_shared(f3, l3))
         return ops.avgpool_fc(f4, fc.weight, fc.bias)
 
     def _encode(self, img):
@@ -309,12 +310,14 @@ class _InstaDepthBase(nn.Module):
     # CUs.  IO_DEPTH_STREAMS=1: the branches run on side streams next to the decoder (fork after the encoder, join before
     # the losses); autograd runs each backward node on its forward stream, so the backward pass overlaps the same way, and
     # a hipGraph capture records the fork / join as parallel branches of the graph.  Same kernels, same arithmetic.
-    _side = None
+    _side = {}           # device index -> side streams (shared by every model on that device)
 
     def _side_streams(self, n):
-        if _InstaDepthBase._side is None or len(_InstaDepthBase._side) < n:
-            _InstaDepthBase._side = [torch.cuda.Stream() for _ in range(n)]
-        return _InstaDepthBase._side[:n]
+        dev = torch.cuda.current_device()
+        cur = _InstaDepthBase._side.get(dev)
+        if cur is None or len(cur) < n:
+            cur = _InstaDepthBase._side[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        return cur[:n]
 
     def _fork_join(self, jobs, main_job, shared=()):
         """jobs: callables for the side streams; main_job runs on the current stream.  Returns ([side results], main result).
@@ -327,17 +330,26 @@ class _InstaDepthBase(nn.Module):
         for t in shared:
             for st in sides:
                 t.record_stream(st)
+        dbg = int(os.environ.get("IO_DEPTH_SYNC", "0"))      # bisecting aid (tools/depth_eager_race.py): full device syncs
+        if dbg & 1:
+            torch.cuda.synchronize()
         ev = torch.cuda.Event()
         ev.record(main)
         out = []
-        for st, job in zip(sides, jobs):
-            st.wait_event(ev)
-            with torch.cuda.stream(st):
-                out.append(job())
-        res = main_job()
-        for st in sides:
-            main.wait_stream(st)
-        self._forked = len(sides)
+        try:
+            for st, job in zip(sides, jobs):
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    out.append(job())
+            res = main_job()
+        finally:
+            # always joined, also when a job raised: a side stream left un-joined would leave a stream capture open-ended
+            for st in sides:
+                main.wait_stream(st)
+            if dbg & 2:
+                torch.cuda.synchronize()
+        # only a forward that recorded a tape has a backward whose side-stream tail must be joined later
+        self._forked = len(sides) if torch.is_grad_enabled() else 0
         return out, res
 
     _forked = 0
@@ -350,8 +362,10 @@ class _InstaDepthBase(nn.Module):
         caller enqueues next (WeightPlan.unpack_grads, the optimiser).  Legal under hipGraph capture: the side streams
         joined this capture at the fork."""
         if self._forked:
+            if int(os.environ.get("IO_DEPTH_SYNC", "0")) & 4:
+                torch.cuda.synchronize()
             main = torch.cuda.current_stream()
-            for st in (_InstaDepthBase._side or [])[:self._forked]:
+            for st in (_InstaDepthBase._side.get(torch.cuda.current_device()) or [])[:self._forked]:
                 main.wait_stream(st)
             self._forked = 0
 
@@ -390,7 +404,7 @@ class InstaDepthNet_od(_InstaDepthBase):
         call (mask1, mask2), rows [B,2B) = call (mask2, mask1).  Same values, gradients and running statistics as the
         two separate calls."""
         with _Counters():
-            if MULTI_STREAM and img.is_cuda:
+            if self.multi_stream and img.is_cuda:
                 with _BnMode(repeat=2):
                     e1, e2, e3, e4 = self._encode(img)
                 x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, (e1, e2, e3), self._act_dtype())
@@ -436,7 +450,7 @@ class InstaDepthNet_d(_InstaDepthBase):
     def forward_pair(self, img, mask1, mask2):
         """See InstaDepthNet_od.forward_pair."""
         with _Counters():
-            if MULTI_STREAM and img.is_cuda:          # the order branch on a side stream next to the decoder (see _fork_join)
+            if self.multi_stream and img.is_cuda:          # the order branch on a side stream next to the decoder (see _fork_join)
                 with _BnMode(repeat=2):
                     e1, e2, e3, e4 = self._encode(img)
                 x8m, (l1, l2, l3) = _pair_inputs(mask1, mask2, (e1, e2, e3), self._act_dtype())

@@ -693,6 +693,33 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _AddShared(torch.autograd.Function):
+    """a + b where b is a tensor OTHER STREAMS consume too (the encoder features injected into an order branch that runs on a
+    side stream, midas/midas_net.py:190-197).  The backward hands b its OWN copy of the gradient.  With `return dy, dy`
+    (what _Add does, and torch's own AddBackward) the branch's next backward node and the node behind b -- on the main
+    stream, where the contributions of both order branches meet in one autograd input buffer -- hold the SAME tensor; the
+    engine accumulates the second contribution IN PLACE as soon as nobody else references the first (use_count == 1), and
+    kernels of the branch that are still queued on the side stream hold no reference: they then read a gradient that
+    already contains the other branch's.  Found in round 5 (two processes sharing a GPU: one branch's layers below the
+    injection point and the encoder stage under it got gradients 10 % off, run to run; tools/depth_eager_race.py)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, "a")
+        _chk(b, "b")
+        out = torch.empty_like(a)
+        _lib.check(_L().io_add(_p(a), _p(b), a.numel(), _p(out), _dt(a), _st()), "io_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy.clone()
+
+
+def add_shared(a, b):
+    return _AddShared.apply(a, b)
+
+
 class _Head1(torch.autograd.Function):
     """nn.Conv2d(C, 1, 1) [+ nn.ReLU] on an input that may carry padding channels (midas_net.py:139-140)."""
 

@@ -678,6 +678,17 @@ class _DepthBase(SingleStageModel):
             logs, loss = self._dp_out
             return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logs.items()}, loss.clone()
         # eager (first step of a shape, profiling, graphs disabled)
+        out = self._staged_fwd_bwd(bk.launch)
+        bk.finish()
+        self._seen_key = key
+        return out
+
+    def _staged_fwd_bwd(self, on_stage=None):
+        """One pass of ``_staged_steps`` with the filter plan prepared / recorded around it; ``on_stage(si)`` is called as
+        soon as stage si's slice of the flat gradient buffer is final (the data-parallel step launches its all-reduce)."""
+        from . import ops
+        plan = self._wplan if (self._wplan and self.PAIR_MODE and self._wplan.dtype == self.net._act_dtype()) else None
+        recording = self._wplan is None and self.PAIR_MODE and hasattr(self.optim, "_spans")
         if recording:
             ops.WeightPlan.start_recording()
         if plan is not None:
@@ -685,14 +696,13 @@ class _DepthBase(SingleStageModel):
         ops.WeightPlan.active = plan
         try:
             for si in self._staged_steps(plan):
-                bk.launch(si)
+                if on_stage is not None:
+                    on_stage(si)
         finally:
             ops.WeightPlan.active = None
             recs = ops.WeightPlan.stop_recording() if recording else None
-        bk.finish()
         if recording:
             self._wplan = ops.WeightPlan(self.optim, recs, self.net._act_dtype()) if recs else False
-        self._seen_key = key
         return self._staged_out
 
     def step(self):
@@ -707,7 +717,10 @@ class _DepthBase(SingleStageModel):
             from . import ops
             ops.WEIGHTS_EPOCH[0] += 1
             return logs, {"loss": loss}
-        if (self.world_size > 1 or self._force_overlap) and self._overlap_comm and self.PAIR_MODE:     # (the literal two-call mode keeps the flat exchange)
+        # world_size > 1: the backward in four stages, each stage's slice of the flat gradient buffer all-reduced as soon as
+        # the stage is enqueued, one hipGraph per stage (the literal two-call mode keeps the flat exchange)
+        staged = self.PAIR_MODE and (self.world_size > 1 or self._force_overlap) and self._overlap_comm
+        if staged:
             logs, loss = self._step_overlapped()
             self.optim.step(gathered=True)
             return logs, {"loss": loss}

@@ -76,13 +76,18 @@ def main():
         idx = (np.arange(64, dtype=np.int64) * 2654435761)
         num = den = 0.0
         bad = 0
-        for (off, k), ref_norm, ref_s in zip(m.optim._spans, g["grad_norms"], g["grad_samples"]):
+        pnames = {id(p): n for n, p in m.net.named_parameters()}
+        bad_names = []
+        for (off, k), ref_norm, ref_s, prm in zip(m.optim._spans, g["grad_norms"], g["grad_samples"], m.optim._params):
             gr = m.optim.flat_grads[off:off + k].double().cpu().numpy()
             got = float(np.sqrt((gr * gr).sum()))
-            bad += int(ref_norm > 1e-6 and abs(got - ref_norm) > 0.1 * ref_norm)
+            if ref_norm > 1e-6 and abs(got - ref_norm) > 0.1 * ref_norm:
+                bad += 1
+                bad_names.append("%s %.3g/%.3g" % (pnames.get(id(prm), "?"), got, float(ref_norm)))
             s = gr[idx % max(k, 1)]
             num += float(((s - ref_s.astype(np.float64)) ** 2).sum())
             den += float((ref_s.astype(np.float64) ** 2).sum())
+        res["bad_names"] = bad_names
         assert bad <= len(m.optim._spans) // 50, bad
         assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
         pn = np.array([float(m.optim.flat_params[off:off + k].double().norm()) for off, k in m.optim._spans])

@@ -52,6 +52,11 @@ def relerr(got, ref):
 CASES = [(2, 8, 8, 64, 64, 1), (4, 16, 16, 64, 128, 2), (2, 32, 32, 128, 64, 2), (2, 8, 16, 256, 256, 1),
          (8, 8, 8, 512, 512, 2), (2, 64, 64, 64, 64, 1), (4, 4, 8, 128, 192, 1)]
 FWD_ONLY = [(2, 64, 64, 32, 64, 1), (2, 16, 32, 96, 64, 2)]      # input channel counts the data gradient does not take
+# widths that are not powers of two -- what 'orig'-mode inference and the 384 x 384 MiDaS decoder (96 / 48 / 24 / 12 wide maps)
+# send here: F(4,3) WITHOUT the HALO staging (256 % W != 0), tiles that straddle image rows and samples, the F(2,3)
+# fallback where 4 does not divide W or 256 does not divide M, the filter gradient at 8 | W but 16 !| W
+NONPOW2 = [(4, 8, 24, 64, 64, 1), (2, 24, 48, 128, 64, 1), (4, 8, 40, 64, 128, 1), (16, 6, 20, 64, 64, 1),
+           (8, 8, 12, 64, 64, 2), (4, 16, 6, 64, 64, 1), (2, 12, 96, 64, 64, 1)]
 
 
 def _scratch(Cin, Cout):
@@ -59,7 +64,7 @@ def _scratch(Cin, Cout):
     return torch.empty(n, device=DEV), n
 
 
-@pytest.mark.parametrize("case", CASES + FWD_ONLY)
+@pytest.mark.parametrize("case", CASES + FWD_ONLY + NONPOW2)
 def test_wino_forward_plain_xf_stats(case):
     N, H, W, Cin, Cout, G = case
     g = torch.Generator().manual_seed(11 + Cin + W)
@@ -104,7 +109,7 @@ def test_wino_forward_plain_xf_stats(case):
     assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < 2e-5
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + NONPOW2)
 def test_wino_dgrad_with_bn_backward_epilogue(case):
     """dz = dgrad(conv3x3)(dy) * [relu(bn_a(y_a)) > 0] with the per-tile sums of dz and dz * xhat and relu(bn_a(y_a)) as a
     side output: the launch the executor makes for conv2 of a Bottleneck (net.hip dgrad_then_bn), Winograd form against the
@@ -167,7 +172,7 @@ def test_wino_dgrad_with_bn_backward_epilogue(case):
     assert torch.equal(outs[0][1], outs[1][1])          # the side output does not depend on the product form
 
 
-@pytest.mark.parametrize("case", CASES + [(16, 32, 32, 64, 64, 1), (64, 16, 16, 128, 128, 1)])
+@pytest.mark.parametrize("case", CASES + NONPOW2 + [(16, 32, 32, 64, 64, 1), (64, 16, 16, 128, 128, 1)])
 def test_wino_wgrad(case):
     """Filter gradient of the 3x3 stride-1 convolution in the Winograd row form (conv_wgrad_wino_kernel: the launcher takes it
     for fp32, 8 | W, 64 | N*H*W) against fp64 autograd; the last cases split the reduction over many blocks."""

@@ -152,6 +152,117 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_dma(const bf16_t* __r
     }
 }
 
+
+// PERSISTENT form of gemm_dma: the grid is one block per CU slot; a block walks the tiles b, b + grid, ... and treats their
+// k-tiles as ONE stream -- the fetch of the next tile's first k-tile is in flight while the last k-tile of the current tile is
+// multiplied and its output leaves through the stage that multiply has just freed (2 stages).  PRIO: s_setprio 1 around the MFMAs.
+template <int BM, int BN, int WM, int WN, int MINB, bool PRIO>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_dma_persist(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                       bf16_t* __restrict__ C, int M, int N, int K) {
+    constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 128, CH = (BM + BN) / 8, CPW = CH / NW, CHA = BM / 8;
+    static_assert(CH % NW == 0, "chunks per wave");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = N / BN, ntiles = (M / BM) * ntn;
+    const int nk = K / 64;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int r8 = lane >> 3, p8 = lane & 7;
+    const unsigned v_even = (unsigned)(r8 * K * 2 + ((p8 ^ (r8 >> 1)) << 4));
+    const unsigned v_odd = v_even ^ 64u;
+    const u32x4 rsA = dma_rsrc(A, (size_t)M * K * 2 > 0xFFFFFFFFull ? 0xFFFFFFFFull : (size_t)M * K * 2);   // (probe: M K < 2^31)
+    const u32x4 rsB = dma_rsrc(B, (size_t)N * K * 2);
+    auto issue = [&](int tile, int kt, int stage) {
+        const int mt = tile / ntn, m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+        const unsigned koff = (unsigned)kt * 128u;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const int ch = wave * CPW + u;
+            if (ch < CHA) dma16(rsA, sb + (unsigned)(ch * 1024), (ch & 1) ? v_odd : v_even, koff + (unsigned)((m0 + ch * 8) * K * 2));
+            else dma16(rsB, sb + (unsigned)(ch * 1024), ((ch - CHA) & 1) ? v_odd : v_even, koff + (unsigned)((n0 + (ch - CHA) * 8) * K * 2));
+        }
+    };
+    const int swz = (lane >> 1) & 7;
+    unsigned ko[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ko[kk] = (unsigned)(((2 * kk + (lane >> 5)) ^ swz) << 4);
+    const unsigned a_row = (unsigned)((wm * TM * 32 + (lane & 31)) * 128);
+    const unsigned b_row = (unsigned)(BM * 128 + (wn * TN * 32 + (lane & 31)) * 128);
+    constexpr int JG = TN >= 2 ? 2 : 1, WC = JG * 32, EPP = WC + 4, ER = 16;       // epilogue: 16 rows x 64 columns at a time
+    static_assert(NW * ER * EPP * 4 <= STAGE, "epilogue slice must fit one stage");
+
+    f32x16 acc[TM][TN];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int kt = 0, q = 0;
+    if (tile < ntiles) issue(tile, 0, 0);
+    while (tile < ntiles) {
+        if (kt == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        vm_wait<0>();
+        __syncthreads();
+        // the item after this one: next k-tile of the tile, or the first k-tile of the block's next tile
+        const bool last = kt + 1 == nk;
+        const int ntile = last ? tile + (int)gridDim.x : tile, nkt = last ? 0 : kt + 1;
+        if (ntile < ntiles) issue(ntile, nkt, (q + 1) & 1);
+        const char* sb = smem + (q & 1) * STAGE;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + a_row + i * 4096 + ko[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + j * 4096 + ko[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (last) {
+            __syncthreads();                  // every wave is done with stage q & 1: it carries the output now
+            const int mt = tile / ntn, m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+            float* ep = reinterpret_cast<float*>(smem + (q & 1) * STAGE) + wave * (ER * EPP);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jg = 0; jg < TN / JG; ++jg)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {      // rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5): h = r >> 3 picks 16 of the 32
+#pragma unroll
+                        for (int j = 0; j < JG; ++j)
+#pragma unroll
+                            for (int r8i = 0; r8i < 8; ++r8i) {
+                                const int r = h * 8 + r8i;
+                                ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][jg * JG + j][r];
+                            }
+                        constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = ER / RPI;
+#pragma unroll
+                        for (int k = 0; k < NI; ++k) {
+                            const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 8;
+                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc);
+                            const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc + 4);
+                            const u32x4 pk = {f2bf2(q0[0], q0[1]), f2bf2(q0[2], q0[3]), f2bf2(q1[0], q1[1]), f2bf2(q1[2], q1[3])};
+                            *reinterpret_cast<u32x4*>(C + (size_t)(m0 + wm * TM * 32 + i * 32 + h * 16 + row) * N + n0 + wn * TN * 32 + jg * WC + cc) = pk;
+                        }
+                    }
+        }
+        tile = ntile;
+        kt = nkt;
+        ++q;
+    }
+}
+
 // the library's structure (tools/bf16_depth_probe.hip, depth 1): register staging, one LDS buffer, two barriers per k-tile
 constexpr int P = 72;
 template <int MINB, int TI, int TJ>
@@ -316,22 +427,36 @@ int main(int argc, char** argv) {
             double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(256), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
             report("lib " #TI_ "x" #TJ_ " tiles/wave minb " #MB_, ms);                                                       \
         }
+#define RUN_PER(BM_, BN_, WM_, WN_, MB_, PR_, BPC_)                                                                        \
+        if (M % BM_ == 0 && N % BN_ == 0) {                                                                                  \
+            const size_t lds = (size_t)2 * (BM_ + BN_) * 128;                                                                \
+            auto kfn = gemm_dma_persist<BM_, BN_, WM_, WN_, MB_, PR_>;                                                       \
+            CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            const int nt_ = (M / BM_) * (N / BN_);                                                                           \
+            const dim3 grid(nt_ < 256 * BPC_ ? nt_ : 256 * BPC_);                                                            \
+            for (int r = 0; r < NR; ++r) CK(hipMemsetAsync(dC[r], 0, (size_t)M * N * 2));                                    \
+            double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
+            report("persist " #BM_ "x" #BN_ " waves " #WM_ "x" #WN_ " prio " #PR_ " blocks/CU " #BPC_, ms);                   \
+        }
         RUN_LIB(3, 2, 2)
-        RUN_LIB(3, 2, 1)
         RUN_DMA(128, 128, 2, 2, 2, 2)
-        RUN_DMA(128, 128, 2, 2, 3, 1)
         RUN_DMA(128, 64, 2, 2, 2, 3)
-        RUN_DMA(128, 64, 2, 2, 3, 2)
         RUN_DMA(256, 64, 4, 1, 2, 2)
-        RUN_DMA(256, 64, 4, 1, 3, 1)
-        RUN_DMA(256, 128, 2, 2, 2, 1)
         RUN_DMA(256, 128, 2, 2, 3, 1)
-        RUN_DMA(128, 256, 2, 2, 2, 1)
         RUN_DMA(128, 256, 2, 2, 3, 1)
         RUN_DMA(256, 128, 4, 2, 2, 1)
         RUN_DMA(256, 128, 4, 2, 3, 1)
         RUN_DMA(256, 256, 2, 4, 2, 1)
         RUN_DMA(256, 256, 4, 2, 2, 1)
+        RUN_PER(256, 256, 2, 4, 1, false, 1)
+        RUN_PER(256, 256, 2, 4, 1, true, 1)
+        RUN_PER(256, 128, 4, 2, 1, false, 1)
+        RUN_PER(256, 128, 4, 2, 1, true, 1)
+        RUN_PER(256, 64, 4, 1, 2, false, 2)
+        RUN_PER(256, 64, 4, 1, 2, false, 3)
+        RUN_PER(128, 128, 2, 2, 2, false, 2)
+        RUN_PER(128, 128, 2, 2, 2, false, 3)
+        RUN_PER(128, 64, 2, 2, 3, false, 4)
         for (int r = 0; r < NR; ++r) { CK(hipFree(dA[r])); CK(hipFree(dC[r])); }
         CK(hipFree(dB));
         fflush(stdout);

@@ -23,7 +23,7 @@ def dirty():
         return
     from instaorder_amd import midas_net
     val = float("nan") if DIRTY == "nan" else 1e30
-    streams = [torch.cuda.current_stream()] + list(midas_net._InstaDepthBase._side or [])
+    streams = [torch.cuda.current_stream()] + list(midas_net._InstaDepthBase._side.get(torch.cuda.current_device()) or [])
     for st in streams:
         with torch.cuda.stream(st):
             keep = []
@@ -86,6 +86,11 @@ def diff(a, b, names, what):
     bad = [(n, int((d[off:off + k] > 0).sum()), k, float(d[off:off + k].max()), float(a[off:off + k].abs().max()))
            for n, off, k in names if bool((d[off:off + k] > 0).any())]
     print("  %s: %d parameters differ" % (what, len(bad)))
+    groups = {}
+    for row in bad:
+        key = ".".join(row[0].split(".")[1:4] if row[0].startswith("module.pretrained") else row[0].split(".")[1:3])
+        groups[key] = groups.get(key, 0) + 1
+    print("     by module:", " ".join("%s=%d" % kv for kv in sorted(groups.items())))
     for row in bad[:12]:
         print("     %-60s %d of %d elements, max |d| %.3e (max |v| %.3e)" % row)
     return len(bad)
