@@ -48,6 +48,12 @@ int io_device_count(void);
  * Workspace sizes do not depend on it.  Returns the previous value. */
 int io_set_winograd(int on);
 int io_get_winograd(void);
+/* bf16 forward convolutions / data gradients on whole 256-row tiles with Cin % 64 == 0, Cout % 128 == 0 and a dense output:
+ * 1 (default) = the persistent LDS-DMA kernel of csrc/conv_p256.hip, 0 = the 128-row kernel every other launch runs (same
+ * arithmetic, fp32 accumulation; sums may associate differently).  Process-wide; initial value from the environment variable
+ * IO_P256 (unset = 1).  Returns the previous value. */
+int io_set_bf16_p256(int on);
+int io_get_bf16_p256(void);
 
 /* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
  * nn.Conv2d(bias=False) forward as used by conv1x1 / conv3x3 / the 7x7 stem

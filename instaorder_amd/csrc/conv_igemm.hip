@@ -66,7 +66,9 @@ constexpr unsigned kInvalidOff = 0xFFFFFFFFu;
 // epilogues that matter store whole rows through LDS instead.  (sc0 / sc1 bits: no gain / -15 %.)
 constexpr int kStAux = 2;       // aux bits of the epilogue stores: nt
 constexpr int kTrBkm = 64;      // rows (output pixels) per k-tile of the LDS-DMA filter-gradient kernel ...
-constexpr int kTrMinB = 2;      // ... and the blocks per CU asked of the register allocator
+constexpr int kTrMinB = 2;      // ... the blocks per CU asked of the register allocator ...
+constexpr int kTrStages = 2;    // ... and its LDS stages.  Round 5, same-box A/B on the bf16 step (filter-gradient class 9.6 ms): 3 or
+                                // 4 stages of 32 rows at two blocks per CU 9.7-9.9 ms, 3 or 4 stages of 64 rows at one block 10.3-10.5
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -1718,7 +1720,11 @@ template <int W> __device__ __forceinline__ void tr_chunk_src(int pos, int& r, i
     }
 }
 
-template <int BMO, int BNC, bool STEM = false, int MINB = 2, int BKM = 64>
+// STAGES: LDS stages.  With 2, one k-tile is in flight per block and every k-tile pays a full memory latency (the launch of
+// layer 3's 1024 -> 256 gradient: 64 k-tiles x 2 us = its 0.12 ms); with more, STAGES - 1 k-tiles are in flight and the wait
+// in front of the barrier is for the OLDEST of them only (counted vmcnt).
+template <int N> __device__ __forceinline__ void dma_wait_left() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int BMO, int BNC, bool STEM = false, int MINB = 2, int BKM = 64, int STAGES = 2>
 __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoConvGeom g, const bf16_t* __restrict__ in,
                                                                      const bf16_t* __restrict__ dy,
                                                                      float* __restrict__ dst, int ntile_c, int tiles,
@@ -1870,13 +1876,19 @@ __global__ __launch_bounds__(kThreads, MINB) void conv_wgrad_bf16_tr_kernel(IoCo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) issue(kt0, 0);
+    constexpr int DPT = CA + CB;         // DMA instructions per wave and k-tile
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+        if (kt0 + s0 < kt1) issue(kt0 + s0, s0);
+    int stage = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int stage = (kt - kt0) & 1;
-        dma_wait_all();                  // the own fetches of tile kt have landed ...
-        __syncthreads();                 // ... everybody's have, and every wave is done reading the other stage
-        if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+        // the own fetches of tile kt have landed when at most the younger STAGES - 2 tiles are outstanding ...
+        if (STAGES > 2 && kt + STAGES - 2 < kt1) dma_wait_left<DPT*(STAGES > 2 ? STAGES - 2 : 0)>();
+        else dma_wait_all();
+        __syncthreads();                 // ... everybody's have, and every wave is done reading the stage refilled next
+        if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
         const lds_cptr sb = lds + stage * STAGE;
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
 #pragma unroll
         for (int kk = 0; kk < BKM / 16; ++kk) {
             bf16x8 a[TI], b[TJ];
@@ -2933,6 +2945,12 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const size_t in_bytes = (size_t)es * g.N * g.Hi * g.Wi * g.Ci;
     const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
     const unsigned w_bytes = (unsigned)w_b;
+    // bf16: the persistent 256-row LDS-DMA kernel where the shape and the form are its own (conv_p256.hip)
+    if (dt_in == IO_BF16 && dt_out == IO_BF16 && !stem) {
+        const int rc = io_launch_conv_p256(g, in, wgt, out, add, mask, st, st_mean, st_m2, bw ? &bws : nullptr, in_bytes,
+                                           w_bytes, out_bytes);
+        if (rc <= 0) return rc;
+    }
     // Output-channel tile: 128 wide where that leaves enough tiles to fill the chip, 64 wide otherwise -- a small per-GPU batch
     // (the reference's own 32 pairs per GPU, or a strong-scaling rank) gives layers 3-4 only 32..128 row tiles, and 128-wide
     // tiles then occupy a fraction of the 256 CUs with one block each (measured at 32 pairs: 43-51 TF/s on the 8 x 8 maps).
@@ -3257,13 +3275,13 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
                          g.Wo % rb_rows == 0;
 #define IO_LAUNCH_WGTR(BMO_, BNC_, STEM_)                                                                               \
     do {                                                                                                         \
-        const size_t lds = (size_t)2 * (BMO_ + BNC_) * kTrBkm * 2;                                            \
+        const size_t lds = (size_t)kTrStages * (BMO_ + BNC_) * kTrBkm * 2;                                    \
         static std::atomic<unsigned long long> attr_done{0};                                                                           \
         if (io_first_on_device(attr_done)) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm>, \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm, kTrStages>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         }                                                                                                        \
-        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm>), grid1, block,  \
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<BMO_, BNC_, STEM_, kTrMinB, kTrBkm, kTrStages>), grid1, block,  \
                            lds, st, g, (const bf16_t*)in, (const bf16_t*)dy, dst, p.ntile_c, p.tiles,            \
                            kps64 * (64 / kTrBkm), in_bytes, dy_bytes);                                        \
     } while (0)

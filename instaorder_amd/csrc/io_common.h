@@ -172,6 +172,10 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                       const void* mask, int stem, hipStream_t st, float* st_mean = nullptr,
                       float* st_m2 = nullptr, const IoBwStats* bw = nullptr, int dt_in = IO_F32,
                       int dt_out = IO_F32);
+// conv_p256.hip: IO_OK = launched, 1 = not this kernel's shape / form (fall through), < 0 = error
+int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add, const void* mask,
+                        hipStream_t st, float* st_mean, float* st_m2, const IoBwStats* bw, size_t in_bytes,
+                        unsigned w_bytes, size_t out_bytes);
 int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, int M, int C, int G,
                          const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                          void* dy, float* coef, hipStream_t st, int dt = IO_F32);

@@ -1,0 +1,187 @@
+"""The persistent 256-row LDS-DMA bf16 kernel (csrc/conv_p256.hip) behind the storage-typed C entry points, against fp64
+torch on the same bf16-rounded inputs AND against the 128-row kernel it replaces (io_set_bf16_p256): forward convolutions
+(resnet_cls.py:23-31: 1x1 / 3x3, stride 1 / 2) plain, with the statistics epilogue and with the folded-BatchNorm inference
+epilogue; data gradients with the fused BatchNorm-backward epilogue (residual gradient, ReLU mask read and recomputed).
+Bar: bf16 output rounding (2^-8 relative per element) on top of fp32 accumulation -- 1e-2 of the output scale."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from instaorder_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = 1
+TOL = 1e-2
+_KEEP = []
+
+
+def P(t):
+    if t is None:
+        return C.c_void_p(0)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:-64]
+    return C.c_void_p(t.data_ptr())
+
+
+def ST():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bf(x):
+    """fp64 tensor -> (bf16 device tensor NHWC / as is, the fp64 values it holds)"""
+    d = x.to(torch.bfloat16)
+    return d.to(DEV).contiguous(), d.double()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    prev = _lib.lib().io_get_bf16_p256()
+    yield
+    _lib.lib().io_set_bf16_p256(prev)
+
+
+# N, H, W, Cin, Cout, R, stride     (N * Ho * Wo a multiple of 256)
+CASES = [(2, 16, 16, 64, 256, 1, 1), (4, 8, 8, 128, 128, 3, 1), (2, 32, 32, 64, 128, 3, 1), (8, 16, 16, 128, 256, 1, 2),
+         (8, 16, 16, 64, 128, 3, 2), (4, 8, 8, 512, 512, 1, 1), (32, 64, 64, 64, 256, 1, 1), (1, 16, 16, 256, 384, 3, 1)]
+
+
+def _inputs(case, seed):
+    N, H, W, Cin, Cout, R, stride = case
+    g = torch.Generator().manual_seed(seed)
+    x, xr = bf(nhwc(torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)))
+    w, wr = bf((torch.randn(Cout, Cin, R, R, generator=g, dtype=torch.float64) / (R * Cin ** 0.5)).permute(0, 2, 3, 1).contiguous())
+    return x, xr.permute(0, 3, 1, 2), w.view(Cout, R * R, Cin), wr.permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_p256_forward_plain_stats_bias(case):
+    N, H, W, Cin, Cout, R, stride = case
+    pad = R // 2
+    lib = _lib.lib()
+    x, xr, w, wr = _inputs(case, 3 + Cin + H)
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    outs = []
+    for on in (1, 0):
+        lib.io_set_bf16_p256(on)
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_dt(P(x), P(w), P(y), N, H, W, Cin, Cout, R, R, stride, pad, BF, BF, ST()), "fwd")
+        assert relerr(y.permute(0, 3, 1, 2), ref) < TOL, on
+        outs.append(y)
+    assert relerr(outs[0], outs[1].double().cpu()) < TOL
+    # statistics epilogue (G = 2 when the rows per group stay whole 128-row tiles)
+    M = N * Ho * Wo
+    G = 2 if (N % 2 == 0 and (M // 2) % 128 == 0) else 1
+    gen = torch.Generator().manual_seed(9)
+    gamma, beta = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    for on in (1, 0):
+        lib.io_set_bf16_p256(on)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        mean, rstd, sc, sh = (torch.empty(G * Cout, device=DEV) for _ in range(4))
+        nws = lib.io_conv2d_bnstats_workspace_floats(N, H, W, Cout, R, R, stride, pad, G)
+        ws = torch.empty(nws, device=DEV)
+        y2 = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_bnstats_dt(P(x), P(w), P(y2), N, H, W, Cin, Cout, R, R, stride, pad, G, P(gamma.to(DEV)),
+                                                P(beta.to(DEV)), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(sc), P(sh),
+                                                P(ws), nws, BF, 0, ST()), "fwd+stats")
+        assert relerr(y2.permute(0, 3, 1, 2), ref) < TOL
+        # the statistics are those of the fp32 accumulators (before the bf16 rounding of y): against the fp64 convolution
+        per = N // G
+        mref = torch.stack([ref[gi * per:(gi + 1) * per].mean((0, 2, 3)) for gi in range(G)])
+        vref = torch.stack([ref[gi * per:(gi + 1) * per].var((0, 2, 3), unbiased=False) for gi in range(G)])
+        assert float((mean.view(G, Cout).double().cpu() - mref).abs().max()) < 2e-4 * float(ref.abs().max())
+        assert relerr(rstd.view(G, Cout), 1.0 / torch.sqrt(vref + 1e-5)) < 2e-4
+    # inference epilogue: relu(conv + bias + add)
+    bias = torch.randn(Cout, generator=gen)
+    addd, addr = bf(torch.randn(N, Ho, Wo, Cout, generator=gen, dtype=torch.float64))
+    ref3 = F.relu(ref + bias.double().view(1, -1, 1, 1) + addr.permute(0, 3, 1, 2))
+    for on in (1, 0):
+        lib.io_set_bf16_p256(on)
+        y3 = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_bias_dt(P(x), P(w), P(y3), N, H, W, Cin, Cout, R, R, stride, pad, P(bias.to(DEV)), P(addd), 1,
+                                             BF, 0, ST()), "fwd+bias")
+        assert relerr(y3.permute(0, 3, 1, 2), ref3) < TOL, on
+
+
+DG_CASES = [(2, 16, 16, 256, 64, 1), (4, 8, 8, 128, 128, 3), (2, 32, 32, 128, 64, 3), (4, 16, 16, 512, 128, 1), (32, 32, 32, 256, 64, 1)]
+
+
+@pytest.mark.parametrize("case", DG_CASES)
+@pytest.mark.parametrize("form", ["recompute_mask", "read_mask_add"])
+def test_p256_dgrad_with_bn_backward_epilogue(case, form):
+    """dz = (dgrad(conv)(dy) [+ add]) * mask with the per-tile sums of dz and dz * xhat -- the launches the executor makes for
+    conv3 / conv2 (mask recomputed from y) and conv1 (identity-path gradient added, mask read) of a Bottleneck."""
+    N, H, W, Cin, Cout, R = case       # the data gradient has Cin output channels (>= 128) and reduces over Cout
+    pad = R // 2
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(7 + Cin + H)
+    M = N * H * W
+    G = 2 if (N % 2 == 0 and (M // 2) % 256 == 0) else 1
+    per = N // G
+    dy, dyr = bf(torch.randn(N, H, W, Cout, generator=g, dtype=torch.float64))
+    w64 = torch.randn(Cout, Cin, R, R, generator=g, dtype=torch.float64) / (R * Cout ** 0.5)
+    wt, wtr = bf(w64.permute(1, 2, 3, 0).reshape(Cin, R * R, Cout).contiguous())          # W^T [Cin][taps][Cout]
+    wr = wtr.view(Cin, R, R, Cout).permute(3, 0, 1, 2)                                   # back to OIHW, as rounded
+    ya, yar = bf(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))
+    yn = yar.permute(0, 3, 1, 2)
+    mean = torch.stack([yn[gi * per:(gi + 1) * per].mean((0, 2, 3)) for gi in range(G)])
+    var = torch.stack([yn[gi * per:(gi + 1) * per].var((0, 2, 3), unbiased=False) for gi in range(G)])
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    gam = torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5
+    bet = torch.randn(Cin, generator=g, dtype=torch.float64) * 0.3
+    mean_f, rstd_f = mean.float(), rstd.float()
+    scale_f = gam.float() * rstd_f
+    shift_f = bet.float().expand(G, Cin).contiguous()
+    grp = torch.arange(N) // per
+    v = lambda t: t[grp].view(N, Cin, 1, 1)          # noqa: E731
+    a_in = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    da = torch.autograd.grad(F.conv2d(a_in, wr, padding=pad), a_in, dyr.permute(0, 3, 1, 2))[0]
+    addd = maskd = None
+    if form == "recompute_mask":
+        t32 = torch.addcmul(v(shift_f), (yn.float() - v(mean_f)), v(scale_f))
+        dz_ref = da * (t32 > 0)
+    else:
+        addd, addr = bf(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))
+        maskd, maskr = bf(F.relu(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64)))
+        dz_ref = (da + addr.permute(0, 3, 1, 2)) * (maskr.permute(0, 3, 1, 2) > 0)
+    nt = lib.io_bn_tile_partial_floats(M, Cin, G)
+    outs = []
+    for on in (1, 0):
+        lib.io_set_bf16_p256(on)
+        p1, p2 = torch.zeros(nt, device=DEV), torch.zeros(nt, device=DEV)
+        dx = torch.full((N, H, W, Cin), float("nan"), device=DEV, dtype=torch.bfloat16)
+        opt = _lib.DgradFused()
+        tabs = [t.to(DEV).contiguous() for t in (mean_f, rstd_f, scale_f, shift_f)]
+        opt.ep_y, opt.ep_mean, opt.ep_rstd = ya.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr()
+        if form == "recompute_mask":
+            opt.ep_scale, opt.ep_shift = tabs[2].data_ptr(), tabs[3].data_ptr()
+        else:
+            opt.add, opt.relu_mask = addd.data_ptr(), maskd.data_ptr()
+        opt.ep_p1, opt.ep_p2 = p1.data_ptr(), p2.data_ptr()
+        _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dy), P(wt), P(dx), N, H, W, Cin, Cout, R, R, pad, G, C.byref(opt), BF, ST()),
+                   "dgrad_fused p256=%d" % on)
+        torch.cuda.synchronize()
+        assert relerr(dx.permute(0, 3, 1, 2), dz_ref) < TOL, on
+        # tile partials: sums of the kernel's fp32 dz (before rounding) -- against fp64 sums of the reference dz
+        dzk = dz_ref.permute(0, 2, 3, 1).reshape(M // 128, 128, Cin)
+        xhat = ((yn - v(mean)) * v(rstd)).permute(0, 2, 3, 1).reshape(M // 128, 128, Cin)
+        s1, s2 = dzk.sum(1), (dzk * xhat).sum(1)
+        assert float((p1[:M // 128 * Cin].view(M // 128, Cin).double().cpu() - s1).abs().max()) < 2e-3 * float(s1.abs().max())
+        assert float((p2[:M // 128 * Cin].view(M // 128, Cin).double().cpu() - s2).abs().max()) < 2e-3 * float(s2.abs().max())
+        outs.append(dx)
+        del tabs
+    assert relerr(outs[0], outs[1].double().cpu()) < TOL
