@@ -244,6 +244,12 @@ int io_bn_stats_finalize_dt(const void* y, int M, int C, int G, const float* gam
                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
                             float* rstd, float* scale, float* shift, float* partial, size_t partial_floats, int dtype,
                             hipStream_t stream);
+/* io_bn_apply_dt with relu != 0 that also writes the sign mask of its output, one bit per element: bits[(m * C + c) / 32] bit
+ * c % 32 = (out[m][c] > 0); C % 32 == 0, M * C / 32 words.  What the executor keeps of a block output for the ReLU backward
+ * (resnet_cls.py:114 `out = self.relu(out)`) instead of re-reading the tensor in the data gradient that completes d(out). */
+int io_bn_apply_bits_dt(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
+                        const float* shift, const void* identity, const float* mean2, const float* scale2,
+                        const float* shift2, void* out, uint32_t* bits, int dtype, hipStream_t stream);
 int io_bn_apply_dt(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
                    const float* shift, const void* identity, const float* mean2, const float* scale2,
                    const float* shift2, int relu, void* out, int dtype, hipStream_t stream);
@@ -388,6 +394,10 @@ typedef struct io_dgrad_fused {
      * MFMAs; results differ from the direct form at rounding level) */
     float* wino_scratch;
     size_t wino_scratch_floats;
+    /* optional, NEXT TO relu_mask (same information): the mask as ONE BIT per element -- word (m * Cin + c) / 32, bit c % 32
+     * set where the masking activation was > 0 (io_bn_apply_bits_dt writes it beside the activation).  The bf16 256-row
+     * kernel reads it instead of the tensor (1/16 of the bytes); every other launch reads relu_mask.  Cin % 32 == 0. */
+    const uint32_t* relu_maskbits;
 } io_dgrad_fused;
 int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout, int R,
                              int S, int pad, int G, const io_dgrad_fused* f, int dtype, hipStream_t stream);

@@ -45,7 +45,7 @@ class DgradFused(C.Structure):
     """io_dgrad_fused of include/instaorder_hip.h (device pointers as integers, None = NULL)"""
     _fields_ = [(n, C.c_void_p) for n in ("xb_y", "xb_coef", "xb_dy_out", "add", "relu_mask", "ep_y", "ep_mean", "ep_rstd",
                                           "ep_scale", "ep_shift", "ep_act_out", "ep_p1", "ep_p2", "wino_scratch")] + \
-               [("wino_scratch_floats", C.c_size_t)]
+               [("wino_scratch_floats", C.c_size_t), ("relu_maskbits", C.c_void_p)]
 
 
 class ProfEntry(C.Structure):
@@ -112,6 +112,7 @@ SIGNATURES = {
     "io_filter_prepare": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "io_bn_stats_finalize_dt": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "io_bn_apply_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "io_bn_apply_bits_dt": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "io_bn_bwd_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     "io_gconv_pack": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "io_gconv_unpack_grad": (_I, [_P, _I, _I, _I, _P, _P]),

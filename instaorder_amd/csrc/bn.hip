@@ -260,10 +260,12 @@ struct BnTab {
 // Grid (x, G): blockIdx.y is the BN group, the x blocks grid-stride over the group's chunks with a stride that is a
 // multiple of the chunks per row -- so a thread keeps ONE channel chunk for its whole life and its table entries
 // are loaded once; the loop body is nothing but 4 independent chunk loads per tensor, the arithmetic and the stores.
-template <int MODE, typename T>   // MODE 0 none, 1 identity tensor, 2 second BN (downsample branch)
+// BITS: also the sign mask of the output, one bit per element (IoBwStats::maskbits): the 32 / VEC consecutive lanes that hold
+// the 32 channels of one word combine their pieces with shuffles, the first of them stores the word.
+template <int MODE, typename T, bool BITS = false>   // MODE 0 none, 1 identity tensor, 2 second BN (downsample branch)
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ y, size_t per_group, int cvmask,
                                                            int sg, BnTab t, const T* __restrict__ idt, BnTab t2,
-                                                           int relu, T* __restrict__ out) {
+                                                           int relu, T* __restrict__ out, uint32_t* __restrict__ bits = nullptr) {
     constexpr int VEC = Chunk<T>::VEC, NV = Chunk<T>::NV, U = 4;
     const int g = blockIdx.y;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -303,6 +305,19 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
                     a[u].v[k] = v;
                 }
                 stc(out + (base + j) * VEC, a[u]);
+                if constexpr (BITS) {
+                    // (the 32 / VEC lanes of a word are all inside the `j < per_group` branch: per_group is a multiple of it)
+                    constexpr int LPW = 32 / VEC;
+                    unsigned w = 0;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w |= (a[u].v[k][e] > 0.f ? 1u : 0u) << (k * 4 + e);
+                    w <<= (threadIdx.x & (LPW - 1)) * VEC;
+#pragma unroll
+                    for (int sft = 1; sft < LPW; sft <<= 1) w |= (unsigned)__shfl_xor((int)w, sft, 64);
+                    if ((threadIdx.x & (LPW - 1)) == 0) bits[((base + j) * VEC) >> 5] = w;
+                }
             }
         }
     }
@@ -775,8 +790,9 @@ extern "C" int io_bn_eval_prepare(int C, const float* gamma, const float* beta, 
 
 int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
                   const float* shift, const void* identity, const float* mean2, const float* scale2,
-                  const float* shift2, int relu, void* out, hipStream_t st, int dt) {
+                  const float* shift2, int relu, void* out, hipStream_t st, int dt, uint32_t* bits) {
     const int vec = 16 / io_dtype_bytes(dt);
+    IO_REQUIRE(!bits || (C % 32 == 0 && relu), IO_ERR_SHAPE, "bn_apply: the sign mask needs C %% 32 == 0 and a ReLU");
     IO_REQUIRE(C % vec == 0 && ilog2_exact(C / vec) >= 0, IO_ERR_SHAPE, "bn_apply: C=%d must be %d*2^k", C, vec);
     IO_REQUIRE(G >= 1 && M % G == 0, IO_ERR_SHAPE, "bn_apply: M=%d not divisible by G=%d", M, G);
     const int Mg = M / G, sg = per_group_tables ? C : 0, cv = C / vec;
@@ -786,8 +802,14 @@ int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, cons
     const BnTab t{mean, scale, shift}, t2{mean2, scale2, shift2};
     const int mode = (identity && scale2) ? 2 : (identity ? 1 : 0);
 #define IO_BN_APPLY(MODE_, T_)                                                                                     \
-    hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_>), grid, block, 0, st, (const T_*)y, per_group, cv - 1, sg, t,   \
-                       (const T_*)identity, t2, relu, (T_*)out)
+    do {                                                                                                           \
+        if (bits)                                                                                                  \
+            hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_, true>), grid, block, 0, st, (const T_*)y, per_group,    \
+                               cv - 1, sg, t, (const T_*)identity, t2, relu, (T_*)out, bits);                      \
+        else                                                                                                       \
+            hipLaunchKernelGGL((bn_apply_kernel<MODE_, T_, false>), grid, block, 0, st, (const T_*)y, per_group,   \
+                               cv - 1, sg, t, (const T_*)identity, t2, relu, (T_*)out, (uint32_t*)nullptr);        \
+    } while (0)
     if (dt == IO_BF16) {
         if (mode == 2) IO_BN_APPLY(2, bf16_t);
         else if (mode == 1) IO_BN_APPLY(1, bf16_t);

@@ -364,6 +364,15 @@ extern "C" int io_bn_apply_dt(const void* y, int M, int C, int G, int per_group_
                          st, dtype);
 }
 
+extern "C" int io_bn_apply_bits_dt(const void* y, int M, int C, int G, int per_group_tables, const float* mean,
+                                   const float* scale, const float* shift, const void* identity, const float* mean2,
+                                   const float* scale2, const float* shift2, void* out, uint32_t* bits, int dtype,
+                                   hipStream_t st) {
+    IO_REQUIRE(bits, IO_ERR_SHAPE, "bn_apply_bits: no bit mask given");
+    return io_bn_apply_t(y, M, C, G, per_group_tables, mean, scale, shift, identity, mean2, scale2, shift2, 1, out, st,
+                         dtype, bits);
+}
+
 extern "C" int io_bn_bwd_dt(const void* dout, const void* act, const float* mask_scale, const float* mask_shift,
                             const void* y, int M, int C, int G, const float* gamma, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, void* dy, void* dz_out, float* partial,
@@ -571,8 +580,13 @@ extern "C" int io_conv2d_dgrad_fused_dt(const void* dy, const void* wt, void* dx
                    io_conv2d_wino_scratch_floats(Cin, Cout));
         bw.wino_u = f->wino_scratch;
     }
+    if (f->relu_maskbits) {
+        IO_REQUIRE(f->relu_mask && Cin % 32 == 0, IO_ERR_SHAPE,
+                   "conv2d_dgrad_fused: relu_maskbits goes WITH relu_mask (the same mask, one bit per element), 32 | Cin");
+        bw.maskbits = f->relu_maskbits;
+    }
     return io_run_dgrad(dy, wt, dx, f->add, f->relu_mask, N, H, W, Cin, Cout, R, S, 1, pad, st,
-                        (grouped || f->wino_scratch) ? &bw : nullptr, dtype);
+                        (grouped || f->wino_scratch || f->relu_maskbits) ? &bw : nullptr, dtype);
 }
 
 /* Forward convolution whose INPUT goes through the BatchNorm + ReLU of the layer that produced it, applied while the

@@ -270,7 +270,10 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
             // BWE: per channel sum(dz) and sum(dz * y) over the wave's 128 rows; sum(dz * xhat) = rstd * (sum(dz y) - mean sum(dz))
             // is formed at the end (no mean / rstd tables alive in the pass loop)
             float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
-            const bool nomask = a.mask == nullptr;
+            const bool nomask = a.mask == nullptr && a.bw.maskbits == nullptr;
+            // the mask as one bit per element (IoBwStats::maskbits): a lane's 8 channels are one byte
+            const __amdgpu_buffer_rsrc_t rs_bits = rsrc_at(a.bw.maskbits ? (const void*)a.bw.maskbits : (const void*)a.out,
+                                                           out_base / 16, a.bw.maskbits ? a.out_bytes / 16 : out_base / 16);
             const int gcol = BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;     // (a 256-row tile never straddles two groups)
             if constexpr (BWE) {
 #pragma unroll
@@ -298,12 +301,14 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                 return (unsigned)((wm * 128 + i * 32 + h * 16 + k * RPI + lane / LPR) * g.Co + ecol) * 2u;
             };
             u32x4 pav[PD], pmv[PD], pyv[PD];
+            unsigned pbv[PD];
             auto pass_load = [&](int p, int sl) {
                 const unsigned off = pass_off(p);
                 if constexpr (EPI == EPI_PLAIN || EPI == EPI_BWE_READ) {
                     // absent operands have zero-length descriptors: their loads return 0 without touching memory
                     pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
                     pmv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_msk, off, 0, 0);
+                    pbv[sl] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_bits, off >> 4, 0, 0);      // (off = element index * 2)
                 }
                 if constexpr (BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
             };
@@ -346,10 +351,13 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                             }
                         }
                     }
+                    // branch-free over the two forms of the mask: the absent one loads zeros (a runtime branch around the uses lets
+                    // hipcc sink the loads into it and wait for each: +7 ms on the step, measured)
+                    const unsigned bb = pbv[sl];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        v[2 * d] = (nomask || bf_lo(mv[d]) > 0.f) ? v[2 * d] : 0.f;
-                        v[2 * d + 1] = (nomask || bf_hi(mv[d]) > 0.f) ? v[2 * d + 1] : 0.f;
+                        v[2 * d] = (nomask || ((bb >> (2 * d)) & 1u) || bf_lo(mv[d]) > 0.f) ? v[2 * d] : 0.f;
+                        v[2 * d + 1] = (nomask || ((bb >> (2 * d + 1)) & 1u) || bf_hi(mv[d]) > 0.f) ? v[2 * d + 1] : 0.f;
                     }
                 }
                 if constexpr (BWE) {
@@ -431,7 +439,7 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     if (bw && (bw->in_scale || bw->xb_a || bw->a_out || bw->wino_u)) return 1;
     if (st_mean && (add || mask || (bw && (bw->y || bw->bias)))) return 1;
     if (bw && bw->y && (bw->Mg % 256 != 0 || bw->bias)) return 1;
-    if (bw && bw->y && bw->mscale && (add || mask)) return 1;         // (the executor never combines them)
+    if (bw && bw->y && bw->mscale && (add || mask || bw->maskbits)) return 1;         // (the executor never combines them)
     // 32-bit offsets inside a tile's reach: 256 rows of the output, the samples a tile touches of the input
     const double span = 256.0 / ((double)g.Ho * g.Wo) + 2.0;
     if (span * 2.0 * g.Hi * g.Wi * g.Ci >= 4.0e9 || 256.0 * g.Co * 2.0 >= 4.0e9) return 1;
@@ -446,7 +454,7 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     a.wgt = (const bf16_t*)wgt;
     a.out = (bf16_t*)out;
     a.add = (const bf16_t*)add;
-    a.mask = (const bf16_t*)mask;
+    a.mask = (bw && bw->maskbits) ? nullptr : (const bf16_t*)mask;      // (the bit form of the same mask, when there is one)
     a.in_bytes = in_bytes;
     a.out_bytes = out_bytes;
     a.w_bytes = w_bytes;

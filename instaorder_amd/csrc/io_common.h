@@ -161,6 +161,10 @@ struct IoBwStats {
     // wino_filter_kernel) before it starts conv_nt_kernel<..., WINO>.  Null: the direct form.  (A caller-owned buffer
     // because no entry point of the library allocates.)
     float* wino_u;
+    // Independent again: the ReLU mask of a data-gradient epilogue ALSO as one bit per element, next to `mask` (same information):
+    // word (m * Co + c) / 32, bit c % 32 set where the masking activation was > 0 (io_bn_apply_t writes it).  The 256-row bf16
+    // kernel (conv_p256.hip) reads it instead of the tensor -- 1/16 of the bytes; conv_nt_kernel ignores it and reads `mask`.
+    const uint32_t* maskbits;
 };
 
 // run-time switch of the Winograd row forms (io_set_winograd / IO_WINOGRAD, capi.hip)
@@ -193,9 +197,10 @@ int io_bn_stats_finalize_t(const void* y, int M, int C, int G, const float* gamm
                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
                            float* rstd, float* scale, float* shift, float* partial, size_t partial_floats,
                            hipStream_t st, int dt);
+// bits (optional, C % 32 == 0): [M][C / 32] words, bit c % 32 of word (m C + c) / 32 = (out[m][c] > 0) -- IoBwStats::maskbits
 int io_bn_apply_t(const void* y, int M, int C, int G, int per_group_tables, const float* mean, const float* scale,
                   const float* shift, const void* identity, const float* mean2, const float* scale2,
-                  const float* shift2, int relu, void* out, hipStream_t st, int dt);
+                  const float* shift2, int relu, void* out, hipStream_t st, int dt, uint32_t* bits = nullptr);
 int io_bn_bwd_t(const void* dout, const void* act, const float* mask_scale, const float* mask_shift, const void* y,
                 int M, int C, int G, const float* gamma, const float* mean, const float* rstd, float* dgamma,
                 float* dbeta, void* dy, void* dz_out, float* partial, size_t partial_floats, float* coef,

@@ -102,6 +102,7 @@ BnL add_bn(io_net* net, const char* name, int C) {
 constexpr size_t kNoBuf = ~(size_t)0;
 struct BlockBufs {
     size_t y1, a1, y2, a2, y3, yd, out;   // byte offsets (a1 / a2 = kNoBuf: never materialised, see fuse_in)
+    size_t bits;                          // training: [out > 0] as one bit per element (IoBwStats::maskbits), kNoBuf: none
 };
 struct Plan {
     size_t y0, a0, p0, idx0, pooled;
@@ -185,6 +186,12 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
             bb.y3 = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
             bb.yd = b.down ? a.take((size_t)N * Ho * Ho * b.planes * 4 * e) : 0;
             bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
+            // bf16: the ReLU mask of the block output as one bit per element, for the data gradient that completes d(out) on
+            // the 256-row kernel (conv_p256.hip): 1/16 of the tensor it would otherwise read.  Written by the BatchNorm pass
+            // that builds the output; outputs built inside the next conv1 (xr_ok) have none.  fp32 never: measured round 5 --
+            // packing the bits in conv_nt_kernel's operand staging and reading them in its column-layout epilogue cost the
+            // fp32 step 3 % (59.7 -> 64.6 ms in the 128-wide class) for 4 of 136 bytes per element saved.
+            bb.bits = (net->dtype == IO_BF16 && Mo % 256 == 0) ? a.take((size_t)Mo * b.planes * 4 / 8) : kNoBuf;
             H = Ho;
         }
         for (int i = 0; i < 5; ++i) p.gbuf[i] = a.take(maxact);
@@ -225,7 +232,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
         size_t xin = r0, xout = r5;
         for (size_t i = 0; i < net->blocks.size(); ++i) {
             BlockBufs& bb = p.blk[i];
-            bb.y1 = r3; bb.a1 = r1; bb.y2 = r3; bb.a2 = r2; bb.y3 = r3; bb.yd = r4; bb.out = xout;
+            bb.y1 = r3; bb.a1 = r1; bb.y2 = r3; bb.a2 = r2; bb.y3 = r3; bb.yd = r4; bb.out = xout; bb.bits = kNoBuf;
             const size_t t = xin; xin = xout; xout = t;
         }
         for (int i = 0; i < 5; ++i) p.gbuf[i] = 0;
@@ -409,12 +416,28 @@ bool xr_ok(const Ctx& c, int Mout, int planes) {
     return c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
+// the one-bit ReLU mask of block i's output (training plans; nullptr where the plan has none)
+uint32_t* bits_of(const Ctx& c, size_t i) {
+    const size_t off = c.plan.blk[i].bits;
+    return (c.training && off != kNoBuf) ? reinterpret_cast<uint32_t*>(c.ws + off) : nullptr;
+}
+
+// ... and whether the forward wrote it: block outputs built by the next block's conv1 (xr_ok) have no BatchNorm pass to do it
+bool bits_written(const Ctx& c, size_t i) {
+    const Block& b = c.net->blocks[i];
+    if (c.plan.blk[i].bits == kNoBuf) return false;
+    int H = c.S / 4;
+    for (size_t k = 0; k <= i; ++k) H /= c.net->blocks[k].stride;
+    const int Mout = c.N * H * H;
+    return !(i + 1 < c.net->blocks.size() && xr_ok(c, Mout, b.planes));
+}
+
 bool fuse_in(const Ctx& c, int Mout) {
     return c.training && c.net->dtype == IO_F32 && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
 }
 
 int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, const BnL* b2, int relu,
-           void* out) {
+           void* out, uint32_t* bits = nullptr) {
     Tables t = c.tables(b);
     const float *m2 = nullptr, *s2 = nullptr, *h2 = nullptr;
     if (b2) {
@@ -425,7 +448,7 @@ int bn_act(const Ctx& c, const BnL& b, const void* y, int M, const void* idt, co
     }
     // tables are laid out with a group stride of C (training) -- eval uses one shared row
     return io_bn_apply_t(y, M, b.C, c.training ? c.G : 1, c.training ? 1 : 0, t.mean, t.scale, t.shift, idt, m2, s2,
-                         h2, relu, out, c.st, c.dt());
+                         h2, relu, out, c.st, c.dt(), bits);
 }
 
 // conv + folded BatchNorm (+ residual) (+ ReLU) of an inference forward
@@ -568,7 +591,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
                 pend_id = c.act(bb.yd);
                 pend_two = true;
             } else {
-                IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out)));
+                IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out), bits_of(c, i)));
             }
         } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
             pend_bn = &b.b3;                 // built by the next block's conv1
@@ -576,7 +599,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
             pend_id = x;
             pend_two = false;
         } else {
-            IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, x, nullptr, 1, c.act(bb.out)));
+            IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, x, nullptr, 1, c.act(bb.out), bits_of(c, i)));
         }
         x = c.act(bb.out);
         H = Ho;
@@ -857,7 +880,11 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
             const bool carry = ii > 0 && tiles_ok(c, Min);
             if (carry) bw = bw_for(c, net->blocks[ii - 1].b3, c.act(p.blk[ii - 1].y3), Min, false);
             if (x1) xb_fill(c, bw, b.b1, c.act(bb.y1), Min, Gb);
-            IO_TRY(conv_dgrad(c, b.c1, x1 ? Ga : Gb, Ge, partial, xmask, H, (carry || x1) ? &bw : nullptr));
+            // [x_in > 0] also as one bit per element where the forward left it: the 256-row kernel reads that instead of the
+            // tensor (4 of the 17 bytes per element this launch moves in bf16); conv_nt_kernel ignores it
+            const uint32_t* mbits = (ii > 0 && xmask && bits_written(c, ii - 1)) ? bits_of(c, ii - 1) : nullptr;
+            if (mbits) bw.maskbits = mbits;
+            IO_TRY(conv_dgrad(c, b.c1, x1 ? Ga : Gb, Ge, partial, xmask, H, (carry || x1 || mbits) ? &bw : nullptr));
             have_tiles = carry;
         }
         if (x1) IO_TRY(conv_wgrad(c, b.c1, xin, Gb, H));

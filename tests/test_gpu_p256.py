@@ -185,3 +185,68 @@ def test_p256_dgrad_with_bn_backward_epilogue(case, form):
         outs.append(dx)
         del tabs
     assert relerr(outs[0], outs[1].double().cpu()) < TOL
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("p256", [1, 0])
+def test_relu_mask_as_bits(dtype, p256):
+    """The ReLU mask of a block output kept as one bit per element: io_bn_apply_bits_dt writes bit c % 32 of word (m Cc + c) / 32
+    = (relu(bn(y) + identity) > 0) next to the activation, and the 1x1 data gradient that completes d(out) (conv1 of the next
+    Bottleneck, resnet_cls.py:99, 114) on the 256-row kernel masks with it -- bit-identical to the same launch reading the
+    activation tensor, in both epilogue forms (plain add + mask, and with the BatchNorm-backward sums of the previous block's
+    bn3); the 128-row kernel takes the tensor either way."""
+    if dtype == "fp32" and p256 == 1:
+        pytest.skip("the 256-row kernel is a bf16 kernel")
+    lib = _lib.lib()
+    lib.io_set_bf16_p256(p256)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    dt = BF if dtype == "bf16" else 0
+    N, H, W, Cc, Cr = 4, 16, 16, 256, 64         # out / d(out): Cc channels; conv1: Cc -> Cr
+    M = N * H * W
+    g = torch.Generator().manual_seed(21)
+    y3 = torch.randn(N, H, W, Cc, generator=g).to(tdt).to(DEV)
+    idt = torch.randn(N, H, W, Cc, generator=g).to(tdt).to(DEV)
+    mean, scale, shift = (torch.randn(Cc, generator=g) * 0.2).to(DEV), (torch.rand(Cc, generator=g) + 0.5).to(DEV), \
+        (torch.randn(Cc, generator=g) * 0.3).to(DEV)
+    out = torch.empty_like(y3)
+    bits = torch.zeros(M * Cc // 32, dtype=torch.int32, device=DEV)
+    _lib.check(lib.io_bn_apply_bits_dt(P(y3), M, Cc, 1, 0, P(mean), P(scale), P(shift), P(idt), None, None, None, P(out), P(bits),
+                                       dt, ST()), "bn_apply_bits")
+    out2 = torch.empty_like(y3)
+    _lib.check(lib.io_bn_apply_dt(P(y3), M, Cc, 1, 0, P(mean), P(scale), P(shift), P(idt), None, None, None, 1, P(out2), dt, ST()),
+               "bn_apply")
+    assert torch.equal(out, out2)
+    want = (out.float() > 0).view(M, Cc // 32, 32).to(torch.int64)
+    words = (want << torch.arange(32, device=DEV)).sum(-1)
+    got = bits.to(torch.int64) & 0xffffffff
+    assert torch.equal(got.view(M, Cc // 32), words)
+    assert 0.2 < float(want.float().mean()) < 0.8
+    # the data gradient of conv1 (Cr -> Cc in the gradient direction) with the identity-path gradient added
+    dy = torch.randn(N, H, W, Cr, generator=g).to(tdt).to(DEV)
+    wt = (torch.randn(Cc, 1, Cr, generator=g) / Cr ** 0.5).to(tdt).to(DEV)
+    addt = torch.randn(N, H, W, Cc, generator=g).to(tdt).to(DEV)
+    yprev = torch.randn(N, H, W, Cc, generator=g).to(tdt).to(DEV)
+    mu, rs = (torch.randn(Cc, generator=g) * 0.1).to(DEV), (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    nt = lib.io_bn_tile_partial_floats(M, Cc, 1)
+    for with_sums in (False, True):
+        res = []
+        for use_bits in (True, False):
+            dx = torch.full((N, H, W, Cc), float("nan"), device=DEV, dtype=tdt)
+            p1, p2 = torch.zeros(nt, device=DEV), torch.zeros(nt, device=DEV)
+            opt = _lib.DgradFused()
+            opt.add = addt.data_ptr()
+            opt.relu_mask = out.data_ptr()
+            if use_bits:                       # the bit form rides along; the 256-row kernel then reads it INSTEAD of the tensor
+                opt.relu_maskbits = bits.data_ptr()
+            if with_sums:
+                opt.ep_y, opt.ep_mean, opt.ep_rstd = yprev.data_ptr(), mu.data_ptr(), rs.data_ptr()
+                opt.ep_p1, opt.ep_p2 = p1.data_ptr(), p2.data_ptr()
+            _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dy), P(wt), P(dx), N, H, W, Cc, Cr, 1, 1, 0, 1, C.byref(opt), dt, ST()),
+                       "dgrad bits=%s sums=%s" % (use_bits, with_sums))
+            torch.cuda.synchronize()
+            res.append((dx, p1, p2))
+        assert torch.isfinite(res[0][0].float()).all()
+        assert torch.equal(res[0][0], res[1][0]), (with_sums, "dx")
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]), (with_sums, "sums")
+        zero = (out.float() <= 0)
+        assert float(res[0][0].float()[zero].abs().max()) == 0.0
