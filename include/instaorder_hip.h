@@ -49,11 +49,16 @@ int io_device_count(void);
 int io_set_winograd(int on);
 int io_get_winograd(void);
 /* bf16 forward convolutions / data gradients on whole 256-row tiles with Cin % 64 == 0, Cout % 128 == 0 and a dense output:
- * 1 (default) = the persistent LDS-DMA kernel of csrc/conv_p256.hip, 0 = the 128-row kernel every other launch runs (same
- * arithmetic, fp32 accumulation; sums may associate differently).  Process-wide; initial value from the environment variable
- * IO_P256 (unset = 1).  Returns the previous value. */
+ * 1 (default) = the persistent LDS-DMA kernels -- csrc/conv_p256.hip, and csrc/conv_halo3.hip for the 3x3 stride-1 launches
+ * with 64 / 128 channels on 64- / 32-wide maps (input staged once per tile as a halo image); 2 = conv_p256 only; 3 = both, also for
+ * launches with too few tiles to fill a round of persistent blocks (where 1 prefers the 128-row kernel: tests); 0 = the
+ * 128-row kernel every other launch runs (same arithmetic, fp32 accumulation; sums may associate differently).
+ * Process-wide; initial value from the environment variable IO_P256 (unset = 1).  Returns the previous value. */
 int io_set_bf16_p256(int on);
 int io_get_bf16_p256(void);
+/* Test hook: the kernel family the most recent forward / data-gradient launch of this process went to -- 0 = the 128-row
+ * kernel, 1 = conv_p256, 2 = conv_halo3 (so a parity test can assert that the kernel it means to check is the one that ran). */
+int io_debug_last_nt_route(void);
 
 /* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
  * nn.Conv2d(bias=False) forward as used by conv1x1 / conv3x3 / the 7x7 stem

@@ -1,0 +1,550 @@
+// bf16 3x3 stride-1 same-size convolutions / data gradients of the NARROW layers (64 / 128 channels on 64 / 32 wide maps:
+// conv2 of the layer-1 and layer-2 Bottlenecks, models/backbone/resnet_cls.py:23-26, 88) with the input staged ONCE per
+// tile as a halo image.
+//
+// The implicit-GEMM kernels (conv_nt_kernel, conv_p256.hip) fetch the A operand once per filter tap: nine times the input
+// through L2 and LDS.  On the wide layers that hides behind the matrix pipe; on the 64- and 128-channel layers the output
+// tile has only 64 / 128 columns, a k-tile is 64 .. 128 MFMAs per CU, and the nine-fold operand traffic is what the launch
+// waits for (layer 1 at the bench batch: 0.28 ms forward, 0.37 ms data gradient against 0.09 ms of HBM time and 0.06 ms of
+// matrix time -- profiles/r05_per_launch_bf16.txt).  Here a tile is 256 output pixels = R = 256 / W whole rows of one image
+// times ALL output channels, and its input -- rows h0 - 1 .. h0 + R, columns -1 .. W, zeros outside the image -- goes to LDS
+// once per 64-channel chunk ((R + 2)(W + 2) pixels x 128 bytes, by LDS-DMA, XOR-swizzled); the nine taps read it at nine row
+// offsets.  Only the filter taps stream (TPS taps per stage, two stages).  Blocks are persistent (one per CU, 8 waves): the
+// halo image of the next (tile, channel chunk) is in flight while the current one is multiplied (two A buffers), and the
+// output leaves as 16-byte row pieces through LDS, as in conv_p256.hip.
+//   EPI_STATS  per-(128-row tile, channel) mean / M2 of the output (training forward);
+//   EPI_BWE    fused BatchNorm-backward epilogue with the ReLU mask recomputed from y (IoBwStats: the data gradient of conv2);
+//   EPI_PLAIN  optional bias (+ ReLU) (+ add).
+// A wave owns 64 rows here (8 waves = WM x WN over 256 x BN): the two waves of a 128-row statistics tile combine their
+// halves through LDS (Chan's update for the statistics, plain sums for the BatchNorm-backward partials).
+#include <stdlib.h>
+#include <string.h>
+
+#include "io_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+__device__ __forceinline__ u32x4 dma_rsrc_raw(unsigned long long a, size_t bytes) {
+    const u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void* p, size_t base, size_t total) {
+    const size_t rest = total > base ? total - base : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p)) + base, 0,
+                                             rest > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)rest, 0x00020000);
+}
+__device__ __forceinline__ void dma16(u32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void dma_wait_left() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWE = 2 };
+
+struct Halo3Args {
+    const bf16_t* in;
+    const bf16_t* wgt;
+    bf16_t* out;
+    const bf16_t* add;
+    size_t in_bytes, out_bytes;
+    unsigned w_bytes;
+    float *st_mean, *st_m2;
+    IoBwStats bw;
+    int ntiles, tiles_per_img;
+    int dbg;
+};
+
+// W: map width (32 | W, W | 256).  BN = Co (64 or 128).  WM x WN = 8 waves of (256 / WM) x (BN / WN).  TPS: filter taps per
+// B stage (1 or 3).
+template <int W, int BN, int WM, int WN, int TPS, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void conv_halo3_kernel(IoConvGeom g, Halo3Args a) {
+    constexpr int TP = 256, R = TP / W, NW = 8;
+    static_assert(WM * WN == NW && TP % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave layout");
+    constexpr int TM = TP / WM / 32, TN = BN / WN / 32;
+    constexpr int WP = W + 2, HP = (R + 2) * WP;           // halo image: (R + 2) rows of W + 2 pixels
+    constexpr int NCH = (HP + 7) / 8;                      // 8-pixel DMA chunks of it
+    constexpr int NAW = (NCH + NW - 1) / NW;               // ... per wave (every wave issues exactly NAW: see the counted wait)
+    constexpr int ABUF = NAW * NW * 1024;                  // bytes of one A buffer (padded to whole chunks per wave)
+    constexpr int BST = TPS * BN * 128;                    // bytes of one B stage
+    constexpr int NBW = TPS * BN / 8 / NW;                 // B chunks per wave and stage
+    static_assert(TPS * BN % (8 * NW) == 0, "B chunks per wave");
+    constexpr int NST = 9 / TPS;                           // B stages per channel chunk
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // LDS: [A buffer 0][A buffer 1][B stage 0][B stage 1]
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ncc = g.Ci / 64;                             // channel chunks
+    const int r8 = lane >> 3, p8 = lane & 7;
+    const unsigned rowB = (unsigned)(g.wT * g.Ci * 2);
+    const unsigned slot_e = (unsigned)((p8 ^ (r8 >> 1)) << 4), slot_o = slot_e ^ 64u;
+    const unsigned vb_e = (unsigned)r8 * rowB + slot_e, vb_o = (unsigned)r8 * rowB + slot_o;
+    const u32x4 rsB = dma_rsrc_raw((unsigned long long)a.wgt, a.w_bytes);
+
+    // ---- A fetches: halo pixel hp = chunk * 8 + r8 of the image is (hy, hx) = (hp / WP, hp % WP) -> input pixel
+    // (h0 - 1 + hy, hx - 1); the decomposition does not depend on the tile
+    const unsigned padpx = (unsigned)(W + 1);              // the descriptor of a tile starts this many pixels before its first
+    unsigned arel[NAW];                                    // byte offset of the lane's pixel relative to that start (+ slot)
+    int ahy[NAW];                                          // hy, or -1000 where the pixel does not exist / is left-right padding
+#pragma unroll
+    for (int u = 0; u < NAW; ++u) {
+        const int ch = wave * NAW + u, hp = ch * 8 + r8;
+        const int hy = hp / WP, hx = hp - hy * WP;
+        const bool colok = hp < HP && hx >= 1 && hx <= W;
+        ahy[u] = colok ? hy : -1000;
+        arel[u] = (unsigned)(((hy - 1) * W + (hx - 1) + (int)padpx) * g.Ci * 2) + ((ch & 1) ? slot_o : slot_e);
+    }
+    // chunks u0 .. u1 - 1 of the wave's share of A item (tile, cc) into A buffer `buf`
+    auto issue_a = [&](int tile, int cc, int buf, int u0, int u1) {
+        const int img = tile / a.tiles_per_img, h0 = (tile - img * a.tiles_per_img) * R;
+        // (address arithmetic only for the pixels before the tensor: lanes that would read there are out of the image)
+        const long long start = ((long long)img * g.Hi * g.Wi + (long long)h0 * W - (long long)padpx) * (long long)(g.Ci * 2);
+        const u32x4 rsA = dma_rsrc_raw((unsigned long long)((const char*)a.in + start),
+                                       (size_t)((long long)a.in_bytes - start));
+        const unsigned sb = lds0 + (unsigned)(buf * ABUF);
+        const unsigned coff = (unsigned)(cc * 128);
+#pragma unroll
+        for (int u = 0; u < NAW; ++u) {
+            if (u < u0 || u >= u1) continue;
+            const bool ok = (unsigned)(h0 - 1 + ahy[u]) < (unsigned)g.Hi;
+            dma16(rsA, sb + (unsigned)((wave * NAW + u) * 1024), ok ? arel[u] + coff : kOob, 0u);
+        }
+    };
+    auto issue_b = [&](int cc, int st, int stage) {       // the TPS taps of B stage `st` of channel chunk cc
+        const unsigned sb = lds0 + (unsigned)(2 * ABUF + stage * BST);
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) {
+            const int ch = wave * NBW + u;                 // chunk of the stage: tap ch / (BN / 8), rows (ch % (BN / 8)) * 8 ..
+            const int t = ch / (BN / 8), rc = ch - t * (BN / 8);
+            const int tap = st * TPS + t, th = tap / 3, tw = tap - th * 3;
+            const int widx = (g.r0 + g.rs * th) * g.S + (g.s0 + g.ss * tw);
+            dma16(rsB, sb + (unsigned)(ch * 1024), (rc & 1) ? vb_o : vb_e,
+                  (unsigned)((widx * g.Ci + cc * 64) * 2) + (unsigned)(rc * 8) * rowB);
+        }
+    };
+
+    // ---- fragment reads
+    // A: MFMA row tile i of the wave = 32 consecutive output pixels of one image row: halo pixel hpb[i] + (lane & 31) + tap shift
+    int hpb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = wm * (TP / WM) + i * 32;             // tile-local pixel
+        hpb[i] = (p / W + 1) * WP + (p % W) + 1 + (lane & 31);
+    }
+    const int swzb = (lane >> 1) & 7;                      // B rows: row & 31 = lane & 31
+    unsigned kob[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kob[kk] = (unsigned)(((2 * kk + (lane >> 5)) ^ swzb) << 4);
+    const unsigned b_row = (unsigned)((wn * TN * 32 + (lane & 31)) * 128);
+
+    f32x16 acc[TM][TN];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int cc = 0, abuf = 0, bstage = 0;
+    // The stream of B stages (tile, cc, st), one per iteration; A item (tile, cc) is read from st == 0 of its chunk on.
+    // Issue order inside iteration k: [B stage k + 1][a piece of the NEXT A item].  The wait of iteration k + 1 needs stage
+    // k + 1 and everything older, i.e. it may leave exactly the piece issued after it outstanding (`pend` fetches): a piece
+    // has two iterations to land, a B stage one.  The pieces go out in the first NST - 1 iterations of a chunk, so the
+    // wait at st == 0 of the next chunk (pend == 0) covers the whole item.
+    constexpr int NPC = NST - 1, PMAX = (NAW + NPC - 1) / NPC;       // iterations that carry a piece; fetches per piece
+    static_assert(PMAX <= 4, "piece size");
+    if (tile < a.ntiles) {
+        issue_a(tile, 0, 0, 0, NAW);
+        issue_b(0, 0, 0);
+    }
+    int st = 0, pend = 0;
+    while (tile < a.ntiles) {
+        if (cc == 0 && st == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        if (pend == 0) dma_wait_left<0>();
+        else if (pend == 1) dma_wait_left<1>();
+        else if (pend == 2) dma_wait_left<2>();
+        else if (pend == 3) dma_wait_left<3>();
+        else dma_wait_left<4>();
+        if constexpr (!(DBG & 64)) __syncthreads();
+        // what comes next in the stream
+        const bool last_st = st + 1 == NST, last_cc = cc + 1 == ncc;
+        const int nst = last_st ? 0 : st + 1;
+        const int ncc_ = last_st ? (last_cc ? 0 : cc + 1) : cc;
+        const int ntile = (last_st && last_cc) ? tile + (int)gridDim.x : tile;
+        if (ntile < a.ntiles && !(DBG & 2)) issue_b(ncc_, nst, bstage ^ 1);
+        pend = 0;
+        if (st < NPC) {
+            // the A item AFTER the current one goes into the other A buffer (free: its last reader was the previous chunk)
+            const int acc_ = last_cc ? 0 : cc + 1;
+            const int atile = last_cc ? tile + (int)gridDim.x : tile;
+            const int u0 = (NAW * st) / NPC, u1 = (NAW * (st + 1)) / NPC;
+            if (atile < a.ntiles && !(DBG & 4)) {
+                issue_a(atile, acc_, abuf ^ 1, u0, u1);
+                pend = u1 - u0;
+            }
+        }
+        const char* sa = smem + abuf * ABUF;
+        const char* sbp = smem + 2 * ABUF + bstage * BST;
+        // TPS x 4 k-steps of 16 channels; the fragments of step s + PF are requested before the products of step s (a ring of
+        // PF + 1 register sets: with TM x TN = 2 .. 4 MFMAs per step the LDS latency spans several steps)
+        constexpr int S = TPS * 4, PF = 3;
+        unsigned arow[TPS][TM], asw[TPS][TM];
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+            const int tap = st * TPS + t, th = tap / 3, tw = tap - th * 3;
+            const int sh = (g.dh0 + g.dhs * th) * WP + (g.dw0 + g.dws * tw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hp = hpb[i] + sh;
+                arow[t][i] = (unsigned)(hp * 128);
+                asw[t][i] = (unsigned)((hp >> 1) & 7);
+            }
+        }
+        bf16x8 fa[PF + 1][TM], fb[PF + 1][TN];
+        auto frag_load = [&](int s_, int slot) {
+            const int t = s_ / 4, kk = s_ % 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[slot][i] = *reinterpret_cast<const bf16x8*>(sa + arow[t][i] + ((((unsigned)(2 * kk + (lane >> 5))) ^ asw[t][i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[slot][j] = *reinterpret_cast<const bf16x8*>(sbp + t * (BN * 128) + b_row + j * 4096 + kob[kk]);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) frag_load(s_, s_ % (PF + 1));
+#pragma unroll
+        for (int s_ = 0; s_ < ((DBG & 8) ? 0 : S); ++s_) {
+            if (s_ + PF < S && !(DBG & 16)) frag_load(s_ + PF, (s_ + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);       // (left alone the scheduler sinks every read to just before its use)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr ((DBG & 32) != 0) asm volatile("" ::"v"(fa[s_ % (PF + 1)][i]), "v"(fb[s_ % (PF + 1)][j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_ % (PF + 1)][i], fb[s_ % (PF + 1)][j], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr ((DBG & 128) != 0) {
+            if (last_st && last_cc) {
+                float sm = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sm += acc[i][j][r];
+                if (sm == 12345.678f) a.out[tid] = (bf16_t)1;
+            }
+        }
+        if (last_st && last_cc && !(DBG & 1) && !(DBG & 128)) {
+            // ---- epilogue of the tile.  D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            const int m0 = tile * TP;
+            const int mt128 = (m0 >> 7) + (wm * (TP / WM)) / 128;          // the statistics tile this wave's rows belong to
+            constexpr int WPT = 128 / (TP / WM);                            // waves (along rows) per statistics tile
+            __syncthreads();                     // every wave is done with the A buffer just read: it becomes scratch
+            float* scr = reinterpret_cast<float*>(smem + abuf * ABUF);   // the A buffer just read: refilled from the next iteration on
+            if constexpr (EPI == EPI_STATS) {
+                // per wave: mean / M2 of its TP / WM rows per column; the WPT waves of a tile merged with Chan's update
+                constexpr int RW = TP / WM;
+                float wmean[TN], wm2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+                    s += __shfl_xor(s, 32, 64);
+                    wmean[j] = s * (1.0f / RW);
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d2 += (acc[i][j][r] - wmean[j]) * (acc[i][j][r] - wmean[j]);
+                    d2 += __shfl_xor(d2, 32, 64);
+                    wm2[j] = d2;
+                    if (lane < 32) {
+                        scr[(wave * TN + j) * 64 + lane] = wmean[j];
+                        scr[(wave * TN + j) * 64 + 32 + lane] = d2;
+                    }
+                }
+                __syncthreads();
+                if (wm % WPT == 0 && lane < 32) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float n = (float)RW, mu = wmean[j], m2 = wm2[j];
+#pragma unroll
+                        for (int k = 1; k < WPT; ++k) {
+                            const int ow = (wm + k) * WN + wn;
+                            const float mb = scr[(ow * TN + j) * 64 + lane], m2b = scr[(ow * TN + j) * 64 + 32 + lane];
+                            const float tot = n + (float)RW, delta = mb - mu;
+                            mu += delta * ((float)RW / tot);
+                            m2 += m2b + delta * delta * (n * (float)RW / tot);
+                            n = tot;
+                        }
+                        const size_t o = (size_t)mt128 * g.Co + wn * TN * 32 + j * 32 + lane;
+                        a.st_mean[o] = mu;
+                        a.st_m2[o] = m2;
+                    }
+                }
+                __syncthreads();
+            }
+            // rows through LDS: 16 rows x WC columns of the wave at a time -> 8 consecutive channels of a row per lane
+            constexpr int WC = TN * 32, EPP = WC + 4, ER = 16;
+            constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = (ER + RPI - 1) / RPI;
+            static_assert(NW * ER * EPP * 4 + NW * 2 * LPR * 8 * 4 <= ABUF, "scratch");
+            float* ep = scr + wave * (ER * EPP);
+            float* red = scr + NW * ER * EPP;                               // [wave][2 sums][LPR lanes][8] for the BWE partials
+            const int ecol = wn * WC + (lane % LPR) * 8;
+            const size_t out_base = (size_t)m0 * (size_t)(g.Co * 2);
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_at(a.out, out_base, a.out_bytes);
+            const __amdgpu_buffer_rsrc_t rs_add = rsrc_at(a.add ? (const void*)a.add : (const void*)a.out, out_base,
+                                                          a.add ? a.out_bytes : out_base);
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(EPI == EPI_BWE ? a.bw.y : (const void*)a.out, out_base,
+                                                        EPI == EPI_BWE ? a.out_bytes : out_base);
+            float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
+            const int gcol = EPI == EPI_BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;
+            if constexpr (EPI == EPI_BWE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    t_mu[e] = a.bw.mean[gcol + e];
+                    t_sc[e] = a.bw.mscale[gcol + e];
+                    t_sh[e] = a.bw.mshift[gcol + e];
+                    s1[e] = s2[e] = 0.f;
+                }
+            }
+            if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
+            }
+            constexpr int NP = TM * 2 * NI, PD = EPI == EPI_STATS ? 1 : 3;
+            auto pass_row = [&](int p) -> int {
+                const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+                return wm * (TP / WM) + i * 32 + h * 16 + k * RPI + lane / LPR;
+            };
+            const bool rowok = NI * RPI == ER || (lane / LPR) < ER;          // (RPI = 16 = ER here: always true)
+            u32x4 pav[PD], pyv[PD];
+            auto pass_load = [&](int p, int sl) {
+                const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+                if constexpr (EPI == EPI_PLAIN) pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
+                if constexpr (EPI == EPI_BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+            };
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+                if (d < NP) pass_load(d, d);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+                if (k == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r8i = 0; r8i < 8; ++r8i) {
+                            const int r = h * 8 + r8i;
+                            ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][j][r];
+                        }
+                }
+                const int row = k * RPI + lane / LPR;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8 + 4);
+                float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+                const int sl = p % PD;
+                if constexpr (EPI == EPI_PLAIN) {
+                    const u32x4 av = pav[sl];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        v[2 * d] += bf_lo(av[d]);
+                        v[2 * d + 1] += bf_hi(av[d]);
+                    }
+                    if (a.bw.bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v[e] += t_bias[e];
+                            v[e] = (a.bw.relu && v[e] < 0.f) ? 0.f : v[e];
+                        }
+                    }
+                }
+                if constexpr (EPI == EPI_BWE) {
+                    const u32x4 yv = pyv[sl];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int e = 2 * d + hh;
+                            const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
+                            const float t = __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
+                            v[e] = t > 0.f ? v[e] : 0.f;
+                            s1[e] += v[e];
+                            s2[e] = __builtin_fmaf(v[e], y, s2[e]);
+                        }
+                }
+                if (p + PD < NP) pass_load(p + PD, sl);
+                const u32x4 pk = {io_f2bf2(v[0], v[1]), io_f2bf2(v[2], v[3]), io_f2bf2(v[4], v[5]), io_f2bf2(v[6], v[7])};
+                if (rowok) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
+            }
+            if constexpr (EPI == EPI_BWE) {
+                // lanes with the same lane % LPR hold the same 8 channels: sum them, then the WPT waves of the statistics tile
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int sft = LPR; sft < 64; sft <<= 1) {
+                        s1[e] += __shfl_xor(s1[e], sft, 64);
+                        s2[e] += __shfl_xor(s2[e], sft, 64);
+                    }
+                if (lane < LPR) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        red[((wave * 2 + 0) * LPR + lane) * 8 + e] = s1[e];
+                        red[((wave * 2 + 1) * LPR + lane) * 8 + e] = s2[e];
+                    }
+                }
+                __syncthreads();
+                if (wm % WPT == 0 && lane < LPR) {
+                    const size_t o = (size_t)mt128 * g.Co + ecol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t1 = s1[e], t2 = s2[e];
+#pragma unroll
+                        for (int k = 1; k < WPT; ++k) {
+                            const int ow = (wm + k) * WN + wn;
+                            t1 += red[((ow * 2 + 0) * LPR + lane) * 8 + e];
+                            t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
+                        }
+                        a.bw.p1[o + e] = t1;
+                        a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
+                    }
+                }
+            }
+            // (the next iteration's barrier orders these LDS uses before the buffer is refilled)
+        }
+        // advance the stream
+        if (last_st) abuf ^= 1;
+        bstage ^= 1;
+        st = nst;
+        cc = ncc_;
+        tile = ntile;
+    }
+}
+
+}  // namespace
+
+// IO_OK = launched, 1 = not this kernel's shape / form (the caller falls through), < 0 = error
+int io_launch_conv_halo3(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add, const void* mask,
+                         hipStream_t st, float* st_mean, float* st_m2, const IoBwStats* bw, size_t in_bytes,
+                         unsigned w_bytes, size_t out_bytes) {
+    const int mode = io_bf16_persist_mode();
+    if (mode != 1 && mode != 3) return 1;
+    const bool same3 = g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho &&
+                       g.Wi == g.Wo && g.outH == g.Ho && g.outW == g.Wo && !g.gw && !g.cr && g.dhs * g.dhs == 1 &&
+                       g.dws * g.dws == 1 && g.dh0 == -g.dhs && g.dw0 == -g.dws;
+    if (!same3 || mask) return 1;
+    if (!((g.Co == 64 || g.Co == 128) && (g.Ci == 64 || g.Ci == 128))) return 1;
+    if (!(g.Wo == 64 || g.Wo == 32) || (g.Ho * g.Wo) % 256 != 0) return 1;
+    if (bw && (bw->in_scale || bw->xb_a || bw->a_out || bw->wino_u || bw->maskbits)) return 1;
+    if (st_mean && (add || (bw && (bw->y || bw->bias)))) return 1;
+    if (bw && bw->y && (!bw->mscale || add || bw->bias || bw->Mg % 256 != 0)) return 1;
+    const long M = (long)g.N * g.Ho * g.Wo;
+    if ((double)g.Hi * g.Wi * g.Ci * 2.0 >= 2.0e9 || 256.0 * g.Co * 2.0 >= 4.0e9) return 1;
+    const int epi = st_mean ? EPI_STATS : ((bw && bw->y) ? EPI_BWE : EPI_PLAIN);
+    Halo3Args a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const bf16_t*)in;
+    a.wgt = (const bf16_t*)wgt;
+    a.out = (bf16_t*)out;
+    a.add = (const bf16_t*)add;
+    a.in_bytes = in_bytes;
+    a.out_bytes = out_bytes;
+    a.w_bytes = w_bytes;
+    a.st_mean = st_mean;
+    a.st_m2 = st_m2;
+    if (bw) a.bw = *bw;
+    a.ntiles = (int)(M / 256);
+    a.tiles_per_img = g.Ho * g.Wo / 256;
+    { const char* e = getenv("IO_HALO3_DBG"); a.dbg = e ? atoi(e) : 0; }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    {
+        const long rounds = ((long)a.ntiles + ncu - 1) / ncu;
+        if (mode != 3 && (long)a.ntiles * 10 < rounds * ncu * 8) return 1;     // (conv_p256.hip's rule)
+    }
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    const double kred = 9.0 * g.Ci;
+    IoProfScope prof(IO_PROF_CONV_NT64, 2.0 * (double)M * g.Co * kred,
+                     2.0 * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
+                         2.0 * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
+                     st);
+#define IO_HALO3_LAUNCH(W_, BN_, WM_, WN_, TPS_, EPI_)                                                                    \
+    do {                                                                                                                  \
+        constexpr int HP_ = (256 / W_ + 2) * (W_ + 2), NAW_ = ((HP_ + 7) / 8 + 7) / 8;                                    \
+        const size_t lds = (size_t)2 * NAW_ * 8 * 1024 + (size_t)2 * TPS_ * BN_ * 128;                                    \
+        static std::atomic<unsigned long long> attr_done{0};                                                              \
+        if (io_first_on_device(attr_done))                                                                                \
+            (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<W_, BN_, WM_, WN_, TPS_, EPI_>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        hipLaunchKernelGGL((conv_halo3_kernel<W_, BN_, WM_, WN_, TPS_, EPI_>), dim3((unsigned)grid), dim3(512), lds, st,  \
+                           g, a);                                                                                         \
+    } while (0)
+#define IO_HALO3_EPI(W_, BN_, WM_, WN_, TPS_)                                     \
+    do {                                                                          \
+        if (epi == EPI_STATS) IO_HALO3_LAUNCH(W_, BN_, WM_, WN_, TPS_, EPI_STATS);  \
+        else if (epi == EPI_BWE) IO_HALO3_LAUNCH(W_, BN_, WM_, WN_, TPS_, EPI_BWE); \
+        else IO_HALO3_LAUNCH(W_, BN_, WM_, WN_, TPS_, EPI_PLAIN);                   \
+    } while (0)
+    if (a.dbg && g.Wo == 64 && g.Co == 64 && epi == EPI_PLAIN) {
+#define IO_HALO3_DBGL(D_)                                                                                                \
+    do {                                                                                                                 \
+        const size_t lds = (size_t)2 * 7 * 8 * 1024 + (size_t)2 * 3 * 64 * 128;                                          \
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<64, 64, 4, 2, 3, EPI_PLAIN, D_>,                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+        hipLaunchKernelGGL((conv_halo3_kernel<64, 64, 4, 2, 3, EPI_PLAIN, D_>), dim3((unsigned)grid), dim3(512), lds, st, g, a); \
+    } while (0)
+        switch (a.dbg) {
+            case 1: IO_HALO3_DBGL(1); break;
+            case 7: IO_HALO3_DBGL(7); break;
+            case 23: IO_HALO3_DBGL(23); break;
+            case 39: IO_HALO3_DBGL(39); break;
+            case 55: IO_HALO3_DBGL(55); break;
+            case 15: IO_HALO3_DBGL(15); break;
+            case 6: IO_HALO3_DBGL(6); break;
+            case 22: IO_HALO3_DBGL(22); break;
+            case 86: IO_HALO3_DBGL(86); break;
+            case 150: IO_HALO3_DBGL(150); break;
+            case 214: IO_HALO3_DBGL(214); break;
+            case 134: IO_HALO3_DBGL(134); break;
+            case 128: IO_HALO3_DBGL(128); break;
+            case 70: IO_HALO3_DBGL(70); break;
+            case 38: IO_HALO3_DBGL(38); break;
+            default: IO_HALO3_DBGL(14); break;
+        }
+        return io_check_launch("conv_halo3 dbg");
+    }
+    // 64 output channels: 4 x 2 waves of 64 x 32, three taps per stage; 128: 4 x 2 waves of 64 x 64, one tap per stage
+    if (g.Wo == 64 && g.Co == 64) IO_HALO3_EPI(64, 64, 4, 2, 3);
+    else if (g.Wo == 64 && g.Co == 128) IO_HALO3_EPI(64, 128, 4, 2, 1);
+    else if (g.Wo == 32 && g.Co == 64) IO_HALO3_EPI(32, 64, 4, 2, 3);
+    else IO_HALO3_EPI(32, 128, 4, 2, 1);
+#undef IO_HALO3_EPI
+#undef IO_HALO3_LAUNCH
+    return io_check_launch("conv_halo3");
+}

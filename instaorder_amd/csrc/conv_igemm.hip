@@ -2889,6 +2889,10 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     return need;
 }
 
+// which kernel family the last forward / data-gradient launch went to (tests: 0 = conv_nt_kernel, 1 = conv_p256, 2 = conv_halo3)
+static std::atomic<int> g_last_route{0};
+extern "C" int io_debug_last_nt_route(void) { return g_last_route.load(std::memory_order_relaxed); }
+
 int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add,
                       const void* mask, int stem, hipStream_t st, float* st_mean, float* st_m2,
                       const IoBwStats* bw, int dt_in, int dt_out) {
@@ -2947,10 +2951,20 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const unsigned w_bytes = (unsigned)w_b;
     // bf16: the persistent 256-row LDS-DMA kernel where the shape and the form are its own (conv_p256.hip)
     if (dt_in == IO_BF16 && dt_out == IO_BF16 && !stem) {
+        const int rh = io_launch_conv_halo3(g, in, wgt, out, add, mask, st, st_mean, st_m2, bw ? &bws : nullptr, in_bytes,
+                                            w_bytes, out_bytes);
+        if (rh <= 0) {
+            g_last_route.store(2, std::memory_order_relaxed);
+            return rh;
+        }
         const int rc = io_launch_conv_p256(g, in, wgt, out, add, mask, st, st_mean, st_m2, bw ? &bws : nullptr, in_bytes,
                                            w_bytes, out_bytes);
-        if (rc <= 0) return rc;
+        if (rc <= 0) {
+            g_last_route.store(1, std::memory_order_relaxed);
+            return rc;
+        }
     }
+    g_last_route.store(0, std::memory_order_relaxed);
     // Output-channel tile: 128 wide where that leaves enough tiles to fill the chip, 64 wide otherwise -- a small per-GPU batch
     // (the reference's own 32 pairs per GPU, or a strong-scaling rank) gives layers 3-4 only 32..128 row tiles, and 128-wide
     // tiles then occupy a fraction of the 256 CUs with one block each (measured at 32 pairs: 43-51 TF/s on the 8 x 8 maps).

@@ -412,7 +412,7 @@ int p256_enabled() {
     int on = g_p256.load(std::memory_order_relaxed);
     if (on < 0) {
         const char* e = getenv("IO_P256");
-        on = (e && e[0] == '0') ? 0 : 1;
+        on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : ((e && e[0] == '3') ? 3 : 1));
         g_p256.store(on, std::memory_order_relaxed);
     }
     return on;
@@ -423,9 +423,10 @@ int p256_enabled() {
 extern "C" int io_get_bf16_p256(void) { return p256_enabled(); }
 extern "C" int io_set_bf16_p256(int on) {
     const int prev = p256_enabled();
-    g_p256.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_p256.store((on == 2 || on == 3) ? on : (on ? 1 : 0), std::memory_order_relaxed);
     return prev;
 }
+int io_bf16_persist_mode() { return p256_enabled(); }
 
 // Returns IO_OK when the launch was taken, 1 when the shape / form is not this kernel's (the caller falls through to
 // conv_nt_kernel), < 0 on a launch error.
@@ -477,7 +478,7 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     // and 12 x 12 maps: 9..144 row tiles), where taking every eligible launch cost 2.8 %.
     {
         const long rounds = (tiles + ncu - 1) / ncu;
-        if (tiles * 10 < rounds * ncu * 8) return 1;          // less than 80 % of the rounds' slots used
+        if (p256_enabled() != 3 && tiles * 10 < rounds * ncu * 8) return 1;          // less than 80 % of the rounds' slots used
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const double kred = (double)g.Th * g.Tw * g.Ci;

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ALGO_CLASSES, synthetic
+from helpers import ALGO_CLASSES, orc, rel_err, synthetic
 from instaorder_amd import _lib
 from test_gpu_ops import L, P, ST
 
@@ -107,6 +107,22 @@ def test_config3_1024_pairs_bf16_step():
         m.forward_only(ret_loss=False)
         small = m.last_logits
         assert torch.equal(small[:32], big[lo:lo + 32]) and torch.equal(small[32:], big[B + lo:B + lo + 32])
+    # ... and four of the 1024 pairs (the first two and the last two, both directions) against the fp32 ORACLE on the same
+    # images and state: the eval-mode bar of test_gpu_bf16.py (1e-2 of the logit scale)
+    sd = synthetic.make_state_dict(11, 5, ALGO_CLASSES[algo], prefix="module.", style="kaiming")
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] = (sd[k] * 0.1).astype(np.float32)
+    state = orc.state_from_numpy(sd, prefix="module.")
+    idx = torch.tensor([0, 1, B - 2, B - 1], device=DEV)
+    rgb, m1, m2 = (t[k][idx].float().cpu() for k in ("rgb", "modal1", "modal2"))
+    with torch.no_grad():
+        zo = torch.cat([torch.cat(orc.resnet_forward(state, torch.cat([a_, b_, rgb], 1), False), 1)
+                        for a_, b_ in ((m1, m2), (m2, m1))], 0)                      # [8, 5]: first direction, then second
+    zh = torch.cat([big[idx], big[B + idx]], 0).float().cpu()
+    e = rel_err(zh.numpy(), zo.numpy())
+    print("configs[2] eval logits of 4 of the 1024 pairs vs the fp32 oracle: rel err %.3e" % e)
+    assert e < 1e-2, e
 
     def train_step(m):
         m.switch_to("train")

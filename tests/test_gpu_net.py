@@ -807,11 +807,13 @@ def test_trained_model_accuracy_fp32_and_bf16():
 # ------------------------------------------------------------------------------------------------
 # edge shapes: the smallest input the network accepts (layer4 is 1x1), a single pair, odd batches
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S,B", [(32, 3), (32, 5), (64, 1), (96, 3)])
+@pytest.mark.parametrize("S,B", [(32, 3), (32, 5), (64, 1), (96, 3), (256, 32)])
 def test_edge_shapes_forward_and_step(S, B):
     """S = 32: layer4 works on 1x1 maps (3x3 convolutions that only see padding around one pixel, a stride-2
     convolution from 2x2 to 1x1, a 1-pixel average pool); B = 1: each BatchNorm group is a single sample; S = 96 /
-    odd B: row counts that are not multiples of the 128-row tile anywhere (unfused statistics path, ragged tiles).
+    odd B: row counts that are not multiples of the 128-row tile anywhere (unfused statistics path, ragged tiles);
+    S = 256, B = 32: the reference's own per-GPU batch (BASELINE configs[0]) -- the launches where layers 3-4 have at most
+    one 128-wide tile per CU and run 64 wide instead (conv_igemm.hip, IO_NT_SMALL_TILES).
     (Batch statistics over TWO values -- S = 32 with 2 samples -- are left out: every normalised value is +-1 by the
     sign of a difference, which no two fp32 implementations agree on.)"""
     algo = "InstaOrderNet_od"
