@@ -55,15 +55,15 @@ def _restore():
 
 
 # N, H, W, Cin, Cout, R, stride     (N * Ho * Wo a multiple of 256)
-# The cases of csrc/conv_halo3.hip (3x3 stride 1, 64 / 128 channels, 64- / 32-wide maps).  Mode 3 takes the persistent kernels
+# The cases of csrc/conv_halo3.hip (3x3 stride 1, 64 output channels from 64 -- filters in registers -- or 128, 64- / 32-wide maps).  Mode 3 takes the persistent kernels
 # for every eligible shape (mode 1 leaves launches that fill < 80 % of a round of 256 blocks to the 128-row kernel); the
 # route is asserted (io_debug_last_nt_route: 1 = conv_p256, 2 = conv_halo3).  One tile .. several rounds, ragged last round.
-HALO_CASES = [(1, 64, 64, 64, 64, 3, 1), (3, 32, 32, 128, 128, 3, 1), (16, 64, 64, 128, 64, 3, 1), (67, 32, 32, 64, 128, 3, 1),
-              (40, 64, 64, 64, 64, 3, 1), (2, 128, 64, 64, 64, 3, 1), (5, 64, 32, 128, 128, 3, 1)]
+HALO_CASES = [(1, 64, 64, 64, 64, 3, 1), (3, 32, 32, 128, 64, 3, 1), (16, 64, 64, 128, 64, 3, 1), (67, 32, 32, 64, 64, 3, 1),
+              (40, 64, 64, 64, 64, 3, 1), (2, 128, 64, 64, 64, 3, 1), (5, 64, 32, 64, 64, 3, 1)]
 
 
 def _halo_shape(N, H, W, Cin, Cout, R, stride=1):
-    return R == 3 and stride == 1 and Cin in (64, 128) and Cout in (64, 128) and W in (32, 64) and (H * W) % 256 == 0
+    return R == 3 and stride == 1 and Cin in (64, 128) and Cout == 64 and W in (32, 64) and (H * W) % 256 == 0
 
 
 CASES = [(2, 16, 16, 64, 256, 1, 1), (4, 8, 8, 128, 128, 3, 1), (2, 32, 32, 64, 128, 3, 1), (8, 16, 16, 128, 256, 1, 2),
@@ -133,7 +133,7 @@ def test_p256_forward_plain_stats_bias(case):
 
 
 # (the halo kernel's data gradients: conv2 of layers 1-2, mask recomputed from y)
-HALO_DG = [(2, 64, 64, 64, 64, 3), (6, 32, 32, 128, 128, 3), (40, 64, 64, 64, 64, 3), (34, 32, 32, 64, 128, 3)]
+HALO_DG = [(2, 64, 64, 64, 64, 3), (6, 32, 32, 64, 64, 3), (40, 64, 64, 64, 64, 3), (34, 32, 32, 64, 128, 3)]
 DG_CASES = [(2, 16, 16, 256, 64, 1), (4, 8, 8, 128, 128, 3), (2, 32, 32, 128, 64, 3), (4, 16, 16, 512, 128, 1), (32, 32, 32, 256, 64, 1)]
 
 
@@ -145,7 +145,7 @@ def test_p256_dgrad_with_bn_backward_epilogue(case, form):
     N, H, W, Cin, Cout, R = case       # the data gradient has Cin output channels (>= 128) and reduces over Cout
     pad = R // 2
     lib = _lib.lib()
-    halo = _halo_shape(*case) and form == "recompute_mask"
+    halo = _halo_shape(N, H, W, Cout, Cin, R) and form == "recompute_mask"     # (output channels of the gradient: Cin)
     if case in HALO_DG and form != "recompute_mask":
         pytest.skip("the halo kernel recomputes the mask (conv2's data gradient); a mask tensor goes to the other kernels")
     g = torch.Generator().manual_seed(7 + Cin + H)
