@@ -336,3 +336,31 @@ def test_config4_depthnet_384(dtype):
     gn = float(m.optim.flat_grads.double().norm())
     print("config4 %s step 384^2: gradient norm %.5f (oracle %.5f)" % (dtype, gn, ref_gn))
     assert abs(gn - ref_gn) < (0.03 if dtype == "fp32" else 0.1) * ref_gn
+    # every parameter tensor's gradient against the oracle's (PyTorch-CPU fp32, the reference's arithmetic) at this size:
+    # the decoder's filter gradients run here on 24 / 48 / 96 / 192-wide maps (the Winograd filter-gradient kernels at
+    # widths that are not powers of two), which the 64 x 64 anchor test of test_gpu_midas.py does not reach
+    g = np.load(os.path.join(GOLDEN, "depthnet_od_S64_B2.npz"), allow_pickle=False)
+    names = [str(n) for n in g["names"]]
+    errs, num, den = [], 0.0, 0.0
+    for n, (off, k) in zip(names, m.optim._spans):
+        p_ = st.get(n)
+        if p_ is None or p_.grad is None:
+            continue
+        ref = p_.grad.double().reshape(-1)
+        gh = m.optim.flat_grads[off:off + k].double().cpu()
+        nr = float(ref.norm())
+        if nr < 1e-12 * ref_gn:
+            continue
+        errs.append((float((gh - ref).norm()) / nr, n))
+        num += float((gh - ref).norm() ** 2)
+        den += nr ** 2
+    errs.sort(reverse=True)
+    glob = (num / den) ** 0.5
+    # (bf16: reported only -- on this random-weight state single tensors of the deepest encoder layers differ by O(1), the
+    # chaos the bf16 tests of test_gpu_bf16.py damp with bn3 x 0.1; the bf16 kernels are held to the oracle there)
+    per_bound, glob_bound = (3e-2, 5e-3) if dtype == "fp32" else (2.0, 0.3)       # measured fp32: worst 9.7e-3, global 1.3e-3
+    over = [e for e in errs if e[0] > per_bound]
+    print("config4 %s step 384^2: %d gradient tensors vs the oracle: global rel L2 %.2e, worst %.2e (%s), median %.2e, %d over %.0e"
+          % (dtype, len(errs), glob, errs[0][0], errs[0][1], errs[len(errs) // 2][0], len(over), per_bound))
+    assert len(errs) > 300 and glob < glob_bound, glob
+    assert len(over) <= len(errs) // 50, over[:10]
