@@ -57,7 +57,7 @@ int io_get_winograd(void);
 int io_set_bf16_p256(int on);
 int io_get_bf16_p256(void);
 /* Test hook: the kernel family the most recent forward / data-gradient launch of this process went to -- 0 = the 128-row
- * kernel, 1 = conv_p256, 2 = conv_halo3 (so a parity test can assert that the kernel it means to check is the one that ran). */
+ * kernel, 1 = conv_p256, 2 = conv_halo3, 3 = stem_halo (so a parity test can assert that the kernel it means to check is the one that ran). */
 int io_debug_last_nt_route(void);
 
 /* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------

@@ -70,6 +70,211 @@ struct Halo3Args {
     int ntiles, tiles_per_img;
 };
 
+// The epilogue of one 256-row x BN tile (rows m0 .. m0 + 255 of the output matrix) out of the waves' accumulators: statistics
+// or BatchNorm-backward partials per 128-row tile, then the rows as 16-byte pieces through the LDS scratch `scr` (SCRB bytes,
+// free once every wave has passed the barrier at the top).  D layout of a 32 x 32 MFMA tile: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  LTAB: the mean / scale / shift rows of the BatchNorm-backward epilogue are
+// read per pass from `ltab` ([3][BN] floats of LDS) instead of living in 24 registers.
+template <int TP, int BN, int WM, int WN, int EPI, bool LTAB, int SCRB>
+__device__ __forceinline__ void halo_epilogue(f32x16 (&acc)[TP / WM / 32][BN / WN / 32], float* scr, float* ltab,
+                                              const IoConvGeom& g, const Halo3Args& a, int m0, int tid) {
+    constexpr int NW = WM * WN, TM = TP / WM / 32, TN = BN / WN / 32, ABUF = SCRB;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+        // ---- epilogue of the tile.  D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            const int mt128 = (m0 >> 7) + (wm * (TP / WM)) / 128;          // the statistics tile this wave's rows belong to
+        constexpr int WPT = 128 / (TP / WM);                            // waves (along rows) per statistics tile
+        // (filters in registers: no room for the 24 table values of the BatchNorm-backward epilogue next to them -- the
+        // tile's mean / scale / shift rows go to LDS behind the A buffers and are read per pass)
+                if constexpr (LTAB) {
+            if (tid < 3 * BN) {
+                const int which = tid / BN, c = tid - which * BN;
+                const float* src = which == 0 ? a.bw.mean : (which == 1 ? a.bw.mscale : a.bw.mshift);
+                ltab[tid] = src[(m0 / a.bw.Mg) * g.Co + c];
+            }
+        }
+        __syncthreads();                     // every wave is done with the A buffer just read: it becomes scratch
+            if constexpr (EPI == EPI_STATS) {
+            // per wave: mean / M2 of its TP / WM rows per column; the WPT waves of a tile merged with Chan's update
+            constexpr int RW = TP / WM;
+            float wmean[TN], wm2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+                s += __shfl_xor(s, 32, 64);
+                wmean[j] = s * (1.0f / RW);
+                float d2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d2 += (acc[i][j][r] - wmean[j]) * (acc[i][j][r] - wmean[j]);
+                d2 += __shfl_xor(d2, 32, 64);
+                wm2[j] = d2;
+                if (lane < 32) {
+                    scr[(wave * TN + j) * 64 + lane] = wmean[j];
+                    scr[(wave * TN + j) * 64 + 32 + lane] = d2;
+                }
+            }
+            __syncthreads();
+            if (wm % WPT == 0 && lane < 32) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float n = (float)RW, mu = wmean[j], m2 = wm2[j];
+#pragma unroll
+                    for (int k = 1; k < WPT; ++k) {
+                        const int ow = (wm + k) * WN + wn;
+                        const float mb = scr[(ow * TN + j) * 64 + lane], m2b = scr[(ow * TN + j) * 64 + 32 + lane];
+                        const float tot = n + (float)RW, delta = mb - mu;
+                        mu += delta * ((float)RW / tot);
+                        m2 += m2b + delta * delta * (n * (float)RW / tot);
+                        n = tot;
+                    }
+                    const size_t o = (size_t)mt128 * g.Co + wn * TN * 32 + j * 32 + lane;
+                    a.st_mean[o] = mu;
+                    a.st_m2[o] = m2;
+                }
+            }
+            __syncthreads();
+        }
+        // rows through LDS: 16 rows x WC columns of the wave at a time -> 8 consecutive channels of a row per lane
+        constexpr int WC = TN * 32, EPP = WC + 4, ER = 16;
+        constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = (ER + RPI - 1) / RPI;
+        static_assert(NW * ER * EPP * 4 + NW * 2 * LPR * 8 * 4 <= ABUF, "scratch");
+        float* ep = scr + wave * (ER * EPP);
+        float* red = scr + NW * ER * EPP;                               // [wave][2 sums][LPR lanes][8] for the BWE partials
+        const int ecol = wn * WC + (lane % LPR) * 8;
+        const size_t out_base = (size_t)m0 * (size_t)(g.Co * 2);
+        const __amdgpu_buffer_rsrc_t rs_out = rsrc_at(a.out, out_base, a.out_bytes);
+        const __amdgpu_buffer_rsrc_t rs_add = rsrc_at(a.add ? (const void*)a.add : (const void*)a.out, out_base,
+                                                      a.add ? a.out_bytes : out_base);
+        const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(EPI == EPI_BWE ? a.bw.y : (const void*)a.out, out_base,
+                                                    EPI == EPI_BWE ? a.out_bytes : out_base);
+        float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
+        const int gcol = EPI == EPI_BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;
+        if constexpr (EPI == EPI_BWE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (!LTAB) {
+                    t_mu[e] = a.bw.mean[gcol + e];
+                    t_sc[e] = a.bw.mscale[gcol + e];
+                    t_sh[e] = a.bw.mshift[gcol + e];
+                }
+                s1[e] = s2[e] = 0.f;
+            }
+        }
+        if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
+        }
+        constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS || LTAB) ? 1 : 3;
+        auto pass_row = [&](int p) -> int {
+            const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+            return wm * (TP / WM) + i * 32 + h * 16 + k * RPI + lane / LPR;
+        };
+        const bool rowok = NI * RPI == ER || (lane / LPR) < ER;          // (RPI = 16 = ER here: always true)
+        u32x4 pav[PD], pyv[PD];
+        auto pass_load = [&](int p, int sl) {
+            const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+            if constexpr (EPI == EPI_PLAIN) pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
+            if constexpr (EPI == EPI_BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d < NP) pass_load(d, d);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+            if (k == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r8i = 0; r8i < 8; ++r8i) {
+                        const int r = h * 8 + r8i;
+                        ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][j][r];
+                    }
+            }
+            const int row = k * RPI + lane / LPR;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8 + 4);
+            float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+            const int sl = p % PD;
+            if constexpr (EPI == EPI_PLAIN) {
+                const u32x4 av = pav[sl];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    v[2 * d] += bf_lo(av[d]);
+                    v[2 * d + 1] += bf_hi(av[d]);
+                }
+                if (a.bw.bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] += t_bias[e];
+                        v[e] = (a.bw.relu && v[e] < 0.f) ? 0.f : v[e];
+                    }
+                }
+            }
+            if constexpr (EPI == EPI_BWE) {
+                const u32x4 yv = pyv[sl];
+                int tc = ecol;                   // (opaque per pass: the table reads stay inside the pass)
+                if constexpr (LTAB) asm volatile("" : "+v"(tc));
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int e = 2 * d + hh;
+                        const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
+                        const float t = LTAB ? __builtin_fmaf(y - ltab[tc + e], ltab[BN + tc + e], ltab[2 * BN + tc + e])
+                                             : __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
+                        v[e] = t > 0.f ? v[e] : 0.f;
+                        s1[e] += v[e];
+                        s2[e] = __builtin_fmaf(v[e], y, s2[e]);
+                    }
+            }
+            if (p + PD < NP) pass_load(p + PD, sl);
+            const u32x4 pk = {io_f2bf2(v[0], v[1]), io_f2bf2(v[2], v[3]), io_f2bf2(v[4], v[5]), io_f2bf2(v[6], v[7])};
+            if (rowok) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
+        }
+        if constexpr (EPI == EPI_BWE) {
+            // lanes with the same lane % LPR hold the same 8 channels: sum them, then the WPT waves of the statistics tile
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int sft = LPR; sft < 64; sft <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], sft, 64);
+                    s2[e] += __shfl_xor(s2[e], sft, 64);
+                }
+            if (lane < LPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[((wave * 2 + 0) * LPR + lane) * 8 + e] = s1[e];
+                    red[((wave * 2 + 1) * LPR + lane) * 8 + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            if (wm % WPT == 0 && lane < LPR) {
+                const size_t o = (size_t)mt128 * g.Co + ecol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t1 = s1[e], t2 = s2[e];
+#pragma unroll
+                    for (int k = 1; k < WPT; ++k) {
+                        const int ow = (wm + k) * WN + wn;
+                        t1 += red[((ow * 2 + 0) * LPR + lane) * 8 + e];
+                        t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
+                    }
+                    a.bw.p1[o + e] = t1;
+                    a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
+                }
+            }
+        }
+        // (the next iteration's barrier orders these LDS uses before the buffer is refilled)
+}
+
 // W: map width (32 | W, W | 256).  BN = Co (64 or 128).  WM x WN = 8 waves of (256 / WM) x (BN / WN).  TPS: filter taps per
 // B stage (1 or 3) -- or 0: the filters live in REGISTERS (64 input channels only: 36 k-steps x TN fragments per lane, loaded
 // once per block), nothing but the halo images streams, and a tile is one barrier interval instead of 9 / TPS.
@@ -274,208 +479,132 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_kernel(IoConvGeom g, Halo3A
             __builtin_amdgcn_sched_barrier(0);
         }
         if (last_st && last_cc) {
-            // ---- epilogue of the tile.  D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-            const int m0 = tile * TP;
-            const int mt128 = (m0 >> 7) + (wm * (TP / WM)) / 128;          // the statistics tile this wave's rows belong to
-            constexpr int WPT = 128 / (TP / WM);                            // waves (along rows) per statistics tile
             // (filters in registers: no room for the 24 table values of the BatchNorm-backward epilogue next to them -- the
             // tile's mean / scale / shift rows go to LDS behind the A buffers and are read per pass)
-            constexpr bool LTAB = BREG && EPI == EPI_BWE;
-            float* ltab = reinterpret_cast<float*>(smem + 2 * ABUF + 2 * BST);        // [3][BN]
-            if constexpr (LTAB) {
-                if (tid < 3 * BN) {
-                    const int which = tid / BN, c = tid - which * BN;
-                    const float* src = which == 0 ? a.bw.mean : (which == 1 ? a.bw.mscale : a.bw.mshift);
-                    ltab[tid] = src[(m0 / a.bw.Mg) * g.Co + c];
-                }
-            }
-            __syncthreads();                     // every wave is done with the A buffer just read: it becomes scratch
-            float* scr = reinterpret_cast<float*>(smem + abuf * ABUF);   // the A buffer just read: refilled from the next iteration on
-            if constexpr (EPI == EPI_STATS) {
-                // per wave: mean / M2 of its TP / WM rows per column; the WPT waves of a tile merged with Chan's update
-                constexpr int RW = TP / WM;
-                float wmean[TN], wm2[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-                    s += __shfl_xor(s, 32, 64);
-                    wmean[j] = s * (1.0f / RW);
-                    float d2 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) d2 += (acc[i][j][r] - wmean[j]) * (acc[i][j][r] - wmean[j]);
-                    d2 += __shfl_xor(d2, 32, 64);
-                    wm2[j] = d2;
-                    if (lane < 32) {
-                        scr[(wave * TN + j) * 64 + lane] = wmean[j];
-                        scr[(wave * TN + j) * 64 + 32 + lane] = d2;
-                    }
-                }
-                __syncthreads();
-                if (wm % WPT == 0 && lane < 32) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        float n = (float)RW, mu = wmean[j], m2 = wm2[j];
-#pragma unroll
-                        for (int k = 1; k < WPT; ++k) {
-                            const int ow = (wm + k) * WN + wn;
-                            const float mb = scr[(ow * TN + j) * 64 + lane], m2b = scr[(ow * TN + j) * 64 + 32 + lane];
-                            const float tot = n + (float)RW, delta = mb - mu;
-                            mu += delta * ((float)RW / tot);
-                            m2 += m2b + delta * delta * (n * (float)RW / tot);
-                            n = tot;
-                        }
-                        const size_t o = (size_t)mt128 * g.Co + wn * TN * 32 + j * 32 + lane;
-                        a.st_mean[o] = mu;
-                        a.st_m2[o] = m2;
-                    }
-                }
-                __syncthreads();
-            }
-            // rows through LDS: 16 rows x WC columns of the wave at a time -> 8 consecutive channels of a row per lane
-            constexpr int WC = TN * 32, EPP = WC + 4, ER = 16;
-            constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = (ER + RPI - 1) / RPI;
-            static_assert(NW * ER * EPP * 4 + NW * 2 * LPR * 8 * 4 <= ABUF, "scratch");
-            float* ep = scr + wave * (ER * EPP);
-            float* red = scr + NW * ER * EPP;                               // [wave][2 sums][LPR lanes][8] for the BWE partials
-            const int ecol = wn * WC + (lane % LPR) * 8;
-            const size_t out_base = (size_t)m0 * (size_t)(g.Co * 2);
-            const __amdgpu_buffer_rsrc_t rs_out = rsrc_at(a.out, out_base, a.out_bytes);
-            const __amdgpu_buffer_rsrc_t rs_add = rsrc_at(a.add ? (const void*)a.add : (const void*)a.out, out_base,
-                                                          a.add ? a.out_bytes : out_base);
-            const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(EPI == EPI_BWE ? a.bw.y : (const void*)a.out, out_base,
-                                                        EPI == EPI_BWE ? a.out_bytes : out_base);
-            float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
-            const int gcol = EPI == EPI_BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;
-            if constexpr (EPI == EPI_BWE) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (!LTAB) {
-                        t_mu[e] = a.bw.mean[gcol + e];
-                        t_sc[e] = a.bw.mscale[gcol + e];
-                        t_sh[e] = a.bw.mshift[gcol + e];
-                    }
-                    s1[e] = s2[e] = 0.f;
-                }
-            }
-            if constexpr (EPI == EPI_PLAIN) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
-            }
-            constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS || LTAB) ? 1 : 3;
-            auto pass_row = [&](int p) -> int {
-                const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
-                return wm * (TP / WM) + i * 32 + h * 16 + k * RPI + lane / LPR;
-            };
-            const bool rowok = NI * RPI == ER || (lane / LPR) < ER;          // (RPI = 16 = ER here: always true)
-            u32x4 pav[PD], pyv[PD];
-            auto pass_load = [&](int p, int sl) {
-                const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
-                if constexpr (EPI == EPI_PLAIN) pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
-                if constexpr (EPI == EPI_BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
-            };
-#pragma unroll
-            for (int d = 0; d < PD; ++d)
-                if (d < NP) pass_load(d, d);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
-                if (k == 0) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r8i = 0; r8i < 8; ++r8i) {
-                            const int r = h * 8 + r8i;
-                            ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][j][r];
-                        }
-                }
-                const int row = k * RPI + lane / LPR;
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8);
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8 + 4);
-                float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
-                const int sl = p % PD;
-                if constexpr (EPI == EPI_PLAIN) {
-                    const u32x4 av = pav[sl];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        v[2 * d] += bf_lo(av[d]);
-                        v[2 * d + 1] += bf_hi(av[d]);
-                    }
-                    if (a.bw.bias) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            v[e] += t_bias[e];
-                            v[e] = (a.bw.relu && v[e] < 0.f) ? 0.f : v[e];
-                        }
-                    }
-                }
-                if constexpr (EPI == EPI_BWE) {
-                    const u32x4 yv = pyv[sl];
-                    int tc = ecol;                   // (opaque per pass: the table reads stay inside the pass)
-                    if constexpr (LTAB) asm volatile("" : "+v"(tc));
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int e = 2 * d + hh;
-                            const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
-                            const float t = LTAB ? __builtin_fmaf(y - ltab[tc + e], ltab[BN + tc + e], ltab[2 * BN + tc + e])
-                                                 : __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
-                            v[e] = t > 0.f ? v[e] : 0.f;
-                            s1[e] += v[e];
-                            s2[e] = __builtin_fmaf(v[e], y, s2[e]);
-                        }
-                }
-                if (p + PD < NP) pass_load(p + PD, sl);
-                const u32x4 pk = {io_f2bf2(v[0], v[1]), io_f2bf2(v[2], v[3]), io_f2bf2(v[4], v[5]), io_f2bf2(v[6], v[7])};
-                if (rowok) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
-            }
-            if constexpr (EPI == EPI_BWE) {
-                // lanes with the same lane % LPR hold the same 8 channels: sum them, then the WPT waves of the statistics tile
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-#pragma unroll
-                    for (int sft = LPR; sft < 64; sft <<= 1) {
-                        s1[e] += __shfl_xor(s1[e], sft, 64);
-                        s2[e] += __shfl_xor(s2[e], sft, 64);
-                    }
-                if (lane < LPR) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        red[((wave * 2 + 0) * LPR + lane) * 8 + e] = s1[e];
-                        red[((wave * 2 + 1) * LPR + lane) * 8 + e] = s2[e];
-                    }
-                }
-                __syncthreads();
-                if (wm % WPT == 0 && lane < LPR) {
-                    const size_t o = (size_t)mt128 * g.Co + ecol;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float t1 = s1[e], t2 = s2[e];
-#pragma unroll
-                        for (int k = 1; k < WPT; ++k) {
-                            const int ow = (wm + k) * WN + wn;
-                            t1 += red[((ow * 2 + 0) * LPR + lane) * 8 + e];
-                            t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
-                        }
-                        a.bw.p1[o + e] = t1;
-                        a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
-                    }
-                }
-            }
-            // (the next iteration's barrier orders these LDS uses before the buffer is refilled)
+            halo_epilogue<TP, BN, WM, WN, EPI, BREG && EPI == EPI_BWE, ABUF>(
+                acc, reinterpret_cast<float*>(smem + abuf * ABUF), reinterpret_cast<float*>(smem + 2 * ABUF + 2 * BST), g, a,
+                tile * TP, tid);
+            // (the next iteration's barrier orders the scratch uses before the buffer is refilled)
         }
         // advance the stream
         if (last_st) abuf ^= 1;
         bstage ^= 1;
         st = nst;
         cc = ncc_;
+        tile = ntile;
+    }
+}
+
+
+// ---- the stem (7x7 stride 2 pad 3 on the packed 8-channel input -> 64 channels; resnet_cls.py:155 `conv1`) ----------------
+// The same recipe: a tile is 256 output pixels = TWO output rows of one image (Wo = 128), whose 9 input rows x 261 input
+// pixels x 16 bytes go to LDS once, split by pixel PARITY -- plane (row, parity) holds pixels ix = 2 j + parity - 4, j = 0 ..
+// 131 -- so that the stride-2 walk of 32 consecutive output pixels reads 32 consecutive 16-byte entries (conflict-free).  A
+// pixel's 8 channels are one MFMA operand chunk; a k-step is two filter taps (lane half = tap parity), 25 steps for the 49
+// taps (the 50th has a zero filter and re-reads tap 48's pixels).  The filters live in registers (25 fragments = 100 VGPRs per
+// lane), one barrier interval per tile, epilogue shared with conv_halo3_kernel.
+// Measured at the bench batch (512 x 256 x 256): see DESIGN.md (the 64-wide implicit-GEMM kernel it replaces: 0.89 ms).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void stem_halo_kernel(IoConvGeom g, Halo3Args a) {
+    constexpr int TP = 256, BN = 64, WM = 4, WN = 2, NW = 8, TM = 2;
+    constexpr int PJ = 132, ROWS = 9, SLOTS = ROWS * 2 * PJ;       // 16-byte entries of one patch
+    constexpr int NCH = (SLOTS + 63) / 64, NAW = (NCH + NW - 1) / NW, ABUF = NAW * NW * 1024;
+    constexpr int S = 25, PF = 3;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+    // ---- fetches: entry q = chunk * 64 + lane of the patch is (plane rp = q / PJ, j = q % PJ) -> input row 2 oy0 - 3 + (rp >> 1),
+    // pixel 2 j + (rp & 1) - 4.  arel: byte offset from the tile's descriptor start (pixel (2 oy0 - 3, -4)), the patch row in
+    // the low four bits (15: no such pixel)
+    unsigned arel[NAW];
+#pragma unroll
+    for (int u = 0; u < NAW; ++u) {
+        const int q = (wave * NAW + u) * 64 + lane;
+        const int rp = q / PJ, j = q - rp * PJ, rr = rp >> 1, ix = 2 * j + (rp & 1) - 4;
+        const bool ok = q < SLOTS && ix >= 0 && ix < g.Wi;
+        arel[u] = ((unsigned)((rr * g.Wi + ix + 4) * 16)) | (ok ? (unsigned)rr : 15u);
+    }
+    const int tpi = g.Ho >> 1;                              // tiles per image
+    auto issue_a = [&](int tile, int buf) {
+        const int img = tile / tpi, oy0 = (tile - img * tpi) * 2;
+        const long long start = (((long long)img * g.Hi + (2 * oy0 - 3)) * g.Wi - 4) * 16;
+        const u32x4 rsA = dma_rsrc_raw((unsigned long long)((const char*)a.in + start), (size_t)((long long)a.in_bytes - start));
+        const unsigned sb = lds0 + (unsigned)(buf * ABUF);
+#pragma unroll
+        for (int u = 0; u < NAW; ++u) {
+            const unsigned rr = arel[u] & 15u;
+            const bool ok = rr != 15u && (unsigned)(2 * oy0 - 3 + (int)rr) < (unsigned)g.Hi;
+            dma16(rsA, sb + (unsigned)((wave * NAW + u) * 1024), ok ? (arel[u] & ~15u) : kOob, 0u);
+        }
+    };
+    // ---- the filters: lane (column wn 32 + l31, tap parity hh) holds the 8 channels of tap 2 s + hh for every k-step s
+    bf16x8 breg[S];
+    {
+        const __amdgpu_buffer_rsrc_t rw = rsrc_at(a.wgt, 0, a.w_bytes);
+        const unsigned rowB = (unsigned)(g.wT * 8 * 2);
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int t0 = 2 * s_, t1 = 2 * s_ + 1 < 49 ? 2 * s_ + 1 : -1;
+            const int w0 = (g.r0 + g.rs * (t0 / 7)) * g.S + (g.s0 + g.ss * (t0 % 7));
+            const int w1 = t1 < 0 ? 0 : (g.r0 + g.rs * (t1 / 7)) * g.S + (g.s0 + g.ss * (t1 % 7));
+            const unsigned off = (unsigned)(wn * 32 + l31) * rowB + (unsigned)((hh ? w1 : w0) * 16);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (t1 < 0 && hh) ? kOob : off, 0, 0);      // (out of range: zeros)
+            breg[s_] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // A fragments: output pixel p = wm 64 + 32 i + l31 of the tile = (row p >> 7, column p & 127); under tap (ty, tx) it reads
+    // entry ((2 (p >> 7) + ty) 2 + (tx + 1 & 1)) PJ + (p & 127) + (tx + 1 >> 1) -- a per-lane base plus a per-tap constant
+    int ab[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pp = wm * 64 + i * 32 + l31;
+        ab[i] = ((4 * (pp >> 7)) * PJ + (pp & 127)) * 16;
+    }
+    f32x16 acc[TM][1];
+    int tile = xcd_remap(blockIdx.x, gridDim.x), abuf = 0;
+    if (tile < a.ntiles) issue_a(tile, 0);
+    while (tile < a.ntiles) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        dma_wait_left<0>();
+        __syncthreads();
+        const int ntile = tile + (int)gridDim.x;
+        if (ntile < a.ntiles) issue_a(ntile, abuf ^ 1);
+        const char* sa = smem + abuf * ABUF;
+        int hb[TM];                                          // (opaque per tile, as in conv_halo3_kernel)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            hb[i] = ab[i];
+            asm volatile("" : "+v"(hb[i]));
+        }
+        bf16x8 fa[PF + 1][TM];
+        auto frag_load = [&](int s_, int slot) {
+            const int t0 = 2 * s_, t1 = 2 * s_ + 1 < 49 ? 2 * s_ + 1 : 48;
+            const int c0 = ((2 * (t0 / 7) + ((t0 % 7 + 1) & 1)) * PJ + ((t0 % 7 + 1) >> 1)) * 16;
+            const int c1 = ((2 * (t1 / 7) + ((t1 % 7 + 1) & 1)) * PJ + ((t1 % 7 + 1) >> 1)) * 16;
+            const int cs = hh ? c1 : c0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sa + hb[i] + cs);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) frag_load(s_, s_ % (PF + 1));
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            if (s_ + PF < S) frag_load(s_ + PF, (s_ + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_ % (PF + 1)][i], breg[s_], acc[i][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        halo_epilogue<TP, BN, WM, WN, EPI, false, ABUF>(acc, reinterpret_cast<float*>(smem + abuf * ABUF), nullptr, g, a, tile * TP,
+                                                        tid);
+        abuf ^= 1;
         tile = ntile;
     }
 }
@@ -564,4 +693,60 @@ int io_launch_conv_halo3(const IoConvGeom& g, const void* in, const void* wgt, v
 #undef IO_HALO3_EPI
 #undef IO_HALO3_LAUNCH
     return io_check_launch("conv_halo3");
+}
+
+// The stem in bf16 (packed 8-channel input, 7x7 stride 2, 64 channels, 128-wide output rows): same contract.
+int io_launch_conv_stem_halo(const IoConvGeom& g, const void* in, const void* wgt, void* out, hipStream_t st, float* st_mean,
+                             float* st_m2, const IoBwStats* bw, size_t in_bytes, unsigned w_bytes, size_t out_bytes) {
+    const int mode = io_bf16_persist_mode();
+    if (mode != 1 && mode != 3) return 1;
+    if (!(g.Th == 7 && g.Tw == 7 && g.S == 7 && g.wT == 49 && g.is == 2 && g.os == 1 && g.Ci == 8 && g.Co == 64 && !g.gw && !g.cr &&
+          g.Wo == 128 && g.Wi == 256 && g.Hi == 2 * g.Ho && (g.Ho & 1) == 0 && g.outH == g.Ho && g.outW == g.Wo && g.dh0 == -3 &&
+          g.dw0 == -3 && g.dhs == 1 && g.dws == 1))
+        return 1;
+    if (bw && (bw->in_scale || bw->xb_a || bw->a_out || bw->wino_u || bw->maskbits || bw->y)) return 1;
+    if (st_mean && bw && bw->bias) return 1;
+    if ((double)g.Hi * g.Wi * 16.0 >= 2.0e9) return 1;
+    const long M = (long)g.N * g.Ho * g.Wo;
+    Halo3Args a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const bf16_t*)in;
+    a.wgt = (const bf16_t*)wgt;
+    a.out = (bf16_t*)out;
+    a.in_bytes = in_bytes;
+    a.out_bytes = out_bytes;
+    a.w_bytes = w_bytes;
+    a.st_mean = st_mean;
+    a.st_m2 = st_m2;
+    if (bw) a.bw = *bw;
+    a.ntiles = (int)(M / 256);
+    a.tiles_per_img = g.Ho / 2;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    {
+        const long rounds = ((long)a.ntiles + ncu - 1) / ncu;
+        if (mode != 3 && (long)a.ntiles * 10 < rounds * ncu * 8) return 1;
+    }
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    IoProfScope prof(IO_PROF_CONV_STEM, 2.0 * (double)M * g.Co * 49.0 * 5.0,
+                     2.0 * M * g.Co + 2.0 * ((double)g.N * g.Hi * g.Wi * 8 + 64.0 * 49 * 8), st);
+    constexpr size_t lds = (size_t)2 * 5 * 8 * 1024;
+    static_assert((9 * 2 * 132 + 63) / 64 <= 5 * 8, "patch chunks");
+    if (st_mean) {
+        static std::atomic<unsigned long long> done{0};
+        if (io_first_on_device(done))
+            (void)hipFuncSetAttribute((const void*)stem_halo_kernel<EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((stem_halo_kernel<EPI_STATS>), dim3((unsigned)grid), dim3(512), lds, st, g, a);
+    } else {
+        static std::atomic<unsigned long long> done{0};
+        if (io_first_on_device(done))
+            (void)hipFuncSetAttribute((const void*)stem_halo_kernel<EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((stem_halo_kernel<EPI_PLAIN>), dim3((unsigned)grid), dim3(512), lds, st, g, a);
+    }
+    return io_check_launch("stem_halo");
 }

@@ -2889,7 +2889,7 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     return need;
 }
 
-// which kernel family the last forward / data-gradient launch went to (tests: 0 = conv_nt_kernel, 1 = conv_p256, 2 = conv_halo3)
+// which kernel family the last forward / data-gradient launch went to (tests: 0 = conv_nt_kernel, 1 = conv_p256, 2 = conv_halo3, 3 = stem_halo)
 static std::atomic<int> g_last_route{0};
 extern "C" int io_debug_last_nt_route(void) { return g_last_route.load(std::memory_order_relaxed); }
 
@@ -2949,6 +2949,15 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     const size_t in_bytes = (size_t)es * g.N * g.Hi * g.Wi * g.Ci;
     const size_t out_bytes = (size_t)os * g.N * g.outH * g.outW * g.Co;
     const unsigned w_bytes = (unsigned)w_b;
+    // bf16 stem on 128-wide output rows: the patch-in-LDS / filters-in-registers kernel of conv_halo3.hip
+    if (dt_in == IO_BF16 && dt_out == IO_BF16 && stem && !add && !mask) {
+        const int rs = io_launch_conv_stem_halo(g, in, wgt, out, st, st_mean, st_m2, bw ? &bws : nullptr, in_bytes, w_bytes,
+                                                out_bytes);
+        if (rs <= 0) {
+            g_last_route.store(3, std::memory_order_relaxed);
+            return rs;
+        }
+    }
     // bf16: the persistent 256-row LDS-DMA kernel where the shape and the form are its own (conv_p256.hip)
     if (dt_in == IO_BF16 && dt_out == IO_BF16 && !stem) {
         const int rh = io_launch_conv_halo3(g, in, wgt, out, add, mask, st, st_mean, st_m2, bw ? &bws : nullptr, in_bytes,

@@ -185,6 +185,8 @@ int io_bf16_persist_mode();   // io_set_bf16_p256's value: 0 = neither kernel, 1
 int io_launch_conv_halo3(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add, const void* mask,
                          hipStream_t st, float* st_mean, float* st_m2, const IoBwStats* bw, size_t in_bytes,
                          unsigned w_bytes, size_t out_bytes);
+int io_launch_conv_stem_halo(const IoConvGeom& g, const void* in, const void* wgt, void* out, hipStream_t st, float* st_mean,
+                             float* st_m2, const IoBwStats* bw, size_t in_bytes, unsigned w_bytes, size_t out_bytes);
 int io_bn_bwd_from_tiles(float* p1, float* p2, const void* dz, const void* y, int M, int C, int G,
                          const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                          void* dy, float* coef, hipStream_t st, int dt = IO_F32);

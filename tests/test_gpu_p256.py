@@ -274,3 +274,57 @@ def test_relu_mask_as_bits(dtype, p256):
         assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]), (with_sums, "sums")
         zero = (out.float() <= 0)
         assert float(res[0][0].float()[zero].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,H", [(2, 256), (3, 256), (1, 512)])
+def test_stem_halo_forward_plain_stats_bias(N, H):
+    """The bf16 stem (7x7 stride 2 on the packed 8-channel input, resnet_cls.py:155) on 128-wide output rows: stem_halo_kernel of
+    csrc/conv_halo3.hip (patch of two output rows in LDS by pixel parity, filters in registers) against fp64 torch on the same
+    bf16-rounded operands and against the 64-wide implicit-GEMM kernel it replaces -- plain, with the statistics epilogue, and
+    with the folded-BatchNorm inference epilogue.  (H = 512: Wo = 256, not this kernel's shape -- both modes take the old one.)"""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(40 + N)
+    x5 = torch.randn(N, 5, H, H, generator=g, dtype=torch.float64)
+    x8, x8r = bf(nhwc(torch.cat([x5, torch.zeros(N, 3, H, H, dtype=torch.float64)], 1)))
+    w, wr = bf((torch.randn(64, 8, 7, 7, generator=g, dtype=torch.float64) * 0.05).permute(0, 2, 3, 1).contiguous())   # [64][7][7][8]
+    ref = F.conv2d(x8r.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), stride=2, padding=3)
+    Ho = ref.shape[2]
+    want = 3 if Ho == 128 else 0
+    wd = w.view(64, 49, 8)
+    outs = []
+    for on in (3, 0):
+        lib.io_set_bf16_p256(on)
+        y = torch.full((N, Ho, Ho, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_dt(P(x8), P(wd), P(y), N, H, H, 8, 64, 7, 7, 2, 3, BF, BF, ST()), "stem fwd")
+        assert lib.io_debug_last_nt_route() == (want if on == 3 else 0), on
+        assert relerr(y.permute(0, 3, 1, 2), ref) < TOL, on
+        outs.append(y)
+    assert relerr(outs[0], outs[1].double().cpu()) < TOL
+    M = N * Ho * Ho
+    G = 2 if N % 2 == 0 else 1
+    gen = torch.Generator().manual_seed(9)
+    gamma, beta = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen)
+    for on in (3, 0):
+        lib.io_set_bf16_p256(on)
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        mean, rstd, sc, sh = (torch.empty(G * 64, device=DEV) for _ in range(4))
+        nws = lib.io_conv2d_bnstats_workspace_floats(N, H, H, 64, 7, 7, 2, 3, G)
+        ws = torch.empty(nws, device=DEV)
+        y2 = torch.full((N, Ho, Ho, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_bnstats_dt(P(x8), P(wd), P(y2), N, H, H, 8, 64, 7, 7, 2, 3, G, P(gamma.to(DEV)),
+                                                P(beta.to(DEV)), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(sc), P(sh),
+                                                P(ws), nws, BF, 0, ST()), "stem fwd+stats")
+        assert relerr(y2.permute(0, 3, 1, 2), ref) < TOL
+        per = N // G
+        mref = torch.stack([ref[gi * per:(gi + 1) * per].mean((0, 2, 3)) for gi in range(G)])
+        vref = torch.stack([ref[gi * per:(gi + 1) * per].var((0, 2, 3), unbiased=False) for gi in range(G)])
+        assert float((mean.view(G, 64).double().cpu() - mref).abs().max()) < 2e-4 * float(ref.abs().max())
+        assert relerr(rstd.view(G, 64), 1.0 / torch.sqrt(vref + 1e-5)) < 2e-4
+    bias = torch.randn(64, generator=gen)
+    ref3 = F.relu(ref + bias.double().view(1, -1, 1, 1))
+    for on in (3, 0):
+        lib.io_set_bf16_p256(on)
+        y3 = torch.full((N, Ho, Ho, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.check(lib.io_conv2d_fwd_bias_dt(P(x8), P(wd), P(y3), N, H, H, 8, 64, 7, 7, 2, 3, P(bias.to(DEV)), None, 1,
+                                             BF, 0, ST()), "stem fwd+bias")
+        assert relerr(y3.permute(0, 3, 1, 2), ref3) < TOL, on
