@@ -501,11 +501,20 @@ def main():
             try:
                 f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bf16.json")))[-1]
                 tj = json.load(open(f))
-                kk = [k for k in tj["kernels"] if k.startswith("conv_nt_kernel")]
-                if kk and name == "conv_nt_kernel<128,false>" and args.algo == "InstaOrderNet_o" and B == 256 and S == 256 \
+                # the class's launches run on four kernel families (conv_p256 / conv_halo3 / stem_halo / conv_nt_kernel) that
+                # the launch classes cut differently: the counters give ONE ratio of measured to algorithmic bytes over all
+                # forward / data-gradient launches of the step; `traffic` = that ratio x this class's algorithmic bytes per launch
+                allf = tj["kernels"].get("_forward_and_data_gradient_launches")
+                if allf and name.startswith("conv_nt_kernel") and args.algo == "InstaOrderNet_o" and B == 256 and S == 256 \
                         and args.mode == "train" and tj.get("csrc_sha") == digest:
-                    traffic = tj["kernels"][kk[0]]["bytes_per_launch_corrected"]
-                    traffic_src = "%s (measured at commit %s)" % (os.path.basename(f), tj.get("commit"))
+                    traffic = allf["traffic_ratio"] * d["bytes"] / d["launches"]
+                    traffic_src = ("%s (commit %s): measured / algorithmic bytes = %.3f over all %d forward and data-gradient "
+                                   "launches of a step (kernel families %s), applied to this class's algorithmic bytes per launch"
+                                   % (os.path.basename(f), tj.get("commit"), allf["traffic_ratio"],
+                                      int(round(allf["launches_per_step"])), ", ".join(x.split("<")[0] for x in allf["families"])))
+                elif allf and tj.get("csrc_sha") != digest:
+                    traffic_src = "stale: %s was measured on other kernel sources (csrc %s, now %s)" % (
+                        os.path.basename(f), tj.get("csrc_sha", "unrecorded"), digest)
             except Exception:
                 pass
         gbs = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
@@ -517,7 +526,7 @@ def main():
                               "share_of_gpu_time": d["total_ms"] / tot_ms,
                               # the other roof, always: algorithmic bytes of the same launches against HBM
                               "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}}
-        if not depthnet and args.mode == "train" and name.startswith("conv_nt_kernel"):
+        if not depthnet and args.mode == "train" and args.dtype == "fp32" and name.startswith("conv_nt_kernel"):
             # what the FLOP rate of this class does not show ("Round 3")
             result["roofline"]["note"] = (
                 "algorithmic conv FLOPs only: about half of this class's launches per step also evaluate a BatchNorm pass on "

@@ -81,198 +81,194 @@ __device__ __forceinline__ void halo_epilogue(f32x16 (&acc)[TP / WM / 32][BN / W
     constexpr int NW = WM * WN, TM = TP / WM / 32, TN = BN / WN / 32, ABUF = SCRB;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-        // ---- epilogue of the tile.  D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-            const int mt128 = (m0 >> 7) + (wm * (TP / WM)) / 128;          // the statistics tile this wave's rows belong to
-        constexpr int WPT = 128 / (TP / WM);                            // waves (along rows) per statistics tile
-        // (filters in registers: no room for the 24 table values of the BatchNorm-backward epilogue next to them -- the
-        // tile's mean / scale / shift rows go to LDS behind the A buffers and are read per pass)
-                if constexpr (LTAB) {
-            if (tid < 3 * BN) {
-                const int which = tid / BN, c = tid - which * BN;
-                const float* src = which == 0 ? a.bw.mean : (which == 1 ? a.bw.mscale : a.bw.mshift);
-                ltab[tid] = src[(m0 / a.bw.Mg) * g.Co + c];
+    const int mt128 = (m0 >> 7) + (wm * (TP / WM)) / 128;          // the statistics tile this wave's rows belong to
+    constexpr int WPT = 128 / (TP / WM);                            // waves (along rows) per statistics tile
+    if constexpr (LTAB) {
+        if (tid < 3 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            const float* src = which == 0 ? a.bw.mean : (which == 1 ? a.bw.mscale : a.bw.mshift);
+            ltab[tid] = src[(m0 / a.bw.Mg) * g.Co + c];
+        }
+    }
+    __syncthreads();                     // every wave is done with the A buffer just read: it becomes scratch
+    if constexpr (EPI == EPI_STATS) {
+        // per wave: mean / M2 of its TP / WM rows per column; the WPT waves of a tile merged with Chan's update
+        constexpr int RW = TP / WM;
+        float wmean[TN], wm2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+            s += __shfl_xor(s, 32, 64);
+            wmean[j] = s * (1.0f / RW);
+            float d2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d2 += (acc[i][j][r] - wmean[j]) * (acc[i][j][r] - wmean[j]);
+            d2 += __shfl_xor(d2, 32, 64);
+            wm2[j] = d2;
+            if (lane < 32) {
+                scr[(wave * TN + j) * 64 + lane] = wmean[j];
+                scr[(wave * TN + j) * 64 + 32 + lane] = d2;
             }
         }
-        __syncthreads();                     // every wave is done with the A buffer just read: it becomes scratch
-            if constexpr (EPI == EPI_STATS) {
-            // per wave: mean / M2 of its TP / WM rows per column; the WPT waves of a tile merged with Chan's update
-            constexpr int RW = TP / WM;
-            float wmean[TN], wm2[TN];
+        __syncthreads();
+        if (wm % WPT == 0 && lane < 32) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                float s = 0.f;
+                float n = (float)RW, mu = wmean[j], m2 = wm2[j];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-                s += __shfl_xor(s, 32, 64);
-                wmean[j] = s * (1.0f / RW);
-                float d2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) d2 += (acc[i][j][r] - wmean[j]) * (acc[i][j][r] - wmean[j]);
-                d2 += __shfl_xor(d2, 32, 64);
-                wm2[j] = d2;
-                if (lane < 32) {
-                    scr[(wave * TN + j) * 64 + lane] = wmean[j];
-                    scr[(wave * TN + j) * 64 + 32 + lane] = d2;
+                for (int k = 1; k < WPT; ++k) {
+                    const int ow = (wm + k) * WN + wn;
+                    const float mb = scr[(ow * TN + j) * 64 + lane], m2b = scr[(ow * TN + j) * 64 + 32 + lane];
+                    const float tot = n + (float)RW, delta = mb - mu;
+                    mu += delta * ((float)RW / tot);
+                    m2 += m2b + delta * delta * (n * (float)RW / tot);
+                    n = tot;
                 }
+                const size_t o = (size_t)mt128 * g.Co + wn * TN * 32 + j * 32 + lane;
+                a.st_mean[o] = mu;
+                a.st_m2[o] = m2;
             }
-            __syncthreads();
-            if (wm % WPT == 0 && lane < 32) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float n = (float)RW, mu = wmean[j], m2 = wm2[j];
-#pragma unroll
-                    for (int k = 1; k < WPT; ++k) {
-                        const int ow = (wm + k) * WN + wn;
-                        const float mb = scr[(ow * TN + j) * 64 + lane], m2b = scr[(ow * TN + j) * 64 + 32 + lane];
-                        const float tot = n + (float)RW, delta = mb - mu;
-                        mu += delta * ((float)RW / tot);
-                        m2 += m2b + delta * delta * (n * (float)RW / tot);
-                        n = tot;
-                    }
-                    const size_t o = (size_t)mt128 * g.Co + wn * TN * 32 + j * 32 + lane;
-                    a.st_mean[o] = mu;
-                    a.st_m2[o] = m2;
-                }
-            }
-            __syncthreads();
         }
-        // rows through LDS: 16 rows x WC columns of the wave at a time -> 8 consecutive channels of a row per lane
-        constexpr int WC = TN * 32, EPP = WC + 4, ER = 16;
-        constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = (ER + RPI - 1) / RPI;
-        static_assert(NW * ER * EPP * 4 + NW * 2 * LPR * 8 * 4 <= ABUF, "scratch");
-        float* ep = scr + wave * (ER * EPP);
-        float* red = scr + NW * ER * EPP;                               // [wave][2 sums][LPR lanes][8] for the BWE partials
-        const int ecol = wn * WC + (lane % LPR) * 8;
-        const size_t out_base = (size_t)m0 * (size_t)(g.Co * 2);
-        const __amdgpu_buffer_rsrc_t rs_out = rsrc_at(a.out, out_base, a.out_bytes);
-        const __amdgpu_buffer_rsrc_t rs_add = rsrc_at(a.add ? (const void*)a.add : (const void*)a.out, out_base,
-                                                      a.add ? a.out_bytes : out_base);
-        const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(EPI == EPI_BWE ? a.bw.y : (const void*)a.out, out_base,
-                                                    EPI == EPI_BWE ? a.out_bytes : out_base);
-        float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
-        const int gcol = EPI == EPI_BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;
+        __syncthreads();
+    }
+    // rows through LDS: 16 rows x WC columns of the wave at a time -> 8 consecutive channels of a row per lane
+    constexpr int WC = TN * 32, EPP = WC + 4, ER = 16;
+    constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = (ER + RPI - 1) / RPI;
+    static_assert(NW * ER * EPP * 4 + NW * 2 * LPR * 8 * 4 <= ABUF, "scratch");
+    float* ep = scr + wave * (ER * EPP);
+    float* red = scr + NW * ER * EPP;                               // [wave][2 sums][LPR lanes][8] for the BWE partials
+    const int ecol = wn * WC + (lane % LPR) * 8;
+    const size_t out_base = (size_t)m0 * (size_t)(g.Co * 2);
+    const __amdgpu_buffer_rsrc_t rs_out = rsrc_at(a.out, out_base, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = rsrc_at(a.add ? (const void*)a.add : (const void*)a.out, out_base,
+                                                  a.add ? a.out_bytes : out_base);
+    const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(EPI == EPI_BWE ? a.bw.y : (const void*)a.out, out_base,
+                                                EPI == EPI_BWE ? a.out_bytes : out_base);
+    float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
+    const int gcol = EPI == EPI_BWE ? (m0 / a.bw.Mg) * g.Co + ecol : 0;
+    if constexpr (EPI == EPI_BWE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (!LTAB) {
+                t_mu[e] = a.bw.mean[gcol + e];
+                t_sc[e] = a.bw.mscale[gcol + e];
+                t_sh[e] = a.bw.mshift[gcol + e];
+            }
+            s1[e] = s2[e] = 0.f;
+        }
+    }
+    if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
+    }
+    constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS || LTAB) ? 1 : 3;
+    auto pass_row = [&](int p) -> int {
+        const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+        return wm * (TP / WM) + i * 32 + h * 16 + k * RPI + lane / LPR;
+    };
+    const bool rowok = NI * RPI == ER || (lane / LPR) < ER;          // (RPI = 16 = ER here: always true)
+    u32x4 pav[PD], pyv[PD];
+    auto pass_load = [&](int p, int sl) {
+        const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+        if constexpr (EPI == EPI_PLAIN) pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
+        if constexpr (EPI == EPI_BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < NP) pass_load(d, d);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
+        if (k == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r8i = 0; r8i < 8; ++r8i) {
+                    const int r = h * 8 + r8i;
+                    ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][j][r];
+                }
+        }
+        const int row = k * RPI + lane / LPR;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8 + 4);
+        float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
+        const int sl = p % PD;
+        if constexpr (EPI == EPI_PLAIN) {
+            const u32x4 av = pav[sl];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                v[2 * d] += bf_lo(av[d]);
+                v[2 * d + 1] += bf_hi(av[d]);
+            }
+            if (a.bw.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] += t_bias[e];
+                    v[e] = (a.bw.relu && v[e] < 0.f) ? 0.f : v[e];
+                }
+            }
+        }
         if constexpr (EPI == EPI_BWE) {
+            const u32x4 yv = pyv[sl];
+            int tc = ecol;                   // (opaque per pass: the table reads stay inside the pass)
+            if constexpr (LTAB) asm volatile("" : "+v"(tc));
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int e = 2 * d + hh;
+                    const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
+                    const float t = LTAB ? __builtin_fmaf(y - ltab[tc + e], ltab[BN + tc + e], ltab[2 * BN + tc + e])
+                                         : __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
+                    v[e] = t > 0.f ? v[e] : 0.f;
+                    s1[e] += v[e];
+                    s2[e] = __builtin_fmaf(v[e], y, s2[e]);
+                }
+        }
+        if (p + PD < NP) pass_load(p + PD, sl);
+        const u32x4 pk = {io_f2bf2(v[0], v[1]), io_f2bf2(v[2], v[3]), io_f2bf2(v[4], v[5]), io_f2bf2(v[6], v[7])};
+        if (rowok) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
+    }
+    if constexpr (EPI == EPI_BWE) {
+        // lanes with the same lane % LPR hold the same 8 channels: sum them, then the WPT waves of the statistics tile
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int sft = LPR; sft < 64; sft <<= 1) {
+                s1[e] += __shfl_xor(s1[e], sft, 64);
+                s2[e] += __shfl_xor(s2[e], sft, 64);
+            }
+        if (lane < LPR) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if constexpr (!LTAB) {
-                    t_mu[e] = a.bw.mean[gcol + e];
-                    t_sc[e] = a.bw.mscale[gcol + e];
-                    t_sh[e] = a.bw.mshift[gcol + e];
-                }
-                s1[e] = s2[e] = 0.f;
+                red[((wave * 2 + 0) * LPR + lane) * 8 + e] = s1[e];
+                red[((wave * 2 + 1) * LPR + lane) * 8 + e] = s2[e];
             }
         }
-        if constexpr (EPI == EPI_PLAIN) {
+        __syncthreads();
+        if (wm % WPT == 0 && lane < LPR) {
+            const size_t o = (size_t)mt128 * g.Co + ecol;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
-        }
-        constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS || LTAB) ? 1 : 3;
-        auto pass_row = [&](int p) -> int {
-            const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
-            return wm * (TP / WM) + i * 32 + h * 16 + k * RPI + lane / LPR;
-        };
-        const bool rowok = NI * RPI == ER || (lane / LPR) < ER;          // (RPI = 16 = ER here: always true)
-        u32x4 pav[PD], pyv[PD];
-        auto pass_load = [&](int p, int sl) {
-            const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
-            if constexpr (EPI == EPI_PLAIN) pav[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
-            if constexpr (EPI == EPI_BWE) pyv[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
-        };
+            for (int e = 0; e < 8; ++e) {
+                float t1 = s1[e], t2 = s2[e];
 #pragma unroll
-        for (int d = 0; d < PD; ++d)
-            if (d < NP) pass_load(d, d);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
-            if (k == 0) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r8i = 0; r8i < 8; ++r8i) {
-                        const int r = h * 8 + r8i;
-                        ep[((r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][j][r];
-                    }
-            }
-            const int row = k * RPI + lane / LPR;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + (lane % LPR) * 8 + 4);
-            float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-            const unsigned off = (unsigned)(pass_row(p) * g.Co + ecol) * 2u;
-            const int sl = p % PD;
-            if constexpr (EPI == EPI_PLAIN) {
-                const u32x4 av = pav[sl];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    v[2 * d] += bf_lo(av[d]);
-                    v[2 * d + 1] += bf_hi(av[d]);
+                for (int k = 1; k < WPT; ++k) {
+                    const int ow = (wm + k) * WN + wn;
+                    t1 += red[((ow * 2 + 0) * LPR + lane) * 8 + e];
+                    t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
                 }
-                if (a.bw.bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[e] += t_bias[e];
-                        v[e] = (a.bw.relu && v[e] < 0.f) ? 0.f : v[e];
-                    }
-                }
-            }
-            if constexpr (EPI == EPI_BWE) {
-                const u32x4 yv = pyv[sl];
-                int tc = ecol;                   // (opaque per pass: the table reads stay inside the pass)
-                if constexpr (LTAB) asm volatile("" : "+v"(tc));
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int e = 2 * d + hh;
-                        const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
-                        const float t = LTAB ? __builtin_fmaf(y - ltab[tc + e], ltab[BN + tc + e], ltab[2 * BN + tc + e])
-                                             : __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
-                        v[e] = t > 0.f ? v[e] : 0.f;
-                        s1[e] += v[e];
-                        s2[e] = __builtin_fmaf(v[e], y, s2[e]);
-                    }
-            }
-            if (p + PD < NP) pass_load(p + PD, sl);
-            const u32x4 pk = {io_f2bf2(v[0], v[1]), io_f2bf2(v[2], v[3]), io_f2bf2(v[4], v[5]), io_f2bf2(v[6], v[7])};
-            if (rowok) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
-        }
-        if constexpr (EPI == EPI_BWE) {
-            // lanes with the same lane % LPR hold the same 8 channels: sum them, then the WPT waves of the statistics tile
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int sft = LPR; sft < 64; sft <<= 1) {
-                    s1[e] += __shfl_xor(s1[e], sft, 64);
-                    s2[e] += __shfl_xor(s2[e], sft, 64);
-                }
-            if (lane < LPR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[((wave * 2 + 0) * LPR + lane) * 8 + e] = s1[e];
-                    red[((wave * 2 + 1) * LPR + lane) * 8 + e] = s2[e];
-                }
-            }
-            __syncthreads();
-            if (wm % WPT == 0 && lane < LPR) {
-                const size_t o = (size_t)mt128 * g.Co + ecol;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t1 = s1[e], t2 = s2[e];
-#pragma unroll
-                    for (int k = 1; k < WPT; ++k) {
-                        const int ow = (wm + k) * WN + wn;
-                        t1 += red[((ow * 2 + 0) * LPR + lane) * 8 + e];
-                        t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
-                    }
-                    a.bw.p1[o + e] = t1;
-                    a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
-                }
+                a.bw.p1[o + e] = t1;
+                a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
             }
         }
-        // (the next iteration's barrier orders these LDS uses before the buffer is refilled)
+    }
 }
 
 // W: map width (32 | W, W | 256).  BN = Co (64 or 128).  WM x WN = 8 waves of (256 / WM) x (BN / WN).  TPS: filter taps per

@@ -330,9 +330,6 @@ class _InstaDepthBase(nn.Module):
         for t in shared:
             for st in sides:
                 t.record_stream(st)
-        dbg = int(os.environ.get("IO_DEPTH_SYNC", "0"))      # bisecting aid (tools/depth_eager_race.py): full device syncs
-        if dbg & 1:
-            torch.cuda.synchronize()
         ev = torch.cuda.Event()
         ev.record(main)
         out = []
@@ -346,8 +343,6 @@ class _InstaDepthBase(nn.Module):
             # always joined, also when a job raised: a side stream left un-joined would leave a stream capture open-ended
             for st in sides:
                 main.wait_stream(st)
-            if dbg & 2:
-                torch.cuda.synchronize()
         # only a forward that recorded a tape has a backward whose side-stream tail must be joined later
         self._forked = len(sides) if torch.is_grad_enabled() else 0
         return out, res
@@ -362,8 +357,6 @@ class _InstaDepthBase(nn.Module):
         caller enqueues next (WeightPlan.unpack_grads, the optimiser).  Legal under hipGraph capture: the side streams
         joined this capture at the fork."""
         if self._forked:
-            if int(os.environ.get("IO_DEPTH_SYNC", "0")) & 4:
-                torch.cuda.synchronize()
             main = torch.cuda.current_stream()
             for st in (_InstaDepthBase._side.get(torch.cuda.current_device()) or [])[:self._forked]:
                 main.wait_stream(st)

@@ -20,6 +20,12 @@ Two layers:
    **Parity unpinned** for this layer: there is no cv2 here to run, and the reference holds no fixture for it.  The
    known closed forms it is checked against (tests/test_oracle_golden.py): identity at equal size, 2x2 box average for
    an exact 2x linear down-scale (OpenCV's INTER_AREA shortcut gives the same numbers), nearest index rule.
+   A SECOND, independent source since round 5 (tests/test_datasets_cpu.py): ``torch.nn.functional.interpolate`` -- float
+   arithmetic on the same half-pixel geometry (``align_corners=False``; bicubic with A = -0.75, nearest with OpenCV's
+   floor rule) -- agrees with this restatement to within the 8-bit fixed-point rounding (<= 1 grey level, linear and
+   cubic; identical nearest pixels; the float64 cubic to 1e-4) over 7 size pairs and the crops of the dataset fixtures'
+   scenes.  That bounds a wrong geometry or kernel constant; it does not pin the fixed-point rounding itself, so the
+   status stays "parity unpinned".
 
 2. The item assembly of ``SupOcclusionOrderDataset`` / ``SupDepthOccOrderDataset`` (crop box arithmetic, padding, flip,
    normalisation, label layout, and the ORDER of the np.random draws): ``pair_plan`` / ``render_pair`` below follow

@@ -6,16 +6,17 @@ set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
-NT='conv_nt_kernel<unsigned short, unsigned short, 128, 0,'
-WG='conv_wgrad_bf16_tr_kernel<128, 128'
+# the forward / data-gradient launches of the bf16 step run four kernel families since round 5 (conv_p256.hip, conv_halo3.hip's
+# two kernels, and conv_nt_kernel for what is left); the filter gradients one
+FAMS=('conv_p256_kernel' 'conv_halo3_kernel' 'stem_halo_kernel' 'conv_nt_kernel<unsigned short, unsigned short' 'conv_wgrad_bf16_tr_kernel<128, 128')
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c
   rocprofv3 --pmc $c -d /tmp/pmcb_$c -o t --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /tmp/pmcb_$c.log 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pmcb_$c "$NT" > $R/gpurun_out/bf16_traffic_$c.txt
-  python3 $R/tools/pmc_summary.py /tmp/pmcb_$c "$WG" >> $R/gpurun_out/bf16_traffic_$c.txt
+  : > $R/gpurun_out/bf16_traffic_$c.txt
+  for f in "${FAMS[@]}"; do python3 $R/tools/pmc_summary.py /tmp/pmcb_$c "$f" >> $R/gpurun_out/bf16_traffic_$c.txt; done
 done
 rm -rf /tmp/pmcb_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d /tmp/pmcb_mfma -o t --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /tmp/pmcb_mfma.log 2>&1
-python3 $R/tools/pmc_summary.py /tmp/pmcb_mfma "$NT" > $R/gpurun_out/bf16_mfma_busy.txt
-python3 $R/tools/pmc_summary.py /tmp/pmcb_mfma "$WG" >> $R/gpurun_out/bf16_mfma_busy.txt
+: > $R/gpurun_out/bf16_mfma_busy.txt
+for f in "${FAMS[@]}"; do python3 $R/tools/pmc_summary.py /tmp/pmcb_mfma "$f" >> $R/gpurun_out/bf16_mfma_busy.txt; done
 cat $R/gpurun_out/bf16_traffic_FETCH_SIZE.txt $R/gpurun_out/bf16_traffic_WRITE_SIZE.txt $R/gpurun_out/bf16_mfma_busy.txt

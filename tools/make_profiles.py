@@ -47,6 +47,18 @@ for src, dst in (("bench_c2.json", "bench_config2_od_bf16_1024.json"), ("bench_c
         except Exception as ex:
             print("skipped", src, ex)
 
+for src, dst in (("bench_b32_fp32.json", "bench_fp32_b32.json"), ("bench_b64_fp32.json", "bench_fp32_b64.json"),
+                 ("bench_2ranks_gloo.json", "bench_o_fp32_b64_2ranks_gloo_one_gpu.json"),
+                 ("bench_c4_2ranks_gloo.json", "bench_config4_depthnet_od_bf16_2ranks_gloo_one_gpu.json")):
+    if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 100:
+        try:
+            json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (rnd, dst)), "w"), indent=1)
+        except Exception as ex:
+            print("skipped", src, ex)
+src = os.path.join(G, "per_launch_fp32_b32.txt")
+if os.path.exists(src) and os.path.getsize(src) > 1000:
+    open(os.path.join(P, "%s_per_launch_fp32_b32.txt" % rnd), "w").write(open(src).read())
+
 csv.field_size_limit(1 << 30)
 for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv", "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
                               ("kernel_stats_bf16_raw.csv", "_bench_bf16_kernel_stats.csv",
@@ -157,12 +169,28 @@ for fam in fz:
 bfb = os.path.join(G, "bench_n1_bf16.json")
 if bf and os.path.exists(bfb):
     b = last_json(bfb)
-    kc = b.get("kernel_classes", {}).get("conv_nt_kernel<128,false>")
+    # The forward / data-gradient launches are spread over four kernel families (conv_p256, conv_halo3, stem_halo and what is
+    # left on conv_nt_kernel) that bench.py's launch classes (128-wide, 64-wide, stem) cut differently: one traffic ratio for
+    # all of them -- measured bytes of every such launch of the profiled run over the algorithmic bytes of the same launches.
+    kcs = b.get("kernel_classes", {})
+    nt_classes = [kcs[k] for k in ("conv_nt_kernel<128,false>", "conv_nt_kernel<64,false>", "conv_nt_kernel<64,true>") if k in kcs]
+    nt_fams = [f for f in bf if f.startswith(("conv_p256", "conv_halo3", "stem_halo", "conv_nt_kernel"))
+               and "bytes_per_launch_corrected" in bf[f]]
+    if nt_classes and nt_fams:
+        steps = b["profiled"]["steps"]
+        alg_step = sum(k["gbs"] * 1e9 * k["ms_per_step"] * 1e-3 for k in nt_classes)
+        launches_step = sum(k["launches"] for k in nt_classes) / steps
+        meas = sum(bf[f]["launches_profiled"] * bf[f]["bytes_per_launch_corrected"] for f in nt_fams)
+        nl = sum(bf[f]["launches_profiled"] for f in nt_fams)
+        bf["_forward_and_data_gradient_launches"] = {
+            "families": nt_fams, "launches_profiled": nl, "launches_per_step": launches_step,
+            "measured_bytes_per_step": meas / (nl / launches_step), "algorithmic_bytes_per_step": alg_step,
+            "traffic_ratio": meas / (nl / launches_step) / alg_step}
+    wk = kcs.get("conv_wgrad_kernel")
     for fam, e in bf.items():
-        if fam.startswith("conv_nt_kernel") and kc and "bytes_per_launch_corrected" in e:
-            alg = kc["gbs"] * 1e9 * (kc["ms_per_step"] * 1e-3) / (kc["launches"] / b["profiled"]["steps"])
-            e["algorithmic_bytes_per_launch"] = alg
-            e["traffic_ratio"] = e["bytes_per_launch_corrected"] / alg
+        if fam.startswith("conv_wgrad") and wk and "bytes_per_launch_corrected" in e:
+            alg = wk["gbs"] * 1e9 * (wk["ms_per_step"] * 1e-3) / (wk["launches"] / b["profiled"]["steps"])
+            e["algorithmic_bytes_per_launch_class_mean"] = alg
     json.dump({"_comment": "bf16 headline configuration (bench.py --dtype bf16 --steps 2 --warmup 1), rocprofv3 --pmc, counters only, "
                            "separate passes (tools/collect_traffic_bf16.sh).  FETCH_SIZE / WRITE_SIZE in KiB; bytes = (2*FETCH_SIZE + "
                            "WRITE_SIZE)*1024 (gfx950 correction, MI355X_MICROARCH.md).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; "

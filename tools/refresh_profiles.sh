@@ -43,4 +43,12 @@ rm -rf /tmp/kt2
 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o kt --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt2.log 2>&1
 cp $(find /tmp/kt2 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_bf16_raw.csv
 cd $R
+# small per-GPU batches (the reference's own 32 pairs per GPU) and the two-rank path on ONE GPU over gloo (the product path of
+# --gpus 2 with the collectives on the CPU backend: what one box can show of the distributed step -- world size, per-rank times,
+# staged-overlap vs flat exchange)
+python3 tools/per_launch.py fp32 32 > $O/per_launch_fp32_b32.txt 2>> $O/bench_n1.err
+python3 bench.py --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | tail -1 > $O/bench_b32_fp32.json
+python3 bench.py --batch 64 --steps 12 --warmup 4 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | tail -1 > $O/bench_b64_fp32.json
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --backend gloo --batch 64 --steps 6 --warmup 3 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_2ranks_gloo.json
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --backend gloo --algo InstaDepthNet_od --size 384 --batch 8 --dtype bf16 --steps 5 --warmup 3 --no-cpu-baseline 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_c4_2ranks_gloo.json
 tail -3 $O/bench_n1.err
