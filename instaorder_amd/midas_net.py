@@ -216,6 +216,14 @@ class _Scratch(nn.Module):
     pass
 
 
+def _ranks_share_a_device():
+    import torch.distributed as dist
+    try:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > max(1, torch.cuda.device_count())
+    except Exception:
+        return False
+
+
 class _InstaDepthBase(nn.Module):
     def __init__(self, path=None, features=256, non_negative=True):
         super(_InstaDepthBase, self).__init__()
@@ -227,8 +235,12 @@ class _InstaDepthBase(nn.Module):
         for i in (4, 3, 2, 1):
             setattr(self.scratch, "refinenet%d" % i, FeatureFusionBlock(features))
         self.non_negative = non_negative
-        # IO_DEPTH_STREAMS=0: everything on one stream (read per model, so a test can build both forms in one process)
-        self.multi_stream = os.environ.get("IO_DEPTH_STREAMS", "1") != "0"
+        # IO_DEPTH_STREAMS=0: everything on one stream (read per model, so a test can build both forms in one process).
+        # The side streams are for a process that has its GPU to itself (the deployment: one process per GPU): when several
+        # ranks SHARE a device (more ranks than devices -- the two-rank gloo runs on a one-GPU box) the streams of the
+        # processes are time-sliced against each other and the staged step ran 0.27 .. 8.7 s per step instead of 0.27
+        # (profiles/r05_bench_config4_*_2ranks_gloo_one_gpu.json was taken with this rule).
+        self.multi_stream = os.environ.get("IO_DEPTH_STREAMS", "1") != "0" and not _ranks_share_a_device()
         self.dtype = "fp32"       # 'bf16': activations / GEMM operands in bf16 (set by SingleStageModel from params['dtype'])
         self.scratch.output_conv = nn.Sequential(                              # midas_net.py:134-141
             Conv2d(features, 128, 3, 1, 1, bias=True),
