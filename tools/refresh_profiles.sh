@@ -51,4 +51,9 @@ python3 bench.py --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-fwd-onl
 python3 bench.py --batch 64 --steps 12 --warmup 4 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | tail -1 > $O/bench_b64_fp32.json
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --backend gloo --batch 64 --steps 6 --warmup 3 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_2ranks_gloo.json
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --backend gloo --algo InstaDepthNet_od --size 384 --batch 8 --dtype bf16 --steps 5 --warmup 3 --no-cpu-baseline 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_c4_2ranks_gloo.json
+# the two headline lines once more with the counters of THIS run behind them (bench.py quotes profiles/rNN_pmc_*.json only while
+# their csrc digest is that of the sources it runs on): make the profile files here, re-run, keep the new lines
+python3 tools/make_profiles.py ${RND:-5} > /dev/null 2>> $O/bench_n1.err
+python3 bench.py > $O/bench_n1.json 2>> $O/bench_n1.err
+python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_n1_bf16.json 2>> $O/bench_n1.err
 tail -3 $O/bench_n1.err
