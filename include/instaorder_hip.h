@@ -450,6 +450,17 @@ typedef struct io_weight_desc {
 } io_weight_desc;
 int io_weights_prepare(const void* table, int n, const float* params, void* ops, int dtype, hipStream_t stream);
 int io_weights_unpack_grads(const void* table, int n, const float* gk, float* grads, hipStream_t stream);
+/* bf16 counterpart (round 5; csrc/conv_halo3.hip: stem_wgrad_halo_kernel): x8 / da / y bf16, dw fp32 [64][49][8].  256 x 256 inputs
+ * (128-wide output rows), G | N; workspace of io_stem_wgrad_bf16_workspace_bytes(); IO_ERR_SHAPE where the kernel does not apply
+ * (other sizes, too few rows for its persistent blocks, io_set_bf16_p256(0)): use io_bn_bwd_dt + io_conv2d_wgrad_dt there.
+ * The plain filter gradient of the bf16 stem (io_conv2d_wgrad_dt with Cin = 8) takes the same kernel without the fold when its
+ * workspace (io_conv2d_wgrad_workspace_bytes) allows; io_debug_last_wgrad_route() = 1 tells a test that it did. */
+size_t io_stem_wgrad_bf16_workspace_bytes(void);
+int io_stem_wgrad_bn_bf16(const void* x8, const void* da, const void* y, float* dw, int N, int H, int W, int G,
+                          const float* gamma, const float* mean, const float* rstd, const float* scale, const float* shift,
+                          float* dgamma, float* dbeta, float* coef, float* bn_partial, size_t bn_partial_floats,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream);
+int io_debug_last_wgrad_route(void);
 /* The stem's pooling over a transformed input (see io_conv2d_fwd_xf_dt; tables [G][C], group = sample / (N / G)):
  * nn.MaxPool2d(3, 2, 1) over relu(bn1(x)) (resnet_cls.py:205-208) with the arg-max indices io_maxpool_bwd consumes. */
 int io_maxpool_fwd_xf_dt(const void* x, int N, int H, int W, int C, void* out, uint32_t* idx, int G,

@@ -140,6 +140,10 @@ SIGNATURES = {
     "io_stem_wgrad_exact": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "io_stem_wgrad_exact_bn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P,
                                     _P]),
+    # x8, da, y, dw, N, H, W, G, gamma, mean, rstd, scale, shift, dgamma, dbeta, coef, bn_partial, bn_partial_floats, ws, ws_bytes, stream
+    "io_stem_wgrad_bn_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "io_stem_wgrad_bf16_workspace_bytes": (_Z, []),
+    "io_debug_last_wgrad_route": (_I, []),
     "io_conv2d_fwd_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P,
                                  _P, _P, _Z, _P]),
     "io_smooth_loss_workspace_floats": (_Z, [_I, _I, _I]),

@@ -530,6 +530,32 @@ extern "C" int io_stem_wgrad_exact_bn(const float* x8, const float* da, const fl
     return io_stem_unpack_grad(packed, dw, 64, 49, real_channels, st);
 }
 
+extern "C" size_t io_stem_wgrad_bf16_workspace_bytes(void) { return io_stem_wgrad_halo_partial_bytes(); }
+extern "C" int io_stem_wgrad_bn_bf16(const void* x8, const void* da, const void* y, float* dw, int N, int H, int W, int G,
+                                     const float* gamma, const float* mean, const float* rstd, const float* scale,
+                                     const float* shift, float* dgamma, float* dbeta, float* coef, float* bn_partial,
+                                     size_t bn_partial_floats, void* ws, size_t ws_bytes, hipStream_t st) {
+    IO_REQUIRE(x8 && da && y && dw && coef && ws, IO_ERR_SHAPE, "stem_wgrad_bn_bf16: null argument");
+    IoConvGeom g = io_geom_fwd(N, H, W, 8, 64, 7, 7, 2, 3);
+    IO_REQUIRE(io_stem_wgrad_halo_ok(g, ws_bytes, G), IO_ERR_SHAPE,
+               "stem_wgrad_bn_bf16: needs 256 x 256 inputs (128-wide output rows), G | N, io_stem_wgrad_bf16_workspace_bytes() of "
+               "workspace and enough rows for the persistent blocks (else: io_bn_bwd_dt + io_conv2d_wgrad_dt)");
+    const int M = N * g.Ho * g.Wo;
+    int rc = io_bn_bwd_coefs_t(da, y, M, 64, G, gamma, mean, rstd, dgamma, dbeta, coef, bn_partial, bn_partial_floats, st, IO_BF16,
+                               scale, shift);
+    if (rc) return rc;
+    IoStemXb xb{};
+    xb.y = (const float*)y;
+    xb.a = coef;
+    xb.b = coef + (size_t)G * 64;
+    xb.c = coef + (size_t)2 * G * 64;
+    xb.mean = mean;
+    xb.scale = scale;
+    xb.shift = shift;
+    xb.G = G;
+    return io_launch_stem_wgrad_halo(g, x8, da, dw, (float*)ws, ws_bytes, st, &xb);
+}
+
 extern "C" size_t io_bn_tile_partial_floats(int M, int C, int G) {
     if (M <= 0 || C <= 0 || G <= 0) return 0;
     const size_t tiles = (size_t)(M + kIoStatTileRows - 1) / kIoStatTileRows;

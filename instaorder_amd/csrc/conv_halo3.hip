@@ -605,6 +605,206 @@ __global__ __launch_bounds__(512, 2) void stem_halo_kernel(IoConvGeom g, Halo3Ar
     }
 }
 
+
+// ---- the stem's filter gradient (bf16), with bn1's backward folded in ------------------------------------------------------
+// dW[co][tap][c] = sum over output pixels of dy[px][co] * x8[2 px + tap][c]: the reduction index of the MFMA is the PIXEL, so
+// both operands are needed with 8 consecutive pixels per lane -- the transpose of what memory holds.  `ds_read_b64_tr_b16`
+// delivers exactly that from pixel-major LDS images (per 16-lane group: lane 4 j + q points at 4 channels of pixel j, lane c
+// receives channel c of the four pixels), and because every lane brings its own address the "16 columns" of a read can be
+// two filter taps x 8 channels taken from two different places of the parity-split patch of stem_halo_kernel.  Tile = two
+// output rows (256 pixels) of one image: the patch by LDS-DMA as in the forward kernel, the 256 x 64 dy rows through
+// registers -- because with XB they are not read but COMPUTED while staged: dy = a * (dz where relu(bn1(y)) > 0) + b * y + c
+// with the [G][64] tables of io_bn_bwd_coefs_t (resnet_cls.py:157; the stem has no data gradient, so this kernel is dy's
+// only reader and the apply pass -- read dz, read y, write dy, read dy -- does not exist).  Output: D[64 co][392 -> 416
+// columns (tap, c)] = 2 x 13 MFMA tiles, wave w owns column tiles w and w + 8 for both row tiles; the accumulators stay in
+// registers across all tiles of the (persistent) block, which leaves one [64][392] partial for io_splitk_reduce.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char* lds_cptr;
+
+struct StemWgArgs {
+    const bf16_t* x8;
+    const bf16_t* dz;       // XB: gradient of relu(bn1(y)); else dy itself
+    const bf16_t* y;        // XB
+    const float *ta, *tb, *tc, *mean, *scale, *shift;       // XB: [G][64]
+    float* partial;         // [gridDim.x][64][392]
+    size_t x_bytes, dy_bytes;
+    int ntiles, tiles_per_img, tiles_per_group;
+};
+
+template <bool XB>
+__global__ __launch_bounds__(512, 2) void stem_wgrad_halo_kernel(IoConvGeom g, StemWgArgs a) {
+    constexpr int NW = 8, PJ = 132, ROWS = 9, SLOTS = ROWS * 2 * PJ;
+    constexpr int NCH = (SLOTS + 63) / 64, NAW = (NCH + NW - 1) / NW, ABUF = NAW * NW * 1024;       // 40 KB patch buffer
+    constexpr int DBUF = 256 * 128;                                                                    // 32 KB dy buffer
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // LDS: [patch 0][patch 1][dy 0][dy 1]
+    const lds_cptr lds = (lds_cptr)smem;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- patch fetches (as stem_halo_kernel)
+    unsigned arel[NAW];
+#pragma unroll
+    for (int u = 0; u < NAW; ++u) {
+        const int q = (wave * NAW + u) * 64 + lane;
+        const int rp = q / PJ, j = q - rp * PJ, rr = rp >> 1, ix = 2 * j + (rp & 1) - 4;
+        const bool ok = q < SLOTS && ix >= 0 && ix < g.Wi;
+        arel[u] = ((unsigned)((rr * g.Wi + ix + 4) * 16)) | (ok ? (unsigned)rr : 15u);
+    }
+    auto issue_a = [&](int tile, int buf) {
+        const int img = tile / a.tiles_per_img, oy0 = (tile - img * a.tiles_per_img) * 2;
+        const long long start = (((long long)img * g.Hi + (2 * oy0 - 3)) * g.Wi - 4) * 16;
+        const u32x4 rsA = dma_rsrc_raw((unsigned long long)((const char*)a.x8 + start), (size_t)((long long)a.x_bytes - start));
+        const unsigned sb = lds0 + (unsigned)(buf * ABUF);
+#pragma unroll
+        for (int u = 0; u < NAW; ++u) {
+            const unsigned rr = arel[u] & 15u;
+            const bool ok = rr != 15u && (unsigned)(2 * oy0 - 3 + (int)rr) < (unsigned)g.Hi;
+            dma16(rsA, sb + (unsigned)((wave * NAW + u) * 1024), ok ? (arel[u] & ~15u) : kOob, 0u);
+        }
+    };
+    // ---- dy rows: thread = (pixel tid >> 3 + 64 i, channels 8 (tid & 7) ..), 16 bytes per tensor and i
+    const int spx = tid >> 3, scg = tid & 7;
+    u32x4 rdz[4], ry[4];
+    float t_a[8], t_b[8], t_c[8], t_mu[8], t_sc[8], t_sh[8];
+    auto dy_load = [&](int tile) {
+        // (descriptors rebased per TILE -- wave-uniform; the thread's part rides in the vector offset)
+        const size_t base = (size_t)tile * 256 * 128;
+        const __amdgpu_buffer_rsrc_t rz = rsrc_at(a.dz, base, a.dy_bytes);
+        const __amdgpu_buffer_rsrc_t rq = rsrc_at(XB ? a.y : a.dz, base, a.dy_bytes);
+        const unsigned vo = (unsigned)(spx * 128 + scg * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rdz[i] = __builtin_amdgcn_raw_buffer_load_b128(rz, vo + (unsigned)(i * 64 * 128), 0, 0);
+            if constexpr (XB) ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo + (unsigned)(i * 64 * 128), 0, 0);
+        }
+        if constexpr (XB) {
+            const int go = (tile / a.tiles_per_group) * 64 + scg * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t_a[e] = a.ta[go + e];
+                t_b[e] = a.tb[go + e];
+                t_c[e] = a.tc[go + e];
+                t_mu[e] = a.mean[go + e];
+                t_sc[e] = a.scale[go + e];
+                t_sh[e] = a.shift[go + e];
+            }
+        }
+    };
+    // the LDS image of dy: pixel px at px * 128, its 32-byte block b (16 channels) in slot b ^ ((px >> 1) & 1): the four pixels
+    // a transposing read touches (128 bytes apart) then sit in four different 64-byte bank groups
+    auto dy_store = [&](int buf) {
+        char* dst = smem + 2 * ABUF + buf * DBUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = spx + 64 * i;
+            u32x4 v = rdz[i];
+            if constexpr (XB) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float o[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int e = 2 * d + hh;
+                        const float yv = hh ? bf_hi(ry[i][d]) : bf_lo(ry[i][d]);
+                        const float zv = hh ? bf_hi(rdz[i][d]) : bf_lo(rdz[i][d]);
+                        const float act = __builtin_fmaf(yv - t_mu[e], t_sc[e], t_sh[e]);       // bn_apply's fma: the mask the forward saw
+                        const float dzm = act > 0.f ? zv : 0.f;
+                        o[hh] = __builtin_fmaf(t_a[e], dzm, __builtin_fmaf(t_b[e], yv, t_c[e]));
+                    }
+                    v[d] = io_f2bf2(o[0], o[1]);
+                }
+            }
+            *reinterpret_cast<u32x4*>(dst + px * 128 + (((scg >> 1) ^ ((px >> 1) & 1)) << 5) + ((scg & 1) << 4)) = v;
+        }
+    };
+    // ---- fragment addresses.  16-lane group g4 = lane >> 4: (g4 & 1) = which 16 of a tile's 32 rows / columns, (g4 >> 1) = k half;
+    // within the group lane 4 fj + fq points at 4 channels (quad fq) of k row fj
+    const int g4 = lane >> 4, fj = (lane >> 2) & 3, fq = lane & 3;
+    const unsigned krow = (unsigned)((g4 >> 1) * 8 + fj);                   // pixel of the k-step this lane points at (+ 4 for the 2nd read)
+    unsigned fa[2];                                                         // A = dy^T: row tile rt = 32 output channels
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int co = rt * 32 + (g4 & 1) * 16 + 4 * fq;
+        // (the slot swizzle depends on bit 1 of the pixel = bit 1 of fj: k-steps start at multiples of 8)
+        fa[rt] = (unsigned)(2 * ABUF) + krow * 128u + (unsigned)((((co >> 4) ^ ((fj >> 1) & 1)) << 5) + (co & 15) * 2);
+    }
+    const int nct = wave + 8 < 13 ? 2 : 1;                                  // column tiles of this wave: wave, wave + 8
+    unsigned fb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = (wave + 8 * j) * 32 + (g4 & 1) * 16 + 4 * fq;      // first of the lane's four columns
+        int tap = col >> 3;
+        if (tap > 48) tap = 48;                                             // padding columns 392 .. 415: any valid pixels
+        const int ty = tap / 7, tx = tap - ty * 7;
+        fb[j] = (unsigned)((((2 * ty + ((tx + 1) & 1)) * PJ + ((tx + 1) >> 1)) * 16) + (col & 7) * 2) + krow * 16u;
+    }
+    auto tr8 = [&](unsigned off, unsigned second) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + off + second));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+    if (tile < a.ntiles) {
+        issue_a(tile, 0);
+        dy_load(tile);
+        dy_store(0);
+    }
+    while (tile < a.ntiles) {
+        dma_wait_left<0>();
+        __syncthreads();                 // patch and dy rows of this tile are in LDS; every wave is done with the other buffers
+        const int ntile = tile + (int)gridDim.x;
+        if (ntile < a.ntiles) {
+            issue_a(ntile, buf ^ 1);
+            dy_load(ntile);
+        }
+        const unsigned pa = (unsigned)(buf * ABUF), pd = (unsigned)(buf * DBUF);
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            // k-step s: pixels 16 s .. 16 s + 15 of the tile = row s >> 3, columns 16 (s & 7) ..
+            const unsigned ka = pd + (unsigned)(s_ * 16 * 128);
+            const unsigned kb = pa + (unsigned)(((4 * (s_ >> 3)) * PJ + (s_ & 7) * 16) * 16);
+            bf16x8 A[2], B[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) A[rt] = tr8(fa[rt] + ka, 4 * 128);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (j < nct) B[j] = tr8(fb[j] + kb, 4 * 16);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < nct) acc[rt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[rt], B[j], acc[rt][j], 0, 0, 0);
+        }
+        if (ntile < a.ntiles) dy_store(buf ^ 1);
+        buf ^= 1;
+        tile = ntile;
+    }
+    // the block's partial: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* dst = a.partial + (size_t)blockIdx.x * 64 * 392;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = (wave + 8 * j) * 32 + (lane & 31);
+        if (j < nct && n < 392) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    dst[(size_t)co * 392 + n] = acc[rt][j][r];
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // IO_OK = launched, 1 = not this kernel's shape / form (the caller falls through), < 0 = error
@@ -745,4 +945,78 @@ int io_launch_conv_stem_halo(const IoConvGeom& g, const void* in, const void* wg
         hipLaunchKernelGGL((stem_halo_kernel<EPI_PLAIN>), dim3((unsigned)grid), dim3(512), lds, st, g, a);
     }
     return io_check_launch("stem_halo");
+}
+
+// The stem's filter gradient in bf16 (see stem_wgrad_halo_kernel): dw[64][49][8] fp32 = reduction of one partial per block.
+// xb: bn1's backward folded in (dz / y / tables), or null (dz is dy).  IO_OK, 1 = not this kernel's shape / workspace, < 0 error.
+size_t io_stem_wgrad_halo_partial_bytes() { return (size_t)io_stem_wgrad_rows_max_blocks() * 64 * 392 * sizeof(float); }
+static int stem_wg_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+// would io_launch_stem_wgrad_halo take this launch (shape, mode, enough tiles for its persistent blocks, workspace)?
+bool io_stem_wgrad_halo_ok(const IoConvGeom& g, size_t partial_bytes, int G) {
+    const int mode = io_bf16_persist_mode();
+    if (mode != 1 && mode != 3) return false;
+    if (!(g.Th == 7 && g.Tw == 7 && g.S == 7 && g.wT == 49 && g.is == 2 && g.Ci == 8 && g.Co == 64 && !g.gw && !g.cr && g.Wo == 128 &&
+          g.Wi == 256 && g.Hi == 2 * g.Ho && (g.Ho & 1) == 0 && g.dh0 == -3 && g.dw0 == -3 && g.dhs == 1 && g.dws == 1))
+        return false;
+    if ((double)g.Hi * g.Wi * 16.0 >= 2.0e9 || G < 1 || g.N % G != 0) return false;
+    const long ntiles = (long)g.N * g.Ho * g.Wo / 256;
+    long grid = ntiles < stem_wg_ncu() ? ntiles : stem_wg_ncu();
+    if (grid > io_stem_wgrad_rows_max_blocks()) grid = io_stem_wgrad_rows_max_blocks();
+    if ((size_t)grid * 64 * 392 * sizeof(float) > partial_bytes) return false;
+    const long rounds = (ntiles + grid - 1) / grid;
+    return mode == 3 || ntiles * 10 >= rounds * grid * 8;
+}
+int io_launch_stem_wgrad_halo(const IoConvGeom& g, const void* x8, const void* dz, float* dw, float* partial, size_t partial_bytes,
+                              hipStream_t st, const IoStemXb* xb) {
+    if (!io_stem_wgrad_halo_ok(g, partial_bytes, xb ? xb->G : 1)) return 1;
+    const long M = (long)g.N * g.Ho * g.Wo;
+    StemWgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x8 = (const bf16_t*)x8;
+    a.dz = (const bf16_t*)dz;
+    a.partial = partial;
+    a.x_bytes = (size_t)g.N * g.Hi * g.Wi * 16;
+    a.dy_bytes = (size_t)M * 128;
+    a.ntiles = (int)(M / 256);
+    a.tiles_per_img = g.Ho / 2;
+    if (xb) {
+        a.y = (const bf16_t*)xb->y;
+        a.ta = xb->a;
+        a.tb = xb->b;
+        a.tc = xb->c;
+        a.mean = xb->mean;
+        a.scale = xb->scale;
+        a.shift = xb->shift;
+        a.tiles_per_group = (g.N / xb->G) * a.tiles_per_img;
+    }
+    int grid = a.ntiles < stem_wg_ncu() ? a.ntiles : stem_wg_ncu();
+    if (grid > io_stem_wgrad_rows_max_blocks()) grid = io_stem_wgrad_rows_max_blocks();
+    {
+        IoProfScope prof(IO_PROF_WGRAD_STEM, 2.0 * (double)M * 64 * 49.0 * 5.0,
+                         (xb ? 4.0 : 2.0) * M * 64 + 2.0 * (double)g.N * g.Hi * g.Wi * 8, st);
+        constexpr size_t lds = (size_t)2 * 5 * 8 * 1024 + (size_t)2 * 256 * 128;
+        if (xb) {
+            static std::atomic<unsigned long long> done{0};
+            if (io_first_on_device(done))
+                (void)hipFuncSetAttribute((const void*)stem_wgrad_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((stem_wgrad_halo_kernel<true>), dim3((unsigned)grid), dim3(512), lds, st, g, a);
+        } else {
+            static std::atomic<unsigned long long> done{0};
+            if (io_first_on_device(done))
+                (void)hipFuncSetAttribute((const void*)stem_wgrad_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((stem_wgrad_halo_kernel<false>), dim3((unsigned)grid), dim3(512), lds, st, g, a);
+        }
+        const int rc = io_check_launch("stem_wgrad_halo");
+        if (rc) return rc;
+    }
+    return io_splitk_reduce(partial, dw, (size_t)64 * 392 / 4, grid, st);
 }

@@ -2886,9 +2886,13 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
         const size_t rows = (size_t)io_stem_wgrad_rows_max_blocks() * g.Co * io_filter_row(g) * sizeof(float);
         if (rows > need) need = rows;
     }
+    if (stem && !g.cr && g.Ci == 8 && g.Co == 64 && g.Wo == 128)      // the bf16 stem's one partial per block (conv_halo3.hip)
+        if (io_stem_wgrad_halo_partial_bytes() > need) need = io_stem_wgrad_halo_partial_bytes();
     return need;
 }
 
+static std::atomic<int> g_last_wgrad_route{0};      // tests: 1 = the last filter gradient ran on stem_wgrad_halo_kernel
+extern "C" int io_debug_last_wgrad_route(void) { return g_last_wgrad_route.load(std::memory_order_relaxed); }
 // which kernel family the last forward / data-gradient launch went to (tests: 0 = conv_nt_kernel, 1 = conv_p256, 2 = conv_halo3, 3 = stem_halo)
 static std::atomic<int> g_last_route{0};
 extern "C" int io_debug_last_nt_route(void) { return g_last_route.load(std::memory_order_relaxed); }
@@ -3167,6 +3171,15 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
     // the fp32 exact-K stem on whole 128-pixel output rows: the row-persistent kernel of stem.hip, one partial per block
     if (stem && dt_in == IO_F32 && dt_dy == IO_F32 && g.cr && io_stem_rows_ok(g))
         return io_launch_stem_wgrad_rows(g, (const float*)in, (const float*)dy, dw, partial, partial_bytes, st);
+    // the bf16 stem on 128-wide output rows: patch in LDS, transposing fragment reads (conv_halo3.hip)
+    if (stem && dt_in == IO_BF16 && dt_dy == IO_BF16) {
+        const int rh = io_launch_stem_wgrad_halo(g, in, dy, dw, partial, partial_bytes, st, nullptr);
+        if (rh <= 0) {
+            g_last_wgrad_route.store(1, std::memory_order_relaxed);
+            return rh;
+        }
+    }
+    g_last_wgrad_route.store(0, std::memory_order_relaxed);
     if (dt_in == IO_F32 && dt_dy == IO_F32 && wgrad_wino_ok(g, stem)) {
         const WgradPlan pw = plan_wgrad_wino(g);
         float* dstw = pw.splits == 1 ? dw : partial;

@@ -258,6 +258,11 @@ struct IoStemXb {
 };
 int io_launch_stem_wgrad_rows(const IoConvGeom& g, const float* x8, const float* dy, float* dwp, float* partial,
                               size_t partial_bytes, hipStream_t st, const IoStemXb* xb = nullptr);
+// conv_halo3.hip: the bf16 stem's filter gradient (xb: bn1's backward folded in; y is bf16 there).  IO_OK / 1 = not its shape / < 0
+size_t io_stem_wgrad_halo_partial_bytes();
+bool io_stem_wgrad_halo_ok(const IoConvGeom& g, size_t partial_bytes, int G);
+int io_launch_stem_wgrad_halo(const IoConvGeom& g, const void* x8, const void* dz, float* dw, float* partial, size_t partial_bytes,
+                              hipStream_t st, const IoStemXb* xb);
 // dst[i] = sum over `splits` slabs of n4 float4, fixed order (conv_igemm.hip)
 int io_splitk_reduce(const float* partial, float* dst, size_t n4, int splits, hipStream_t st);
 // all filter transposes of a network in one launch (misc.hip): entry l = filter [O][T][C] at element offset off[l] of the

@@ -920,6 +920,29 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
                                        net->stem.cin, c.st);
         }
     }
+    // bf16: the same fusion on stem_wgrad_halo_kernel (conv_halo3.hip) where the stem has 128-wide output rows
+    if (c.net->dtype == IO_BF16) {
+        IoConvGeom g = io_geom_fwd(c.N, c.S, c.S, 8, 64, 7, 7, 2, 3);
+        if (io_stem_wgrad_halo_ok(g, c.plan.wg_partial_bytes, c.G)) {
+            const BnL& b = net->bn1;
+            Tables t = c.tables(b);
+            IO_TRY(io_bn_bwd_coefs_t(Ge, c.act(p.y0), c.N * H0 * H0, b.C, c.G, c.params + b.g_off, t.mean, t.rstd,
+                                     c.grads + b.g_off, c.grads + b.b_off, c.buf(c.plan.coef), c.buf(c.plan.bn_partial),
+                                     c.plan.bn_partial_floats, c.st, c.dt(), t.scale, t.shift));
+            const size_t gs = (size_t)c.G * b.C;
+            IoStemXb xb{};
+            xb.y = (const float*)c.act(p.y0);        // (bf16 storage)
+            xb.a = c.buf(c.plan.coef);
+            xb.b = c.buf(c.plan.coef) + gs;
+            xb.c = c.buf(c.plan.coef) + 2 * gs;
+            xb.mean = t.mean;
+            xb.scale = t.scale;
+            xb.shift = t.shift;
+            xb.G = c.G;
+            return io_launch_stem_wgrad_halo(g, x8, Ge, c.grads + net->stem.w_off, c.buf(c.plan.wg_partial),
+                                             c.plan.wg_partial_bytes, c.st, &xb);
+        }
+    }
     IO_TRY(bn_back(c, net->bn1, Ge, 1, nullptr, c.act(p.y0), c.N * H0 * H0, Ga, nullptr));
     IO_TRY(conv_wgrad(c, net->stem, x8, Ga, c.S));
     return IO_OK;

@@ -328,3 +328,92 @@ def test_stem_halo_forward_plain_stats_bias(N, H):
         _lib.check(lib.io_conv2d_fwd_bias_dt(P(x8), P(wd), P(y3), N, H, H, 8, 64, 7, 7, 2, 3, P(bias.to(DEV)), None, 1,
                                              BF, 0, ST()), "stem fwd+bias")
         assert relerr(y3.permute(0, 3, 1, 2), ref3) < TOL, on
+
+
+@pytest.mark.parametrize("N,G", [(2, 2), (3, 1), (4, 2)])
+def test_stem_wgrad_halo_plain_and_with_bn1_backward(N, G):
+    """The bf16 stem's filter gradient on stem_wgrad_halo_kernel (csrc/conv_halo3.hip: patch of two output rows in LDS, dy rows
+    through registers, transposing fragment reads, one partial per persistent block): (1) the plain gradient through
+    io_conv2d_wgrad_dt against fp64 on the same bf16 operands and against the kernel it replaces; (2) with bn1's backward folded
+    into the staging of dy (io_stem_wgrad_bn_bf16; resnet_cls.py:155-158: relu(bn1(conv1(x)))) against the BatchNorm-backward
+    formula in fp64 on the tables and the ReLU mask the kernels see, and against the unfused pair io_bn_bwd_dt +
+    io_conv2d_wgrad_dt."""
+    lib = _lib.lib()
+    H = 256
+    g = torch.Generator().manual_seed(70 + N)
+    x5 = torch.randn(N, 5, H, H, generator=g, dtype=torch.float64)
+    x8, x8r = bf(nhwc(torch.cat([x5, torch.zeros(N, 3, H, H, dtype=torch.float64)], 1)))
+    w, wr = bf((torch.randn(64, 8, 7, 7, generator=g, dtype=torch.float64) * 0.05).permute(0, 2, 3, 1).contiguous())
+    xr = x8r.permute(0, 3, 1, 2)
+    Ho = H // 2
+    M = N * Ho * Ho
+    dy, dyr = bf(torch.randn(N, Ho, Ho, 64, generator=g, dtype=torch.float64))
+
+    def wgrad_ref(dy_nchw):
+        wq = wr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        return torch.autograd.grad(F.conv2d(xr, wq, stride=2, padding=3), wq, dy_nchw)[0]        # [64][8][7][7]
+
+    gref = wgrad_ref(dyr.permute(0, 3, 1, 2))
+    nb = lib.io_conv2d_wgrad_workspace_bytes(N, H, H, 8, 64, 7, 7, 2, 3)
+    assert nb >= lib.io_stem_wgrad_bf16_workspace_bytes()
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    res = []
+    for on in (3, 0):
+        lib.io_set_bf16_p256(on)
+        dw = torch.full((64, 49, 8), float("nan"), device=DEV)
+        _lib.check(lib.io_conv2d_wgrad_dt(P(x8), P(dy), P(dw), N, H, H, 8, 64, 7, 7, 2, 3, P(ws), nb, BF, BF, ST()), "stem wgrad")
+        assert lib.io_debug_last_wgrad_route() == (1 if on == 3 else 0)
+        assert relerr(dw.view(64, 7, 7, 8).permute(0, 3, 1, 2), gref) < 2e-5, on     # fp32 accumulation of exact bf16 products
+        res.append(dw)
+    # ---- with bn1's backward: y and its tables from the forward kernel, da = gradient of relu(bn1(y))
+    lib.io_set_bf16_p256(3)
+    gen = torch.Generator().manual_seed(5)
+    gamma, beta = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen) * 0.3
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    mean, rstd, sc, sh = (torch.empty(G * 64, device=DEV) for _ in range(4))
+    nws = lib.io_conv2d_bnstats_workspace_floats(N, H, H, 64, 7, 7, 2, 3, G)
+    wsf = torch.empty(nws, device=DEV)
+    y = torch.empty(N, Ho, Ho, 64, device=DEV, dtype=torch.bfloat16)
+    _lib.check(lib.io_conv2d_fwd_bnstats_dt(P(x8), P(w.view(64, 49, 8)), P(y), N, H, H, 8, 64, 7, 7, 2, 3, G, P(gamma.to(DEV)),
+                                            P(beta.to(DEV)), P(rm), P(rv), 0.1, 1e-5, P(mean), P(rstd), P(sc), P(sh), P(wsf), nws,
+                                            BF, 0, ST()), "stem fwd + stats")
+    da, dar = bf(torch.randn(N, Ho, Ho, 64, generator=g, dtype=torch.float64))
+    per = N // G
+    grp = (torch.arange(N) // per)
+    tv = lambda t: t.view(G, 64).cpu()[grp].view(N, 1, 1, 64)          # noqa: E731
+    yf = y.float().cpu()
+    act = torch.addcmul(tv(sh), yf - tv(mean), tv(sc))                  # fma(y - mean, scale, shift) in fp32, as bn_apply
+    dz = dar * (act > 0)
+    xhat = (yf.double() - tv(mean).double()) * tv(rstd).double()
+    dy_ref = torch.empty_like(dz)
+    dgam_ref, dbet_ref = torch.zeros(64, dtype=torch.float64), torch.zeros(64, dtype=torch.float64)
+    for gi in range(G):
+        sl = slice(gi * per, (gi + 1) * per)
+        s1 = dz[sl].mean((0, 1, 2))
+        s2 = (dz[sl] * xhat[sl]).mean((0, 1, 2))
+        dy_ref[sl] = gamma.double() * rstd.view(G, 64)[gi].double().cpu() * (dz[sl] - s1 - xhat[sl] * s2)
+        dgam_ref += (dz[sl] * xhat[sl]).sum((0, 1, 2))
+        dbet_ref += dz[sl].sum((0, 1, 2))
+    gw = wgrad_ref(dy_ref.permute(0, 3, 1, 2))
+    npart = lib.io_bn_partial_floats(M, 64, G)
+    part = torch.empty(npart, device=DEV)
+    coef = torch.full((3 * G * 64,), float("nan"), device=DEV)
+    dgam, dbet = torch.full((64,), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
+    dw2 = torch.full((64, 49, 8), float("nan"), device=DEV)
+    _lib.check(lib.io_stem_wgrad_bn_bf16(P(x8), P(da), P(y), P(dw2), N, H, H, G, P(gamma.to(DEV)), P(mean), P(rstd), P(sc), P(sh),
+                                         P(dgam), P(dbet), P(coef), P(part), npart, P(ws), nb, ST()), "stem wgrad + bn1")
+    got2 = dw2.view(64, 7, 7, 8).permute(0, 3, 1, 2)
+    # (dy is rounded to bf16 on its way into the matrix pipe, as the unfused pair rounds it when it writes the tensor; BatchNorm
+    # backward subtracts two projections, so the result is small against its terms)
+    assert relerr(got2, gw) < 2e-3
+    assert relerr(dgam, dgam_ref) < 1e-3 and relerr(dbet, dbet_ref) < 1e-3
+    # the unfused pair on the same operands
+    dyt = torch.empty(N, Ho, Ho, 64, device=DEV, dtype=torch.bfloat16)
+    dg3, db3 = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    _lib.check(lib.io_bn_bwd_dt(P(da), None, P(sc), P(sh), P(y), M, 64, G, P(gamma.to(DEV)), P(mean), P(rstd), P(dg3), P(db3),
+                                P(dyt), None, P(part), npart, P(torch.empty(3 * G * 64, device=DEV)), BF, ST()), "bn_bwd")
+    dw3 = torch.full((64, 49, 8), float("nan"), device=DEV)
+    lib.io_set_bf16_p256(0)
+    _lib.check(lib.io_conv2d_wgrad_dt(P(x8), P(dyt), P(dw3), N, H, H, 8, 64, 7, 7, 2, 3, P(ws), nb, BF, BF, ST()), "stem wgrad (unfused)")
+    assert relerr(dw2, dw3.double().cpu()) < 2e-3
+    assert relerr(dgam, dg3.double().cpu()) < 1e-5 and relerr(dbet, db3.double().cpu()) < 1e-5
