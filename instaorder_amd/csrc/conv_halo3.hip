@@ -805,6 +805,153 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_halo_kernel(IoConvGeom g, S
     }
 }
 
+
+// ---- filter gradient of the 3x3 stride-1 64 -> 64 layer (conv2 of layer 1), bf16 --------------------------------------------
+// The recipe of stem_wgrad_halo_kernel on the geometry of conv_halo3_kernel: dW[co][tap][ci] = sum over pixels of dy[px][co] *
+// x[px + tap][ci].  conv_wgrad_bf16_tr_kernel gives every tap its own blocks -- x and dy go through L2 nine times and the
+// launch runs at 0.5 PF/s (0.29 ms against 0.09 of HBM time at 256 pairs).  Here a tile is 128 output pixels = two image rows:
+// its 4 x 66-pixel halo image of x (the swizzled image of conv_halo3_kernel) and its 128 x 64 dy rows go to LDS once, by LDS-DMA,
+// and all nine taps are multiplied from them: D[64 co][576 columns (tap, ci)] = 2 x 18 MFMA tiles, wave w owns column tiles
+// w, w + 8, w + 16 for both row tiles (<= 96 accumulator registers, resident across all tiles of the persistent block: one
+// partial per block).  A transposing read's 16 columns are 16 input channels of ONE tap: 32 contiguous bytes of a halo pixel.
+struct Wg3Args {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* partial;         // [gridDim.x][64][576]
+    size_t x_bytes, dy_bytes;
+    int ntiles, tiles_per_img;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, Wg3Args a) {
+    constexpr int NW = 8, W = 64, WP = W + 2, HP = 4 * WP;          // halo image: rows h0 - 1 .. h0 + 2
+    constexpr int NCH = (HP + 7) / 8, NAW = (NCH + NW - 1) / NW, ABUF = NAW * NW * 1024;      // 40 KB
+    constexpr int DBUF = 128 * 128;                                                              // 16 KB of dy rows
+    constexpr int STG = ABUF + DBUF;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // LDS: [x halo 0][dy 0][x halo 1][dy 1]
+    const lds_cptr lds = (lds_cptr)smem;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r8 = lane >> 3, p8 = lane & 7;
+    // ---- x fetches (as conv_halo3_kernel: halo pixel hp = chunk * 8 + r8 -> (hy, hx), slot p8 holds chunk p8 ^ ((hp >> 1) & 7))
+    const unsigned slot_e = (unsigned)((p8 ^ (r8 >> 1)) << 4), slot_o = slot_e ^ 64u;
+    const unsigned padpx = (unsigned)(W + 1);
+    unsigned arel[NAW];
+#pragma unroll
+    for (int u = 0; u < NAW; ++u) {
+        const int ch = wave * NAW + u, hp = ch * 8 + r8;
+        const int hy = hp / WP, hx = hp - hy * WP;
+        const bool colok = hp < HP && hx >= 1 && hx <= W;
+        arel[u] = ((unsigned)(((hy - 1) * W + (hx - 1) + (int)padpx) * 128) + ((ch & 1) ? slot_o : slot_e)) | (colok ? (unsigned)hy : 15u);
+    }
+    // ---- dy fetches: 16 chunks of 8 pixels, two per wave; pixel px at px * 128, its 32-byte block b in slot b ^ ((px >> 1) & 1)
+    // (stem_wgrad_halo_kernel's image): LDS position p8 of a row holds the global 16-byte chunk (((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)
+    const unsigned dvo = (unsigned)(r8 * 128 + (((((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)) << 4));
+    auto issue = [&](int tile, int buf) {
+        const int img = tile / a.tiles_per_img, h0 = (tile - img * a.tiles_per_img) * 2;
+        const long long start = ((long long)img * g.Hi * g.Wi + (long long)h0 * W - (long long)padpx) * 128;
+        const u32x4 rsA = dma_rsrc_raw((unsigned long long)((const char*)a.x + start), (size_t)((long long)a.x_bytes - start));
+        const unsigned sb = lds0 + (unsigned)(buf * STG);
+#pragma unroll
+        for (int u = 0; u < NAW; ++u) {
+            const unsigned hy = arel[u] & 15u;
+            const bool ok = hy != 15u && (unsigned)(h0 - 1 + (int)hy) < (unsigned)g.Hi;
+            dma16(rsA, sb + (unsigned)((wave * NAW + u) * 1024), ok ? (arel[u] & ~15u) : kOob, 0u);
+        }
+        const size_t dbase = (size_t)tile * 128 * 128;
+        const u32x4 rsD = dma_rsrc_raw((unsigned long long)((const char*)a.dy + dbase), a.dy_bytes - dbase);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = wave * 2 + u;                        // pixels 8 ch .. 8 ch + 7 (8 ch is a multiple of 8: the swizzle bit is r8's)
+            dma16(rsD, sb + (unsigned)(ABUF + ch * 1024), dvo, (unsigned)(ch * 1024));
+        }
+    };
+    // ---- fragment addresses (16-lane group g4: (g4 & 1) = which 16 of a tile's 32 rows / columns, (g4 >> 1) = k half; lane 4 fj + fq
+    // of the group points at 4 channels (quad fq) of k row fj)
+    const int g4 = lane >> 4, fj = (lane >> 2) & 3, fq = lane & 3;
+    const int krow = (g4 >> 1) * 8 + fj;
+    unsigned fa[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int co = rt * 32 + (g4 & 1) * 16 + 4 * fq;
+        fa[rt] = (unsigned)ABUF + (unsigned)krow * 128u + (unsigned)((((co >> 4) ^ ((fj >> 1) & 1)) << 5) + (co & 15) * 2);
+    }
+    const int nct = wave + 16 < 18 ? 3 : 2;                     // column tiles of this wave: wave, wave + 8 (, wave + 16)
+    int bl[3];                                                  // halo pixel of k row 0 of k-step 0 under the lane's tap, + krow
+    unsigned bc[3];                                             // the lane's 16-byte chunk (bits 4..) and byte inside it
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int col = (wave + 8 * j) * 32 + (g4 & 1) * 16 + 4 * fq;          // (j = 2 of the waves without a third tile: unused)
+        const int tap = (col >> 6) < 9 ? (col >> 6) : 8, ci = col & 63;
+        const int th = tap / 3, tw = tap - th * 3;
+        bl[j] = (1 + g.dh0 + g.dhs * th) * WP + 1 + (g.dw0 + g.dws * tw) + krow;
+        bc[j] = (unsigned)(((ci >> 3) << 4) | ((ci & 7) * 2));
+    }
+    auto tr_a = [&](unsigned off) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + off + 4 * 128));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto tr_b = [&](unsigned base, int hp, unsigned cb) -> bf16x8 {       // k rows hp .. hp + 3 and hp + 4 .. hp + 7 (this lane: one of each)
+        const unsigned o0 = base + (unsigned)hp * 128u + ((((cb >> 4) ^ (((unsigned)hp >> 1) & 7u)) << 4) | (cb & 15u));
+        const unsigned h1 = (unsigned)hp + 4u;
+        const unsigned o1 = base + h1 * 128u + ((((cb >> 4) ^ ((h1 >> 1) & 7u)) << 4) | (cb & 15u));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + o1));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+    if (tile < a.ntiles) issue(tile, 0);
+    while (tile < a.ntiles) {
+        dma_wait_left<0>();
+        __syncthreads();
+        const int ntile = tile + (int)gridDim.x;
+        if (ntile < a.ntiles) issue(ntile, buf ^ 1);
+        const unsigned sb = (unsigned)(buf * STG);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            // k-step s: pixels 16 s .. 16 s + 15 of the tile = image row s >> 2, columns 16 (s & 3) ..
+            const int hps = (s_ >> 2) * WP + 16 * (s_ & 3);
+            bf16x8 A[2], B[3];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) A[rt] = tr_a(sb + fa[rt] + (unsigned)(s_ * 16 * 128));
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < nct) B[j] = tr_b(sb, bl[j] + hps, bc[j]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < nct) acc[rt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[rt], B[j], acc[rt][j], 0, 0, 0);
+        }
+        buf ^= 1;
+        tile = ntile;
+    }
+    float* dst = a.partial + (size_t)blockIdx.x * 64 * 576;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < nct) {
+            const int n = (wave + 8 * j) * 32 + (lane & 31);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    dst[(size_t)co * 576 + n] = acc[rt][j][r];
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // IO_OK = launched, 1 = not this kernel's shape / form (the caller falls through), < 0 = error
@@ -1019,4 +1166,46 @@ int io_launch_stem_wgrad_halo(const IoConvGeom& g, const void* x8, const void* d
         if (rc) return rc;
     }
     return io_splitk_reduce(partial, dw, (size_t)64 * 392 / 4, grid, st);
+}
+
+// Filter gradient of a bf16 3x3 stride-1 64 -> 64 convolution on 64-wide maps (conv_wgrad_halo3_kernel).  IO_OK / 1 / < 0.
+size_t io_wgrad_halo3_partial_bytes() { return (size_t)io_stem_wgrad_rows_max_blocks() * 64 * 576 * sizeof(float); }
+bool io_wgrad_halo3_shape(const IoConvGeom& g) {
+    return g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && !g.gw && !g.cr &&
+           g.Ci == 64 && g.Co == 64 && g.Wo == 64 && (g.Ho & 1) == 0 && g.dhs == 1 && g.dws == 1 && g.dh0 == -1 && g.dw0 == -1 && g.r0 == 0 &&
+           g.rs == 1 && g.s0 == 0 && g.ss == 1;
+}
+int io_launch_conv_wgrad_halo3(const IoConvGeom& g, const void* x, const void* dy, float* dw, float* partial, size_t partial_bytes,
+                               hipStream_t st) {
+    const int mode = io_bf16_persist_mode();
+    if (mode != 1 && mode != 3) return 1;
+    if (!io_wgrad_halo3_shape(g) || (double)g.Hi * g.Wi * 128.0 >= 2.0e9) return 1;
+    const long M = (long)g.N * g.Ho * g.Wo;
+    Wg3Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const bf16_t*)x;
+    a.dy = (const bf16_t*)dy;
+    a.partial = partial;
+    a.x_bytes = (size_t)g.N * g.Hi * g.Wi * 128;
+    a.dy_bytes = (size_t)M * 128;
+    a.ntiles = (int)(M / 128);
+    a.tiles_per_img = g.Ho / 2;
+    int grid = a.ntiles < stem_wg_ncu() ? a.ntiles : stem_wg_ncu();
+    if (grid > io_stem_wgrad_rows_max_blocks()) grid = io_stem_wgrad_rows_max_blocks();
+    if ((size_t)grid * 64 * 576 * sizeof(float) > partial_bytes) return 1;
+    {
+        const long rounds = ((long)a.ntiles + grid - 1) / grid;
+        if (mode != 3 && (long)a.ntiles * 10 < rounds * grid * 8) return 1;
+    }
+    {
+        IoProfScope prof(IO_PROF_WGRAD, 2.0 * (double)M * 64 * 576.0, 2.0 * (2.0 * M * 64 + 64.0 * 576), st);
+        constexpr size_t lds = (size_t)2 * (5 * 8 * 1024 + 128 * 128);
+        static std::atomic<unsigned long long> done{0};
+        if (io_first_on_device(done))
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_halo3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv_wgrad_halo3_kernel, dim3((unsigned)grid), dim3(512), lds, st, g, a);
+        const int rc = io_check_launch("conv_wgrad_halo3");
+        if (rc) return rc;
+    }
+    return io_splitk_reduce(partial, dw, (size_t)64 * 576 / 4, grid, st);
 }

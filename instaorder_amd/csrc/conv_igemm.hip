@@ -2888,10 +2888,11 @@ size_t io_conv_wgrad_partial_bytes(const IoConvGeom& g, int stem) {
     }
     if (stem && !g.cr && g.Ci == 8 && g.Co == 64 && g.Wo == 128)      // the bf16 stem's one partial per block (conv_halo3.hip)
         if (io_stem_wgrad_halo_partial_bytes() > need) need = io_stem_wgrad_halo_partial_bytes();
+    if (!stem && io_wgrad_halo3_shape(g) && io_wgrad_halo3_partial_bytes() > need) need = io_wgrad_halo3_partial_bytes();
     return need;
 }
 
-static std::atomic<int> g_last_wgrad_route{0};      // tests: 1 = the last filter gradient ran on stem_wgrad_halo_kernel
+static std::atomic<int> g_last_wgrad_route{0};      // tests: 1 = the last filter gradient ran on stem_wgrad_halo_kernel, 2 = conv_wgrad_halo3_kernel
 extern "C" int io_debug_last_wgrad_route(void) { return g_last_wgrad_route.load(std::memory_order_relaxed); }
 // which kernel family the last forward / data-gradient launch went to (tests: 0 = conv_nt_kernel, 1 = conv_p256, 2 = conv_halo3, 3 = stem_halo)
 static std::atomic<int> g_last_route{0};
@@ -3176,6 +3177,14 @@ int io_launch_conv_wgrad(const IoConvGeom& g, const void* in, const void* dy, fl
         const int rh = io_launch_stem_wgrad_halo(g, in, dy, dw, partial, partial_bytes, st, nullptr);
         if (rh <= 0) {
             g_last_wgrad_route.store(1, std::memory_order_relaxed);
+            return rh;
+        }
+    }
+    // the bf16 3x3 stride-1 64 -> 64 layer on 64-wide maps: all nine taps from one halo image (conv_halo3.hip)
+    if (!stem && dt_in == IO_BF16 && dt_dy == IO_BF16) {
+        const int rh = io_launch_conv_wgrad_halo3(g, in, dy, dw, partial, partial_bytes, st);
+        if (rh <= 0) {
+            g_last_wgrad_route.store(2, std::memory_order_relaxed);
             return rh;
         }
     }

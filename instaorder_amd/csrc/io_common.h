@@ -263,6 +263,11 @@ size_t io_stem_wgrad_halo_partial_bytes();
 bool io_stem_wgrad_halo_ok(const IoConvGeom& g, size_t partial_bytes, int G);
 int io_launch_stem_wgrad_halo(const IoConvGeom& g, const void* x8, const void* dz, float* dw, float* partial, size_t partial_bytes,
                               hipStream_t st, const IoStemXb* xb);
+// ... and the filter gradient of the bf16 3x3 stride-1 64 -> 64 layer on 64-wide maps
+size_t io_wgrad_halo3_partial_bytes();
+bool io_wgrad_halo3_shape(const IoConvGeom& g);
+int io_launch_conv_wgrad_halo3(const IoConvGeom& g, const void* x, const void* dy, float* dw, float* partial, size_t partial_bytes,
+                               hipStream_t st);
 // dst[i] = sum over `splits` slabs of n4 float4, fixed order (conv_igemm.hip)
 int io_splitk_reduce(const float* partial, float* dst, size_t n4, int splits, hipStream_t st);
 // all filter transposes of a network in one launch (misc.hip): entry l = filter [O][T][C] at element offset off[l] of the

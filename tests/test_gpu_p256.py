@@ -417,3 +417,29 @@ def test_stem_wgrad_halo_plain_and_with_bn1_backward(N, G):
     _lib.check(lib.io_conv2d_wgrad_dt(P(x8), P(dyt), P(dw3), N, H, H, 8, 64, 7, 7, 2, 3, P(ws), nb, BF, BF, ST()), "stem wgrad (unfused)")
     assert relerr(dw2, dw3.double().cpu()) < 2e-3
     assert relerr(dgam, dg3.double().cpu()) < 1e-5 and relerr(dbet, db3.double().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("N,H", [(1, 64), (5, 64), (3, 128), (70, 64)])
+def test_wgrad_halo3_64_channels(N, H):
+    """Filter gradient of the bf16 3x3 stride-1 64 -> 64 convolution on 64-wide maps (conv2 of layer 1, resnet_cls.py:88) on
+    conv_wgrad_halo3_kernel (csrc/conv_halo3.hip: halo image of x + dy rows in LDS once per 128-pixel tile, all nine taps from
+    them through transposing fragment reads, one partial per persistent block) against fp64 on the same bf16 operands and
+    against conv_wgrad_bf16_tr_kernel.  One tile per block .. several rounds, ragged last round."""
+    lib = _lib.lib()
+    W, Cc = 64, 64
+    g = torch.Generator().manual_seed(90 + N + H)
+    x, xr = bf(torch.randn(N, H, W, Cc, generator=g, dtype=torch.float64))
+    dy, dyr = bf(torch.randn(N, H, W, Cc, generator=g, dtype=torch.float64))
+    wq = torch.zeros(Cc, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
+    gref = torch.autograd.grad(F.conv2d(xr.permute(0, 3, 1, 2), wq, padding=1), wq, dyr.permute(0, 3, 1, 2))[0]
+    nb = lib.io_conv2d_wgrad_workspace_bytes(N, H, W, Cc, Cc, 3, 3, 1, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    res = []
+    for on in (3, 0):
+        lib.io_set_bf16_p256(on)
+        dw = torch.full((Cc, 9, Cc), float("nan"), device=DEV)
+        _lib.check(lib.io_conv2d_wgrad_dt(P(x), P(dy), P(dw), N, H, W, Cc, Cc, 3, 3, 1, 1, P(ws), nb, BF, BF, ST()), "wgrad")
+        assert lib.io_debug_last_wgrad_route() == (2 if on == 3 else 0)
+        assert relerr(dw.view(Cc, 3, 3, Cc).permute(0, 3, 1, 2), gref) < 2e-5, on
+        res.append(dw)
+    assert relerr(res[0], res[1].double().cpu()) < 2e-5
