@@ -806,27 +806,33 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_halo_kernel(IoConvGeom g, S
 }
 
 
-// ---- filter gradient of the 3x3 stride-1 64 -> 64 layer (conv2 of layer 1), bf16 --------------------------------------------
+// ---- filter gradient of the 3x3 stride-1 layers (conv2 of the layer-1 .. layer-3 Bottlenecks), bf16 --------------------------
 // The recipe of stem_wgrad_halo_kernel on the geometry of conv_halo3_kernel: dW[co][tap][ci] = sum over pixels of dy[px][co] *
 // x[px + tap][ci].  conv_wgrad_bf16_tr_kernel gives every tap its own blocks -- x and dy go through L2 nine times and the
-// launch runs at 0.5 PF/s (0.29 ms against 0.09 of HBM time at 256 pairs).  Here a tile is 128 output pixels = two image rows:
-// its 4 x 66-pixel halo image of x (the swizzled image of conv_halo3_kernel) and its 128 x 64 dy rows go to LDS once, by LDS-DMA,
-// and all nine taps are multiplied from them: D[64 co][576 columns (tap, ci)] = 2 x 18 MFMA tiles, wave w owns column tiles
-// w, w + 8, w + 16 for both row tiles (<= 96 accumulator registers, resident across all tiles of the persistent block: one
-// partial per block).  A transposing read's 16 columns are 16 input channels of ONE tap: 32 contiguous bytes of a halo pixel.
+// launch runs at 0.5 .. 0.9 PF/s (layer 1: 0.29 ms against 0.09 of HBM time at 256 pairs).  Here a tile is 128 output pixels =
+// 128 / W whole image rows: the halo image of a 64-channel slice of x (the swizzled image of conv_halo3_kernel) and the tile's
+// rows of a 64-channel slice of dy go to LDS once, by LDS-DMA, and all nine taps are multiplied from them: D[64 co][576 columns
+// (tap, ci)] = 2 x 18 MFMA tiles, wave w owns column tiles w, w + 8, w + 16 for both row tiles (<= 96 accumulator registers,
+// resident across all tiles a block walks: one partial per block).  A transposing read's 16 columns are 16 input channels of ONE
+// tap: 32 contiguous bytes of a halo pixel.  With more than 64 channels the (Co / 64) x (Ci / 64) slice pairs are separate
+// SUB-PROBLEMS: block b works on pair b % nsp and walks the tiles (b / nsp) + k (grid / nsp) -- x is read Co / 64 times and dy
+// Ci / 64 times instead of nine times each.
 struct Wg3Args {
     const bf16_t* x;
     const bf16_t* dy;
     float* partial;         // [gridDim.x][64][576]
     size_t x_bytes, dy_bytes;
-    int ntiles, tiles_per_img;
+    int ntiles, tiles_per_img, nci, nsp;
 };
 
+template <int W>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, Wg3Args a) {
-    constexpr int NW = 8, W = 64, WP = W + 2, HP = 4 * WP;          // halo image: rows h0 - 1 .. h0 + 2
-    constexpr int NCH = (HP + 7) / 8, NAW = (NCH + NW - 1) / NW, ABUF = NAW * NW * 1024;      // 40 KB
-    constexpr int DBUF = 128 * 128;                                                              // 16 KB of dy rows
+    constexpr int NW = 8, R = 128 / W, WP = W + 2, HP = (R + 2) * WP;      // halo image: rows h0 - 1 .. h0 + R
+    constexpr int NAW = 5, ABUF = NAW * NW * 1024;                           // 40 KB (<= 320 halo pixels)
+    static_assert((HP + 7) / 8 <= NAW * NW, "halo image");
+    constexpr int DBUF = 128 * 128;                                          // 16 KB of dy rows
     constexpr int STG = ABUF + DBUF;
+    constexpr int LW = W == 64 ? 6 : (W == 32 ? 5 : 4);                      // log2 W
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     // LDS: [x halo 0][dy 0][x halo 1][dy 1]
     const lds_cptr lds = (lds_cptr)smem;
@@ -834,6 +840,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r8 = lane >> 3, p8 = lane & 7;
+    const int sp = (int)blockIdx.x % a.nsp, gsz = (int)gridDim.x / a.nsp;
+    // the blocks of one tile (its nsp slice pairs) sit on nsp consecutive XCDs (block b runs on XCD b % 8): 8 / nsp groups of XCDs
+    // take turns through the tile ranks -- remapped so that each group walks a CONTIGUOUS run of tiles (neighbouring tiles share
+    // two of their halo rows: out of the same L2)
+    int rank = (int)blockIdx.x / a.nsp;
+    {
+        const int ng = a.nsp <= 8 ? 8 / a.nsp : 1;
+        const int xg = rank % ng, ig = rank / ng, qg = gsz / ng, rg = gsz % ng;
+        rank = (xg < rg ? xg * (qg + 1) : rg * (qg + 1) + (xg - rg) * qg) + ig;
+    }
+    const int co0 = (sp / a.nci) * 64, ci0 = (sp % a.nci) * 64;
+    const unsigned xpix = (unsigned)(g.Ci * 2), dpix = (unsigned)(g.Co * 2);      // bytes per pixel of x / dy
     // ---- x fetches (as conv_halo3_kernel: halo pixel hp = chunk * 8 + r8 -> (hy, hx), slot p8 holds chunk p8 ^ ((hp >> 1) & 7))
     const unsigned slot_e = (unsigned)((p8 ^ (r8 >> 1)) << 4), slot_o = slot_e ^ 64u;
     const unsigned padpx = (unsigned)(W + 1);
@@ -843,14 +861,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
         const int ch = wave * NAW + u, hp = ch * 8 + r8;
         const int hy = hp / WP, hx = hp - hy * WP;
         const bool colok = hp < HP && hx >= 1 && hx <= W;
-        arel[u] = ((unsigned)(((hy - 1) * W + (hx - 1) + (int)padpx) * 128) + ((ch & 1) ? slot_o : slot_e)) | (colok ? (unsigned)hy : 15u);
+        arel[u] = ((unsigned)((hy - 1) * W + (hx - 1) + (int)padpx) * xpix + (unsigned)(ci0 * 2) + ((ch & 1) ? slot_o : slot_e)) |
+                  (colok ? (unsigned)hy : 15u);
     }
     // ---- dy fetches: 16 chunks of 8 pixels, two per wave; pixel px at px * 128, its 32-byte block b in slot b ^ ((px >> 1) & 1)
-    // (stem_wgrad_halo_kernel's image): LDS position p8 of a row holds the global 16-byte chunk (((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)
-    const unsigned dvo = (unsigned)(r8 * 128 + (((((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)) << 4));
+    // (stem_wgrad_halo_kernel's image): LDS position p8 of a row holds the 16-byte chunk (((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)
+    const unsigned dvo = (unsigned)r8 * dpix + (unsigned)(co0 * 2) + (unsigned)(((((p8 >> 1) ^ ((r8 >> 1) & 1)) << 1) | (p8 & 1)) << 4);
     auto issue = [&](int tile, int buf) {
-        const int img = tile / a.tiles_per_img, h0 = (tile - img * a.tiles_per_img) * 2;
-        const long long start = ((long long)img * g.Hi * g.Wi + (long long)h0 * W - (long long)padpx) * 128;
+        const int img = tile / a.tiles_per_img, h0 = (tile - img * a.tiles_per_img) * R;
+        const long long start = ((long long)img * g.Hi * g.Wi + (long long)h0 * W - (long long)padpx) * (long long)xpix;
         const u32x4 rsA = dma_rsrc_raw((unsigned long long)((const char*)a.x + start), (size_t)((long long)a.x_bytes - start));
         const unsigned sb = lds0 + (unsigned)(buf * STG);
 #pragma unroll
@@ -859,12 +878,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
             const bool ok = hy != 15u && (unsigned)(h0 - 1 + (int)hy) < (unsigned)g.Hi;
             dma16(rsA, sb + (unsigned)((wave * NAW + u) * 1024), ok ? (arel[u] & ~15u) : kOob, 0u);
         }
-        const size_t dbase = (size_t)tile * 128 * 128;
+        const size_t dbase = (size_t)tile * 128 * dpix;
         const u32x4 rsD = dma_rsrc_raw((unsigned long long)((const char*)a.dy + dbase), a.dy_bytes - dbase);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int ch = wave * 2 + u;                        // pixels 8 ch .. 8 ch + 7 (8 ch is a multiple of 8: the swizzle bit is r8's)
-            dma16(rsD, sb + (unsigned)(ABUF + ch * 1024), dvo, (unsigned)(ch * 1024));
+            dma16(rsD, sb + (unsigned)(ABUF + ch * 1024), dvo, (unsigned)(ch * 8) * dpix);
         }
     };
     // ---- fragment addresses (16-lane group g4: (g4 & 1) = which 16 of a tile's 32 rows / columns, (g4 >> 1) = k half; lane 4 fj + fq
@@ -878,14 +897,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
         fa[rt] = (unsigned)ABUF + (unsigned)krow * 128u + (unsigned)((((co >> 4) ^ ((fj >> 1) & 1)) << 5) + (co & 15) * 2);
     }
     const int nct = wave + 16 < 18 ? 3 : 2;                     // column tiles of this wave: wave, wave + 8 (, wave + 16)
-    int bl[3];                                                  // halo pixel of k row 0 of k-step 0 under the lane's tap, + krow
+    int bl[3];                                                  // halo pixel of pixel 0 of the tile under the lane's tap, + the lane's k row
     unsigned bc[3];                                             // the lane's 16-byte chunk (bits 4..) and byte inside it
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int col = (wave + 8 * j) * 32 + (g4 & 1) * 16 + 4 * fq;          // (j = 2 of the waves without a third tile: unused)
         const int tap = (col >> 6) < 9 ? (col >> 6) : 8, ci = col & 63;
         const int th = tap / 3, tw = tap - th * 3;
-        bl[j] = (1 + g.dh0 + g.dhs * th) * WP + 1 + (g.dw0 + g.dws * tw) + krow;
+        // pixel 16 s + krow of the tile = image row (16 s + krow) >> LW, column (16 s + krow) & (W - 1): W >= 16 keeps krow (< 16)
+        // inside the row of pixel 16 s
+        bl[j] = (1 + g.dh0 + g.dhs * th) * WP + 1 + (g.dw0 + g.dws * tw) + (krow & (W - 1));
         bc[j] = (unsigned)(((ci >> 3) << 4) | ((ci & 7) * 2));
     }
     auto tr_a = [&](unsigned off) -> bf16x8 {
@@ -909,18 +930,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+    int tile = rank, buf = 0;
     if (tile < a.ntiles) issue(tile, 0);
     while (tile < a.ntiles) {
         dma_wait_left<0>();
         __syncthreads();
-        const int ntile = tile + (int)gridDim.x;
+        const int ntile = tile + gsz;
         if (ntile < a.ntiles) issue(ntile, buf ^ 1);
         const unsigned sb = (unsigned)(buf * STG);
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
-            // k-step s: pixels 16 s .. 16 s + 15 of the tile = image row s >> 2, columns 16 (s & 3) ..
-            const int hps = (s_ >> 2) * WP + 16 * (s_ & 3);
+            // k-step s: pixels 16 s .. 16 s + 15 of the tile = image row (16 s) >> LW, columns (16 s) & (W - 1) ..
+            const int hps = ((16 * s_) >> LW) * WP + ((16 * s_) & (W - 1));
             bf16x8 A[2], B[3];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) A[rt] = tr_a(sb + fa[rt] + (unsigned)(s_ * 16 * 128));
@@ -949,6 +970,43 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo3_kernel(IoConvGeom g, 
                     dst[(size_t)co * 576 + n] = acc[rt][j][r];
                 }
         }
+    }
+}
+
+// dw[co][tap][ci] = sum over the blocks of slice pair (co / 64, ci / 64) of their partial [64][9 x 64], fixed order (the shape of
+// splitk_reduce_kernel: 32 outputs x 8 partial groups per block, eight loads in flight per thread)
+__global__ __launch_bounds__(256) void wgrad_halo3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Ci,
+                                                                 int Co, int nci, int nsp, int gsz) {
+    __shared__ f32x4 red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t i4 = (size_t)blockIdx.x * 32 + tx;                    // float4 index into dw
+    const size_t n4 = (size_t)Co * 9 * Ci / 4;
+    const bool ok = i4 < n4;
+    const size_t e = ok ? i4 * 4 : 0;
+    const int ci = (int)(e % (size_t)Ci), rest = (int)(e / (size_t)Ci), tap = rest % 9, co = rest / 9;
+    const int sp = (co >> 6) * nci + (ci >> 6);
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(partial) + (size_t)sp * (64 * 576 / 4) +
+                      ((size_t)(co & 63) * 576 + tap * 64 + (ci & 63)) / 4;
+    const size_t stride = (size_t)nsp * (64 * 576 / 4);               // between the partials of consecutive blocks of the pair
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        for (int z0 = ty; z0 < gsz; z0 += 64) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + 8 * u;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                v[u] = z < gsz ? p4[(size_t)z * stride] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && ok) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += red[k][tx];
+        reinterpret_cast<f32x4*>(dw)[i4] = s;
     }
 }
 
@@ -1168,44 +1226,63 @@ int io_launch_stem_wgrad_halo(const IoConvGeom& g, const void* x8, const void* d
     return io_splitk_reduce(partial, dw, (size_t)64 * 392 / 4, grid, st);
 }
 
-// Filter gradient of a bf16 3x3 stride-1 64 -> 64 convolution on 64-wide maps (conv_wgrad_halo3_kernel).  IO_OK / 1 / < 0.
+// Filter gradient of a bf16 3x3 stride-1 convolution with 64 / 128 / 256 channels on 64- / 32- / 16-wide maps
+// (conv_wgrad_halo3_kernel).  IO_OK / 1 = not this kernel's / < 0.
 size_t io_wgrad_halo3_partial_bytes() { return (size_t)io_stem_wgrad_rows_max_blocks() * 64 * 576 * sizeof(float); }
 bool io_wgrad_halo3_shape(const IoConvGeom& g) {
     return g.Th == 3 && g.Tw == 3 && g.S == 3 && g.wT == 9 && g.is == 1 && g.os == 1 && g.Hi == g.Ho && g.Wi == g.Wo && !g.gw && !g.cr &&
-           g.Ci == 64 && g.Co == 64 && g.Wo == 64 && (g.Ho & 1) == 0 && g.dhs == 1 && g.dws == 1 && g.dh0 == -1 && g.dw0 == -1 && g.r0 == 0 &&
-           g.rs == 1 && g.s0 == 0 && g.ss == 1;
+           g.Ci == g.Co && (g.Ci == 64 || g.Ci == 128 || g.Ci == 256) && (g.Wo == 64 || g.Wo == 32 || g.Wo == 16) &&
+           (g.Ho * g.Wo) % 128 == 0 && g.dhs == 1 && g.dws == 1 && g.dh0 == -1 && g.dw0 == -1 && g.r0 == 0 && g.rs == 1 && g.s0 == 0 &&
+           g.ss == 1;
 }
 int io_launch_conv_wgrad_halo3(const IoConvGeom& g, const void* x, const void* dy, float* dw, float* partial, size_t partial_bytes,
                                hipStream_t st) {
     const int mode = io_bf16_persist_mode();
     if (mode != 1 && mode != 3) return 1;
-    if (!io_wgrad_halo3_shape(g) || (double)g.Hi * g.Wi * 128.0 >= 2.0e9) return 1;
+    if (!io_wgrad_halo3_shape(g) || (double)g.Hi * g.Wi * g.Ci * 2.0 >= 2.0e9 || 128.0 * g.Co * 2.0 >= 2.0e9) return 1;
     const long M = (long)g.N * g.Ho * g.Wo;
     Wg3Args a;
     memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x;
     a.dy = (const bf16_t*)dy;
     a.partial = partial;
-    a.x_bytes = (size_t)g.N * g.Hi * g.Wi * 128;
-    a.dy_bytes = (size_t)M * 128;
+    a.x_bytes = (size_t)g.N * g.Hi * g.Wi * g.Ci * 2;
+    a.dy_bytes = (size_t)M * g.Co * 2;
     a.ntiles = (int)(M / 128);
-    a.tiles_per_img = g.Ho / 2;
-    int grid = a.ntiles < stem_wg_ncu() ? a.ntiles : stem_wg_ncu();
-    if (grid > io_stem_wgrad_rows_max_blocks()) grid = io_stem_wgrad_rows_max_blocks();
+    a.tiles_per_img = g.Ho * g.Wo / 128;
+    a.nci = g.Ci / 64;
+    a.nsp = a.nci * (g.Co / 64);
+    int cap = stem_wg_ncu() < io_stem_wgrad_rows_max_blocks() ? stem_wg_ncu() : io_stem_wgrad_rows_max_blocks();
+    int gsz = cap / a.nsp;                                  // blocks per slice pair
+    if (gsz > a.ntiles) gsz = a.ntiles;
+    if (gsz < 1) return 1;
+    const int grid = gsz * a.nsp;
     if ((size_t)grid * 64 * 576 * sizeof(float) > partial_bytes) return 1;
     {
-        const long rounds = ((long)a.ntiles + grid - 1) / grid;
-        if (mode != 3 && (long)a.ntiles * 10 < rounds * grid * 8) return 1;
+        const long rounds = ((long)a.ntiles + gsz - 1) / gsz;
+        if (mode != 3 && ((long)a.ntiles * 10 < rounds * gsz * 8 || grid * 10 < cap * 8)) return 1;
     }
     {
-        IoProfScope prof(IO_PROF_WGRAD, 2.0 * (double)M * 64 * 576.0, 2.0 * (2.0 * M * 64 + 64.0 * 576), st);
+        IoProfScope prof(IO_PROF_WGRAD, 2.0 * (double)M * g.Co * 9.0 * g.Ci, 2.0 * ((double)M * (g.Ci + g.Co) + 9.0 * g.Co * g.Ci), st);
         constexpr size_t lds = (size_t)2 * (5 * 8 * 1024 + 128 * 128);
-        static std::atomic<unsigned long long> done{0};
-        if (io_first_on_device(done))
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_halo3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv_wgrad_halo3_kernel, dim3((unsigned)grid), dim3(512), lds, st, g, a);
-        const int rc = io_check_launch("conv_wgrad_halo3");
+#define IO_WG3_LAUNCH(W_)                                                                                                  \
+    do {                                                                                                                  \
+        static std::atomic<unsigned long long> done{0};                                                                   \
+        if (io_first_on_device(done))                                                                                     \
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_halo3_kernel<W_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                          \
+        hipLaunchKernelGGL((conv_wgrad_halo3_kernel<W_>), dim3((unsigned)grid), dim3(512), lds, st, g, a);                \
+    } while (0)
+        if (g.Wo == 64) IO_WG3_LAUNCH(64);
+        else if (g.Wo == 32) IO_WG3_LAUNCH(32);
+        else IO_WG3_LAUNCH(16);
+#undef IO_WG3_LAUNCH
+        int rc = io_check_launch("conv_wgrad_halo3");
         if (rc) return rc;
+        const size_t n4 = (size_t)g.Co * 9 * g.Ci / 4;
+        hipLaunchKernelGGL(wgrad_halo3_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, partial, dw, g.Ci, g.Co,
+                           a.nci, a.nsp, gsz);
+        rc = io_check_launch("wgrad_halo3_reduce");
+        return rc;
     }
-    return io_splitk_reduce(partial, dw, (size_t)64 * 576 / 4, grid, st);
 }

@@ -419,15 +419,16 @@ def test_stem_wgrad_halo_plain_and_with_bn1_backward(N, G):
     assert relerr(dgam, dg3.double().cpu()) < 1e-5 and relerr(dbet, db3.double().cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("N,H", [(1, 64), (5, 64), (3, 128), (70, 64)])
-def test_wgrad_halo3_64_channels(N, H):
-    """Filter gradient of the bf16 3x3 stride-1 64 -> 64 convolution on 64-wide maps (conv2 of layer 1, resnet_cls.py:88) on
-    conv_wgrad_halo3_kernel (csrc/conv_halo3.hip: halo image of x + dy rows in LDS once per 128-pixel tile, all nine taps from
-    them through transposing fragment reads, one partial per persistent block) against fp64 on the same bf16 operands and
-    against conv_wgrad_bf16_tr_kernel.  One tile per block .. several rounds, ragged last round."""
+@pytest.mark.parametrize("N,H,W,Cc", [(1, 64, 64, 64), (5, 64, 64, 64), (3, 128, 64, 64), (70, 64, 64, 64), (2, 32, 32, 128),
+                                       (37, 32, 32, 128), (4, 16, 16, 256), (50, 16, 16, 256), (3, 64, 32, 128), (2, 8, 16, 256)])
+def test_wgrad_halo3(N, H, W, Cc):
+    """Filter gradient of the bf16 3x3 stride-1 convolutions with 64 / 128 / 256 channels on 64- / 32- / 16-wide maps (conv2 of
+    the layer-1 .. layer-3 Bottlenecks, resnet_cls.py:88) on conv_wgrad_halo3_kernel (csrc/conv_halo3.hip: halo image of a
+    64-channel slice of x + the dy rows in LDS once per 128-pixel tile, all nine taps from them through transposing fragment
+    reads, one partial per persistent block, (Co / 64) x (Ci / 64) slice pairs as sub-problems) against fp64 on the same bf16
+    operands and against conv_wgrad_bf16_tr_kernel.  One tile per block .. several rounds, ragged last round."""
     lib = _lib.lib()
-    W, Cc = 64, 64
-    g = torch.Generator().manual_seed(90 + N + H)
+    g = torch.Generator().manual_seed(90 + N + H + Cc)
     x, xr = bf(torch.randn(N, H, W, Cc, generator=g, dtype=torch.float64))
     dy, dyr = bf(torch.randn(N, H, W, Cc, generator=g, dtype=torch.float64))
     wq = torch.zeros(Cc, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
