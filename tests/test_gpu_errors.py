@@ -223,6 +223,11 @@ def test_round3_entry_points_reject_bad_arguments():
     # ... its fused-BatchNorm form is for whole 128-pixel output rows only (here Wo = 32), and wants G | N
     bad(L().io_stem_wgrad_exact_bn(P(a), P(b), P(c), P(d), 1, 64, 64, 5, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]),
                                    P(t[5]), P(t[0]), P(t[1]), P(d), 1 << 18, P(d), 1 << 20, P(t[2]), ST()))
+    # ... and so is the bf16 one (256 x 256 inputs; here 64 x 64), which also wants its workspace
+    bad(L().io_stem_wgrad_bn_bf16(P(a), P(b), P(c), P(d), 1, 64, 64, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]), P(t[0]),
+                                  P(t[1]), P(d), 1 << 18, P(d), 1 << 20, ST()))
+    bad(L().io_stem_wgrad_bn_bf16(P(a), P(b), P(c), P(d), 2, 256, 256, 1, P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]), P(t[0]),
+                                  P(t[1]), P(d), 1 << 18, P(d), 1 << 10, ST()))                     # workspace too small
     # MiDaS losses
     bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 1, 8, 1.0, P(t[0]), P(c), P(d), 1 << 18, ST()))          # one row: no y edges
     bad(L().io_smooth_loss_fwd(P(a), P(b), 2, 8, 8, 1.0, P(t[0]), P(c), P(d), 1, ST()))                # workspace
