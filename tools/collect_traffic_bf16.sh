@@ -8,7 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 # the forward / data-gradient launches of the bf16 step run four kernel families since round 5 (conv_p256.hip, conv_halo3.hip's
 # two kernels, and conv_nt_kernel for what is left); the filter gradients one
-FAMS=('conv_p256_kernel' 'conv_halo3_kernel' 'stem_halo_kernel' 'conv_nt_kernel<unsigned short, unsigned short' 'conv_wgrad_bf16_tr_kernel<128, 128')
+FAMS=('conv_p256_kernel' 'conv_halo3_kernel' 'stem_halo_kernel' 'conv_nt_kernel<unsigned short, unsigned short' 'conv_wgrad_bf16_tr_kernel<128, 128'
+      'conv_wgrad_halo3_kernel' 'stem_wgrad_halo_kernel')
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c
   rocprofv3 --pmc $c -d /tmp/pmcb_$c -o t --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /tmp/pmcb_$c.log 2>&1
