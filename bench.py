@@ -374,6 +374,8 @@ def main():
                 dist.all_reduce(ta, op=dist.ReduceOp.MAX)
                 overlap_ab = {"stage_buckets_under_backward_ms_per_step": 1e3 * dt / args.steps,
                               "flat_after_backward_ms_per_step": 1e3 * float(ta.item()) / args.steps, "steps": args.steps}
+            except Exception as ex:          # noqa: BLE001 -- a secondary measurement must not cost the line its `value`
+                overlap_ab = {"failed": repr(ex)[:300]}
             finally:
                 model._overlap_comm = True
         else:
