@@ -1,8 +1,14 @@
-"""The persistent 256-row LDS-DMA bf16 kernel (csrc/conv_p256.hip) behind the storage-typed C entry points, against fp64
-torch on the same bf16-rounded inputs AND against the 128-row kernel it replaces (io_set_bf16_p256): forward convolutions
-(resnet_cls.py:23-31: 1x1 / 3x3, stride 1 / 2) plain, with the statistics epilogue and with the folded-BatchNorm inference
-epilogue; data gradients with the fused BatchNorm-backward epilogue (residual gradient, ReLU mask read and recomputed).
-Bar: bf16 output rounding (2^-8 relative per element) on top of fp32 accumulation -- 1e-2 of the output scale."""
+"""The persistent LDS-DMA bf16 kernels of round 5 behind the storage-typed C entry points, each against fp64 torch on the same
+bf16-rounded inputs AND against the kernel it replaces (io_set_bf16_p256: 3 = the new kernels for every eligible shape, 0 = none),
+with the route asserted (io_debug_last_nt_route / io_debug_last_wgrad_route):
+  csrc/conv_p256.hip   forward convolutions (resnet_cls.py:23-31: 1x1 / 3x3, stride 1 / 2) plain, with the statistics epilogue and
+                       with the folded-BatchNorm inference epilogue; data gradients with the fused BatchNorm-backward epilogue
+                       (residual gradient, ReLU mask read -- as a tensor or as bits -- and recomputed);
+  csrc/conv_halo3.hip  conv_halo3_kernel (3x3 stride 1 -> 64 channels from a halo image, filters in registers), stem_halo_kernel (the
+                       7x7 / 2 stem), conv_wgrad_halo3_kernel (3x3 filter gradients, 64 .. 256 channels), stem_wgrad_halo_kernel
+                       (the stem's filter gradient, plain and with bn1's backward folded in).
+Bar: bf16 output rounding (2^-8 relative per element) on top of fp32 accumulation -- 1e-2 of the output scale; filter gradients
+(fp32 outputs of exact bf16 products) 2e-5."""
 import ctypes as C
 
 import pytest
