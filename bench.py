@@ -58,9 +58,14 @@ def cpu_model():
 CPU_BASELINE_MAX_THREADS = 32
 
 
+CPU_BASELINE_BUDGET_S = 28.0       # bounded sample: about 10-30 s of CPU work per default bench run
+
+
 def cpu_baseline(sd, S):
-    """The CPU oracle (plain-PyTorch restatement of the reference step, pinned by tests/golden) timed on
-    the host: a bounded sample of the same workload -- InstaOrderNet_o fwd+bwd+SGD on 256x256 pairs."""
+    """The CPU oracle (plain-PyTorch restatement of the reference step, pinned by tests/golden) timed on the host as
+    SURVEY.md 8(d) prescribes: InstaOrderNet_o fwd+bwd+SGD on 256x256 pairs at B = 12 (BASELINE configs[0]: 4 images x 3
+    pairs) and B = 32 (the reference's per-GPU batch, InstaOrderNet_o/config.yaml:49), median of 5 steps after 2 warm-ups
+    each -- shortened (and said so in `sample`) only where a slow host would push the sample past its time budget."""
     import torch
     from instaorder_amd import synthetic
     from oracle import resnet_oracle as orc                       # CPU baseline leg only
@@ -68,23 +73,43 @@ def cpu_baseline(sd, S):
     torch.set_num_threads(cores)
     state = orc.state_from_numpy(sd, prefix="module.")
     mom = {}
-    # calibrate on a 16x cheaper problem so the sample below stays within ~10-30 s of CPU work
-    t0 = time.perf_counter()
-    orc.train_step(state, mom, synthetic.make_pair_batch(1999, 4, S // 2), "InstaOrderNet_o", 1e-3, 1e-4)
-    probe = time.perf_counter() - t0
-    cb = 12 if probe * 12 < 10.0 else 4                            # 12 pairs = config 1 (4 images x 3 pairs)
-    nrep = 2 if probe * 4 * cb / 4 < 8.0 else 1
-    cbatch = synthetic.make_pair_batch(2000, cb, S)
-    orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)          # warm-up
-    c0 = time.perf_counter()
-    for _ in range(nrep):
-        orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)
-    cdt = (time.perf_counter() - c0) / nrep
-    return {"value": cb / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model(), "usable_cores": usable_cores(),
-            "sample": "%d pairs at %dx%d, InstaOrderNet_o fwd+bwd+SGD, PyTorch-CPU fp32 oracle on %s, %d threads of %d "
-                      "usable cores (capped at %d: a 12-pair step does not scale further on oneDNN), mean of %d step(s) "
-                      "after 1 warm-up" % (cb, S, S, cpu_model(), cores, usable_cores(), CPU_BASELINE_MAX_THREADS, nrep)}
+    # calibrate on a 16x cheaper problem (4 pairs at half the side): seconds per full-size pair, pessimistic
+    cal = synthetic.make_pair_batch(1999, 4, S // 2)
+    for _ in range(2):                                             # (the first call pays oneDNN's primitive set-up)
+        t0 = time.perf_counter()
+        orc.train_step(state, mom, cal, "InstaOrderNet_o", 1e-3, 1e-4)
+        t_pair = time.perf_counter() - t0
+    left = CPU_BASELINE_BUDGET_S
+
+    def leg(cb, seed):
+        nonlocal left
+        plans = [(2, 5), (1, 3), (1, 1)]
+        warm, reps = next(((w, r) for w, r in plans if (w + r) * cb * t_pair <= left), (0, 0))
+        if reps == 0:
+            return None
+        cbatch = synthetic.make_pair_batch(seed, cb, S)
+        ts = []
+        for i in range(warm + reps):
+            c0 = time.perf_counter()
+            orc.train_step(state, mom, cbatch, "InstaOrderNet_o", 1e-3, 1e-4)
+            ts.append(time.perf_counter() - c0)
+        left -= sum(ts)
+        ts = sorted(ts[warm:])
+        med = 0.5 * (ts[(len(ts) - 1) // 2] + ts[len(ts) // 2])
+        return {"pairs": cb, "pairs_per_s": cb / med, "s_per_step_median": med, "steps": reps, "warmup": warm}
+
+    small = 12 if 2 * 12 * t_pair <= left else 4               # a host too slow for two 12-pair steps: 4 pairs
+    l12 = leg(small, 2000)
+    l32 = leg(32, 2001)
+    what = lambda l: "%d pairs: median of %d step(s) after %d warm-up(s)" % (l["pairs"], l["steps"], l["warmup"])   # noqa: E731
+    return {"value": l12["pairs_per_s"], "unit": "pairs/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "usable_cores": usable_cores(), "b12": l12, "b32": l32,
+            "sample": "InstaOrderNet_o fwd+bwd+SGD at %dx%d, PyTorch-CPU fp32 oracle on %s, %d threads of %d usable cores "
+                      "(capped at %d: a 12-pair step does not scale further on oneDNN); `value` = %s; b32 = %s "
+                      "(SURVEY.md 8(d): median of 5 after 2 at B = 12 and B = 32; fewer steps only where the %.0f s budget "
+                      "of this sample would be exceeded)" % (
+                          S, S, cpu_model(), cores, usable_cores(), CPU_BASELINE_MAX_THREADS, what(l12),
+                          what(l32) if l32 else "skipped (over the time budget on this host)", CPU_BASELINE_BUDGET_S)}
 
 
 def cpu_baseline_depthnet(algo, S, cfg):
@@ -153,6 +178,8 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-overlap-ab", action="store_true", help="N > 1: skip the extra pass with the flat gradient exchange")
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward-only secondary measurement of the default line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (bf16 at 256 pairs, fp32 at 32 "
+                    "pairs) the default line measures after its timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the multi-rank path when several ranks must share one GPU)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak (default, the reference's "
@@ -184,7 +211,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     _lib.require_gpu()
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1:
+        # one process per GPU: RCCL cannot put two ranks on one device, and silently stacking them (local % ndev) would
+        # report a "scaling" number measured on fewer GPUs than the line says
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        assert ndev >= lws, ("bench.py --gpus %d: this node shows %d GPU(s) to rank %d (HIP_VISIBLE_DEVICES=%r); one process "
+                             "per GPU needs at least %d.  To exercise the multi-rank path on fewer GPUs use --backend gloo."
+                             % (args.gpus, ndev, rank, os.environ.get("HIP_VISIBLE_DEVICES"), lws))
+    torch.cuda.set_device(local % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -472,6 +507,63 @@ def main():
                                           "one GPU, measured after the timed region"}
         except Exception as ex:          # noqa: BLE001 -- a secondary measurement must not cost the line its `value`
             result["fwd_only"] = {"failed": repr(ex)[:300]}
+    # Secondary workloads on the driver's own command (after the timed region; each leg in its own try: it cannot cost the
+    # line its `value`): the bf16 step of BASELINE configs[2] at this batch, and the reference's own per-GPU batch of 32 pairs
+    # (experiments/InstaOrder/InstaOrderNet_o/config.yaml:49) in fp32 -- replayed steps of the product path, as the headline.
+    headline = (args.algo == "InstaOrderNet_o" and B == 256 and S == 256 and args.mode == "train" and args.dtype == "fp32"
+                and world == 1 and not args.host_inputs and pair_src is None)
+    if headline and not args.no_secondary:
+        def secondary_leg(dtype, b2, nsteps=5):
+            cfg2 = dict(cfg, dtype=dtype)
+            m2 = ia.InstaOrderNet_o(cfg2, dist_model=False)
+            m2.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            m2.switch_to("train")
+            d2 = {k: v[:b2].contiguous() for k, v in dev.items()}
+
+            def st():
+                m2.set_input(d2["rgb"], d2["modal1"], d2["modal2"], d2["occ_order"])
+                return m2.step()
+            for _ in range(3):                       # eager, capture, first replay
+                st()
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(nsteps):
+                o2 = st()
+            torch.cuda.synchronize()
+            sdt = (time.perf_counter() - s0) / nsteps
+            leg = {"pairs_per_s": b2 / sdt, "ms_per_step": 1e3 * sdt, "steps": nsteps, "pairs_per_gpu": b2, "dtype": dtype,
+                   "hip_graph": bool(getattr(m2, "_graph", None) is not None), "final_loss": float(o2["loss"]),
+                   "tflops": b2 / sdt * FLOP_PER_PAIR_TRAIN / 1e12}
+            # algorithmic HBM bytes of one step (what the launch classes account for, one profiled eager step) over the
+            # replayed step time, against the 8 TB/s peak
+            try:
+                m2._use_graph = False
+                st()
+                torch.cuda.synchronize()
+                engine.prof_begin(share_events=True)
+                st()
+                torch.cuda.synchronize()
+                pr = engine.prof_end()
+                by = sum(v["bytes"] for v in pr.values())
+                leg["algorithmic_gb_per_step"] = by / 1e9
+                leg["hbm_frac"] = by / sdt / 1e9 / PEAK_HBM_GBS
+            except Exception as ex:      # noqa: BLE001
+                leg["hbm_frac"] = None
+                leg["hbm_note"] = repr(ex)[:200]
+            del m2
+            torch.cuda.empty_cache()
+            return leg
+        result["secondary"] = {}
+        for tag, dtype2, b2 in (("bf16_b256", "bf16", 256), ("fp32_b32", "fp32", 32)):
+            try:
+                result["secondary"][tag] = secondary_leg(dtype2, b2)
+            except Exception as ex:      # noqa: BLE001
+                result["secondary"][tag] = {"failed": repr(ex)[:300]}
+        if "pairs_per_s" in result["secondary"].get("fp32_b32", {}):
+            result["secondary"]["fp32_b32"]["rate_vs_256_pairs"] = result["secondary"]["fp32_b32"]["pairs_per_s"] / pairs_per_s
+        result["secondary"]["what"] = ("measured after the timed region on the same GPU: InstaOrderNet_o fwd+bwd+SGD, hipGraph "
+                                       "replay; bf16_b256 = the bf16 mode (BASELINE configs[2] arithmetic) at 256 pairs; fp32_b32 = "
+                                       "the reference's own per-GPU batch; hbm_frac = algorithmic bytes of the step / step time / 8 TB/s")
     if prof:
         result["profiled"] = {"steps": prof_steps, "ms_per_step": 1e3 * prof_dt / prof_steps, "hip_graph": False,
                               "note": "eager launches + one HIP event per launch group; never the source of `value`"}

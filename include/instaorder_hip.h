@@ -439,6 +439,23 @@ int io_conv2d_fwd_resid(const float* y3, const float* identity, const float* w, 
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                         float eps, float* mean, float* rstd, float* scale, float* shift, float* workspace,
                         size_t workspace_floats, hipStream_t stream);
+/* The same fusion for either storage type, with the second table form and the one-bit mask (round 6): operand =
+ *   two == 0:  relu((y3 - tb[g][c]) * ta[g][c] + tc[g][c] + second)   ta / tb / tc = scale / mean / shift of bn3, second = identity
+ *   two != 0:  relu(ta[g][c] * y3 + tb[g][c] * second + tc[g][c])     a block with a downsample branch: second = the downsample
+ *              convolution's raw output, the two BatchNorms folded into one table set (io_bn_resid2_tables)
+ * written to `out` (optional) and, as [out > 0] one bit per element (word (m * Cin + c) / 32, bit c % 32; optional, bf16
+ * 256-row kernel only), to out_bits.  tile_mean / tile_m2 (a pair, optional): per-(128-row tile, channel) mean / M2 of y,
+ * io_bn_tile_partial_floats(M, Cout, G) floats each, for io_bn_finalize_tiles.  bf16: launches of whole 256-row tiles with
+ * 64 | Cin, 128 | Cout and 256 | rows per group run on conv_p256_kernel, the transform applied IN LDS to each A k-tile
+ * after its DMA has landed (IO_P256_XOP=0 / io_set_bf16_p256_xop(0): on conv_nt_kernel's staging registers instead). */
+int io_conv2d_fwd_resid_dt(const void* y3, const void* second, const void* w, void* y, void* out, uint32_t* out_bits, int N,
+                           int H, int W, int Cin, int Cout, int G, int two, const float* ta, const float* tb, const float* tc,
+                           float* tile_mean, float* tile_m2, int dtype, hipStream_t stream);
+/* Run-time switch of the in-LDS operand forms of the bf16 256-row kernel (process-wide; initial value from IO_P256_XOP,
+ * unset = 1): with 0 the network executor keeps the stand-alone BatchNorm passes on layers 2-4 (the round-5 step) and a
+ * launch that asks for an operand form runs on conv_nt_kernel.  Returns the previous value. */
+int io_set_bf16_p256_xop(int on);
+int io_get_bf16_p256_xop(void);
 /* All filters of a module tree in one launch (the op-by-op graphs of instaorder_amd.ops; midas/midas_net.py's ~200 dense
  * convolutions): `table` is a DEVICE array of n io_weight_desc.  io_weights_prepare writes, for every entry, the
  * [Cop][T][Cip] operand (element type dtype, zero where o >= Co or c >= Ci) of the OIHW fp32 master at params + src to

@@ -64,6 +64,9 @@ SIGNATURES = {
     "io_get_winograd": (_I, []),
     "io_set_bf16_p256": (_I, [_I]),
     "io_get_bf16_p256": (_I, []),
+    "io_set_bf16_p256_xop": (_I, [_I]),
+    "io_get_bf16_p256_xop": (_I, []),
+    "io_conv2d_fwd_resid_dt": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "io_debug_last_nt_route": (_I, []),
     "io_conv2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "io_conv2d_bnstats_workspace_floats": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),

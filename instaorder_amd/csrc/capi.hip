@@ -714,6 +714,24 @@ extern "C" int io_conv2d_fwd_resid(const float* y3, const float* identity, const
                                 rstd, scale, shift, st);
 }
 
+/* io_conv2d_fwd_resid for either storage type, with both table forms and the one-bit mask of `out` (header) */
+extern "C" int io_conv2d_fwd_resid_dt(const void* y3, const void* second, const void* w, void* y, void* out, uint32_t* out_bits,
+                                      int N, int H, int W, int Cin, int Cout, int G, int two, const float* ta, const float* tb,
+                                      const float* tc, float* tile_mean, float* tile_m2, int dtype, hipStream_t st) {
+    IO_REQUIRE(dtype == IO_F32 || dtype == IO_BF16, IO_ERR_SHAPE, "conv2d_fwd_resid_dt: unknown dtype %d", dtype);
+    IO_REQUIRE(ta && tb && tc && second, IO_ERR_SHAPE, "conv2d_fwd_resid_dt: tables and the second operand are required");
+    IO_REQUIRE((tile_mean == nullptr) == (tile_m2 == nullptr), IO_ERR_SHAPE, "conv2d_fwd_resid_dt: statistics outputs come in pairs");
+    IoConvGeom g = io_geom_fwd(N, H, W, Cin, Cout, 1, 1, 1, 0);
+    const int M = N * H * W;
+    IO_REQUIRE(G >= 1 && N % G == 0 && (M / G) % kIoStatTileRows == 0, IO_ERR_SHAPE,
+               "conv2d_fwd_resid_dt: rows per BN group (%d) must be a multiple of %d", G ? M / G : 0, kIoStatTileRows);
+    IoBwStats ep{};
+    ep.xb_y = second; ep.xb_a = ta; ep.xb_b = tb; ep.xb_c = tc; ep.xb_out = out; ep.xb_Mg = M / G;
+    ep.xb_res = two ? 2 : 1;
+    ep.xb_bits = out_bits;
+    return io_launch_conv_nt(g, y3, w, y, nullptr, nullptr, 0, st, tile_mean, tile_m2, &ep, dtype, dtype);
+}
+
 /* convolution with an inference epilogue: y = [relu](conv(x, w) + bias[o] (+ add)) -- a BatchNorm in eval mode folded
  * into pre-scaled filters, or a biased nn.Conv2d; dense (gw = 0) or grouped-window (gw = 64) */
 extern "C" int io_conv2d_fwd_bias_dt(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int R,

@@ -81,6 +81,17 @@ struct P256Args {
     float *st_mean, *st_m2; // EPI_STATS: [M / 128][Co]
     IoBwStats bw;           // EPI_BWE: y, mean, rstd, mscale, mshift, p1, p2, Mg.  EPI_PLAIN: bias, relu
     int ntn, ntiles;
+    // XOP (operand transform in LDS, dense 1x1 only): the A operand is a function of `in` and a second tensor xy of the same
+    // shape, evaluated on the k-tile AFTER its DMA has landed and written back in place; the blocks of the first
+    // output-channel tile also write it out (xout; xbits: [value > 0] as one bit per element).  Tables [G][Ci].
+    //   xmode 1: a * in + (b * xy + c)               BatchNorm-backward apply (IoBwStats::xb_a, conv_igemm.hip XB = 1)
+    //   xmode 2: relu((in - b) * a + c + xy)         block output relu(bn3(y3) + identity)               (XB = 2)
+    //   xmode 3: relu(a * in + (b * xy + c))         block output with a downsample branch                (XB = 3)
+    const bf16_t* xy;
+    const float *xa, *xb, *xc;
+    bf16_t* xout;
+    uint8_t* xbits;
+    int xmode, xMg;
 };
 
 // Block = 512 threads = 8 waves as 2 (rows) x 4 (columns): a wave owns 128 rows (ONE BatchNorm statistics tile) x BN / 4
@@ -88,8 +99,9 @@ struct P256Args {
 // tile at r * 128, its 16-byte k-chunk c in slot c ^ ((r >> 1) & 7) (the 16 rows a ds_read_b128 lane group touches -- distinct
 // mod 16 -- land in 16 distinct bank quads).  A DMA instruction fills 8 rows: lane i fetches what belongs in slot i & 7 of row
 // i >> 3.  Wave w fetches A chunks 4w .. 4w+3 and B chunks (BN / 64) w .. of every k-tile.
-template <int BN, int EPI, bool GATHER>
+template <int BN, int EPI, bool GATHER, bool XOP = false>
 __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Args a) {
+    static_assert(!XOP || !GATHER, "the in-LDS operand transform is for dense 1x1 launches");
     constexpr int BM = 256, TM = 4, TN = BN / 128, NW = 8;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int CA = 4, CB = BN / 64;          // DMA chunks (8 rows) per wave and k-tile
@@ -183,12 +195,36 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
     const unsigned a_row = (unsigned)((wm * 128 + (lane & 31)) * 128);
     const unsigned b_row = (unsigned)(BM * 128 + (wn * TN * 32 + (lane & 31)) * 128);
 
+    // XOP: thread t owns the 16-byte chunk t & 7 (8 channels) of rows (t >> 3) + 64 u, u = 0..3, of every A k-tile -- the
+    // pattern of the DMA (8 lanes = one 128-byte row piece: coalesced for xy and the side output, conflict-free in LDS).
+    // xy and the three coefficient rows of the NEXT k-tile are fetched into registers behind the sweep of this one.
+    u32x4 xyv[XOP ? 4 : 1];
+    f32x4 xca[2], xcb[2], xcc[2];
+    const unsigned x_lds = (unsigned)(((tid >> 3) * 128) + (((tid & 7) ^ ((tid >> 4) & 7)) << 4));   // (+ 8192 u: same swizzle bits)
+    const unsigned x_goff = (unsigned)((tid >> 3) * g.Ci * 2 + (tid & 7) * 16);                     // (+ 64 u rows, + 128 kt)
+    auto xop_fetch = [&](int m0f, int ktf) {
+        if constexpr (XOP) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_at(a.xy, (size_t)m0f * (size_t)(g.Ci * 2), a.in_bytes);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                xyv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, x_goff + (unsigned)(u * 64 * g.Ci * 2), ktf * 128, 0);
+            const int co = (m0f / a.xMg) * g.Ci + ktf * 64 + (tid & 7) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xca[h] = *reinterpret_cast<const f32x4*>(a.xa + co + 4 * h);
+                xcb[h] = *reinterpret_cast<const f32x4*>(a.xb + co + 4 * h);
+                xcc[h] = *reinterpret_cast<const f32x4*>(a.xc + co + 4 * h);
+            }
+        }
+    };
+
     f32x16 acc[TM][TN];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     int kt = 0, q = 0;
     if (tile < a.ntiles) {
         setup_tile(tile);
         issue(0);
+        xop_fetch(cur_m0, 0);
     }
     while (tile < a.ntiles) {
         if (kt == 0) {
@@ -209,6 +245,51 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
             if (ntile < a.ntiles) setup_tile(ntile);
         }
         if (ntile < a.ntiles) issue((q + 1) & 1);
+        if constexpr (XOP) {
+            // ---- the operand transform of k-tile kt of tile (m0, n0), in place in stage q & 1
+            char* sa = smem + (q & 1) * STAGE + x_lds;
+            const bool side = n0 == 0;
+            const size_t sbase = (size_t)m0 * (size_t)(g.Ci * 2);
+            const __amdgpu_buffer_rsrc_t rs_side = rsrc_at(a.xout ? (const void*)a.xout : (const void*)a.in, sbase,
+                                                           (side && a.xout) ? a.in_bytes : sbase);
+            const __amdgpu_buffer_rsrc_t rs_xb = rsrc_at(a.xbits ? (const void*)a.xbits : (const void*)a.in, sbase / 16,
+                                                         (side && a.xbits) ? a.in_bytes / 16 : sbase / 16);
+            const int xmode = a.xmode;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(sa + u * 8192);
+                const u32x4 yv = xyv[u];
+                u32x4 o;
+                unsigned bits = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int h = d >> 1, e0 = (d & 1) * 2;
+                    const float lo = bf_lo(av[d]), hi = bf_hi(av[d]), yl = bf_lo(yv[d]), yh = bf_hi(yv[d]);
+                    float vl, vh;
+                    if (xmode == 2) {           // bn_apply_kernel's expression: the tensor a separate pass would have written
+                        vl = __builtin_fmaf(lo - xcb[h][e0], xca[h][e0], xcc[h][e0]) + yl;
+                        vh = __builtin_fmaf(hi - xcb[h][e0 + 1], xca[h][e0 + 1], xcc[h][e0 + 1]) + yh;
+                    } else {
+                        vl = __builtin_fmaf(lo, xca[h][e0], __builtin_fmaf(yl, xcb[h][e0], xcc[h][e0]));
+                        vh = __builtin_fmaf(hi, xca[h][e0 + 1], __builtin_fmaf(yh, xcb[h][e0 + 1], xcc[h][e0 + 1]));
+                    }
+                    if (xmode >= 2) {
+                        vl = vl > 0.f ? vl : 0.f;
+                        vh = vh > 0.f ? vh : 0.f;
+                    }
+                    o[d] = io_f2bf2(vl, vh);
+                    bits |= (vl > 0.f ? 1u : 0u) << (2 * d) | (vh > 0.f ? 1u : 0u) << (2 * d + 1);
+                }
+                *reinterpret_cast<u32x4*>(sa + u * 8192) = o;
+                const unsigned go = x_goff + (unsigned)(u * 64 * g.Ci * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_side, go, kt * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_xb, go >> 4, kt * 8, 0);
+            }
+            __syncthreads();                     // every wave's share is transformed before anybody multiplies
+            // next k-tile's second operand and coefficients (a tile's last k-tile: behind the epilogue, whose register
+            // budget they would otherwise share)
+            if (!last) xop_fetch(m0, kt + 1);
+        }
         const char* sb = smem + (q & 1) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -401,10 +482,27 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                 }
             }
         }
+        if constexpr (XOP) {
+            if (last && ntile < a.ntiles) xop_fetch(cur_m0, 0);
+        }
         tile = ntile;
         kt = last ? 0 : kt + 1;
         ++q;
     }
+}
+
+// CUs of the current device (cached per device ordinal: the persistent grids are sized by it)
+int p256_ncu() {
+    static std::atomic<int> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t p;
+        n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 std::atomic<int> g_p256{-1};          // -1: not read from the environment yet
@@ -418,7 +516,43 @@ int p256_enabled() {
     return on;
 }
 
+// One 512-thread block per CU walks the tiles: with few tiles, or a last round that leaves most CUs idle, the 128-row
+// kernel (four times the blocks, three per CU) fills the chip better -- measured on the MiDaS step at 16 pairs (24 x 24
+// and 12 x 12 maps: 9..144 row tiles), where taking every eligible launch cost 2.8 %.
+bool p256_rounds_ok(long tiles) {
+    const int ncu = p256_ncu();
+    const long rounds = (tiles + ncu - 1) / ncu;
+    return p256_enabled() == 3 || tiles * 10 >= rounds * ncu * 8;          // at least 80 % of the rounds' slots used
+}
+
+// IO_P256_XOP=0 / io_set_bf16_p256_xop(0): the operand forms stay on conv_nt_kernel / separate BatchNorm passes (A/B runs)
+std::atomic<int> g_xop{-1};
+int xop_enabled() {
+    int on = g_xop.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char* e = getenv("IO_P256_XOP");
+        on = (e && e[0] == '0') ? 0 : 1;
+        g_xop.store(on, std::memory_order_relaxed);
+    }
+    return on;
+}
+
 }  // namespace
+
+extern "C" int io_get_bf16_p256_xop(void) { return xop_enabled(); }
+extern "C" int io_set_bf16_p256_xop(int on) {
+    const int prev = xop_enabled();
+    g_xop.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+// Would io_launch_conv_p256 take a dense 1x1 launch [M x Ci] -> [M x Co] WITH an operand form (executor: is the BatchNorm
+// pass worth leaving to the consumer's operand load in bf16)?  Same tests as the launcher, shape part only.
+bool io_conv_p256_takes_xop(long M, int Ci, int Co, int Mg) {
+    if (!p256_enabled() || !xop_enabled()) return false;
+    if (M % 256 != 0 || Ci % 64 != 0 || Co % 128 != 0 || Mg <= 0 || Mg % 256 != 0 || M % Mg != 0) return false;
+    if (256.0 * Ci * 2.0 >= 4.0e9 || 256.0 * Co * 2.0 >= 4.0e9) return false;
+    return p256_rounds_ok(M / 256 * (Co / (Co % 256 == 0 ? 256 : 128)));
+}
 
 extern "C" int io_get_bf16_p256(void) { return p256_enabled(); }
 extern "C" int io_set_bf16_p256(int on) {
@@ -437,7 +571,13 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     const long M = (long)g.N * g.Ho * g.Wo;
     const bool dense_out = g.os == 1 && g.Ho == g.outH && g.Wo == g.outW;
     if (g.gw || g.cr || !dense_out || M % 256 != 0 || g.Ci % 64 != 0 || g.Co % 128 != 0 || g.Th * g.Tw < 1) return 1;
-    if (bw && (bw->in_scale || bw->xb_a || bw->a_out || bw->wino_u)) return 1;
+    if (bw && (bw->in_scale || bw->a_out || bw->wino_u)) return 1;
+    const bool lin = g.Th * g.Tw == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+    // the operand forms (IoBwStats::xb_a) as an in-LDS transform: dense 1x1 launches, groups of whole 256-row tiles
+    const bool xop = bw && bw->xb_a;
+    if (xop && (!lin || !xop_enabled() || !bw->xb_b || !bw->xb_c || !bw->xb_y || bw->xb_Mg <= 0 || bw->xb_Mg % 256 != 0 ||
+                M % bw->xb_Mg != 0 || add || mask || bw->maskbits || bw->bias))
+        return 1;
     if (st_mean && (add || mask || (bw && (bw->y || bw->bias)))) return 1;
     if (bw && bw->y && (bw->Mg % 256 != 0 || bw->bias)) return 1;
     if (bw && bw->y && bw->mscale && (add || mask || bw->maskbits)) return 1;         // (the executor never combines them)
@@ -445,7 +585,6 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     const double span = 256.0 / ((double)g.Ho * g.Wo) + 2.0;
     if (span * 2.0 * g.Hi * g.Wi * g.Ci >= 4.0e9 || 256.0 * g.Co * 2.0 >= 4.0e9) return 1;
     if (g.Hi >= 32768 || g.Wi >= 32768) return 1;
-    const bool lin = g.Th * g.Tw == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     // where the 256-wide tile pays (tools/bf16_dma_probe.hip): N >= 256; 128-wide tiles for N = 128 (mod 256)
     const int bn = g.Co % 256 == 0 ? 256 : 128;
     const int epi = st_mean ? EPI_STATS : ((bw && bw->y) ? (bw->mscale ? EPI_BWE : EPI_BWE_READ) : EPI_PLAIN);
@@ -462,38 +601,37 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     a.st_mean = st_mean;
     a.st_m2 = st_m2;
     if (bw) a.bw = *bw;
+    if (xop) {
+        a.xy = (const bf16_t*)bw->xb_y;
+        a.xa = bw->xb_a;
+        a.xb = bw->xb_b;
+        a.xc = bw->xb_c;
+        a.xout = (bf16_t*)bw->xb_out;
+        a.xbits = (uint8_t*)bw->xb_bits;
+        a.xmode = bw->xb_res == 2 ? 3 : (bw->xb_res ? 2 : 1);
+        a.xMg = bw->xb_Mg;
+    }
     a.ntn = g.Co / bn;
     const long tiles = (M / 256) * a.ntn;
     if (tiles >= (1L << 31)) return 1;
     a.ntiles = (int)tiles;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    // One 512-thread block per CU walks the tiles: with few tiles, or a last round that leaves most CUs idle, the 128-row
-    // kernel (four times the blocks, three per CU) fills the chip better -- measured on the MiDaS step at 16 pairs (24 x 24
-    // and 12 x 12 maps: 9..144 row tiles), where taking every eligible launch cost 2.8 %.
-    {
-        const long rounds = (tiles + ncu - 1) / ncu;
-        if (p256_enabled() != 3 && tiles * 10 < rounds * ncu * 8) return 1;          // less than 80 % of the rounds' slots used
-    }
+    const int ncu = p256_ncu();
+    if (!p256_rounds_ok(tiles)) return 1;
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const double kred = (double)g.Th * g.Tw * g.Ci;
     IoProfScope prof(bn == 256 ? IO_PROF_CONV_NT128 : IO_PROF_CONV_NT64, 2.0 * (double)M * g.Co * kred,
                      2.0 * M * g.Co * (1.0 + (add ? 1.0 : 0.0) + (mask ? 1.0 : 0.0) + ((bw && bw->y) ? 1.0 : 0.0)) +
-                         2.0 * ((double)g.N * g.Hi * g.Wi * g.Ci + (double)g.Co * kred),
+                         2.0 * ((double)g.N * g.Hi * g.Wi * g.Ci * (1.0 + (xop ? 1.0 + (bw->xb_out ? 1.0 : 0.0) : 0.0)) +
+                                (double)g.Co * kred),
                      st);
-#define IO_P256_LAUNCH(BN_, EPI_, G_)                                                                               \
+#define IO_P256_LAUNCH(BN_, EPI_, ...)                                                                              \
     do {                                                                                                            \
         const size_t lds = (size_t)2 * (256 + BN_) * 128;                                                           \
         static std::atomic<unsigned long long> attr_done{0};                                                        \
         if (io_first_on_device(attr_done))                                                                          \
-            (void)hipFuncSetAttribute((const void*)conv_p256_kernel<BN_, EPI_, G_>,                                 \
+            (void)hipFuncSetAttribute((const void*)conv_p256_kernel<BN_, EPI_, __VA_ARGS__>,                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-        hipLaunchKernelGGL((conv_p256_kernel<BN_, EPI_, G_>), dim3((unsigned)grid), dim3(512), lds, st, g, a);      \
+        hipLaunchKernelGGL((conv_p256_kernel<BN_, EPI_, __VA_ARGS__>), dim3((unsigned)grid), dim3(512), lds, st, g, a); \
     } while (0)
 #define IO_P256_EPI(BN_, G_)                                         \
     do {                                                             \
@@ -502,13 +640,24 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
         else if (epi == EPI_BWE_READ) IO_P256_LAUNCH(BN_, EPI_BWE_READ, G_); \
         else IO_P256_LAUNCH(BN_, EPI_PLAIN, G_);                     \
     } while (0)
-    if (bn == 256) {
+#define IO_P256_XOP(BN_)                                                      \
+    do {                                                                      \
+        if (epi == EPI_STATS) IO_P256_LAUNCH(BN_, EPI_STATS, false, true);    \
+        else if (epi == EPI_BWE) IO_P256_LAUNCH(BN_, EPI_BWE, false, true);   \
+        else IO_P256_LAUNCH(BN_, EPI_PLAIN, false, true);                     \
+    } while (0)
+    if (xop && epi == EPI_BWE_READ) return 1;           // (not instantiated: the executor has no such launch)
+    if (xop) {
+        if (bn == 256) IO_P256_XOP(256);
+        else IO_P256_XOP(128);
+    } else if (bn == 256) {
         if (lin) IO_P256_EPI(256, false);
         else IO_P256_EPI(256, true);
     } else {
         if (lin) IO_P256_EPI(128, false);
         else IO_P256_EPI(128, true);
     }
+#undef IO_P256_XOP
 #undef IO_P256_EPI
 #undef IO_P256_LAUNCH
     return io_check_launch("conv_p256");

@@ -156,6 +156,9 @@ struct IoBwStats {
     // xb_res == 2: the block has a downsample branch -- operand = relu(xb_a * y3 + xb_b * yd + xb_c) with xb_y = yd (the
     // downsample convolution's output) and the two BatchNorms folded into one table set (io_bn_resid2_tables).
     int xb_res;
+    // xb_res != 0 on the 256-row bf16 kernel (conv_p256.hip): [operand > 0] of the tensor written to xb_out as one bit per
+    // element (the layout of maskbits below), for the data gradient that later masks by this block output.  Optional.
+    uint32_t* xb_bits;
     // Independent again: scratch for the Winograd form of 3x3 stride-1 same-size launches (fp32, Wo even, whole 128-row
     // tiles, no add / mask): 18 * Co * Ci floats that the launcher fills with the transformed filters ([filter row][4 | 6][Co][Ci],
     // wino_filter_kernel) before it starts conv_nt_kernel<..., WINO>.  Null: the direct form.  (A caller-owned buffer
@@ -176,6 +179,8 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
                       const void* mask, int stem, hipStream_t st, float* st_mean = nullptr,
                       float* st_m2 = nullptr, const IoBwStats* bw = nullptr, int dt_in = IO_F32,
                       int dt_out = IO_F32);
+// conv_p256.hip: would the 256-row bf16 kernel take a dense 1x1 launch [M x Ci] -> [M x Co] with an operand form (xb_a)?
+bool io_conv_p256_takes_xop(long M, int Ci, int Co, int Mg);
 // conv_p256.hip: IO_OK = launched, 1 = not this kernel's shape / form (fall through), < 0 = error
 int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, void* out, const void* add, const void* mask,
                         hipStream_t st, float* st_mean, float* st_m2, const IoBwStats* bw, size_t in_bytes,

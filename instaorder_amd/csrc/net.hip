@@ -188,7 +188,7 @@ Plan make_plan(const io_net* net, int N, int S, bool training, int SW = 0) {
             bb.out = a.take((size_t)N * Ho * Ho * b.planes * 4 * e);
             // bf16: the ReLU mask of the block output as one bit per element, for the data gradient that completes d(out) on
             // the 256-row kernel (conv_p256.hip): 1/16 of the tensor it would otherwise read.  Written by the BatchNorm pass
-            // that builds the output; outputs built inside the next conv1 (xr_ok) have none.  fp32 never: measured round 5 --
+            // that builds the output; outputs built inside the next conv1 on conv_nt_kernel (xr_route 1) have none.  fp32 never: measured round 5 --
             // packing the bits in conv_nt_kernel's operand staging and reading them in its column-layout epilogue cost the
             // fp32 step 3 % (59.7 -> 64.6 ms in the 128-wide class) for 4 of 136 bytes per element saved.
             bb.bits = (net->dtype == IO_BF16 && Mo % 256 == 0) ? a.take((size_t)Mo * b.planes * 4 / 8) : kNoBuf;
@@ -326,7 +326,7 @@ bool stem_exact(const Ctx& c, const ConvL& L) { return L.cin_store == 8 && c.net
 // xr_id), evaluated while it is staged and written to xr_out (IoBwStats::xb_res)
 int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool stats = false, const BnL* xf = nullptr,
              int Mout = 0, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr,
-             bool xr_two = false) {
+             bool xr_two = false, uint32_t* xr_bits = nullptr) {
     IoConvGeom g = io_geom_fwd(c.N, H, H, L.cin_store, L.cout, L.k, L.k, L.stride, L.pad);
     const bool stem = L.cin_store == 8;      // the packed input x8 has the net's storage type too
     const void* w = c.wop(L.w_off);
@@ -355,6 +355,7 @@ int conv_fwd(const Ctx& c, const ConvL& L, const void* x, void* y, int H, bool s
         ep.xb_out = xr_out;
         ep.xb_Mg = Mout / c.G;       // (a 1x1 stride-1 convolution: operand rows = output rows)
         ep.xb_res = 1;
+        ep.xb_bits = xr_bits;
         if (xr_two) {                // previous block with a downsample branch: the folded tables wait in plan.coef
             const size_t gs = (size_t)c.G * xr->C;
             ep.xb_a = c.buf(c.plan.coef);
@@ -388,9 +389,9 @@ int bn_prepare(const Ctx& c, const BnL& b, const void* y, int M, bool from_tiles
 // 128-row tile never straddles two BN groups
 int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, int Hin, int Mout,
             const BnL* xf = nullptr, const BnL* xr = nullptr, const void* xr_id = nullptr, void* xr_out = nullptr,
-            bool xr_two = false) {
+            bool xr_two = false, uint32_t* xr_bits = nullptr) {
     const bool fuse = c.training && (Mout / c.G) % kIoStatTileRows == 0;
-    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout, xr, xr_id, xr_out, xr_two));
+    IO_TRY(conv_fwd(c, L, x, y, Hin, fuse, xf, Mout, xr, xr_id, xr_out, xr_two, xr_bits));
     return bn_prepare(c, b, y, Mout, fuse);
 }
 
@@ -409,11 +410,24 @@ int conv_bn(const Ctx& c, const ConvL& L, const BnL& b, const void* x, void* y, 
 #ifndef IO_XB_BF16_L1
 #define IO_XB_BF16_L1 1   // bf16: the operand forms on the layer-1 (64-plane) blocks only
 #endif
-// bf16: only for the 64-plane blocks of layer 1 -- the form is VALU-bound next to bf16 MFMAs, but those launches are so
-// HBM-bound that dropping the pass still wins (as for the backward form, run_backward)
-bool xr_ok(const Ctx& c, int Mout, int planes) {
-    const bool dt_ok = c.net->dtype == IO_F32 || (IO_XB_BF16_L1 && planes <= IO_XB_BF16_MAXP);
-    return c.training && dt_ok && Mout % c.G == 0 && (Mout / c.G) % kIoStatTileRows == 0;
+// Who builds the output of block i -- out = relu(bn3(y3) + identity)?  0: a BatchNorm pass of its own (bn_act); 1: the NEXT
+// block's conv1 on conv_nt_kernel's staging registers (fp32; bf16 only on the 64-plane blocks of layer 1 -- the form is VALU-bound
+// next to bf16 MFMAs, but those launches are so HBM-bound that dropping the pass still wins, as for the backward form, run_backward);
+// 2 (bf16, round 6): the next block's conv1 on the 256-row kernel, the transform applied IN LDS to every A k-tile after its DMA
+// has landed (conv_p256.hip XOP) -- that launch also writes the one-bit mask of the output.
+int out_rows(const Ctx& c, size_t i) {
+    int H = c.S / 4;
+    for (size_t k = 0; k <= i; ++k) H /= c.net->blocks[k].stride;
+    return c.N * H * H;
+}
+int xr_route(const Ctx& c, size_t i) {
+    if (!c.training || i + 1 >= c.net->blocks.size()) return 0;
+    const Block& b = c.net->blocks[i];
+    const int Mout = out_rows(c, i);
+    if (Mout % c.G != 0 || (Mout / c.G) % kIoStatTileRows != 0) return 0;
+    if (c.net->dtype == IO_F32) return 1;
+    if (IO_XB_BF16_L1 && b.planes <= IO_XB_BF16_MAXP) return 1;
+    return io_conv_p256_takes_xop(Mout, b.planes * 4, c.net->blocks[i + 1].planes, Mout / c.G) ? 2 : 0;
 }
 
 // the one-bit ReLU mask of block i's output (training plans; nullptr where the plan has none)
@@ -422,14 +436,9 @@ uint32_t* bits_of(const Ctx& c, size_t i) {
     return (c.training && off != kNoBuf) ? reinterpret_cast<uint32_t*>(c.ws + off) : nullptr;
 }
 
-// ... and whether the forward wrote it: block outputs built by the next block's conv1 (xr_ok) have no BatchNorm pass to do it
+// ... and whether the forward wrote it: block outputs built by the next block's conv1 on conv_nt_kernel have no launch that does
 bool bits_written(const Ctx& c, size_t i) {
-    const Block& b = c.net->blocks[i];
-    if (c.plan.blk[i].bits == kNoBuf) return false;
-    int H = c.S / 4;
-    for (size_t k = 0; k <= i; ++k) H /= c.net->blocks[k].stride;
-    const int Mout = c.N * H * H;
-    return !(i + 1 < c.net->blocks.size() && xr_ok(c, Mout, b.planes));
+    return c.plan.blk[i].bits != kNoBuf && xr_route(c, i) != 1;
 }
 
 bool fuse_in(const Ctx& c, int Mout) {
@@ -543,7 +552,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
     }
     const void* x = c.act(p.p0);
     int H = H1;
-    // a block output whose construction was left to the next block's conv1 (xr_ok): bn3, y3, identity of that block
+    // a block output whose construction was left to the next block's conv1 (xr_route): bn3, y3, identity of that block
     const BnL* pend_bn = nullptr;
     const void *pend_y3 = nullptr, *pend_id = nullptr;
     bool pend_two = false;        // ... of a block with a downsample branch: identity = bnd(yd), tables folded into plan.coef
@@ -556,7 +565,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
             // x = the previous block's output does not exist yet: conv1 evaluates it from (y3, identity) on its operand
             // and writes it out (first output-channel tile); everything below that reads x comes after this launch
             IO_TRY(conv_bn(c, b.c1, b.b1, pend_y3, c.act(bb.y1), H, Min, nullptr, pend_bn, pend_id,
-                           c.act(p.blk[i - 1].out), pend_two));
+                           c.act(p.blk[i - 1].out), pend_two, xr_route(c, i - 1) == 2 ? bits_of(c, i - 1) : nullptr));
             pend_bn = nullptr;
         } else {
             IO_TRY(conv_bn(c, b.c1, b.b1, x, c.act(bb.y1), H, Min));
@@ -581,7 +590,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
         }
         if (b.down) {
             IO_TRY(conv_bn(c, b.cd, b.bd, x, c.act(bb.yd), H, Mout));
-            if (i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
+            if (xr_route(c, i)) {
                 // relu(bn3(y3) + bnd(yd)) = relu(a * y3 + b * yd + c): one table set, then as below
                 Tables t3 = c.tables(b.b3), td = c.tables(b.bd);
                 IO_TRY(io_bn_resid2_tables(t3.mean, t3.scale, t3.shift, td.mean, td.scale, td.shift, c.G, b.b3.C,
@@ -593,7 +602,7 @@ int run_forward(Ctx& c, const void* x8, float* logits) {
             } else {
                 IO_TRY(bn_act(c, b.b3, c.act(bb.y3), Mout, c.act(bb.yd), &b.bd, 1, c.act(bb.out), bits_of(c, i)));
             }
-        } else if (i + 1 < net->blocks.size() && xr_ok(c, Mout, b.planes)) {
+        } else if (xr_route(c, i)) {
             pend_bn = &b.b3;                 // built by the next block's conv1
             pend_y3 = c.act(bb.y3);
             pend_id = x;
@@ -814,7 +823,11 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // times (once per tap), pays +0.21..0.61 ms and saves 0.04..0.32: bn2 keeps its apply pass.
         // (bf16: the transform is VALU-bound next to bf16 MFMAs and loses everywhere except on layer 1's 256 -> 64 data
         // gradient, which is so HBM-bound that the saved pass still wins: -0.33 ms per launch, r03_xb_microbench_bf16.txt)
-        const bool x3 = xb_ok(c, Mout) ||                        // bn3 -> conv3's data gradient
+        // (bf16, round 6: on layers 2-4 the same form runs on the 256-row kernel as an in-LDS transform of the A k-tiles
+        // (conv_p256.hip XOP) wherever that kernel takes the launch -- conv3's data gradient only: x3p)
+        const bool x3p = c.net->dtype == IO_BF16 && b.planes > IO_XB_BF16_MAXP && tiles_ok(c, Mout) &&
+                         io_conv_p256_takes_xop(Mout, b.planes * 4, b.planes, Mout / c.G);
+        const bool x3 = xb_ok(c, Mout) || x3p ||                 // bn3 -> conv3's data gradient
                         (IO_XB_BF16_L1 && c.net->dtype == IO_BF16 && b.planes <= IO_XB_BF16_MAXP && tiles_ok(c, Mout));
         const bool f3 = fuse_in(c, Mout), f2 = f3 && b.stride == 1;
         // bn1 -> conv1's; needs bn1's tile partials from the epilogue of conv2's dense data gradient
@@ -856,7 +869,7 @@ int run_backward(Ctx& c, const float* dlogits, const void* x8, int stage_lo = 0,
         // does not reach are written as zeros -- so that conv1's dense stride-1 data gradient is again the launch
         // that completes d(x_in) and can carry the previous block's bn3 reductions there too.
         const void* partial = Gd;          // what conv1's data gradient accumulates onto: the identity path ...
-        if (b.down && x3) {
+        if (b.down && x3 && !x3p) {
             // the downsample BatchNorm the same way: reductions over (dz, yd) -> tables, dy evaluated on the operand of the
             // (strided) 1x1 data gradient -- only the lattice class that has a tap stages anything -- and written to Gc for
             // the filter gradient.  (Gc: dy2 has been consumed by conv2's data and filter gradients; Ga may hold dz1.)

@@ -216,12 +216,38 @@ class _Scratch(nn.Module):
     pass
 
 
+def _device_identity():
+    """What names the physical GPU this rank computes on: host + device UUID (PCI address where the build has no UUID).
+    Index-free on purpose: with HIP_VISIBLE_DEVICES isolation every rank calls its GPU "device 0"."""
+    import socket
+    host = socket.gethostname()
+    if not torch.cuda.is_available():
+        return (host, "cpu")
+    prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+    uid = getattr(prop, "uuid", None)
+    if uid is None:
+        uid = tuple(getattr(prop, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if all(v is None for v in uid):
+            uid = ("index", torch.cuda.current_device(), os.environ.get("HIP_VISIBLE_DEVICES"))
+    return (host, str(uid))
+
+
 def _ranks_share_a_device():
+    """Do two ranks of the process group compute on the SAME physical GPU?  Decided from what the ranks themselves report
+    (one all-gather of (hostname, device identity)), not from world_size vs device_count(): that comparison is also true for a
+    multi-node job (16 ranks, 8 GPUs per node) and for launchers that isolate one GPU per process with HIP_VISIBLE_DEVICES
+    (device_count() == 1) -- exactly the one-process-per-GPU deployment the side streams are for.  COLLECTIVE: every rank
+    must call it at the same point (it is called from the first forward of the data-parallel step)."""
     import torch.distributed as dist
     try:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > max(1, torch.cuda.device_count())
-    except Exception:
-        return False
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return False
+        mine = _device_identity()
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        return sum(1 for e in everyone if tuple(e) == tuple(mine)) > 1
+    except Exception:          # noqa: BLE001 -- an undecidable topology keeps the safe single-stream form
+        return True
 
 
 class _InstaDepthBase(nn.Module):
@@ -235,12 +261,15 @@ class _InstaDepthBase(nn.Module):
         for i in (4, 3, 2, 1):
             setattr(self.scratch, "refinenet%d" % i, FeatureFusionBlock(features))
         self.non_negative = non_negative
-        # IO_DEPTH_STREAMS=0: everything on one stream (read per model, so a test can build both forms in one process).
-        # The side streams are for a process that has its GPU to itself (the deployment: one process per GPU): when several
-        # ranks SHARE a device (more ranks than devices -- the two-rank gloo runs on a one-GPU box) the streams of the
-        # processes are time-sliced against each other and the staged step ran 0.27 .. 8.7 s per step instead of 0.27
-        # (profiles/r05_bench_config4_*_2ranks_gloo_one_gpu.json was taken with this rule).
-        self.multi_stream = os.environ.get("IO_DEPTH_STREAMS", "1") != "0" and not _ranks_share_a_device()
+        # Side streams (decoder || order branches, see _fork_join) are for a process that has its GPU to itself -- the
+        # deployment: one process per GPU.  When several ranks SHARE a device (the two-rank gloo runs on a one-GPU box) the
+        # streams of the processes are time-sliced against each other and the staged step ran 0.27 .. 8.7 s per step instead
+        # of 0.27 (profiles/r05_bench_config4_*_2ranks_gloo_one_gpu.json was taken with this rule).  IO_DEPTH_STREAMS: 0 =
+        # one stream, force = side streams whatever the ranks report, anything else = decide at the FIRST forward (the
+        # process group may be initialised after the model is built) from the ranks' device identities.  Read per model, so
+        # a test can build both forms in one process; assigning True / False to multi_stream overrides the rule.
+        mode = os.environ.get("IO_DEPTH_STREAMS", "1")
+        self._multi_stream = False if mode == "0" else (True if mode == "force" else None)      # None: not decided yet
         self.dtype = "fp32"       # 'bf16': activations / GEMM operands in bf16 (set by SingleStageModel from params['dtype'])
         self.scratch.output_conv = nn.Sequential(                              # midas_net.py:134-141
             Conv2d(features, 128, 3, 1, 1, bias=True),
@@ -252,6 +281,22 @@ class _InstaDepthBase(nn.Module):
         )
         if path:
             self.load(path)
+
+    @property
+    def multi_stream(self):
+        if self._multi_stream is None:
+            shared = _ranks_share_a_device()
+            self._multi_stream = not shared
+            if shared:
+                import logging
+                logging.getLogger("instaorder_amd").warning(
+                    "InstaDepthNet: several ranks compute on one device (%s) -- decoder and order branches stay on ONE "
+                    "stream (IO_DEPTH_STREAMS=force overrides)", _device_identity()[1])
+        return self._multi_stream
+
+    @multi_stream.setter
+    def multi_stream(self, on):
+        self._multi_stream = bool(on)
 
     def load(self, path):
         """midas/base_model.py:5-15."""
@@ -267,11 +312,15 @@ class _InstaDepthBase(nn.Module):
     def _act_dtype(self):
         return torch.bfloat16 if self.dtype == "bf16" else torch.float32
 
-    def _order_branch(self, net, fc, x8m, l1, l2, l3):
+    def _order_branch(self, net, fc, x8m, l1, l2, l3, side=False):
+        # l1..l3 feed both branches and the decoder.  ``side``: this branch runs on a side stream, so the shared operand's
+        # gradient must be its own copy (ops._AddShared: three encoder-feature-sized copies per backward); on ONE stream
+        # everything is ordered and the plain add (one gradient tensor handed to both inputs) is safe and cheaper.
+        add = ops.add_shared if side else ops.add
         f1 = net.run_layer1(x8m)
-        f2 = net.layer2(ops.add_shared(f1, l1))       # (l1..l3 feed both branches and the decoder: see ops._AddShared)
-        f3 = net.layer3(ops.add_shared(f2, l2))
-        f4 = net.layer4(ops.add_shared(f3, l3))
+        f2 = net.layer2(add(f1, l1))
+        f3 = net.layer3(add(f2, l2))
+        f4 = net.layer4(add(f3, l3))
         return ops.avgpool_fc(f4, fc.weight, fc.bias)
 
     def _encode(self, img):
@@ -417,7 +466,7 @@ class InstaDepthNet_od(_InstaDepthBase):
                 def branch(net, fc):
                     def run():
                         with _BnMode(groups=2):
-                            return self._order_branch(net, fc, x8m, l1, l2, l3)
+                            return self._order_branch(net, fc, x8m, l1, l2, l3, side=True)
                     return run
 
                 def decode():
@@ -462,7 +511,7 @@ class InstaDepthNet_d(_InstaDepthBase):
 
                 def branch():
                     with _BnMode(groups=2):
-                        return self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3)
+                        return self._order_branch(self.gdo_net, self.fc, x8m, l1, l2, l3, side=True)
 
                 def decode():
                     with _BnMode(repeat=2):

@@ -26,6 +26,20 @@ def _dev(t, dtype=None):
     return t.to(dtype) if dtype is not None and t.dtype != dtype else t
 
 
+
+def _force_overlap_requested():
+    """IO_COMM_OVERLAP=force: the staged data-parallel step on ONE rank.  It issues the backend's all-reduce between the
+    stage graphs, so it needs an initialised process group -- asked for without one, fail HERE with a clear message
+    instead of deep inside the first step, after the stage graphs have been enqueued."""
+    if os.environ.get("IO_COMM_OVERLAP", "1") != "force":
+        return False
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("IO_COMM_OVERLAP=force runs the staged gradient exchange (dist.all_reduce per backward stage): "
+                           "initialise a process group first (torch.distributed.init_process_group, world_size >= 1) or "
+                           "unset IO_COMM_OVERLAP")
+    return True
+
+
 class _OrderBase(SingleStageModel):
     """Shared mechanics of the four wrappers; subclasses define labels and loss configuration."""
 
@@ -55,7 +69,7 @@ class _OrderBase(SingleStageModel):
         self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
         # IO_COMM_OVERLAP=force: the staged path on ONE rank too (an initialised process group of size 1) -- the per-stage
         # hipGraphs with the backend's asynchronous all-reduce in between, exercised where a second GPU is not to be had
-        self._force_overlap = os.environ.get("IO_COMM_OVERLAP", "1") == "force"
+        self._force_overlap = _force_overlap_requested()
         self._buckets = None
         self._dp_graphs = None          # world_size > 1: one hipGraph per backward stage (the collectives sit between them)
         self._dp_key = None
@@ -385,7 +399,7 @@ class _DepthBase(SingleStageModel):
         # world_size > 1: the backward pass in four stages, the all-reduce of each stage's slice of the flat gradient
         # buffer launched as soon as the stage is enqueued (IO_COMM_OVERLAP=0: one flat all-reduce after the backward)
         self._overlap_comm = os.environ.get("IO_COMM_OVERLAP", "1") != "0"
-        self._force_overlap = os.environ.get("IO_COMM_OVERLAP", "1") == "force"     # (as in _OrderBase: one-rank staging)
+        self._force_overlap = _force_overlap_requested()                            # (as in _OrderBase: one-rank staging)
         self._stages = None
         self._buckets = None
         self._dp_graphs = None

@@ -1,0 +1,201 @@
+"""Round 6: the operand forms of the bf16 256-row kernel (csrc/conv_p256.hip, XOP) -- a BatchNorm pass evaluated IN LDS on every
+A k-tile of a dense 1x1 GEMM after its DMA has landed, instead of by a launch of its own:
+  forward   the output of a Bottleneck, out = relu(bn3(y3) + identity) (models/backbone/resnet_cls.py:108-114), built by the
+            next block's conv1 (:99) -- both table forms (plain identity / downsample branch folded in), the tensor and its one-bit
+            mask written as side outputs, the statistics epilogue behind it;
+  backward  bn3's input gradient dy = a dz + b y + c evaluated on the operand of conv3's data gradient (loss.backward(),
+            models/supervised_order.py:545), side output for the filter gradient, fused BatchNorm-backward epilogue of bn2 behind it.
+Each against fp64 torch on the same bf16-rounded inputs AND against the route it replaces (io_set_bf16_p256_xop(0): the same form on
+conv_nt_kernel's staging registers), with the route asserted; then the whole step with the forms on / off."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic
+from instaorder_amd import _lib
+from test_gpu_p256 import BF, DEV, P, ST, TOL, bf, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    lib = _lib.lib()
+    prev, prevx = lib.io_get_bf16_p256(), lib.io_get_bf16_p256_xop()
+    yield
+    lib.io_set_bf16_p256(prev)
+    lib.io_set_bf16_p256_xop(prevx)
+
+
+def _tables(C_, G, g):
+    mean = torch.randn(G, C_, generator=g) * 0.3
+    scale = torch.rand(G, C_, generator=g) + 0.5
+    shift = torch.randn(G, C_, generator=g) * 0.3
+    return mean, scale, shift
+
+
+# N, H, W, Cin (= 4 x planes of the block that ends), Cout (= planes of the next block's conv1), G
+RESID_CASES = [(4, 16, 16, 512, 128, 2), (8, 16, 16, 1024, 256, 2), (4, 8, 8, 2048, 512, 1), (2, 32, 32, 256, 128, 1),
+               (6, 16, 16, 512, 256, 2), (48, 4, 4, 1024, 256, 1)]
+
+
+@pytest.mark.parametrize("case", RESID_CASES)
+@pytest.mark.parametrize("two", [0, 1])
+def test_xop_forward_residual_output_built_by_next_conv1(case, two):
+    N, H, W, Cin, Cout, G = case
+    lib = _lib.lib()
+    M = N * H * W
+    if (M // G) % 256 != 0 or N % G != 0:
+        G = 1
+    assert M % 256 == 0
+    g = torch.Generator().manual_seed(11 + Cin + H + two)
+    y3, y3r = bf(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))
+    sec, secr = bf(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))
+    w, wr = bf(torch.randn(Cout, Cin, generator=g, dtype=torch.float64) / Cin ** 0.5)
+    mean, scale, shift = _tables(Cin, G, g)
+    # two == 0: a / b / c = scale / mean / shift of bn3; two == 1: the folded tables a (times y3), b (times the downsample output), c
+    ta, tb, tc = (scale, mean, shift) if two == 0 else (scale, _tables(Cin, G, g)[1], shift)
+    per = M // G
+    grp = (torch.arange(M) // per)
+    A, B_, Cc = (t.double()[grp] for t in (ta, tb, tc))          # [M, Cin]
+    y3f, secf = y3r.reshape(M, Cin), secr.reshape(M, Cin)
+    if two == 0:
+        out_ref = torch.relu((y3f - B_) * A + Cc + secf)
+    else:
+        out_ref = torch.relu(A * y3f + B_ * secf + Cc)
+    res = {}
+    for xop in (1, 0):
+        lib.io_set_bf16_p256(3)
+        lib.io_set_bf16_p256_xop(xop)
+        y = torch.full((N, H, W, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        out = torch.full((N, H, W, Cin), float("nan"), device=DEV, dtype=torch.bfloat16)
+        bits = torch.zeros(M * Cin // 32, device=DEV, dtype=torch.int32)
+        nt = lib.io_bn_tile_partial_floats(M, Cout, G)
+        tm, tm2 = torch.zeros(nt, device=DEV), torch.zeros(nt, device=DEV)
+        tabs = [t.float().contiguous().to(DEV) for t in (ta, tb, tc)]
+        _lib.check(lib.io_conv2d_fwd_resid_dt(P(y3), P(sec), P(w), P(y), P(out), P(bits), N, H, W, Cin, Cout, G, two, P(tabs[0]),
+                                              P(tabs[1]), P(tabs[2]), P(tm), P(tm2), BF, ST()), "fwd_resid_dt xop=%d" % xop)
+        torch.cuda.synchronize()
+        assert lib.io_debug_last_nt_route() == (1 if xop else 0), xop
+        assert relerr(out.reshape(M, Cin), out_ref) < TOL, xop
+        # the GEMM multiplies the ROUNDED operand: against fp64 on the tensor the launch wrote
+        y_ref = out.double().cpu().reshape(M, Cin) @ wr.t()
+        assert relerr(y.reshape(M, Cout), y_ref) < TOL, xop
+        # per-(128-row tile, channel) mean / M2 of the fp32 accumulators
+        yt = y_ref.reshape(M // 128, 128, Cout)
+        mref, m2ref = yt.mean(1), ((yt - yt.mean(1, keepdim=True)) ** 2).sum(1)
+        assert float((tm[:M // 128 * Cout].view(-1, Cout).double().cpu() - mref).abs().max()) < 2e-4 * float(y_ref.abs().max())
+        assert float((tm2[:M // 128 * Cout].view(-1, Cout).double().cpu() - m2ref).abs().max()) < 2e-3 * float(m2ref.abs().max())
+        if xop:
+            # the one-bit mask: bit c % 32 of word (m * Cin + c) / 32 = [out > 0], for every element
+            word = bits.cpu().numpy().view(np.uint32)
+            got = ((word[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(M, Cin).astype(bool)
+            assert np.array_equal(got, (out.float().cpu().reshape(M, Cin) > 0).numpy())
+        res[xop] = (out.clone(), y.clone())
+        del tabs
+    # the same fp32 expression in both routes: the tensor a separate pass would have written, bit for bit
+    assert torch.equal(res[1][0], res[0][0])
+    assert relerr(res[1][1], res[0][1].double().cpu()) < TOL
+
+
+# N, H, W, planes (the data gradient of conv3: reduces over 4 x planes, writes planes channels), G
+XB_CASES = [(4, 16, 16, 128, 2), (8, 16, 16, 256, 2), (4, 8, 8, 512, 1), (6, 16, 16, 128, 1), (16, 8, 8, 256, 2)]
+
+
+@pytest.mark.parametrize("case", XB_CASES)
+def test_xop_dgrad_bn_backward_apply_on_the_operand(case):
+    N, H, W, p, G = case
+    Cin, Cout = p, 4 * p                 # conv3: Cin = planes -> Cout = 4 planes; its data gradient reduces over Cout
+    lib = _lib.lib()
+    M = N * H * W
+    if (M // G) % 256 != 0 or N % G != 0:
+        G = 1
+    g = torch.Generator().manual_seed(5 + p + H)
+    dz, dzr = bf(torch.randn(N, H, W, Cout, generator=g, dtype=torch.float64))
+    y3, y3r = bf(torch.randn(N, H, W, Cout, generator=g, dtype=torch.float64))
+    coef = torch.cat([(torch.rand(G, Cout, generator=g) + 0.5).reshape(-1), (torch.randn(G, Cout, generator=g) * 0.2).reshape(-1),
+                      (torch.randn(G, Cout, generator=g) * 0.1).reshape(-1)]).float()
+    wt, wtr = bf(torch.randn(Cin, Cout, generator=g, dtype=torch.float64) / Cout ** 0.5)      # W^T [Cin][1][Cout]
+    y2, y2r = bf(torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))
+    per = M // G
+    grp = torch.arange(M) // per
+    ca, cb, cc = (coef.double()[i * G * Cout:(i + 1) * G * Cout].view(G, Cout)[grp] for i in range(3))
+    dy_ref = ca * dzr.reshape(M, Cout) + cb * y3r.reshape(M, Cout) + cc
+    # bn2 behind the gradient: mask recomputed from y2
+    y2f = y2r.reshape(M, Cin)
+    mean = torch.stack([y2f[gi * per:(gi + 1) * per].mean(0) for gi in range(G)])
+    var = torch.stack([y2f[gi * per:(gi + 1) * per].var(0, unbiased=False) for gi in range(G)])
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    gam = torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5
+    bet = torch.randn(Cin, generator=g, dtype=torch.float64) * 0.3
+    mean_f, rstd_f = mean.float(), rstd.float()
+    scale_f = (gam.float() * rstd_f).contiguous()
+    shift_f = bet.float().expand(G, Cin).contiguous()
+    t32 = torch.addcmul(shift_f[grp], (y2f.float() - mean_f[grp]), scale_f[grp])
+    nt = lib.io_bn_tile_partial_floats(M, Cin, G)
+    res = {}
+    for xop in (1, 0):
+        lib.io_set_bf16_p256(3)
+        lib.io_set_bf16_p256_xop(xop)
+        p1, p2 = torch.zeros(nt, device=DEV), torch.zeros(nt, device=DEV)
+        dx = torch.full((N, H, W, Cin), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dyo = torch.full((N, H, W, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        opt = _lib.DgradFused()
+        tabs = [t.to(DEV).contiguous() for t in (mean_f, rstd_f, scale_f, shift_f, coef)]
+        opt.xb_y, opt.xb_coef, opt.xb_dy_out = y3.data_ptr(), tabs[4].data_ptr(), dyo.data_ptr()
+        opt.ep_y, opt.ep_mean, opt.ep_rstd = y2.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr()
+        opt.ep_scale, opt.ep_shift = tabs[2].data_ptr(), tabs[3].data_ptr()
+        opt.ep_p1, opt.ep_p2 = p1.data_ptr(), p2.data_ptr()
+        _lib.check(lib.io_conv2d_dgrad_fused_dt(P(dz), P(wt), P(dx), N, H, W, Cin, Cout, 1, 1, 0, G, C.byref(opt), BF, ST()),
+                   "dgrad_fused xop=%d" % xop)
+        torch.cuda.synchronize()
+        assert lib.io_debug_last_nt_route() == (1 if xop else 0), xop
+        assert relerr(dyo.reshape(M, Cout), dy_ref) < TOL, xop
+        # the data gradient of the ROUNDED operand, masked by [relu(bn2(y2)) > 0]
+        dz2_ref = (dyo.double().cpu().reshape(M, Cout) @ wtr.t()) * (t32 > 0)
+        assert relerr(dx.reshape(M, Cin), dz2_ref) < TOL, xop
+        dzk = dz2_ref.reshape(M // 128, 128, Cin)
+        xhat = ((y2f - mean[grp]) * rstd[grp]).reshape(M // 128, 128, Cin)
+        s1, s2 = dzk.sum(1), (dzk * xhat).sum(1)
+        assert float((p1[:M // 128 * Cin].view(-1, Cin).double().cpu() - s1).abs().max()) < 2e-3 * float(s1.abs().max())
+        assert float((p2[:M // 128 * Cin].view(-1, Cin).double().cpu() - s2).abs().max()) < 2e-3 * float(s2.abs().max())
+        res[xop] = (dyo.clone(), dx.clone())
+        del tabs
+    assert torch.equal(res[1][0], res[0][0])          # the same fma chain in both routes
+    assert relerr(res[1][1], res[0][1].double().cpu()) < TOL
+
+
+def test_xop_whole_step_equals_the_step_with_separate_batchnorm_passes():
+    """The bf16 training step (InstaOrderNet_od.step, models/supervised_order.py:75-95) with the operand forms on the 256-row
+    kernel against the same step with the stand-alone BatchNorm passes (io_set_bf16_p256_xop(0)), persistent kernels forced
+    for every eligible shape so that 128 x 128 inputs reach them: the forward is the same arithmetic launch for launch -- losses
+    bit-identical --, the backward re-associates bn3's apply (one fma chain instead of the pass's) -- gradients within bf16
+    noise; block-output masks from the sweep's bits."""
+    import instaorder_amd as ia
+    lib = _lib.lib()
+    algo, B, S = "InstaOrderNet_od", 16, 128
+    cfg = dict(algo=algo, lr=1e-3, weight_decay=1e-4, optim="SGD", backbone_arch="resnet50_cls",
+               backbone_param=dict(in_channels=5, num_classes=[2, 3]), use_rgb=True, overlap_weight=0.1, distinct_weight=0.9,
+               dtype="bf16")
+    sd = synthetic.make_state_dict(31, 5, [2, 3], prefix="module.", style="kaiming")
+    batch = synthetic.make_pair_batch(32, B, S)
+    t = {k: torch.from_numpy(v.copy()).cuda() for k, v in batch.items()}
+    res = {}
+    for xop in (1, 0):
+        lib.io_set_bf16_p256(3)
+        lib.io_set_bf16_p256_xop(xop)
+        m = ia.InstaOrderNet_od(cfg, dist_model=False)
+        m._use_graph = False
+        m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m.switch_to("train")
+        m.set_input(t["rgb"], t["modal1"], t["modal2"], t["depth_order"], t["count"], t["is_overlap"], t["occ_order"])
+        logs, out = m.step()
+        torch.cuda.synchronize()
+        res[xop] = (float(out["loss"]), m.net.flat_grads.clone(), m.net.flat_running.clone())
+    assert res[1][0] == res[0][0], (res[1][0], res[0][0])
+    assert torch.equal(res[1][2], res[0][2])                     # running statistics: the forward is identical
+    g1, g0 = res[1][1].double(), res[0][1].double()
+    assert torch.isfinite(g1).all() and float(g0.norm()) > 0
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-2

@@ -441,3 +441,34 @@ def test_reference_written_checkpoint_digest(tmp_path):
         assert k in grp
     assert grp["params"] == list(range(163)) and len(ck["optimizer"]["state"]) == 163
     assert sorted(ck["optimizer"]["state"][0].keys()) == [str(k) for k in g["state_keys"]]
+
+
+def test_forced_overlap_without_a_process_group_fails_at_construction(monkeypatch):
+    """IO_COMM_OVERLAP=force drives dist.all_reduce between the stage graphs of the step: without an initialised process
+    group that must be a clear error when the wrapper is built, not a failure deep inside the first step."""
+    import torch.distributed as dist
+    import instaorder_amd as ia
+    assert not dist.is_initialized()
+    monkeypatch.setenv("IO_COMM_OVERLAP", "force")
+    with pytest.raises(RuntimeError, match="initialise a process group"):
+        ia.InstaOrderNet_od(_od_cfg(), dist_model=False)
+    monkeypatch.setenv("IO_COMM_OVERLAP", "1")
+    m = ia.InstaOrderNet_od(_od_cfg(), dist_model=False)
+    assert m._force_overlap is False and m._overlap_comm is True
+
+
+def test_depthnet_side_streams_are_decided_lazily_from_device_identity(monkeypatch):
+    """midas_net: whether decoder and order branches fork onto side streams is decided at the first forward from the ranks'
+    device identities (one process: never shared), not from world_size vs device_count() at construction; IO_DEPTH_STREAMS
+    = 0 / force override in both directions."""
+    from instaorder_amd import midas_net
+    host, ident = midas_net._device_identity()
+    assert host and ident == "cpu"                       # no GPU in this suite
+    assert midas_net._ranks_share_a_device() is False    # no process group: one process, nothing shared
+    for mode, first in (("1", None), ("0", False), ("force", True)):
+        monkeypatch.setenv("IO_DEPTH_STREAMS", mode)
+        net = midas_net.InstaDepthNet_d()
+        assert net._multi_stream is first
+        assert net.multi_stream is (True if first is None else first)
+        net.multi_stream = False
+        assert net.multi_stream is False
