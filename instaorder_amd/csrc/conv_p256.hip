@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+
 #include "io_common.h"
 
 namespace {
@@ -69,6 +70,7 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 // (add / mask tensors are read instead) -- two instantiations because the first keeps three more coefficient tables in
 // registers and the second three operand loads per pass in flight
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWE = 2, EPI_BWE_READ = 3 };
+constexpr int kXopMaxCi = 2048;       // XOP: three coefficient rows of Ci floats wait in LDS behind the two stages (<= 24 KB)
 
 struct P256Args {
     const bf16_t* in;
@@ -99,7 +101,8 @@ struct P256Args {
 // tile at r * 128, its 16-byte k-chunk c in slot c ^ ((r >> 1) & 7) (the 16 rows a ds_read_b128 lane group touches -- distinct
 // mod 16 -- land in 16 distinct bank quads).  A DMA instruction fills 8 rows: lane i fetches what belongs in slot i & 7 of row
 // i >> 3.  Wave w fetches A chunks 4w .. 4w+3 and B chunks (BN / 64) w .. of every k-tile.
-template <int BN, int EPI, bool GATHER, bool XOP = false>
+// XOP: 0 none; 1 the affine forms (xmode 1, and 3 = the same followed by a ReLU); 2 bn_apply_kernel's form (xmode 2)
+template <int BN, int EPI, bool GATHER, int XOP = 0>
 __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Args a) {
     static_assert(!XOP || !GATHER, "the in-LDS operand transform is for dense 1x1 launches");
     constexpr int BM = 256, TM = 4, TN = BN / 128, NW = 8;
@@ -197,24 +200,21 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
 
     // XOP: thread t owns the 16-byte chunk t & 7 (8 channels) of rows (t >> 3) + 64 u, u = 0..3, of every A k-tile -- the
     // pattern of the DMA (8 lanes = one 128-byte row piece: coalesced for xy and the side output, conflict-free in LDS).
-    // xy and the three coefficient rows of the NEXT k-tile are fetched into registers behind the sweep of this one.
-    u32x4 xyv[XOP ? 4 : 1];
-    f32x4 xca[2], xcb[2], xcc[2];
+    // The second operand travels one k-tile ahead in registers, like the DMA: requested (xyn) right behind the fetches of
+    // k-tile q + 1, i.e. a whole k-tile before its sweep -- requested behind the sweep of k-tile q it had only that tile's MFMAs
+    // to land in, and the loop ran at the memory latency (3.7 TB/s on the 1024 -> 256 launches of layer 3).  The three
+    // coefficient rows of the tile's BatchNorm group wait in LDS behind the two stages ([3][Ci] floats, loaded once per group).
+    u32x4 xyv[XOP ? 4 : 1], xyn[XOP ? 4 : 1];
+    float* const xtab = reinterpret_cast<float*>(smem + 2 * STAGE);
+    int xgrp = -1;
     const unsigned x_lds = (unsigned)(((tid >> 3) * 128) + (((tid & 7) ^ ((tid >> 4) & 7)) << 4));   // (+ 8192 u: same swizzle bits)
     const unsigned x_goff = (unsigned)((tid >> 3) * g.Ci * 2 + (tid & 7) * 16);                     // (+ 64 u rows, + 128 kt)
     auto xop_fetch = [&](int m0f, int ktf) {
-        if constexpr (XOP) {
+        if constexpr (XOP != 0) {
             const __amdgpu_buffer_rsrc_t rs = rsrc_at(a.xy, (size_t)m0f * (size_t)(g.Ci * 2), a.in_bytes);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                xyv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, x_goff + (unsigned)(u * 64 * g.Ci * 2), ktf * 128, 0);
-            const int co = (m0f / a.xMg) * g.Ci + ktf * 64 + (tid & 7) * 8;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                xca[h] = *reinterpret_cast<const f32x4*>(a.xa + co + 4 * h);
-                xcb[h] = *reinterpret_cast<const f32x4*>(a.xb + co + 4 * h);
-                xcc[h] = *reinterpret_cast<const f32x4*>(a.xc + co + 4 * h);
-            }
+                xyn[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, x_goff + (unsigned)(u * 64 * g.Ci * 2) + (unsigned)(ktf * 128), 0, 0);
         }
     };
 
@@ -236,7 +236,10 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
         const int m0 = cur_m0, n0 = cur_n0;      // of the tile being multiplied (setup_tile below moves on to the next one)
-        dma_wait_all();                          // this wave's share of k-tile q has landed ...
+        // this wave's share of k-tile q has landed ...  (XOP: this also waits for the eight side-output stores of the previous
+        // sweep; a counted wait that leaves them in flight -- s_waitcnt vmcnt(8), the counter retires in issue order -- was
+        // measured: 47.13 / 47.27 vs 47.12 / 47.39 ms per step, no difference)
+        dma_wait_all();
         __syncthreads();                         // ... everybody's has, and every wave is done reading the other stage
         const bool last = kt + 1 == nk;
         const int ntile = last ? tile + (int)gridDim.x : tile;
@@ -244,9 +247,35 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
             f_th = f_tw = f_cc = 0;
             if (ntile < a.ntiles) setup_tile(ntile);
         }
-        if (ntile < a.ntiles) issue((q + 1) & 1);
-        if constexpr (XOP) {
+        if constexpr (XOP != 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xyv[u] = xyn[u];     // (landed: requested a k-tile ago, waited for above)
+        }
+        if (ntile < a.ntiles) {
+            issue((q + 1) & 1);
+            xop_fetch(last ? cur_m0 : m0, last ? 0 : kt + 1);
+        }
+        if constexpr (XOP != 0) {
+            if (kt == 0 && m0 / a.xMg != xgrp) {          // (block-uniform; at most once per group and block: tiles ascend)
+                xgrp = m0 / a.xMg;
+                for (int i = tid; i < g.Ci; i += 512) {
+                    xtab[i] = a.xa[xgrp * g.Ci + i];
+                    xtab[g.Ci + i] = a.xb[xgrp * g.Ci + i];
+                    xtab[2 * g.Ci + i] = a.xc[xgrp * g.Ci + i];
+                }
+                __syncthreads();
+            }
             // ---- the operand transform of k-tile kt of tile (m0, n0), in place in stage q & 1
+            f32x4 xca[2], xcb[2], xcc[2];
+            {
+                const float* tb = xtab + kt * 64 + (tid & 7) * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    xca[h] = *reinterpret_cast<const f32x4*>(tb + 4 * h);
+                    xcb[h] = *reinterpret_cast<const f32x4*>(tb + g.Ci + 4 * h);
+                    xcc[h] = *reinterpret_cast<const f32x4*>(tb + 2 * g.Ci + 4 * h);
+                }
+            }
             char* sa = smem + (q & 1) * STAGE + x_lds;
             const bool side = n0 == 0;
             const size_t sbase = (size_t)m0 * (size_t)(g.Ci * 2);
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                                                            (side && a.xout) ? a.in_bytes : sbase);
             const __amdgpu_buffer_rsrc_t rs_xb = rsrc_at(a.xbits ? (const void*)a.xbits : (const void*)a.in, sbase / 16,
                                                          (side && a.xbits) ? a.in_bytes / 16 : sbase / 16);
-            const int xmode = a.xmode;
+            const bool xrelu = a.xmode >= 2;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const u32x4 av = *reinterpret_cast<const u32x4*>(sa + u * 8192);
@@ -266,29 +295,28 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                     const int h = d >> 1, e0 = (d & 1) * 2;
                     const float lo = bf_lo(av[d]), hi = bf_hi(av[d]), yl = bf_lo(yv[d]), yh = bf_hi(yv[d]);
                     float vl, vh;
-                    if (xmode == 2) {           // bn_apply_kernel's expression: the tensor a separate pass would have written
+                    if constexpr (XOP == 2) {   // bn_apply_kernel's expression: the tensor a separate pass would have written
                         vl = __builtin_fmaf(lo - xcb[h][e0], xca[h][e0], xcc[h][e0]) + yl;
                         vh = __builtin_fmaf(hi - xcb[h][e0 + 1], xca[h][e0 + 1], xcc[h][e0 + 1]) + yh;
                     } else {
                         vl = __builtin_fmaf(lo, xca[h][e0], __builtin_fmaf(yl, xcb[h][e0], xcc[h][e0]));
                         vh = __builtin_fmaf(hi, xca[h][e0 + 1], __builtin_fmaf(yh, xcb[h][e0 + 1], xcc[h][e0 + 1]));
                     }
-                    if (xmode >= 2) {
-                        vl = vl > 0.f ? vl : 0.f;
-                        vh = vh > 0.f ? vh : 0.f;
-                    }
-                    o[d] = io_f2bf2(vl, vh);
+                    vl = (xrelu && !(vl > 0.f)) ? 0.f : vl;
+                    vh = (xrelu && !(vh > 0.f)) ? 0.f : vh;
                     bits |= (vl > 0.f ? 1u : 0u) << (2 * d) | (vh > 0.f ? 1u : 0u) << (2 * d + 1);
+                    o[d] = io_f2bf2(vl, vh);
                 }
                 *reinterpret_cast<u32x4*>(sa + u * 8192) = o;
-                const unsigned go = x_goff + (unsigned)(u * 64 * g.Ci * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_side, go, kt * 128, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_xb, go >> 4, kt * 8, 0);
+                // (the k-tile's offset rides in the VECTOR offset, scalar offset 0: with an SGPR there hipcc schedules a VALU
+                // write of the store's first data register right behind the 16-byte store -- its hazard table has no wait state
+                // for that form -- and on gfx950 the store then wrote that VALU result for a quarter of the lanes: found by
+                // tests/test_gpu_xop.py, ISA inspected)
+                const unsigned go = x_goff + (unsigned)(u * 64 * g.Ci * 2) + (unsigned)(kt * 128);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_side, go, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_xb, go >> 4, 0, 0);
             }
             __syncthreads();                     // every wave's share is transformed before anybody multiplies
-            // next k-tile's second operand and coefficients (a tile's last k-tile: behind the epilogue, whose register
-            // budget they would otherwise share)
-            if (!last) xop_fetch(m0, kt + 1);
         }
         const char* sb = smem + (q & 1) * STAGE;
 #pragma unroll
@@ -376,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
             // sequence with the global loads of the epilogue operands (residual gradient, mask, BatchNorm input) issued PD
             // passes ahead: a pass that loaded and waited on its own measured 13-18 % SLOWER than conv_nt_kernel's 2-byte
             // column loads on the data gradients of conv1 (three 16-byte loads in flight per lane, one memory latency per pass).
-            constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS) ? 1 : (EPI == EPI_BWE ? 4 : 3);
+            constexpr int NP = TM * 2 * NI, PD = (EPI == EPI_STATS) ? 1 : (EPI == EPI_BWE ? (XOP != 0 ? 2 : 4) : 3);   // (XOP: xyn is alive across the epilogue)
             auto pass_off = [&](int p) -> unsigned {
                 const int i = p / (2 * NI), h = (p / NI) & 1, k = p % NI;
                 return (unsigned)((wm * 128 + i * 32 + h * 16 + k * RPI + lane / LPR) * g.Co + ecol) * 2u;
@@ -482,9 +510,6 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                 }
             }
         }
-        if constexpr (XOP) {
-            if (last && ntile < a.ntiles) xop_fetch(cur_m0, 0);
-        }
         tile = ntile;
         kt = last ? 0 : kt + 1;
         ++q;
@@ -549,7 +574,7 @@ extern "C" int io_set_bf16_p256_xop(int on) {
 // pass worth leaving to the consumer's operand load in bf16)?  Same tests as the launcher, shape part only.
 bool io_conv_p256_takes_xop(long M, int Ci, int Co, int Mg) {
     if (!p256_enabled() || !xop_enabled()) return false;
-    if (M % 256 != 0 || Ci % 64 != 0 || Co % 128 != 0 || Mg <= 0 || Mg % 256 != 0 || M % Mg != 0) return false;
+    if (M % 256 != 0 || Ci % 64 != 0 || Ci > kXopMaxCi || Co % 128 != 0 || Mg <= 0 || Mg % 256 != 0 || M % Mg != 0) return false;
     if (256.0 * Ci * 2.0 >= 4.0e9 || 256.0 * Co * 2.0 >= 4.0e9) return false;
     return p256_rounds_ok(M / 256 * (Co / (Co % 256 == 0 ? 256 : 128)));
 }
@@ -575,7 +600,7 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
     const bool lin = g.Th * g.Tw == 1 && g.is == 1 && g.dh0 == 0 && g.dw0 == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
     // the operand forms (IoBwStats::xb_a) as an in-LDS transform: dense 1x1 launches, groups of whole 256-row tiles
     const bool xop = bw && bw->xb_a;
-    if (xop && (!lin || !xop_enabled() || !bw->xb_b || !bw->xb_c || !bw->xb_y || bw->xb_Mg <= 0 || bw->xb_Mg % 256 != 0 ||
+    if (xop && (!lin || !xop_enabled() || g.Ci > kXopMaxCi || !bw->xb_b || !bw->xb_c || !bw->xb_y || bw->xb_Mg <= 0 || bw->xb_Mg % 256 != 0 ||
                 M % bw->xb_Mg != 0 || add || mask || bw->maskbits || bw->bias))
         return 1;
     if (st_mean && (add || mask || (bw && (bw->y || bw->bias)))) return 1;
@@ -626,11 +651,12 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
                      st);
 #define IO_P256_LAUNCH(BN_, EPI_, ...)                                                                              \
     do {                                                                                                            \
-        const size_t lds = (size_t)2 * (256 + BN_) * 128;                                                           \
+        const size_t lds = (size_t)2 * (256 + BN_) * 128 + (xop ? (size_t)12 * g.Ci : 0);                           \
         static std::atomic<unsigned long long> attr_done{0};                                                        \
         if (io_first_on_device(attr_done))                                                                          \
             (void)hipFuncSetAttribute((const void*)conv_p256_kernel<BN_, EPI_, __VA_ARGS__>,                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,                                   \
+                                      (int)(2 * (256 + BN_) * 128 + (xop ? 12 * kXopMaxCi : 0)));                   \
         hipLaunchKernelGGL((conv_p256_kernel<BN_, EPI_, __VA_ARGS__>), dim3((unsigned)grid), dim3(512), lds, st, g, a); \
     } while (0)
 #define IO_P256_EPI(BN_, G_)                                         \
@@ -640,13 +666,16 @@ int io_launch_conv_p256(const IoConvGeom& g, const void* in, const void* wgt, vo
         else if (epi == EPI_BWE_READ) IO_P256_LAUNCH(BN_, EPI_BWE_READ, G_); \
         else IO_P256_LAUNCH(BN_, EPI_PLAIN, G_);                     \
     } while (0)
-#define IO_P256_XOP(BN_)                                                      \
-    do {                                                                      \
-        if (epi == EPI_STATS) IO_P256_LAUNCH(BN_, EPI_STATS, false, true);    \
-        else if (epi == EPI_BWE) IO_P256_LAUNCH(BN_, EPI_BWE, false, true);   \
-        else IO_P256_LAUNCH(BN_, EPI_PLAIN, false, true);                     \
+#define IO_P256_XOP(BN_)                                                   \
+    do {                                                                   \
+        if (a.xmode == 2) {                                                \
+            if (epi == EPI_STATS) IO_P256_LAUNCH(BN_, EPI_STATS, false, 2); \
+            else IO_P256_LAUNCH(BN_, EPI_PLAIN, false, 2);                 \
+        } else if (epi == EPI_STATS) IO_P256_LAUNCH(BN_, EPI_STATS, false, 1); \
+        else if (epi == EPI_BWE) IO_P256_LAUNCH(BN_, EPI_BWE, false, 1);   \
+        else IO_P256_LAUNCH(BN_, EPI_PLAIN, false, 1);                     \
     } while (0)
-    if (xop && epi == EPI_BWE_READ) return 1;           // (not instantiated: the executor has no such launch)
+    if (xop && (epi == EPI_BWE_READ || (epi == EPI_BWE && a.xmode == 2))) return 1;   // (not instantiated: the executor has no such launch)
     if (xop) {
         if (bn == 256) IO_P256_XOP(256);
         else IO_P256_XOP(128);
