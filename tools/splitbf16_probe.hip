@@ -237,6 +237,121 @@ __global__ __launch_bounds__(256, 2) void gemm_split(const float* __restrict__ A
             }
 }
 
+
+// ---- round 6: the same product on the tile structure of csrc/conv_p256.hip ------------------------------------------------
+// 256 x 128 block tile, 8 waves as 4 x 2 (wave = 64 rows x 64 columns), 32-k tiles, TWO LDS stages, both operands global -> LDS by
+// LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass): A lands as RAW fp32 (128-byte rows, the XOR-swizzled
+// image of conv_p256) and is split into its three bf16 terms AT FRAGMENT-READ TIME (two 16-byte reads -> 8 floats -> 3 x bf16x8:
+// 44 VALU per fragment, under 24 MFMAs per 16-k step); B arrives pre-split ([3][N][K] bf16: 64-byte rows per plane and k-tile,
+// slot = chunk ^ ((row >> 2) & 3)).  One barrier per k-tile, next k-tile in flight under the MFMAs of this one.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t p_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const u32x4_t r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void p_dma16(u32x4_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    unsigned hh[4], mm[4], ll[4];
+    split2(x0[0], x0[1], hh[0], mm[0], ll[0]);
+    split2(x0[2], x0[3], hh[1], mm[1], ll[1]);
+    split2(x1[0], x1[1], hh[2], mm[2], ll[2]);
+    split2(x1[2], x1[3], hh[3], mm[3], ll[3]);
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+template <int TERMS>
+__global__ __launch_bounds__(512, 2) void gemm_split_p256(const float* __restrict__ A, const bf16_t* __restrict__ Bs,
+                                                          float* __restrict__ C, int M, int N, int K) {
+    constexpr int PBM = 256, PBN = 128;
+    constexpr int A_BYTES = PBM * 128, B_PLANE = PBN * 64, STAGE = A_BYTES + 3 * B_PLANE;      // 32 KB + 24 KB
+    extern __shared__ __attribute__((aligned(1024))) char psm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / PBN, mt = blockIdx.x / ntn, m0 = mt * PBM, n0 = (blockIdx.x - mt * ntn) * PBN;
+    const unsigned lds0 = (unsigned)(size_t)psm;
+    const u32x4_t rsA = p_rsrc(A + (size_t)m0 * K, (size_t)PBM * K * 4);
+    const size_t plane = (size_t)N * K;
+    // A: an instruction fills 8 rows x 128 B; lane i -> row i >> 3, slot i & 7 holds chunk (i & 7) ^ ((row >> 1) & 7)
+    const int ar = lane >> 3, as = lane & 7;
+    // B: an instruction fills 16 rows x 64 B; lane i -> row i >> 2, slot i & 3 holds chunk (i & 3) ^ ((row >> 2) & 3)
+    const int br = lane >> 2, bs = lane & 3;
+    auto issue = [&](int stage, int kt) {
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // wave w: A chunks 4w .. 4w+3 (8 rows each)
+            const int ch = wave * 4 + u, row = ch * 8 + ar;
+            const unsigned voff = (unsigned)(row * K * 4) + (unsigned)((as ^ ((row >> 1) & 7)) << 4);
+            p_dma16(rsA, sb + (unsigned)(ch * 1024), voff, (unsigned)(kt * 128));
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                 // wave w: B pieces 3w .. 3w+2 of the 24 (plane p = piece / 8, 16 rows each)
+            const int pc = wave * 3 + u, pl = pc >> 3, row = (pc & 7) * 16 + br;
+            const u32x4_t rsB = p_rsrc(Bs + pl * plane + (size_t)n0 * K, (size_t)PBN * K * 2);
+            const unsigned voff = (unsigned)(row * K * 2) + (unsigned)((bs ^ ((row >> 2) & 3)) << 4);
+            p_dma16(rsB, sb + (unsigned)(A_BYTES + pc * 1024), voff, (unsigned)(kt * 64));
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / 32;
+    issue(0, 0);
+    const int r32 = lane & 31, half = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+        const char* sb = psm + (kt & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + r32, j2 = 2 * (2 * s + half), sw = (row >> 1) & 7;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + row * 128 + ((j2 ^ sw) << 4));
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + row * 128 + (((j2 + 1) ^ sw) << 4));
+                split8(x0, x1, a[0][i], a[1][i], a[2][i]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wn * 64 + j * 32 + r32, c = 2 * s + half;
+                    b[p][j] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + p * B_PLANE + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+                }
+            // term-major: consecutive MFMAs write DIFFERENT accumulators (small terms first)
+            constexpr int NT = TERMS;
+            constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 6 - NT; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta[t]][i], b[tb[t]][j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                C[(size_t)row * N + n0 + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+}
+
 template <typename F> double time_ms(F launch) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -281,13 +396,18 @@ static void errors(const std::vector<float>& hA, const std::vector<float>& hB, c
 }
 
 int main() {
-    const int shapes[2][3] = {{131072, 256, 2304}, {131072, 256, 1024}};
-    const char* names[2] = {"3x3 256->256 at 16x16 x 512 (K = 2304)", "1x1 1024->256 at 16x16 x 512 (K = 1024)"};
+    const int NSH = 3;
+    const int shapes[NSH][3] = {{131072, 256, 2304}, {131072, 256, 1024}, {131072, 1024, 256}};
+    const char* names[NSH] = {"3x3 256->256 at 16x16 x 512 (K = 2304)", "1x1 1024->256 at 16x16 x 512 (K = 1024)",
+                              "1x1 256->1024 at 16x16 x 512 (K = 256)"};
+    const size_t lds_p256 = (size_t)2 * (256 * 128 + 3 * 128 * 64);
+    CK(hipFuncSetAttribute((const void*)gemm_split_p256<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p256));
+    CK(hipFuncSetAttribute((const void*)gemm_split_p256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p256));
     const size_t lds_split = (size_t)6 * 128 * 40 * 2;
     CK(hipFuncSetAttribute((const void*)gemm_split<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     CK(hipFuncSetAttribute((const void*)gemm_split<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     CK(hipFuncSetAttribute((const void*)(gemm_split<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
-    for (int si = 0; si < 2; ++si) {
+    for (int si = 0; si < NSH; ++si) {
         const int M = shapes[si][0], N = shapes[si][1], K = shapes[si][2];
         std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
         unsigned s = 777u + si;
@@ -320,6 +440,17 @@ int main() {
         ms = time_ms([&]() { hipLaunchKernelGGL((gemm_split<6, true>), grid, dim3(256), lds_split, 0, dA, dAs, dBs, dC, M, N, K); });
         errors(hA, hB, dC, M, N, K, emax, erms);
         printf("  split bf16, 6 terms, A pre-split   %7.3f ms  %6.1f TF/s   error vs fp64: max %.2e rms %.2e\n", ms, flop / ms / 1e9, emax, erms);
+        {
+            const dim3 gridp((M / 256) * (N / 128));
+            ms = time_ms([&]() { hipLaunchKernelGGL(gemm_split_p256<6>, gridp, dim3(512), lds_p256, 0, dA, dBs, dC, M, N, K); });
+            errors(hA, hB, dC, M, N, K, emax, erms);
+            printf("  split 6 terms, 256x128 tile, LDS-DMA, split at fragment read  %7.3f ms  %6.1f TF/s   error vs fp64: max %.2e rms %.2e\n",
+                   ms, flop / ms / 1e9, emax, erms);
+            ms = time_ms([&]() { hipLaunchKernelGGL(gemm_split_p256<3>, gridp, dim3(512), lds_p256, 0, dA, dBs, dC, M, N, K); });
+            errors(hA, hB, dC, M, N, K, emax, erms);
+            printf("  split 3 terms, 256x128 tile, LDS-DMA, split at fragment read  %7.3f ms  %6.1f TF/s   error vs fp64: max %.2e rms %.2e\n",
+                   ms, flop / ms / 1e9, emax, erms);
+        }
         ms = time_ms([&]() { hipLaunchKernelGGL(split_rows_kernel, dim3(1024), dim3(256), 0, 0, dB, dBs, hB.size()); });
         printf("  (filter split [3][N][K], once per step: %.3f ms)\n", ms);
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dBs)); CK(hipFree(dAs));
