@@ -98,14 +98,14 @@ class BatchNorm2d(nn.Module):
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                               identity, _BnMode.groups, _BnMode.repeat)
 
-    def after(self, conv, x, relu=False, identity=None, sole=False):
+    def after(self, conv, x, relu=False, identity=None, sole=False, fork=False):
         """bn(conv(x)) (+ identity) (+ ReLU) as one fused node (statistics in the convolution's epilogue).  sole: this is
         the only use of x (ops.conv_bn then runs the backward of x's own BatchNorm inside its data-gradient launch)."""
         if self.training:
             _Counters.bump(self.num_batches_tracked, _BnMode.groups * _BnMode.repeat)
         return ops.conv_bn(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, conv.stride,
                            conv.padding, conv.groups, self.training, relu, identity, _BnMode.groups, _BnMode.repeat,
-                           sole=sole)
+                           sole=sole, fork=fork)
 
 
 class _Fn(nn.Module):
@@ -117,6 +117,9 @@ class _Fn(nn.Module):
 
     def forward(self, x):
         return self.fn(x)
+
+
+_FORK = os.environ.get("IO_DEPTH_FORK", "1") != "0"      # (0: the residual gradient summed by the autograd engine -- A/B runs)
 
 
 class Bottleneck(nn.Module):
@@ -135,7 +138,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.bn1.after(self.conv1, x, relu=True)
+        # fork: the block input feeds conv1 AND the residual path; the alias conv1 hands back carries the residual path, so its
+        # gradient is added inside conv1's data-gradient launch (ops.conv_bn) instead of by an accumulation kernel
+        out = self.bn1.after(self.conv1, x, relu=True, fork=_FORK)
+        if isinstance(out, tuple):
+            out, x = out
         out = self.bn2.after(self.conv2, out, relu=True, sole=True)          # relu(bn1(.)) feeds conv2 only
         identity = x
         if self.downsample is not None:

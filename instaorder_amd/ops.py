@@ -57,6 +57,22 @@ class WeightPlan(object):
                 r[3] += 100        # used with two layouts: never plan it
 
     @classmethod
+    def note_vec(cls, *ps):
+        """the 1-D parameters a node consumes (BatchNorm weight / bias): recorded like the filters -- used exactly once per
+        step, their gradient kernels may write straight into the flat gradient buffer (``grad_target``)"""
+        if cls._recording is not None:
+            for q in ps:
+                if q is not None:
+                    cls._recording.setdefault(id(q), [q, -1, -1, 0])[3] += 1
+
+    @classmethod
+    def grad_target(cls, q):
+        """where the gradient of the 1-D parameter ``q`` goes in the step in flight: its slice of optim.flat_grads (the node
+        then returns no gradient for it), or None = an ordinary autograd gradient"""
+        plan = cls.active
+        return plan.vecs.get(id(q)) if (plan is not None and q is not None) else None
+
+    @classmethod
     def stop_recording(cls):
         recs, cls._recording = cls._recording, None
         return [r for r in (recs or {}).values() if r[3] == 1]
@@ -79,6 +95,17 @@ class WeightPlan(object):
             rows.append((w, _WeightDesc(spans[id(w)], n_op, n_op + sz if need_t else -1, n_g, Co, Ci, T, Cop, Cip)))
             n_op += sz * (2 if need_t else 1)
             n_g += sz
+        # BatchNorm weights / biases used once per step: BatchNorm-backward launches write dgamma / dbeta into these views of
+        # the flat gradient buffer -- no per-tensor gradient, no copy into the flat buffer (gather_grads made 286 of them
+        # per InstaDepthNet_od step: torch._foreach_copy_ decomposes into one hipMemcpyAsync per tensor)
+        self.vecs = {}
+        import os
+        direct = os.environ.get("IO_DEPTH_DIRECT_GRADS", "1") != "0"      # (0: every BatchNorm gradient through autograd + gather -- A/B runs)
+        for q, Cip, _, _ in recs:
+            if direct and Cip == -1 and id(q) in spans and q.dim() == 1:
+                off = spans[id(q)]
+                self.vecs[id(q)] = optim.flat_grads[off:off + q.numel()]
+        self.skip_ids = None
         self.n = len(rows)
         self._row_off = [d.src for _, d in rows]
         self.ops = torch.zeros(max(n_op, 1), device=dev, dtype=dtype)
@@ -92,6 +119,13 @@ class WeightPlan(object):
                                    self.ops[d.dst_t:d.dst_t + sz].view(d.Cip, d.T, d.Cop) if d.dst_t >= 0 else None,
                                    self.gk[d.dst_g:d.dst_g + sz].view(d.Cop, d.T, d.Cip))
 
+    @property
+    def skip(self):
+        """ids of the parameters whose slice of the flat gradient buffer this plan fills (optim.gather_grads leaves them alone)"""
+        if self.skip_ids is None:
+            self.skip_ids = set(self.entries) | set(self.vecs)
+        return self.skip_ids
+
     def lookup(self, w, Cip, Cop, dtype):
         e = self.entries.get(id(w))
         return e if (e is not None and e[0] == Cip and e[1] == Cop and dtype == self.dtype) else None
@@ -101,6 +135,11 @@ class WeightPlan(object):
             # A planned filter whose gradient kernel does not run in this step (a loss weight switched to 0 after the plan
             # was recorded) must deliver zero, not the previous step's gradient: unpack_grads() copies every entry of gk.
             self.gk.zero_()
+            if self.vecs:
+                # ... and so must a directly written BatchNorm gradient, and every parameter no loss reaches (the occlusion
+                # branch of the reference's InstaDepthNet_od recipe: occ_order_weight 0) -- ONE fill of the flat buffer
+                # instead of one per gradient-less parameter in gather_grads (129 per step)
+                self.optim.flat_grads.zero_()
             _lib.check(_L().io_weights_prepare(_p(self.table), self.n, _p(self.optim.flat_params), _p(self.ops),
                                                1 if self.dtype == torch.bfloat16 else 0, _st()), "io_weights_prepare")
 
@@ -285,6 +324,7 @@ class _BatchNorm(torch.autograd.Function):
         G = int(groups) if training else 1
         mean, rstd, scale, shift = (torch.empty(G * Cc, device=dev, dtype=torch.float32) for _ in range(4))
         if training:
+            WeightPlan.note_vec(gamma, beta)
             npart = int(L.io_bn_partial_floats(M, Cc, G))
             part = torch.empty(npart, device=dev, dtype=torch.float32)
             _lib.check(L.io_bn_stats_finalize_dt(_p(x), M, Cc, G, _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
@@ -298,6 +338,7 @@ class _BatchNorm(torch.autograd.Function):
         _lib.check(L.io_bn_apply_dt(_p(x), M, Cc, G, 1 if training else 0, _p(mean), _p(scale), _p(shift), _p(identity), None,
                                     None, None, int(relu), _p(out), _dt(x), _st()), "io_bn_apply_dt")
         ctx.save_for_backward(x, out, gamma, mean, rstd)
+        ctx.beta = beta
         ctx.cfg = (M, Cc, bool(relu), identity is not None, bool(training), G)
         return out
 
@@ -313,13 +354,15 @@ class _BatchNorm(torch.autograd.Function):
         npart = int(L.io_bn_partial_floats(M, Cc, G))
         part = torch.empty(npart, device=dev, dtype=torch.float32)
         coef = torch.empty(2 * G * Cc, device=dev, dtype=torch.float32)
-        dgamma, dbeta = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        tg, tb = WeightPlan.grad_target(gamma), WeightPlan.grad_target(ctx.beta)
+        dgamma = tg if tg is not None else torch.empty(Cc, device=dev)
+        dbeta = tb if tb is not None else torch.empty(Cc, device=dev)
         dx = torch.empty_like(x)
         dz = torch.empty_like(x) if has_id else None          # gradient of the pre-ReLU sum = gradient of `identity`
         _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(x), M, Cc, G, _p(gamma.detach()),
                                   _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(dx), _p(dz), _p(part), npart, _p(coef),
                                   _dt(x), _st()), "io_bn_bwd_dt")
-        return dx, dgamma, dbeta, None, None, None, None, dz, None, None
+        return dx, (None if tg is not None else dgamma), (None if tb is not None else dbeta), None, None, None, None, dz, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, relu=False, identity=None, groups=1, repeat=1):
@@ -335,10 +378,21 @@ class _ConvBn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
-                bn_groups, repeat, prev):
+                bn_groups, repeat, prev, fork):
         _chk(x, "x")
         ctx.prev = None
         ctx.link = None
+        ctx.fork = bool(fork)
+        out = _ConvBn._forward(ctx, x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu,
+                               identity, bn_groups, repeat, prev)
+        # fork: x comes back as a second output (an alias) -- for the residual connection of the Bottleneck this convolution
+        # opens -- so that the gradient of that path arrives HERE and rides in the `add` operand of the data-gradient
+        # launch instead of being summed onto dx by a separate ATen kernel of the autograd engine
+        return (out, x) if fork else out
+
+    @staticmethod
+    def _forward(ctx, x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
+                 bn_groups, repeat, prev):
         _ConvBn.last_offer = None
         if training:
             WEIGHTS_EPOCH[0] += 1      # running statistics move (behind torch's version counters): folded operands are stale
@@ -401,6 +455,9 @@ class _ConvBn(torch.autograd.Function):
             return y
         mean, rstd, scale, shift = (torch.empty(G * Co, device=dev, dtype=torch.float32) for _ in range(4))
         gd, bd = gamma.detach(), beta.detach()
+        if training:
+            WeightPlan.note_vec(gamma, beta)
+        ctx.beta = beta
         if training and M % G == 0 and (M // G) % 128 == 0:
             nws = int(L.io_conv2d_bnstats_workspace_floats(N, H, W_, Co, R, S, stride, pad, G))
             ws = torch.empty(nws, device=dev, dtype=torch.float32)
@@ -433,7 +490,7 @@ class _ConvBn(torch.autograd.Function):
         # Cross-node fusion of the BatchNorm backward (see conv_bn's `sole`): as PRODUCER of relu(bn(y)) this node offers
         # what a consumer's data-gradient epilogue needs; as CONSUMER of such a tensor it keeps the producer's offer.
         if training and relu and identity is None and M % G == 0 and (M // G) % 128 == 0 and Co % 64 == 0:
-            ctx.link = {}
+            ctx.link = {"_gamma": gamma, "_beta": beta}       # (the parameters: a consumer that runs this BatchNorm's backward asks WeightPlan where their gradients go)
             _ConvBn.last_offer = (ctx.link, y, mean, rstd, scale, shift, gamma.detach(), G, M, Co)
         else:
             _ConvBn.last_offer = None
@@ -442,10 +499,12 @@ class _ConvBn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dfork=None):
         N, H, W_, Cs, Co, Cig, R, S, stride, pad, dense, M, G, relu, has_id, training = ctx.cfg
         if not training:
             raise RuntimeError("ops.conv_bn: backward through eval-mode BatchNorm is not implemented")
+        if dfork is not None:
+            dfork = dfork.contiguous()
         x, wback, y, out, gamma, mean, rstd = ctx.saved_tensors
         L = _L()
         dev, dt = x.device, _dt(x)
@@ -453,13 +512,16 @@ class _ConvBn(torch.autograd.Function):
         npart = int(L.io_bn_partial_floats(M, Co, G))
         part = torch.empty(npart, device=dev, dtype=torch.float32)
         coef = torch.empty(2 * G * Co, device=dev, dtype=torch.float32)
-        dgamma, dbeta = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+        tg, tb = WeightPlan.grad_target(gamma), WeightPlan.grad_target(ctx.beta)
         link = ctx.link
         if link is not None and "dy" in link:
             # the sole consumer of this node's output already ran this BatchNorm's backward in its data-gradient launch
+            # (and wrote dgamma / dbeta to the same targets)
             dy, dgamma, dbeta = link.pop("dy"), link.pop("dgamma"), link.pop("dbeta")
             dz = None
         else:
+            dgamma = tg if tg is not None else torch.empty(Co, device=dev)
+            dbeta = tb if tb is not None else torch.empty(Co, device=dev)
             dy = torch.empty_like(y)
             dz = torch.empty_like(y) if has_id else None
             _lib.check(L.io_bn_bwd_dt(_p(dout), _p(out) if relu else None, None, None, _p(y), M, Co, G, _p(gamma.detach()),
@@ -478,7 +540,9 @@ class _ConvBn(torch.autograd.Function):
             wsf = torch.empty(nws, device=dev, dtype=torch.float32)
             dz = torch.empty_like(x)
             dyb = torch.empty_like(x)
-            dg, db = torch.empty(Cp, device=dev), torch.empty(Cp, device=dev)
+            tgp, tbp = WeightPlan.grad_target(link.get("_gamma")), WeightPlan.grad_target(link.get("_beta"))
+            dg = tgp if tgp is not None else torch.empty(Cp, device=dev)
+            db = tbp if tbp is not None else torch.empty(Cp, device=dev)
             _lib.check(L.io_conv2d_dgrad_bnbwd_dt(_p(dy), _p(wt_op), _p(dz), N, H, W_, Cs, Co, R, S, pad, _p(yp), Gp,
                                                   _p(gamma_p), _p(mean_p), _p(rstd_p), _p(scale_p), _p(shift_p), _p(dg),
                                                   _p(db), _p(dyb), _p(wsf), nws, dt, gw, _st()), "io_conv2d_dgrad_bnbwd_dt")
@@ -494,8 +558,9 @@ class _ConvBn(torch.autograd.Function):
                     dx = fused_dgrad(wt, 0)
                 else:
                     dx = torch.empty_like(x)
-                    _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), None, None, N, H, W_, Cs, Co, R, S, stride, pad,
+                    _lib.check(L.io_conv2d_dgrad_dt(_p(dy), _p(wt), _p(dx), _p(dfork), None, N, H, W_, Cs, Co, R, S, stride, pad,
                                                     dt, _st()), "io_conv2d_dgrad_dt")
+                    dfork = None                 # (summed inside the launch)
             nb = int(L.io_conv2d_wgrad_workspace_bytes(N, H, W_, Cs, Co, R, S, stride, pad))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
             dwk = ent[4] if ent is not None else torch.empty((Co, R * S, Cs), device=dev, dtype=torch.float32)
@@ -517,28 +582,39 @@ class _ConvBn(torch.autograd.Function):
                        "io_gconv2d_wgrad")
             dw = torch.empty((Co, Cig, R, S), device=dev, dtype=torch.float32)
             _lib.check(L.io_gconv_unpack_grad(_p(dwc), Co, Cig, R * S, _p(dw), _st()), "io_gconv_unpack_grad")
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, dz, None, None, None
+        if dfork is not None:                    # (forms whose data gradient has no add operand: summed here)
+            dx = dfork if dx is None else dx + dfork
+        return (dx, dw, (None if tg is not None else dgamma), (None if tb is not None else dbeta), None, None, None, None, None,
+                None, None, dz, None, None, None, None)
 
 
 _ConvBn.last_offer = None
 
 
 def conv_bn(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu=False, identity=None,
-            bn_groups=1, repeat=1, sole=False):
+            bn_groups=1, repeat=1, sole=False, fork=False):
     """``sole=True``: the caller promises that THIS call is the only consumer of ``x`` (as conv2 / conv3 of a Bottleneck
     are of relu(bn1(.)) / relu(bn2(.)), resnet_cls.py:99-111).  If ``x`` came out of a conv_bn with ReLU, the backward of
     that BatchNorm then runs inside this node's data-gradient launch (mask recomputed from the producer's conv output,
-    reductions in the epilogue, io_conv2d_dgrad_bnbwd_dt) instead of as separate reduce + apply passes."""
+    reductions in the epilogue, io_conv2d_dgrad_bnbwd_dt) instead of as separate reduce + apply passes.
+    ``fork=True`` (training, x requires a gradient): returns ``(out, x_alias)``; the caller routes every OTHER use of x (the
+    residual connection / the downsample branch of resnet_cls.py:96-114) through ``x_alias``, whose gradient then enters this
+    node and is added inside its data-gradient launch (io_conv2d_dgrad_dt's `add`) -- one launch instead of the data gradient
+    plus the autograd engine's accumulation kernel (65 of them per InstaDepthNet_od step).  Otherwise returns ``out`` alone."""
     if repeat > 1 and bn_groups > 1:
         raise ValueError("conv_bn: repeat and bn_groups are exclusive")
     prev = getattr(x, "_io_offer", None) if (sole and training) else None
     if prev is not None and prev[7] != (int(bn_groups) if training else 1):
         prev = None
+    fork = bool(fork and training and torch.is_grad_enabled() and x.requires_grad)
     out = _ConvBn.apply(x, w, gamma, beta, running_mean, running_var, stride, pad, groups, training, relu, identity,
-                        bn_groups, repeat, prev)
+                        bn_groups, repeat, prev, fork)
+    alias = None
+    if fork:
+        out, alias = out
     if _ConvBn.last_offer is not None:
         out._io_offer, _ConvBn.last_offer = _ConvBn.last_offer, None
-    return out
+    return (out, alias) if fork else out
 
 
 # ---- pooling / heads --------------------------------------------------------------------------------------------------

@@ -109,14 +109,16 @@ class FlatSGD(torch.optim.Optimizer):
                 self._spans.append((off, k))
                 off += ((k + 63) // 64) * 64
 
-    def gather_grads(self, skip=None):
+    def gather_grads(self, skip=None, prezeroed=False):
         """Per-tensor autograd gradients -> the flat gradient buffer (missing gradients count as zero).  ``skip``: ids of
-        parameters whose slice somebody else fills right afterwards (ops.WeightPlan.unpack_grads)."""
+        parameters whose slice somebody else fills (ops.WeightPlan: filters unpacked right afterwards, BatchNorm gradients
+        written in place by their kernels).  ``prezeroed``: the buffer was cleared before the backward pass (WeightPlan.prepare):
+        gradient-less parameters need no fill of their own."""
         with torch.no_grad():
             dst, src = [], []
             for p, (off, k) in zip(self._params, self._spans):
                 if p.grad is None:
-                    if skip is None or id(p) not in skip:
+                    if not prezeroed and (skip is None or id(p) not in skip):
                         self.flat_grads[off:off + k].zero_()
                 else:
                     dst.append(self.flat_grads[off:off + k].view(p.shape))
@@ -126,7 +128,7 @@ class FlatSGD(torch.optim.Optimizer):
                 torch._foreach_copy_(dst, src)
         return self.flat_grads
 
-    def gather_stage(self, idx, grads, skip=None, attach=False):
+    def gather_stage(self, idx, grads, skip=None, attach=False, prezeroed=False):
         """The gradients of the parameters ``idx`` (indices into the flat layout, one stage of a staged backward pass) ->
         their slices of the flat gradient buffer; ``grads``: what torch.autograd.grad returned for them (None = no
         gradient: zeros, unless the parameter is in ``skip`` -- ops.WeightPlan fills those).  attach: ``p.grad`` = the view."""
@@ -137,7 +139,7 @@ class FlatSGD(torch.optim.Optimizer):
                 off, k = self._spans[i]
                 view = self.flat_grads[off:off + k].view(p.shape)
                 if g is None:
-                    if skip is None or id(p) not in skip:
+                    if not prezeroed and (skip is None or id(p) not in skip):
                         view.zero_()
                 else:
                     dst.append(view)

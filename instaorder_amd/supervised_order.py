@@ -528,7 +528,8 @@ class _DepthBase(SingleStageModel):
             ops.WeightPlan.active = None
             recs = ops.WeightPlan.stop_recording() if recording else None
         if flat:
-            self.optim.gather_grads(skip=plan.entries if plan is not None else None)
+            self.optim.gather_grads(skip=plan.skip if plan is not None else None,
+                                    prezeroed=bool(plan is not None and plan.vecs))
         if plan is not None:
             plan.unpack_grads()                  # ... and their gradients back, one launch
         if recording:
@@ -584,7 +585,7 @@ class _DepthBase(SingleStageModel):
         opt = self.optim
         stages = self._stage_plan()
         P = [[opt._params[i] for i in idx] for _, idx in stages]
-        skip = plan.entries if plan is not None else None
+        skip = plan.skip if plan is not None else None
         self.net._stage_cut = True            # every consumer of an encoder stage output reads a detached alias of it
         try:
             outs = self._run(True)
@@ -604,7 +605,7 @@ class _DepthBase(SingleStageModel):
                             loss.detach() if torch.is_tensor(loss) else loss)
 
         def finish(si, idx, got):
-            opt.gather_stage(idx, got, skip=skip, attach=True)
+            opt.gather_stage(idx, got, skip=skip, attach=True, prezeroed=bool(plan is not None and plan.vecs))
             if plan is not None and idx:
                 lo = opt._spans[idx[0]][0]
                 hi = opt._spans[idx[-1]][0] + opt._spans[idx[-1]][1]
