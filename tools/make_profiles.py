@@ -48,6 +48,8 @@ for src, dst in (("bench_c2.json", "bench_config2_od_bf16_1024.json"), ("bench_c
             print("skipped", src, ex)
 
 for src, dst in (("bench_b32_fp32.json", "bench_fp32_b32.json"), ("bench_b64_fp32.json", "bench_fp32_b64.json"),
+                 ("bench_b32_bf16.json", "bench_bf16_b32.json"), ("ab_bf16_xop0.json", "ab_bf16_256_xop_off.json"),
+                 ("ab_bf16_xop1.json", "ab_bf16_256_xop_on.json"), ("ab_c4_r5forms.json", "ab_config4_without_fork_and_direct_grads.json"),
                  ("bench_2ranks_gloo.json", "bench_o_fp32_b64_2ranks_gloo_one_gpu.json"),
                  ("bench_c4_2ranks_gloo.json", "bench_config4_depthnet_od_bf16_2ranks_gloo_one_gpu.json")):
     if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 100:
@@ -151,6 +153,7 @@ def _fam_blocks(path):
 bf = {}
 fz, wz, mb = (_fam_blocks(os.path.join(G, n)) for n in ("bf16_traffic_FETCH_SIZE.txt", "bf16_traffic_WRITE_SIZE.txt",
                                                          "bf16_mfma_busy.txt"))
+ld = _fam_blocks(os.path.join(G, "bf16_lds.txt"))
 for fam in fz:
     e = {}
     if "FETCH_SIZE" in fz.get(fam, {}) and "WRITE_SIZE" in wz.get(fam, {}):
@@ -164,6 +167,10 @@ for fam in fz:
                  mfma_busy_fraction_of_busy_cu_cycles=busy / (4.0 * cu) if cu else None,
                  wave_cycles_wait_any_frac=c["WAIT_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_ANY" in c else None,
                  wave_cycles_wait_inst_any_frac=c["WAIT_INST_ANY"][2] / c["WAVE_CYCLES"][2] if "WAIT_INST_ANY" in c else None)
+    c = ld.get(fam, {})
+    if "LDS_BANK_CONFLICT" in c and "LDS_IDX_ACTIVE" in c and c["LDS_IDX_ACTIVE"][2] > 0:
+        e.update(lds_bank_conflict_cycles_per_lds_active_cycle=c["LDS_BANK_CONFLICT"][2] / c["LDS_IDX_ACTIVE"][2],
+                 lds_instructions_per_launch=c["INSTS_LDS"][1] if "INSTS_LDS" in c else None)
     if e:
         bf[fam] = e
 bfb = os.path.join(G, "bench_n1_bf16.json")
