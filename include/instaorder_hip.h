@@ -55,6 +55,13 @@ int io_get_winograd(void);
  * 128-row kernel every other launch runs (same arithmetic, fp32 accumulation; sums may associate differently).
  * Process-wide; initial value from the environment variable IO_P256 (unset = 1).  Returns the previous value. */
 int io_set_bf16_p256(int on);
+/* Further environment switches of the launchers (read once per process; tuning / A-B runs, results identical up to summation order):
+ *   IO_NT_SMALL_TILES=n   conv_nt_kernel: a forward / data-gradient launch with at most n 128-wide tiles runs 64-wide tiles (default
+ *                         256 = one tile per CU: +3 % at 32 pairs per GPU; 0 = always 128 wide where Cout allows)
+ *   IO_HALO3_BREG=0       conv_halo3_kernel: filters streamed through LDS instead of held in registers (64 -> 64 channels)
+ *   IO_P256_XOP=0         see io_set_bf16_p256_xop below
+ *   IO_DEPTH_STREAMS=0 | force, IO_DEPTH_FORK=0, IO_DEPTH_DIRECT_GRADS=0, IO_COMM_OVERLAP=0 | force, IO_NO_GRAPH=1
+ *                         host-side switches of the Python wrappers (midas_net.py, ops.py, supervised_order.py) */
 int io_get_bf16_p256(void);
 /* Test hook: the kernel family the most recent forward / data-gradient launch of this process went to -- 0 = the 128-row
  * kernel, 1 = conv_p256, 2 = conv_halo3, 3 = stem_halo (so a parity test can assert that the kernel it means to check is the one that ran). */

@@ -1046,13 +1046,7 @@ int io_launch_conv_halo3(const IoConvGeom& g, const void* in, const void* wgt, v
     if (bw) a.bw = *bw;
     a.ntiles = (int)(M / 256);
     a.tiles_per_img = g.Ho * g.Wo / 256;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = io_device_cu_count();
     {
         const long rounds = ((long)a.ntiles + ncu - 1) / ncu;
         if (mode != 3 && (long)a.ntiles * 10 < rounds * ncu * 8) return 1;     // (conv_p256.hip's rule)
@@ -1081,10 +1075,12 @@ int io_launch_conv_halo3(const IoConvGeom& g, const void* in, const void* wgt, v
         else IO_HALO3_LAUNCH(W_, BN_, WM_, WN_, TPS_, EPI_PLAIN);                   \
     } while (0)
     // 64 output channels: 4 x 2 waves of 64 x 32, three taps per stage; 128: 4 x 2 waves of 64 x 64, one tap per stage
-    static int breg = -1;
+    static std::atomic<int> breg_c{-1};
+    int breg = breg_c.load(std::memory_order_relaxed);
     if (breg < 0) {
         const char* e = getenv("IO_HALO3_BREG");
         breg = (e && e[0] == '0') ? 0 : 1;
+        breg_c.store(breg, std::memory_order_relaxed);
     }
     // 4 x 2 waves of 64 x 32; 64 -> 64 channels: the filters in registers, otherwise three taps per LDS stage
     if (breg && g.Wo == 64 && g.Ci == 64) IO_HALO3_EPI(64, 64, 4, 2, 0);
@@ -1122,13 +1118,7 @@ int io_launch_conv_stem_halo(const IoConvGeom& g, const void* in, const void* wg
     if (bw) a.bw = *bw;
     a.ntiles = (int)(M / 256);
     a.tiles_per_img = g.Ho / 2;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = io_device_cu_count();
     {
         const long rounds = ((long)a.ntiles + ncu - 1) / ncu;
         if (mode != 3 && (long)a.ntiles * 10 < rounds * ncu * 8) return 1;
@@ -1156,13 +1146,7 @@ int io_launch_conv_stem_halo(const IoConvGeom& g, const void* in, const void* wg
 // xb: bn1's backward folded in (dz / y / tables), or null (dz is dy).  IO_OK, 1 = not this kernel's shape / workspace, < 0 error.
 size_t io_stem_wgrad_halo_partial_bytes() { return (size_t)io_stem_wgrad_rows_max_blocks() * 64 * 392 * sizeof(float); }
 static int stem_wg_ncu() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ncu = p.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = io_device_cu_count();
     return ncu;
 }
 // would io_launch_stem_wgrad_halo take this launch (shape, mode, enough tiles for its persistent blocks, workspace)?

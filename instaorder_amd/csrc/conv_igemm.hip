@@ -2982,10 +2982,12 @@ int io_launch_conv_nt(const IoConvGeom& g, const void* in, const void* wgt, void
     // Output-channel tile: 128 wide where that leaves enough tiles to fill the chip, 64 wide otherwise -- a small per-GPU batch
     // (the reference's own 32 pairs per GPU, or a strong-scaling rank) gives layers 3-4 only 32..128 row tiles, and 128-wide
     // tiles then occupy a fraction of the 256 CUs with one block each (measured at 32 pairs: 43-51 TF/s on the 8 x 8 maps).
-    static int small_tiles = -1;
+    static std::atomic<int> small_tiles_c{-1};
+    int small_tiles = small_tiles_c.load(std::memory_order_relaxed);
     if (small_tiles < 0) {
         const char* e = getenv("IO_NT_SMALL_TILES");        // (experiments: the largest 128-wide tile count that still goes 64 wide)
         small_tiles = e ? atoi(e) : 256;   // one 128-wide tile per CU or fewer (same-box, 32 pairs: 1388 -> 1428 pairs/s fp32, 3014 -> 3090 bf16)
+        small_tiles_c.store(small_tiles, std::memory_order_relaxed);
     }
     const long tiles128 = (long)io_cdiv(M, 128) * (g.Co / 128);
     const int bn = g.gw ? g.gw : ((g.Co % 128 == 0 && tiles128 > small_tiles) ? 128 : 64);

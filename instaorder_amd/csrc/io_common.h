@@ -24,6 +24,19 @@ static inline int io_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // device id; returns true the first time it is asked on the CURRENT device (a process may launch on several devices; two
 // threads racing here both do the idempotent set-up).  *dev_out: the current device id.
 #include <atomic>
+// CUs of the current device, cached per device ordinal (the persistent grids of conv_p256.hip / conv_halo3.hip are sized by it)
+static inline int io_device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t p;
+        n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 static inline bool io_first_on_device(std::atomic<unsigned long long>& mask, int* dev_out = nullptr) {
     int d = 0;
     (void)hipGetDevice(&d);

@@ -62,7 +62,9 @@ if os.path.exists(src) and os.path.getsize(src) > 1000:
     open(os.path.join(P, "%s_per_launch_fp32_b32.txt" % rnd), "w").write(open(src).read())
 
 csv.field_size_limit(1 << 30)
-for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv", "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
+for rawname, outname, cmd in (("kernel_stats_raw.csv", "_bench_kernel_stats.csv", "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
+                               "  [--no-secondary: the default line's two secondary legs (bf16 at 256 pairs, fp32 at 32 pairs) launch the SAME kernel "
+                               "families at other sizes after the timed region and would blur the per-kernel averages]"),
                               ("kernel_stats_bf16_raw.csv", "_bench_bf16_kernel_stats.csv",
                                "python3 bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline"),
                               ("kernel_stats_depthnet_bf16_raw.csv", "_bench_depthnet_od_bf16_kernel_stats.csv",

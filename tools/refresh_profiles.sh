@@ -22,7 +22,7 @@ for m in fwd infer; do for d in fp32 bf16; do
 done; done
 cd /tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /tmp/kt.log 2>&1
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats_raw.csv
 cd $R
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1
