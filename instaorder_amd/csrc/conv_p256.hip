@@ -70,9 +70,6 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 // (add / mask tensors are read instead) -- two instantiations because the first keeps three more coefficient tables in
 // registers and the second three operand loads per pass in flight
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BWE = 2, EPI_BWE_READ = 3 };
-#ifndef IO_P256_S2_UNCENTRED
-#define IO_P256_S2_UNCENTRED 0
-#endif
 constexpr int kXopMaxCi = 2048;       // XOP: three coefficient rows of Ci floats wait in LDS behind the two stages (<= 24 KB)
 
 struct P256Args {
@@ -379,8 +376,11 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                                                           a.mask ? a.out_bytes : out_base);
             constexpr bool BWE = EPI == EPI_BWE || EPI == EPI_BWE_READ;
             const __amdgpu_buffer_rsrc_t rs_y = rsrc_at(BWE ? a.bw.y : (const void*)a.out, out_base, BWE ? a.out_bytes : out_base);
-            // BWE: per channel sum(dz) and sum(dz * (y - mean)) over the wave's 128 rows; sum(dz * xhat) = rstd * that (the same
-            // per-element centring as conv_nt_kernel's epilogue: the two routes of a launch round alike also where |mean| >> std)
+            // BWE: per channel sum(dz) and the second BatchNorm-backward sum over the wave's 128 rows.  EPI_BWE (the mean is in
+            // registers for the mask): sum(dz * (y - mean)), centred per element as conv_nt_kernel does -- the two routes of a launch
+            // round alike also where |mean| >> std.  EPI_BWE_READ: sum(dz * y) with the mean taken out at the end, sum(dz * xhat) =
+            // rstd * (sum(dz y) - mean sum(dz)) -- eight more registers for the means spill that instantiation (8 / 18 VGPRs, dense /
+            // gather) and cost the bf16 step 0.3 ms (47.2 vs 46.9 ms, same box): measured, not taken
             float t_mu[8], t_sc[8], t_sh[8], s1[8], s2[8], t_bias[8];
             const bool nomask = a.mask == nullptr && a.bw.maskbits == nullptr;
             // the mask as one bit per element (IoBwStats::maskbits): a lane's 8 channels are one byte
@@ -399,12 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                     t_sh[e] = a.bw.mshift[gcol + e];
                 }
             }
-#if !IO_P256_S2_UNCENTRED
-            if constexpr (EPI == EPI_BWE_READ) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t_mu[e] = a.bw.mean[gcol + e];
-            }
-#endif
+
             if constexpr (EPI == EPI_PLAIN) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t_bias[e] = a.bw.bias ? a.bw.bias[ecol + e] : 0.f;
@@ -491,11 +486,8 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
                                 v[e] = t > 0.f ? v[e] : 0.f;
                             }
                             s1[e] += v[e];
-#if IO_P256_S2_UNCENTRED      // (A/B build: the round-5 form, sum(dz y) with the mean taken out at the end)
-                            s2[e] = __builtin_fmaf(v[e], y, s2[e]);
-#else
-                            s2[e] = __builtin_fmaf(v[e], y - t_mu[e], s2[e]);      // (centred per element, as conv_nt_kernel: no cancellation)
-#endif
+                            if constexpr (EPI == EPI_BWE) s2[e] = __builtin_fmaf(v[e], y - t_mu[e], s2[e]);   // (centred: the mean is in registers anyway)
+                            else s2[e] = __builtin_fmaf(v[e], y, s2[e]);
                         }
                     }
                 }
@@ -518,11 +510,8 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         a.bw.p1[o + e] = s1[e];
-#if IO_P256_S2_UNCENTRED
-                        a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (s2[e] - a.bw.mean[gcol + e] * s1[e]);
-#else
-                        a.bw.p2[o + e] = a.bw.rstd[gcol + e] * s2[e];
-#endif
+                        if constexpr (EPI == EPI_BWE) a.bw.p2[o + e] = a.bw.rstd[gcol + e] * s2[e];
+                        else a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (s2[e] - a.bw.mean[gcol + e] * s1[e]);
                     }
                 }
             }
