@@ -153,6 +153,103 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_dma(const bf16_t* __r
 }
 
 
+
+// Round 6: the same GEMM with 32-wide k-tiles (64-byte rows) in a ring of STAGES stages -- the LDS of two 64-wide stages holds FOUR
+// of these, so three k-tiles are in flight instead of one (is the 256-row kernel paced by what one k-tile in
+// flight per CU returns per memory round trip?).  LDS image: row r at r * 64, its 16-byte k-chunk c in slot c ^ ((r >> 2) & 3)
+// (16 consecutive rows of one chunk column land in 16 distinct bank quads); a DMA instruction fills 16 rows: lane i fetches the
+// chunk that belongs in slot i & 3 of row i >> 2.
+template <int BM, int BN, int WM, int WN, int STAGES, int MINB>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_dma32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                bf16_t* __restrict__ C, int M, int N, int K) {
+    constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 64, CH = (BM + BN) / 16, CPW = CH / NW, CHA = BM / 16;
+    static_assert(CH % NW == 0, "chunks per wave");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / ntn, m0 = mt * BM, n0 = (tile - mt * ntn) * BN;
+    const int nk = K / 32;
+    const u32x4 rsA = dma_rsrc(A + (size_t)m0 * K, (size_t)BM * K * 2);
+    const u32x4 rsB = dma_rsrc(B + (size_t)n0 * K, (size_t)BN * K * 2);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int rr = lane >> 2, pp = lane & 3;
+    const unsigned vlane = (unsigned)(rr * K * 2 + ((pp ^ ((rr >> 2) & 3)) << 4));
+    auto issue = [&](int kt, int stage) {
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+        const unsigned koff = (unsigned)kt * 64u;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const int ch = wave * CPW + u;                  // wave-uniform
+            if (ch < CHA) dma16(rsA, sb + (unsigned)(ch * 1024), vlane, koff + (unsigned)(ch * 16 * K * 2));
+            else dma16(rsB, sb + (unsigned)(ch * 1024), vlane, koff + (unsigned)((ch - CHA) * 16 * K * 2));
+        }
+    };
+    const int swz = ((lane & 31) >> 2) & 3;
+    unsigned ko[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) ko[kk] = (unsigned)(((2 * kk + (lane >> 5)) ^ swz) << 4);
+    const unsigned a_row = (unsigned)((wm * TM * 32 + (lane & 31)) * 64);
+    const unsigned b_row = (unsigned)(BM * 64 + (wn * TN * 32 + (lane & 31)) * 64);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (STAGES > 2 && kt + STAGES - 2 < nk) vm_wait<CPW*(STAGES > 2 ? STAGES - 2 : 0)>();
+        else vm_wait<0>();
+        __syncthreads();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const char* sb = smem + (kt % STAGES) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + a_row + i * 2048 + ko[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + j * 2048 + ko[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    constexpr int JG = TN >= 2 ? 2 : 1, WC = JG * 32, EPP = WC + 4;
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPP);
+    static_assert(NW * 32 * EPP * 4 <= STAGES * STAGE, "epilogue slice");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jg = 0; jg < TN / JG; ++jg) {
+#pragma unroll
+            for (int j = 0; j < JG; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPP + j * 32 + (lane & 31)] = acc[i][jg * JG + j][r];
+            constexpr int LPR = WC / 8, RPI = 64 / LPR, NI = 32 / RPI;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int row = k * RPI + lane / LPR, cc = (lane % LPR) * 8;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(ep + row * EPP + cc + 4);
+                const u32x4 pk = {f2bf2(q0[0], q0[1]), f2bf2(q0[2], q0[3]), f2bf2(q1[0], q1[1]), f2bf2(q1[2], q1[3])};
+                *reinterpret_cast<u32x4*>(C + (size_t)(m0 + wm * TM * 32 + i * 32 + row) * N + n0 + wn * TN * 32 + jg * WC + cc) = pk;
+            }
+        }
+    }
+}
+
 // PERSISTENT form of gemm_dma: the grid is one block per CU slot; a block walks the tiles b, b + grid, ... and treats their
 // k-tiles as ONE stream -- the fetch of the next tile's first k-tile is in flight while the last k-tile of the current tile is
 // multiplied and its output leaves through the stage that multiply has just freed (2 stages).  PRIO: s_setprio 1 around the MFMAs.
@@ -437,6 +534,31 @@ int main(int argc, char** argv) {
             for (int r = 0; r < NR; ++r) CK(hipMemsetAsync(dC[r], 0, (size_t)M * N * 2));                                    \
             double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
             report("persist " #BM_ "x" #BN_ " waves " #WM_ "x" #WN_ " prio " #PR_ " blocks/CU " #BPC_, ms);                   \
+        }
+#define RUN_DMA32(BM_, BN_, WM_, WN_, ST_, MB_)                                                                             \
+        if (M % BM_ == 0 && N % BN_ == 0) {                                                                                  \
+            const size_t lds = (size_t)ST_ * (BM_ + BN_) * 64;                                                               \
+            auto kfn = gemm_dma32<BM_, BN_, WM_, WN_, ST_, MB_>;                                                             \
+            CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            const dim3 grid((M / BM_) * (N / BN_));                                                                          \
+            for (int r = 0; r < NR; ++r) CK(hipMemsetAsync(dC[r], 0, (size_t)M * N * 2));                                    \
+            double ms = time_ms([&]() { hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, 0, dA[rot % NR], dB, dC[rot % NR], M, N, K); ++rot; }); \
+            report("dma32 " #BM_ "x" #BN_ " waves " #WM_ "x" #WN_ " 32-k stages " #ST_ " minb " #MB_, ms);                    \
+        }
+        if (argc > 2) {          // round 6: only the ring variants next to their 64-k counterparts
+            RUN_DMA(256, 256, 2, 4, 2, 1)
+            RUN_DMA32(256, 256, 2, 4, 3, 1)
+            RUN_DMA32(256, 256, 2, 4, 4, 1)
+            RUN_DMA32(256, 256, 2, 4, 5, 1)
+            RUN_DMA(256, 128, 4, 2, 2, 1)
+            RUN_DMA(256, 128, 4, 2, 3, 1)
+            RUN_DMA32(256, 128, 4, 2, 4, 1)
+            RUN_DMA32(256, 128, 4, 2, 6, 1)
+            RUN_PER(256, 256, 2, 4, 1, false, 1)
+            for (int r = 0; r < NR; ++r) { CK(hipFree(dA[r])); CK(hipFree(dC[r])); }
+            CK(hipFree(dB));
+            fflush(stdout);
+            continue;
         }
         RUN_LIB(3, 2, 2)
         RUN_DMA(128, 128, 2, 2, 2, 2)
