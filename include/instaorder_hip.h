@@ -460,7 +460,9 @@ int io_conv2d_fwd_resid_dt(const void* y3, const void* second, const void* w, vo
                            float* tile_mean, float* tile_m2, int dtype, hipStream_t stream);
 /* Run-time switch of the in-LDS operand forms of the bf16 256-row kernel (process-wide; initial value from IO_P256_XOP,
  * unset = 1): with 0 the network executor keeps the stand-alone BatchNorm passes on layers 2-4 (the round-5 step) and a
- * launch that asks for an operand form runs on conv_nt_kernel.  Returns the previous value. */
+ * launch that asks for an operand form runs on conv_nt_kernel.  Returns the previous value.  Like io_set_bf16_p256 it decides
+ * which launch builds a block output and its one-bit mask: change either switch BETWEEN training steps, not between
+ * io_net_forward and the io_net_backward* calls of one step. */
 int io_set_bf16_p256_xop(int on);
 int io_get_bf16_p256_xop(void);
 /* All filters of a module tree in one launch (the op-by-op graphs of instaorder_amd.ops; midas/midas_net.py's ~200 dense
