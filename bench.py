@@ -58,7 +58,7 @@ def cpu_model():
 CPU_BASELINE_MAX_THREADS = 32
 
 
-CPU_BASELINE_BUDGET_S = 28.0       # bounded sample: about 10-30 s of CPU work per default bench run
+CPU_BASELINE_BUDGET_S = 20.0       # bounded sample: about 10-30 s of CPU work per default bench run (the whole default run stays near 40 s)
 
 
 def cpu_baseline(sd, S):
