@@ -37,8 +37,10 @@ def _tables(C_, G, g):
 
 
 # N, H, W, Cin (= 4 x planes of the block that ends), Cout (= planes of the next block's conv1), G
+# (the last case: 520 row tiles on at most 256 persistent blocks -- a block walks tiles of BOTH BatchNorm groups and reloads its
+# coefficient rows in LDS at the group boundary)
 RESID_CASES = [(4, 16, 16, 512, 128, 2), (8, 16, 16, 1024, 256, 2), (4, 8, 8, 2048, 512, 1), (2, 32, 32, 256, 128, 1),
-               (6, 16, 16, 512, 256, 2), (48, 4, 4, 1024, 256, 1)]
+               (6, 16, 16, 512, 256, 2), (48, 4, 4, 1024, 256, 1), (520, 16, 16, 512, 128, 2)]
 
 
 @pytest.mark.parametrize("case", RESID_CASES)
@@ -101,7 +103,7 @@ def test_xop_forward_residual_output_built_by_next_conv1(case, two):
 
 
 # N, H, W, planes (the data gradient of conv3: reduces over 4 x planes, writes planes channels), G
-XB_CASES = [(4, 16, 16, 128, 2), (8, 16, 16, 256, 2), (4, 8, 8, 512, 1), (6, 16, 16, 128, 1), (16, 8, 8, 256, 2)]
+XB_CASES = [(4, 16, 16, 128, 2), (8, 16, 16, 256, 2), (4, 8, 8, 512, 1), (6, 16, 16, 128, 1), (16, 8, 8, 256, 2), (520, 16, 16, 128, 2)]
 
 
 @pytest.mark.parametrize("case", XB_CASES)
