@@ -201,9 +201,10 @@ __global__ __launch_bounds__(512, 2) void conv_p256_kernel(IoConvGeom g, P256Arg
     // XOP: thread t owns the 16-byte chunk t & 7 (8 channels) of rows (t >> 3) + 64 u, u = 0..3, of every A k-tile -- the
     // pattern of the DMA (8 lanes = one 128-byte row piece: coalesced for xy and the side output, conflict-free in LDS).
     // The second operand travels one k-tile ahead in registers, like the DMA: requested (xyn) right behind the fetches of
-    // k-tile q + 1, i.e. a whole k-tile before its sweep -- requested behind the sweep of k-tile q it had only that tile's MFMAs
-    // to land in, and the loop ran at the memory latency (3.7 TB/s on the 1024 -> 256 launches of layer 3).  The three
-    // coefficient rows of the tile's BatchNorm group wait in LDS behind the two stages ([3][Ci] floats, loaded once per group).
+    // k-tile q + 1, i.e. a whole k-tile before its sweep.  (Requested behind the sweep of k-tile q instead -- only that tile's
+    // MFMAs to land in -- the launches took the same time, 0.238 ms on layer 3's 1024 -> 256: they are not paced by this load;
+    // kept because it frees the 24 coefficient registers the first form held across the MFMAs.)  The three coefficient rows of
+    // the tile's BatchNorm group wait in LDS behind the two stages ([3][Ci] floats, loaded once per group).
     u32x4 xyv[XOP ? 4 : 1], xyn[XOP ? 4 : 1];
     float* const xtab = reinterpret_cast<float*>(smem + 2 * STAGE);
     int xgrp = -1;
