@@ -225,11 +225,12 @@ __device__ __forceinline__ void halo_epilogue(f32x16 (&acc)[TP / WM / 32][BN / W
                 for (int hh = 0; hh < 2; ++hh) {
                     const int e = 2 * d + hh;
                     const float y = hh ? bf_hi(yv[d]) : bf_lo(yv[d]);
-                    const float t = LTAB ? __builtin_fmaf(y - ltab[tc + e], ltab[BN + tc + e], ltab[2 * BN + tc + e])
-                                         : __builtin_fmaf(y - t_mu[e], t_sc[e], t_sh[e]);     // bn(y), bn_apply's fma
+                    const float yc = y - (LTAB ? ltab[tc + e] : t_mu[e]);                 // (centred: also what the second sum takes)
+                    const float t = LTAB ? __builtin_fmaf(yc, ltab[BN + tc + e], ltab[2 * BN + tc + e])
+                                         : __builtin_fmaf(yc, t_sc[e], t_sh[e]);              // bn(y), bn_apply's fma
                     v[e] = t > 0.f ? v[e] : 0.f;
                     s1[e] += v[e];
-                    s2[e] = __builtin_fmaf(v[e], y, s2[e]);
+                    s2[e] = __builtin_fmaf(v[e], yc, s2[e]);      // sum(dz (y - mean)), per element as conv_nt_kernel: no cancellation
                 }
         }
         if (p + PD < NP) pass_load(p + PD, sl);
@@ -265,7 +266,7 @@ __device__ __forceinline__ void halo_epilogue(f32x16 (&acc)[TP / WM / 32][BN / W
                     t2 += red[((ow * 2 + 1) * LPR + lane) * 8 + e];
                 }
                 a.bw.p1[o + e] = t1;
-                a.bw.p2[o + e] = a.bw.rstd[gcol + e] * (t2 - a.bw.mean[gcol + e] * t1);
+                a.bw.p2[o + e] = a.bw.rstd[gcol + e] * t2;
             }
         }
     }
