@@ -34,7 +34,7 @@ python3 bench.py --algo InstaOrderNet_od --dtype bf16 --size 384 --batch 256 --s
 python3 bench.py --algo InstaOrderNet_od --dtype bf16 --workload images20 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c3.json 2>> $O/bench_n1.err
 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 4 --warmup 2 > $O/bench_c4_prof.json 2>> $O/bench_n1.err
 # (the committed configs[4] line carries roofline + cpu_baseline: the profiled pass and the CPU leg run after the timed region)
-python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 6 --warmup 3 > $O/bench_c4.json 2>> $O/bench_n1.err
+python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 10 --warmup 3 > $O/bench_c4.json 2>> $O/bench_n1.err
 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype fp32 --steps 4 --warmup 3 --no-prof --no-cpu-baseline > $O/bench_c4_fp32.json 2>> $O/bench_n1.err
 cd /tmp
 rm -rf /tmp/kt4
@@ -53,7 +53,7 @@ python3 bench.py --batch 64 --steps 12 --warmup 4 --no-cpu-baseline --no-fwd-onl
 python3 bench.py --batch 32 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | tail -1 > $O/bench_b32_bf16.json
 # same-box A/B of the round-6 operand forms of the bf16 256-row kernel (IO_P256_XOP) and of the MiDaS step's residual fork / direct gradients
 for v in 0 1; do IO_P256_XOP=$v python3 bench.py --dtype bf16 --no-cpu-baseline --no-prof 2>> $O/bench_n1.err | tail -1 > $O/ab_bf16_xop$v.json; done
-IO_DEPTH_FORK=0 IO_DEPTH_DIRECT_GRADS=0 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 8 --warmup 3 --no-prof --no-cpu-baseline 2>> $O/bench_n1.err | tail -1 > $O/ab_c4_r5forms.json
+IO_DEPTH_FORK=0 IO_DEPTH_DIRECT_GRADS=0 python3 bench.py --algo InstaDepthNet_od --size 384 --batch 16 --dtype bf16 --steps 10 --warmup 3 --no-prof --no-cpu-baseline 2>> $O/bench_n1.err | tail -1 > $O/ab_c4_r5forms.json
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --backend gloo --batch 64 --steps 6 --warmup 3 --no-cpu-baseline --no-fwd-only 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_2ranks_gloo.json
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --backend gloo --algo InstaDepthNet_od --size 384 --batch 8 --dtype bf16 --steps 5 --warmup 3 --no-cpu-baseline 2>> $O/bench_n1.err | grep '^{' | tail -1 > $O/bench_c4_2ranks_gloo.json
 # the two headline lines once more with the counters of THIS run behind them (bench.py quotes profiles/rNN_pmc_*.json only while
